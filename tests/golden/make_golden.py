@@ -1,0 +1,228 @@
+"""Generate the golden input/output vectors under tests/golden/ by CALLING the reference on the CPU.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+It drives the reference's own functions in the order its sampling harness does
+(reference: nusc_train.py:957-1105) on seeded synthetic scenes, records every torch.randn_like draw,
+and stores inputs + expected outputs as .npz.  The fixtures are data only.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_harness  # noqa: E402
+from pstl_diffusion_policy_amd.synthetic import make_scene_batch  # noqa: E402
+
+WEIGHTS_FILE = os.path.join(HERE, "weights_seed1007.npz")
+
+
+def np_(x):
+    return x.detach().cpu().numpy()
+
+
+def build_weights(ref):
+    args = ref_harness.parse_reference_args(
+        ["--diffusion", "--load_stlp", "--rect_head", "--flex", "--diverse_loss", "--multi_cands", "5"])
+    torch.manual_seed(1007)
+    net = ref.nusc_model.Net(args)
+    sd = {k: np_(v) for k, v in net.state_dict().items()}
+    np.savez(WEIGHTS_FILE, **sd)
+    return sd
+
+
+def load_net(ref, args, sd):
+    net = ref.nusc_model.Net(args)
+    missing = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not missing.missing_keys, missing
+    net.eval()
+    return net
+
+
+def sampling_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=0.0, stlp_mode="loose",
+                  zero_net_out=False):
+    nt = ref.nusc_train
+    argv = list(argv) + ["--diffusion_steps", str(steps), "--sampling_size", str(S), "--n_randoms", str(S),
+                         "--n_neighbors", str(K), "--test", "--run_sampling_test"]
+    args = ref_harness.parse_reference_args(argv)
+    force_full = not args.diff_full
+    args.diff_full = True          # only changes what the rollout RETURNS (all intermediates), not the math
+    net = load_net(ref, args, sd)
+    if zero_net_out:
+        # damp the random-init denoiser so sampled controls stay small and some rows satisfy the STL formula
+        with torch.no_grad():
+            net.policy_net[4].weight.mul_(0.0)
+            net.policy_net[4].bias.mul_(0.0)
+    coeffs = nt.get_diffusion_coeffs(args)
+    stls = nt.build_stl_cache(args)
+    batch = make_scene_batch(bs, K=K, S=S, seed=seed, invalid_lane_frac=invalid_lane_frac, stlp_mode=stlp_mode)
+    N = bs * S * 3
+    states = batch["ego_traj"][:, 0, :4]
+    new_batch = {k: batch[k] for k in ["ego_traj", "neighbors", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
+                                       "curr_id", "left_id", "right_id", "gt_high_level", "pre_stlp"]}
+    new_batch["neighbor_trajs_aug"] = batch["neighbors_traj"][..., :7]
+    new_batch = nt.augment_batch_data(new_batch, batch["stlp_modes"][:, 0], args, n_randoms=S)
+    hl = new_batch["highlevel_dense"]
+    states_flat = states.unsqueeze(1).unsqueeze(1).repeat(1, S, 3, 1).reshape(N, 4)
+
+    out = {}
+    torch.manual_seed(seed + 17)
+    noise = torch.normal(0, 1, (N, args.nt * 2)).float()
+    gextras = (new_batch, states_flat, stls) if args.guidance else None
+    draws = []
+    with ref_harness.record_randn_like(draws):
+        controls, feature, clist = nt.diffusion_rollout(noise, net, new_batch, hl, None, args, coeffs,
+                                                        fastforward=False, n_randoms=S, return_feature=True,
+                                                        guidance_extras=gextras)
+    E = steps - 1
+    assert len(draws) == 1 + (E - 1), len(draws)
+    out["x_T"] = np_(draws[0])
+    z = torch.stack(draws[1:] + [torch.zeros_like(draws[0])], dim=0)   # z for i=E..1 (the last one is zero)
+    out["z"] = np_(z)
+    out["controls_list"] = np_(torch.stack(clist, dim=0))              # (steps, N, nt, 2), normalised
+    out["controls_rollout"] = np_(controls)
+    out["feature_scene"] = np_(feature.reshape(bs, S * 3, -1)[:, 0])
+    assert torch.equal(feature.reshape(bs, S * 3, -1)[:, 0:1].repeat(1, S * 3, 1).reshape(N, -1), feature)
+
+    nn_controls = controls
+    if args.rect_head and not args.not_use_rect:
+        mc = args.multi_cands
+        states_mul = states_flat.repeat(mc, 1)
+        ctrls_mul = torch.cat(clist[-mc:], dim=0)
+        trajs_mul = nt.generate_trajs(states_mul, ctrls_mul, args.dt)
+        prev_in = nt.pre_prepare_stl_cache(new_batch, dense_trajs=trajs_mul[:, :-1], repeat_n=mc)
+        _, sc_hist, _ = nt.compute_stl_dense(prev_in, stls, hl.repeat(mc, 1), prev_in["dense_valids"].reshape(-1), args)
+        sc_hist = sc_hist.reshape(mc, N)
+        c_hist = ctrls_mul.reshape(mc, N, args.nt, 2)
+        sc_max, sc_idx = torch.max(sc_hist, dim=0)
+        c_max = c_hist[sc_idx, range(N)]
+        out["cand_scores"] = np_(sc_hist)
+        out["sel_scores"] = np_(sc_max)
+        out["sel_idx"] = np_(sc_idx)
+        out["sel_controls"] = np_(c_max)
+        nn_controls = c_max
+        if not args.no_refinenet:
+            nn_controls = net.rect_forward(feature, hl, new_batch["stlp_dense"][:, 0], c_max.detach(), sc_max.detach())
+            out["rect_controls"] = np_(nn_controls)
+        if args.n_rolls is not None:
+            for ri in range(args.n_rolls):
+                tr = nt.generate_trajs(states_flat, nn_controls.detach(), args.dt)
+                pin = nt.pre_prepare_stl_cache(new_batch, dense_trajs=tr[:, :-1].detach())
+                _, sc_re, _ = nt.compute_stl_dense(pin, stls, hl, pin["dense_valids"], args)
+                nn_controls = net.rect_forward(feature, hl, new_batch["stlp_dense"][:, 0], nn_controls.detach(), sc_re.detach())
+                out["roll%d_scores" % ri] = np_(sc_re)
+                out["roll%d_controls" % ri] = np_(nn_controls)
+
+    trajs = nt.generate_trajs(states_flat, nn_controls, args.dt).reshape(N, args.nt + 1, 4)
+    stl_in = nt.pre_prepare_stl_cache(new_batch, dense_trajs=trajs[:, :-1])
+    scores_list, scores, acc, scene_acc = nt.compute_stl_dense(stl_in, stls, hl, stl_in["dense_valids"], args, scene=True)
+    out["final_controls"] = np_(nn_controls)
+    out["final_trajs"] = np_(trajs)
+    out["final_scores3"] = np_(torch.stack(scores_list[:3], dim=0))
+    out["final_scores"] = np_(scores)
+    out["final_acc"] = np.float32(acc.item())
+    out["final_scene_acc"] = np.float32(scene_acc.item())
+    for k in ["x2curr_d", "x2curr_th", "x2left_d", "x2left_th", "x2right_d", "x2right_th", "min_nei_d"]:
+        out["sig_" + k] = np_(stl_in[k])
+
+    for k in ["ego_traj", "neighbors", "neighbors_traj", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
+              "curr_id", "left_id", "right_id", "stlp_modes"]:
+        out["in_" + k] = np_(batch[k])
+    out["in_stlp_dense"] = np_(new_batch["stlp_dense"])
+    out["in_valids_dense"] = np_(new_batch["valids_dense"])
+    out["in_highlevel_dense"] = np_(hl)
+    beta, alpha, alpha_hat = coeffs
+    out["coef_beta"], out["coef_alpha"], out["coef_alpha_hat"] = np_(beta), np_(alpha), np_(alpha_hat)
+    out["meta"] = np.array([bs, S, K, steps, seed, int(args.rect_head), int(args.guidance),
+                            -1 if args.multi_cands is None else args.multi_cands,
+                            int(args.diffusion_clip), int(force_full), args.guidance_before, args.guidance_niters,
+                            -1 if args.n_rolls is None else args.n_rolls, int(zero_net_out)], dtype=np.int64)
+    out["meta_f"] = np.array([args.guidance_lr, args.stl_nn_thres, args.smoothing_factor], dtype=np.float64)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s N=%d acc=%.4f scene_acc=%.4f sat=%d/%d -> %s (%.1f KB)" % (
+        name, N, acc.item(), scene_acc.item(), int((scores > 0).sum()), N, os.path.basename(path),
+        os.path.getsize(path) / 1024))
+
+
+def stl_case(ref, name, bs, S, K, seed, invalid_lane_frac, stlp_mode, ctrl_scale):
+    """STL robustness + gradients w.r.t. the controls, on small random controls (mixed satisfied/violated rows)."""
+    nt = ref.nusc_train
+    args = ref_harness.parse_reference_args(
+        ["--diffusion", "--load_stlp", "--sampling_size", str(S), "--n_randoms", str(S), "--n_neighbors", str(K)])
+    stls = nt.build_stl_cache(args)
+    batch = make_scene_batch(bs, K=K, S=S, seed=seed, invalid_lane_frac=invalid_lane_frac, stlp_mode=stlp_mode)
+    N = bs * S * 3
+    new_batch = {k: batch[k] for k in ["ego_traj", "neighbors", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
+                                       "curr_id", "left_id", "right_id", "gt_high_level", "pre_stlp"]}
+    new_batch["neighbor_trajs_aug"] = batch["neighbors_traj"][..., :7]
+    new_batch = nt.augment_batch_data(new_batch, batch["stlp_modes"][:, 0], args, n_randoms=S)
+    hl = new_batch["highlevel_dense"]
+    states_flat = batch["ego_traj"][:, 0, :4].unsqueeze(1).unsqueeze(1).repeat(1, S, 3, 1).reshape(N, 4)
+    g = torch.Generator().manual_seed(seed + 5)
+    u = torch.randn(N, args.nt, 2, generator=g) * torch.tensor([0.5, 5.0]) * ctrl_scale
+    # steer the lane-change rows towards their target lane so that some of them satisfy "reach"
+    mode = hl.reshape(N)
+    steer = torch.zeros(N, args.nt)
+    steer[:, :4] = 0.12
+    steer[:, 4:8] = -0.12
+    u[..., 0] = u[..., 0] + steer * ((mode == 1).float() - (mode == 2).float())[:, None]
+    u = u.requires_grad_()
+    trajs = nt.generate_trajs(states_flat, u, args.dt).reshape(N, args.nt + 1, 4)
+    stl_in = nt.pre_prepare_stl_cache(new_batch, dense_trajs=trajs[:, :-1])
+    scores_list, scores, acc, scene_acc = nt.compute_stl_dense(stl_in, stls, hl, stl_in["dense_valids"], args, scene=True)
+    valid = stl_in["dense_valids"].reshape(-1)
+    loss = nt.mask_mean(torch.relu(args.stl_nn_thres - scores), valid)
+    g_loss, = torch.autograd.grad(loss, u, retain_graph=True)
+    g_sum, = torch.autograd.grad(scores.sum(), u)
+    out = {"controls": np_(u), "trajs": np_(trajs), "scores3": np_(torch.stack(scores_list[:3], 0)), "scores": np_(scores),
+           "acc": np.float32(acc.item()), "scene_acc": np.float32(scene_acc.item()), "loss": np.float32(loss.item()),
+           "grad_loss": np_(g_loss), "grad_sum": np_(g_sum)}
+    for k in ["x2curr_d", "x2curr_th", "x2left_d", "x2left_th", "x2right_d", "x2right_th", "min_nei_d"]:
+        out["sig_" + k] = np_(stl_in[k])
+    for k in ["ego_traj", "neighbors", "neighbors_traj", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
+              "curr_id", "left_id", "right_id", "stlp_modes"]:
+        out["in_" + k] = np_(batch[k])
+    out["in_stlp_dense"] = np_(new_batch["stlp_dense"])
+    out["in_valids_dense"] = np_(new_batch["valids_dense"])
+    out["in_highlevel_dense"] = np_(hl)
+    out["meta"] = np.array([bs, S, K, seed], dtype=np.int64)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s N=%d acc=%.4f scene_acc=%.4f sat=%d/%d |score|<1e-6: %d -> %s (%.1f KB)" % (
+        name, N, acc.item(), scene_acc.item(), int((scores > 0).sum()), N, int((scores.abs() < 1e-6).sum()),
+        os.path.basename(path), os.path.getsize(path) / 1024))
+
+
+def main():
+    assert ref_harness.reference_available(), "reference not mounted"
+    torch.set_num_threads(8)
+    ref = ref_harness.load_reference()
+    sd = build_weights(ref)
+    e5 = ["--diffusion", "--load_stlp", "--flex"]
+    e7 = ["--diffusion", "--load_stlp", "--rect_head", "--flex", "--diverse_loss", "--multi_cands", "5"]
+    gd = ["--guidance", "--guidance_before", "4", "--guidance_niters", "1", "--guidance_lr", "0.01"]
+    sampling_case(ref, sd, "e5_steps10", e5, bs=3, S=8, K=3, steps=10, seed=11)
+    sampling_case(ref, sd, "e5_steps100", e5, bs=2, S=8, K=2, steps=100, seed=12)
+    sampling_case(ref, sd, "e7_steps12", e7, bs=3, S=8, K=3, steps=12, seed=13, invalid_lane_frac=0.3)
+    sampling_case(ref, sd, "e7_steps50_k8", e7, bs=2, S=16, K=8, steps=50, seed=14)
+    sampling_case(ref, sd, "e7_damped", e7, bs=3, S=8, K=4, steps=12, seed=15, zero_net_out=True)
+    sampling_case(ref, sd, "e7_wide", e7, bs=4, S=8, K=4, steps=12, seed=19, invalid_lane_frac=0.25, stlp_mode="wide")
+    sampling_case(ref, sd, "e7_guid", e7 + gd, bs=2, S=8, K=3, steps=12, seed=16, stlp_mode="wide")
+    sampling_case(ref, sd, "e7_guid_n2_rolls", e7[:-1] + ["3"] + gd[:4] + ["2", "--guidance_lr", "0.02", "--n_rolls", "2"],
+                  bs=2, S=8, K=3, steps=10, seed=17, zero_net_out=True)
+    sampling_case(ref, sd, "e5_guid_all", e5 + ["--guidance", "--guidance_niters", "3"], bs=2, S=8, K=2, steps=8, seed=18,
+                  zero_net_out=True)
+    stl_case(ref, "stl_mixed", bs=6, S=8, K=4, seed=21, invalid_lane_frac=0.3, stlp_mode="loose", ctrl_scale=0.02)
+    stl_case(ref, "stl_mixed_k8", bs=4, S=8, K=8, seed=22, invalid_lane_frac=0.0, stlp_mode="loose", ctrl_scale=0.05)
+    stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
+
+
+if __name__ == "__main__":
+    main()

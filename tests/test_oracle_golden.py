@@ -1,0 +1,85 @@
+"""Pins the CPU oracle against golden vectors produced by the reference itself (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import (SAMPLING_CASES, STL_CASES, golden_meta, golden_weights, load_golden, scene_from_golden)
+from oracle import pstl_oracle as orc
+from pstl_diffusion_policy_amd.synthetic import default_hparams
+
+
+def _weights_for(meta):
+    sd = {k: v.copy() for k, v in golden_weights().items()}
+    if meta["zero_net_out"]:
+        sd["policy_net.4.weight"] *= 0
+        sd["policy_net.4.bias"] *= 0
+    return sd
+
+
+def _guidance_cfg(meta):
+    if not meta["guidance"]:
+        return None
+    return dict(enabled=True, before=meta["guidance_before"], niters=meta["guidance_niters"], lr=meta["guidance_lr"])
+
+
+def test_schedule_matches_reference():
+    for name in ["e5_steps10", "e5_steps100"]:
+        d = load_golden(name)
+        beta, alpha, ah = orc.diffusion_coeffs(golden_meta(d)["steps"])
+        np.testing.assert_array_equal(beta.numpy(), d["coef_beta"])
+        np.testing.assert_array_equal(alpha.numpy(), d["coef_alpha"])
+        np.testing.assert_array_equal(ah.numpy(), d["coef_alpha_hat"])
+
+
+@pytest.mark.parametrize("name", SAMPLING_CASES)
+def test_sampling_region_matches_reference(name):
+    d = load_golden(name)
+    meta = golden_meta(d)
+    hp = default_hparams()
+    out = orc.sampling_region(_weights_for(meta), scene_from_golden(d), meta["S"], meta["steps"], hp, d["x_T"], d["z"],
+                              rect_head=bool(meta["rect_head"]),
+                              multi_cands=None if meta["multi_cands"] < 0 else meta["multi_cands"],
+                              guidance=_guidance_cfg(meta), n_rolls=None if meta["n_rolls"] < 0 else meta["n_rolls"])
+    np.testing.assert_allclose(out["feature_scene"].numpy(), d["feature_scene"], rtol=0, atol=2e-6)
+    # sampled trajectories: the north-star tolerance is 1e-4; the oracle itself sits far inside it
+    tol = 5e-6 if not meta["guidance"] else 2e-5
+    np.testing.assert_allclose(out["controls_list"].numpy(), d["controls_list"], rtol=0, atol=tol)
+    np.testing.assert_allclose(out["final_controls"].numpy(), d["final_controls"], rtol=0, atol=tol)
+    for k in ["cand_scores", "sel_scores", "sel_controls", "rect_controls", "roll0_scores", "roll1_controls"]:
+        if k in d:
+            np.testing.assert_allclose(out[k].numpy(), d[k], rtol=2e-5, atol=2e-4 if "scores" in k else tol, err_msg=k)
+    if "sel_idx" in d:
+        np.testing.assert_array_equal(out["sel_idx"].numpy(), d["sel_idx"])
+    np.testing.assert_allclose(out["final_scores"].numpy(), d["final_scores"], rtol=2e-5, atol=2e-4)
+    np.testing.assert_array_equal(out["final_scores"].numpy() > 0, d["final_scores"] > 0)   # satisfaction mask: exact
+    assert abs(float(out["final_acc"]) - float(d["final_acc"])) == 0.0
+    assert abs(float(out["final_scene_acc"]) - float(d["final_scene_acc"])) == 0.0
+
+
+@pytest.mark.parametrize("name", STL_CASES)
+def test_stl_scores_and_gradients_match_reference(name):
+    d = load_golden(name)
+    bs, S, K, seed = [int(v) for v in d["meta"]]
+    hp = default_hparams()
+    rows = orc.Rows(scene_from_golden(d), S, hp)
+    np.testing.assert_array_equal(rows.stlp.numpy(), d["in_stlp_dense"][:, 0])
+    np.testing.assert_array_equal(rows.hl.numpy(), d["in_highlevel_dense"])
+    np.testing.assert_array_equal(rows.valid.numpy(), d["in_valids_dense"].reshape(-1))
+    u = torch.from_numpy(d["controls"]).requires_grad_()
+    s3, score, sig = rows.score(u)
+    np.testing.assert_allclose(orc.unicycle_rollout(rows.s0, u, hp["dt"]).detach().numpy(), d["trajs"], rtol=0, atol=1e-5)
+    names = {"d_curr": "x2curr_d", "th_curr": "x2curr_th", "d_left": "x2left_d", "th_left": "x2left_th",
+             "d_right": "x2right_d", "th_right": "x2right_th", "nei": "min_nei_d"}
+    for mine, ref in names.items():
+        np.testing.assert_allclose(sig[mine].detach().numpy(), d["sig_" + ref], rtol=1e-5, atol=2e-5, err_msg=mine)
+    np.testing.assert_allclose(s3.detach().numpy(), d["scores3"], rtol=1e-5, atol=5e-5)
+    np.testing.assert_allclose(score.detach().numpy(), d["scores"], rtol=1e-5, atol=5e-5)
+    np.testing.assert_array_equal(score.detach().numpy() > 0, d["scores"] > 0)
+    acc, scene_acc = orc.stl_metrics(score.detach(), rows.valid, S)
+    assert float(acc) == float(d["acc"]) and float(scene_acc) == float(d["scene_acc"])
+    loss = orc.mask_mean(torch.relu(hp["stl_nn_thres"] - score), rows.valid)
+    g_loss, = torch.autograd.grad(loss, u, retain_graph=True)
+    g_sum, = torch.autograd.grad(score.sum(), u)
+    for mine, ref in [(g_loss, d["grad_loss"]), (g_sum, d["grad_sum"])]:
+        scale = np.abs(ref).max() + 1e-30
+        np.testing.assert_allclose(mine.numpy() / scale, ref / scale, rtol=1e-3, atol=1e-5)
