@@ -1,0 +1,180 @@
+/* pstl_hip.h -- C ABI of libpstl_hip.so: the MI355X (gfx950) implementation of the DDPM sampling +
+ * STL-guidance hot path of mengyuest/pSTL-diffusion-policy.
+ *
+ * The reference has no FFI/plugin layer: its boundary for this path is the Python surface
+ * (nusc_train.py: diffusion_rollout :557, compute_stl_dense :318, generate_trajs :39, get_diffusion_coeffs :528;
+ * nusc_model.py: Net.encode_feat :55, Net.forward :97, Net.rect_forward :182).  A maintainer binds the entry
+ * points below with ctypes; each one names the reference lines it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to float32 unless stated otherwise; tensors are dense, row-major;
+ *  - every function enqueues work on `stream` (a hipStream_t passed as void*) and returns immediately;
+ *    return value: 0 = ok, negative = error (pstl_error_string);  nothing throws, nothing allocates;
+ *  - rows: N = bs * rows_per_scene, row r belongs to scene r / rows_per_scene.  The reference's row order is
+ *    r = (b*S + s)*3 + mode (nusc_train.py:20,724-754) => rows_per_scene = 3*S.  Passing rows_per_scene = 1 and
+ *    bs = N gives the reference's "dense" (row-replicated) layout for the scene tensors.
+ *  - thread-safe for distinct streams; no global mutable state.
+ */
+#ifndef PSTL_HIP_H
+#define PSTL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSTL_ABI_VERSION 1
+
+/* compile-time shape of the path (reference defaults: nt=20, n_segs=15, hiddens=[256,256], feat 7*32) */
+#define PSTL_T 20
+#define PSTL_NSEG 15
+#define PSTL_CTRL 40     /* nt*2 */
+#define PSTL_HID 256
+#define PSTL_FEAT 224
+#define PSTL_NEI_PREP 12 /* floats per (scene, neighbour, t) in the prepared neighbour table */
+
+enum {
+  PSTL_OK = 0,
+  PSTL_ERR_ARG = -1,        /* null pointer / bad size */
+  PSTL_ERR_SHAPE = -2,      /* cfg asks for a shape this build is not specialised for */
+  PSTL_ERR_LAUNCH = -3      /* hipGetLastError() after a launch */
+};
+
+enum {
+  PSTL_FLAG_CLIP = 1,       /* clip normalised controls to +-max  (--diffusion_clip, nusc_train.py:651-653) */
+  PSTL_FLAG_MAXIMIZE = 2,   /* guidance loss relu(100 - score)     (nusc_train.py:616-617)                 */
+  PSTL_FLAG_CLIP_RECT = 4,  /* --clip_rect (nusc_model.py:230-233)                                         */
+  PSTL_FLAG_NO_MERGE = 8    /* rect_forward without merge_net pooling (not diverse_loss / --no_arch)       */
+};
+
+typedef struct pstl_cfg {
+  int32_t bs;              /* scenes in this shard                                        */
+  int32_t rows_per_scene;  /* 3*S (scene-indexed) or 1 (dense)                            */
+  int32_t S;               /* samples per (scene, mode): n_randoms == sampling_size       */
+  int32_t K;               /* neighbours                                                  */
+  int32_t steps;           /* --diffusion_steps                                           */
+  int32_t n_shards;        /* --n_shards (merge_net max-pool groups)                      */
+  int32_t flags;           /* PSTL_FLAG_*                                                 */
+  int32_t chain_waves;     /* MLP-chain kernel variant: 0 = default (8 waves), 4 or 8        */
+  float tau;               /* --smoothing_factor                                          */
+  float thres;             /* --stl_nn_thres                                              */
+  float w_max, a_max;      /* --mul_w_max, --mul_a_max                                    */
+  float dt;                /* --dt                                                        */
+  float ego_L, ego_W;      /* --ego_L, --ego_W                                            */
+  float reserved_f;
+} pstl_cfg;
+
+/* state_dict blobs of the reference Net (nusc_model.py:20-46; keys "<net>.{0,2,4}.{weight,bias}").
+ * weight = (out,in) row-major exactly as nn.Linear stores it.  merge/rect may be null (no --rect_head). */
+typedef struct pstl_mlp3 {
+  const float *w0, *b0, *w1, *b1, *w2, *b2;
+} pstl_mlp3;
+
+typedef struct pstl_weight_ptrs {
+  pstl_mlp3 ego_encoder;       /* 6   -> 256 -> 256 -> 32  */
+  pstl_mlp3 neighbor_encoder;  /* 7   -> 256 -> 256 -> 32  */
+  pstl_mlp3 lane_encoder;      /* 45  -> 256 -> 256 -> 32  */
+  pstl_mlp3 policy_net;        /* 303 -> 256 -> 256 -> 40  */
+  pstl_mlp3 merge_net;         /* 40  -> 32  -> 32  -> 40  */
+  pstl_mlp3 rect_net;          /* 271 -> 256 -> 256 -> 40  */
+} pstl_weight_ptrs;
+
+int pstl_version(void);
+const char* pstl_error_string(int code);
+
+/* ---- weights ----------------------------------------------------------------------------------------------- */
+/* Number of floats of the packed (kernel-layout) weight buffer. */
+size_t pstl_packed_weight_floats(void);
+/* Re-lays the state_dict out for the kernels (MFMA operand order, transposed encoder matrices).
+ * Replaces: Net.load_state_dict + the implicit layout of nn.Linear (nusc_train.py:1213-1215). */
+int pstl_pack_weights(const pstl_weight_ptrs* w, float* packed, void* stream);
+/* tbias[t][h] = sum_k W1[h][264+k] * pe(t)[k] for t in [0,steps): the timestep embedding folded into a layer-1
+ * bias.  Replaces Net.pos_encoding (nusc_model.py:48-53) + its 32 columns of policy_net layer 1. */
+int pstl_time_bias(const float* packed, int steps, float* tbias /* (steps,256) */, void* stream);
+
+/* ---- per-batch scene preparation ---------------------------------------------------------------------------- */
+/* neighbors_traj (bs,K,T,7) = valid,x,y,th,v,L,W ; lanes (bs,15,3) x,y,th.
+ * nei_prep (bs,K,T,12): valid, r, cx[4], cy[4], 0, 0  (circle row of each neighbour, utils.py:465-497);
+ * lane_prep (bs,3,15,4): x,y,th,0 for curr,left,right. */
+int pstl_prepare_scene(const pstl_cfg* cfg, const float* neighbors_traj, const float* currlane, const float* leftlane,
+                       const float* rightlane, float* nei_prep, float* lane_prep, void* stream);
+
+/* Scene encoder.  Replaces Net.encode_feat (nusc_model.py:55-95) and the scene-constant 224 columns of layer 1 of
+ * policy_net / rect_net: base_x[b][h] = bias1[h] + sum_k W1[h][k] * feature[b][k].
+ * ego0 (bs,6) = ego_traj[:,0]; neighbors (bs,K,7); lanes (bs,15,3); ids (bs,) each. base_rect may be null. */
+int pstl_encode_scene(const pstl_cfg* cfg, const float* packed, const float* ego0, const float* neighbors,
+                      const float* currlane, const float* leftlane, const float* rightlane, const float* curr_id,
+                      const float* left_id, const float* right_id, float* feature /* (bs,224) */,
+                      float* base_policy /* (bs,256) */, float* base_rect /* (bs,256) or null */, void* stream);
+
+/* ---- reverse diffusion --------------------------------------------------------------------------------------- */
+/* Runs reverse steps i = step_hi ... step_lo (step_hi >= step_lo >= 1) of diffusion_rollout (nusc_train.py:568-630)
+ * for all N rows in ONE launch:  eps = policy_net(...) + x ; mu = (x - (1-a_i)/sqrt(1-ah_i) eps)/sqrt(a_i) ;
+ * x <- mu + sqrt(b_i) z.   noise (steps-1, N, 40): noise[k] is used at step i = steps-1-k and ignored at i == 1
+ * (the reference draws zeros there).  If mu_only != 0 (requires step_hi == step_lo) x_inout receives mu and no
+ * noise is added (the guidance kernel finishes the step).
+ * emit: for every step with i <= n_emit the new state, normalised (x * (w_max,a_max), clipped iff PSTL_FLAG_CLIP), is
+ * written to emit_out[n_emit - i] (N,40) -- i.e. the last n_emit entries of the reference's diff_full list
+ * (nusc_train.py:633-634); n_emit may be 0. */
+int pstl_rollout(const pstl_cfg* cfg, const float* packed, const float* base_policy, const float* tbias,
+                 const float* stlp /* (N,6) */, const float* hl /* (N,) */, const float* beta, const float* alpha,
+                 const float* alpha_hat, const float* noise, int step_hi, int step_lo, int mu_only,
+                 float* x_inout /* (N,40) */, float* emit_out, int n_emit, void* stream);
+
+/* ---- dynamics + STL robustness ------------------------------------------------------------------------------- */
+/* generate_trajs (nusc_train.py:29-49): trajs (N,21,4) from s0 (bs,4) and controls (N,40) in physical units. */
+int pstl_generate_trajs(const pstl_cfg* cfg, const float* s0, const float* controls, float* trajs, void* stream);
+
+/* For rep in [0,reps), row r: traj = unicycle(s0[scene], controls[rep][r]) (generate_trajs, nusc_train.py:29-49),
+ * score = compute_stl_dense(...) (nusc_train.py:318-345; formulas :95-140; stl_d_lib.py).  controls (reps,N,40) are
+ * in physical units (already normalised).  If states != null ((reps,N,20,4), what compute_stl_dense receives as
+ * "ego_traj") they are scored as given and s0/controls may be null.
+ * scores (reps,N); scores3 (3,reps,N) or null (the three formulas before mode select).
+ * If sel_controls != null the best rep per row (max score, lowest rep on ties; nusc_train.py:1006-1007) is written to
+ * sel_controls (N,40), sel_scores (N,), sel_idx (N,) int32. */
+int pstl_stl_forward(const pstl_cfg* cfg, const float* s0 /* (bs,4) */, const float* controls, const float* states,
+                     int reps, const float* nei_prep, const float* lane_prep, const float* stlp, const float* hl,
+                     float* scores, float* scores3, float* sel_controls, float* sel_scores, int32_t* sel_idx,
+                     void* stream);
+
+/* dcontrols[r] = dscore[r] * d score[r] / d controls[r]   (what autograd gives through compute_stl_dense +
+ * generate_trajs).  dscore null = all ones. */
+int pstl_stl_backward(const pstl_cfg* cfg, const float* s0, const float* controls, const float* nei_prep,
+                      const float* lane_prep, const float* stlp, const float* hl, const float* dscore,
+                      float* dcontrols /* (N,40) */, float* scores /* (N,) or null */, void* stream);
+
+/* Guidance block of one reverse step (nusc_train.py:599-628): niters Adam iterations on mu (un-normalised, (N,40))
+ * of loss = mask_mean(relu(thres - score), valid), then x = mu + sqrt(beta_i) z.  Observable reference behaviour
+ * (see oracle/pstl_oracle.py:guidance_update): iteration 0 is a plain Adam step; later iterations are
+ * anchor + clip(|mu - anchor|, -beta_i, beta_i).  valid (N,) 0/1; grad_scale = (1/clip(mean(valid),1e-2))/N_global.
+ * adam_neg_step / adam_bc2_sqrt: host arrays [niters] = float(-lr/(1-0.9^j)), float(sqrt(1-0.999^j)), j=1..niters.
+ * work (3,N,40) scratch (m, v, anchor), only touched when niters > 1.  z (N,40) or null (= zeros, the i == 1 step).
+ * emit_out (N,40) or null: normalised new state, as in pstl_rollout. */
+int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const float* nei_prep, const float* lane_prep,
+                       const float* stlp, const float* hl, const float* valid, float grad_scale, int niters,
+                       const float* adam_neg_step, const float* adam_bc2_sqrt, float beta_i, const float* z,
+                       float* mu_x_inout /* (N,40): mu in, x out */, float* work, float* emit_out, void* stream);
+
+/* ---- RefineNet ------------------------------------------------------------------------------------------------ */
+/* Net.rect_forward (nusc_model.py:182-235) with --interval, diverse_fuse_type "add":
+ * pooled = max over each shard of S/n_shards samples of merge_net(init) per (scene, mode); fused = init + pooled;
+ * raw = tanh(rect_net([feature|hl|stlp|fused])); out = init + interval(raw, init) * [score < 0].
+ * pooled_work (bs,3,n_shards,40) scratch.  Requires rows_per_scene == 3*S. */
+int pstl_refine(const pstl_cfg* cfg, const float* packed, const float* base_rect, const float* stlp, const float* hl,
+                const float* init_controls /* (N,40) */, const float* scores /* (N,) */, float* pooled_work,
+                float* out_controls /* (N,40) */, void* stream);
+
+/* ---- metrics --------------------------------------------------------------------------------------------------- */
+/* counts[0] = #rows with score>0 and valid, counts[1] = #valid rows, counts[2] = #rows,
+ * counts[3] = #(scene,mode) with any sample score>0 and valid, counts[4] = #valid (scene,mode), counts[5] = 3*bs.
+ * (acc / scene_acc numerators and denominators, nusc_train.py:332,339-343.)  counts: 8 x uint64, zeroed by the call.
+ * sat_mask (N,) uint8 or null. */
+int pstl_reduce_metrics(const pstl_cfg* cfg, const float* scores, const float* valid /* (N,) */, uint64_t* counts,
+                        uint8_t* sat_mask, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSTL_HIP_H */

@@ -1,0 +1,800 @@
+// mlp_kernels.hip -- the denoiser / RefineNet MLP chain on gfx950 fp32 MFMA, the scene encoder and weight packing.
+//
+// Design:
+//  * Both 3-layer MLPs of the hot path (policy_net 303->256->256->40, rect_net 271->256->256->40) see only 47
+//    per-row input columns that change (x/fused 40 + highlevel 1 + stlp 6); the other 224 (+32 timestep) columns are
+//    constant per scene (per step) and enter as the INITIAL VALUE of the layer-1 accumulator (base[scene] + tbias[t]).
+//  * Weight-stationary: the 344 KB of per-step weights live in the REGISTER FILE of one workgroup (8 waves x 176
+//    VGPRs, or 4 x 352) as MFMA A-operands for the whole launch.  Activations are the B operand
+//    (v_mfma_f32_16x16x4_f32: D[f][row] += W[f][k] * X[k][row]), 16 rows per tile.
+//  * The accumulator layout of one layer IS the B-operand layout of the next one if the k index is permuted
+//    (lane group g, register r  <->  k = 16q + 4g + r), and the permutation is baked into the packed weights.  So layer
+//    2's output feeds layer 3 straight from registers, and layer 1 -> 2 crosses waves through LDS as plain
+//    lane-linear 16-byte reads/writes (conflict-free).
+//  * A workgroup owns G tiles (192 rows = one scene at S = 64) for ALL reverse steps of a launch: x never leaves
+//    LDS between steps; HBM traffic is the noise read (parity mode) and the emitted candidates.
+//  * f32 MFMA is bit-for-bit a k-ordered fmaf chain, so results match an fp32 torch path to rounding (1e-4 gate).
+#include "pstl_common.hpp"
+
+namespace pstl {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHid = PSTL_HID;     // 256
+constexpr int kFeat = PSTL_FEAT;   // 224
+constexpr int kCtrl = PSTL_CTRL;   // 40
+constexpr int kKx = 48;            // per-row input columns of layer 1 (40 + 1 + 6, padded to 48)
+constexpr int kTileRows = 16;
+constexpr int kG = 12;             // tiles per workgroup
+
+// ---- packed weight buffer (float offsets) -----------------------------------------------------------------------
+struct EncOff {
+  long w0t, b0, w1t, b1, w2t, b2;
+};
+struct ChainOff {       // one of policy_net / rect_net
+  long w1f;             // [224][256]  scene columns, transposed
+  long b1;              // [256]
+  long w1t;             // [32][256]   timestep columns, transposed (policy only)
+  long w1x;             // A-operand layout [16 T][3 q][4 r][64 lanes]
+  long w2;              // A-operand layout [16 T][16 q][4 r][64]
+  long b2;              // [256]
+  long w3;              // A-operand layout [3 j][16 T][4 r][64]
+  long b3;              // [48]
+};
+struct MergeOff {
+  long w0t, b0, w1t, b1, w2t, b2;  // [40][32],[32],[32][32],[32],[32][40],[40]
+};
+struct PackLayout {
+  EncOff enc[3];
+  ChainOff pol, rect;
+  MergeOff mrg;
+  long total;
+};
+
+__host__ __device__ constexpr int enc_in(int e) { return e == 0 ? 6 : e == 1 ? 7 : 45; }
+
+__host__ __device__ inline PackLayout make_layout() {
+  PackLayout L;
+  long o = 0;
+  for (int e = 0; e < 3; ++e) {
+    L.enc[e].w0t = o; o += (long)enc_in(e) * kHid;
+    L.enc[e].b0 = o;  o += kHid;
+    L.enc[e].w1t = o; o += (long)kHid * kHid;
+    L.enc[e].b1 = o;  o += kHid;
+    L.enc[e].w2t = o; o += (long)kHid * 32;
+    L.enc[e].b2 = o;  o += 32;
+  }
+  ChainOff* cs[2] = {&L.pol, &L.rect};
+  for (int c = 0; c < 2; ++c) {
+    cs[c]->w1f = o; o += (long)kFeat * kHid;
+    cs[c]->b1 = o;  o += kHid;
+    cs[c]->w1t = o; o += 32L * kHid;
+    cs[c]->w1x = o; o += 16L * 3 * 4 * 64;
+    cs[c]->w2 = o;  o += 16L * 16 * 4 * 64;
+    cs[c]->b2 = o;  o += kHid;
+    cs[c]->w3 = o;  o += 3L * 16 * 4 * 64;
+    cs[c]->b3 = o;  o += 48;
+  }
+  L.mrg.w0t = o; o += 40 * 32;
+  L.mrg.b0 = o;  o += 32;
+  L.mrg.w1t = o; o += 32 * 32;
+  L.mrg.b1 = o;  o += 32;
+  L.mrg.w2t = o; o += 32 * 40;
+  L.mrg.b2 = o;  o += 40;
+  L.total = (o + 63) / 64 * 64;
+  return L;
+}
+
+// ---- packing ----------------------------------------------------------------------------------------------------
+// dst[k][o] = W[o][k]
+__global__ void k_transpose(const float* W, int out, int in, int col0, int ncol, float* dst) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)ncol * out) return;
+  const int k = (int)(i / out), o = (int)(i % out);
+  dst[i] = W[(long)o * in + col0 + k];
+}
+
+__global__ void k_copy(const float* src, int n, int npad, float* dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npad) dst[i] = i < n ? src[i] : 0.0f;
+}
+
+// A-operand layout: dst[((Tt*nq + q)*4 + r)*64 + lane] = W[16*Tt + (lane&15)][colmap(16q + 4(lane>>4) + r)]
+// mode 0: identity columns; mode 1: policy K-ext (x 224.., hl 296, stlp 297..302); mode 2: rect K-ext
+// (fused 231.., hl 224, stlp 225..230)
+__global__ void k_pack_a(const float* W, int ld, int rows_valid, int n_tiles, int nq, int mode, float* dst) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n_tiles * nq * 256) return;
+  const int lane = (int)(i & 63), r = (int)((i >> 6) & 3);
+  const long tq = i >> 8;
+  const int q = (int)(tq % nq), Tt = (int)(tq / nq);
+  const int row = 16 * Tt + (lane & 15);
+  const int k = 16 * q + 4 * (lane >> 4) + r;
+  int col = k;
+  if (mode == 1) col = k < 40 ? 224 + k : k == 40 ? 296 : k < 47 ? 297 + (k - 41) : -1;
+  if (mode == 2) col = k < 40 ? 231 + k : k == 40 ? 224 : k < 47 ? 225 + (k - 41) : -1;
+  dst[i] = (row < rows_valid && col >= 0) ? W[(long)row * ld + col] : 0.0f;
+}
+
+// ---- timestep bias ----------------------------------------------------------------------------------------------
+// tbias[t][h] = sum_k W1[h][264+k] * pe(t)[k], pe(t) = [sin(t f_j) | cos(t f_j)], f_j = 1/10000^(2j/32)
+__global__ void k_time_bias(const float* w1t /* [32][256] */, int steps, float* tbias) {
+  const int t = blockIdx.x, h = threadIdx.x;
+  __shared__ float pe[32];
+  if (h < 16) {
+    const float inv = 1.0f / powf(10000.0f, (float)(2 * h) / 32.0f);
+    const float arg = (float)t * inv;
+    pe[h] = sinf(arg);
+    pe[16 + h] = cosf(arg);
+  }
+  __syncthreads();
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) acc += w1t[k * kHid + h] * pe[k];
+  tbias[(long)t * kHid + h] = acc;
+}
+
+// ---- scene encoder (A1) -----------------------------------------------------------------------------------------
+struct EncArgs {
+  int bs, K;
+  PackLayout L;
+  const float* packed;
+  const float* ego0;       // (bs,6)
+  const float* neighbors;  // (bs,K,7)
+  const float* lanes[3];   // (bs,15,3)
+  const float* ids[3];     // (bs,)
+  float* feature;          // (bs,224)
+  float* base_policy;      // (bs,256)
+  float* base_rect;        // (bs,256) or null
+};
+
+constexpr int kMaxTok = 20;  // 1 ego + K neighbours + 3 lanes, K <= 16
+
+__global__ __launch_bounds__(256) void k_encode(EncArgs a) {
+  __shared__ float in_s[kMaxTok][48];
+  __shared__ float h_a[kMaxTok][kHid];
+  __shared__ float h_b[kMaxTok][kHid];
+  __shared__ float out_s[kMaxTok][32];
+  __shared__ float feat_s[kFeat];
+  const int b = blockIdx.x, tid = threadIdx.x, K = a.K;
+  const int ntok = 1 + K + 3;
+  const float* ego = a.ego0 + (long)b * 6;
+  const float bx = ego[0], by = ego[1], bth = ego[2];
+  const float cb = cosf(bth), sb = sinf(bth);
+  // token inputs (normalize_xyth, nusc_model.py:238-263): token 0 ego, 1..K neighbours, K+1..K+3 lanes
+  if (tid < 6) in_s[0][tid] = tid < 3 ? 0.0f : ego[tid];
+  for (int i = tid; i < K; i += 256) {
+    const float* n = a.neighbors + ((long)b * K + i) * 7;
+    const float v = n[0];
+    const float xt = n[1] - bx * v, yt = n[2] - by * v;
+    float* o = in_s[1 + i];
+    o[0] = v;
+    o[1] = xt * cb + yt * sb;
+    o[2] = -xt * sb + yt * cb;
+    o[3] = n[3] - bth * v;
+    o[4] = n[4];
+    o[5] = n[5];
+    o[6] = n[6];
+  }
+  __shared__ float lane_n[3][15][3];
+  if (tid < 45) {
+    const int m = tid / 15, j = tid % 15;
+    const float* p = a.lanes[m] + ((long)b * 15 + j) * 3;
+    const float v = a.ids[m][b];
+    const float xt = p[0] - bx * v, yt = p[1] - by * v;
+    lane_n[m][j][0] = xt * cb + yt * sb;
+    lane_n[m][j][1] = -xt * sb + yt * cb;
+    lane_n[m][j][2] = p[2] - bth * v;
+  }
+  __syncthreads();
+  if (tid < 135) {  // difference encoding: first waypoint, then successive differences (nusc_model.py:73-76)
+    const int m = tid / 45, e = tid % 45, j = e / 3, c = e % 3;
+    in_s[1 + K + m][e] = j == 0 ? lane_n[m][0][c] : lane_n[m][j][c] - lane_n[m][j - 1][c];
+  }
+  __syncthreads();
+  // encoder e: tokens [t0, t1)
+  for (int e = 0; e < 3; ++e) {
+    const int t0 = e == 0 ? 0 : e == 1 ? 1 : 1 + K;
+    const int t1 = e == 0 ? 1 : e == 1 ? 1 + K : ntok;
+    const int nin = enc_in(e);
+    const float* w0t = a.packed + a.L.enc[e].w0t;
+    const float* w1t = a.packed + a.L.enc[e].w1t;
+    const float b0 = a.packed[a.L.enc[e].b0 + tid];
+    const float b1 = a.packed[a.L.enc[e].b1 + tid];
+    for (int tk = t0; tk < t1; ++tk) {
+      float acc = b0;
+      for (int k = 0; k < nin; ++k) acc += w0t[k * kHid + tid] * in_s[tk][k];
+      h_a[tk][tid] = fmaxf(acc, 0.0f);
+    }
+    __syncthreads();
+    for (int tk0 = t0; tk0 < t1; tk0 += 8) {  // 8 tokens share each weight load
+      float acc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] = b1;
+      for (int k = 0; k < kHid; ++k) {
+        const float w = w1t[k * kHid + tid];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (tk0 + u < t1) acc[u] += w * h_a[tk0 + u][k];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (tk0 + u < t1) h_b[tk0 + u][tid] = fmaxf(acc[u], 0.0f);
+    }
+    __syncthreads();
+    const float* w2t = a.packed + a.L.enc[e].w2t;
+    const int o = tid & 31;
+    for (int tk = t0 + (tid >> 5); tk < t1; tk += 8) {
+      float acc = a.packed[a.L.enc[e].b2 + o];
+      for (int k = 0; k < kHid; ++k) acc += w2t[k * 32 + o] * h_b[tk][k];
+      out_s[tk][o] = acc;
+    }
+    __syncthreads();
+  }
+  // feature = [ego 32 | nei min 32 | nei mean 32 | nei max 32 | lanes 3x32]  (nusc_model.py:82-93)
+  if (tid < 32) {
+    feat_s[tid] = out_s[0][tid];
+    float mn = INFINITY, mx = -INFINITY, sm = 0.0f;
+    for (int i = 0; i < K; ++i) {
+      const float v = out_s[1 + i][tid];
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+      sm += v;
+    }
+    feat_s[32 + tid] = mn;
+    feat_s[64 + tid] = sm / (float)K;
+    feat_s[96 + tid] = mx;
+    for (int m = 0; m < 3; ++m) feat_s[128 + 32 * m + tid] = out_s[1 + K + m][tid];
+  }
+  __syncthreads();
+  if (tid < kFeat) a.feature[(long)b * kFeat + tid] = feat_s[tid];
+  {
+    float acc = a.packed[a.L.pol.b1 + tid];
+    const float* w = a.packed + a.L.pol.w1f;
+    for (int k = 0; k < kFeat; ++k) acc += w[k * kHid + tid] * feat_s[k];
+    a.base_policy[(long)b * kHid + tid] = acc;
+  }
+  if (a.base_rect) {
+    float acc = a.packed[a.L.rect.b1 + tid];
+    const float* w = a.packed + a.L.rect.w1f;
+    for (int k = 0; k < kFeat; ++k) acc += w[k * kHid + tid] * feat_s[k];
+    a.base_rect[(long)b * kHid + tid] = acc;
+  }
+}
+
+// ---- the MLP chain kernel ---------------------------------------------------------------------------------------
+struct ChainArgs {
+  long N;
+  int rows_per_scene;
+  int steps;
+  int step_hi, step_lo;
+  int mu_only;
+  int n_emit;
+  int clip;
+  float w_max, a_max;
+  ChainOff off;
+  const float* packed;
+  const float* base;     // (bs,256)
+  const float* tbias;    // (steps,256) or null (refine)
+  const float* stlp;     // (N,6)
+  const float* hl;       // (N,)
+  const float* beta;
+  const float* alpha;
+  const float* alpha_hat;
+  const float* noise;    // (steps-1,N,40) or null
+  float* x_inout;        // (N,40)
+  float* emit_out;       // (n_emit,N,40)
+  // refine
+  const float* init;     // (N,40)
+  const float* pooled;   // (bs,3,n_shards,40) or null
+  const float* scores;   // (N,)
+  float* out;            // (N,40)
+  int S, n_shards;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  f32x4 r;
+  r.x = fmaxf(v.x, 0.0f);
+  r.y = fmaxf(v.y, 0.0f);
+  r.z = fmaxf(v.z, 0.0f);
+  r.w = fmaxf(v.w, 0.0f);
+  return r;
+}
+
+// LDS address (in floats) of activation element k (0..47) of tile column c in the B-operand image [q][lane][r]
+__device__ __forceinline__ int xs_addr(int k, int c) { return (((k >> 4) * 64) + (((k >> 2) & 3) * 16 + c)) * 4 + (k & 3); }
+
+template <int NW, bool REFINE>
+__global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
+  constexpr int OT = 16 / NW;       // 16-feature output tiles per wave
+  constexpr int NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;                          // [kG][3][64][4]
+  float* h1 = xs + kG * 768;                // [16][64][4]
+  float* part = h1 + 16 * 256;              // [NW][3][64][4]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const long tile0 = (long)blockIdx.x * kG;
+  const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
+  const int G = (int)((n_tiles - tile0) < kG ? (n_tiles - tile0) : kG);
+
+  // ---- weights -> registers (A operands), once per launch ----
+  float w1x[OT][12], w2[OT][64], w3[3][OT][4];
+  f32x4 b2v[OT];
+  {
+    const float* p1 = a.packed + a.off.w1x;
+    const float* p2 = a.packed + a.off.w2;
+    const float* p3 = a.packed + a.off.w3;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      const int T = w * OT + ot;
+#pragma unroll
+      for (int m = 0; m < 12; ++m) w1x[ot][m] = p1[((long)T * 12 + m) * 64 + lane];
+#pragma unroll
+      for (int m = 0; m < 64; ++m) w2[ot][m] = p2[((long)T * 64 + m) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w3[j][ot][r] = p3[(((long)j * 16 + T) * 4 + r) * 64 + lane];
+      b2v[ot] = *reinterpret_cast<const f32x4*>(a.packed + a.off.b2 + 16 * T + 4 * g);
+    }
+  }
+
+  // ---- per-row constants and the initial state into the B-operand image ----
+  for (int e = tid; e < G * kTileRows * kKx; e += NT) {
+    const int tl = e / (kTileRows * kKx), rem = e % (kTileRows * kKx);
+    const int c = rem / kKx, k = rem % kKx;
+    long row = (tile0 + tl) * kTileRows + c;
+    if (row >= a.N) row = a.N - 1;
+    float v;
+    if (k < kCtrl) {
+      if (REFINE) {
+        v = a.init[row * kCtrl + k];
+        if (a.pooled) {  // fused = init + pooled[scene][mode][shard]   (nusc_model.py:186-200)
+          const long b = row / a.rows_per_scene;
+          const int rr = (int)(row % a.rows_per_scene), s = rr / 3, m = rr % 3;
+          const int sh = s / (a.S / a.n_shards);
+          v += a.pooled[((b * 3 + m) * a.n_shards + sh) * kCtrl + k];
+        }
+      } else {
+        v = a.x_inout[row * kCtrl + k];
+      }
+    } else if (k == 40) {
+      v = a.hl[row];
+    } else if (k < 47) {
+      v = a.stlp[row * 6 + (k - 41)];
+    } else {
+      v = 0.0f;
+    }
+    xs[tl * 768 + xs_addr(k, c)] = v;
+  }
+  if (!REFINE && a.n_emit >= a.steps && a.step_hi == a.steps - 1) {  // x_T itself is entry 0 of the full list
+    for (int e = tid; e < G * kTileRows * kCtrl; e += NT) {
+      const long row = tile0 * kTileRows + e / kCtrl;
+      const int f = e % kCtrl;
+      if (row < a.N) {
+        const float sc = (f & 1) ? a.a_max : a.w_max;
+        float v = a.x_inout[row * kCtrl + f] * sc;
+        if (a.clip) v = fminf(fmaxf(v, -sc), sc);
+        a.emit_out[((long)(a.n_emit - a.steps) * a.N + row) * kCtrl + f] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int s_hi = REFINE ? 1 : a.step_hi, s_lo = REFINE ? 1 : a.step_lo;
+  for (int i = s_hi; i >= s_lo; --i) {
+    float c1 = 0.0f, inv_sa = 0.0f, sbeta = 0.0f;
+    const float* tb = nullptr;
+    const float* zsrc = nullptr;
+    if (!REFINE) {
+      const float al = a.alpha[i], ah = a.alpha_hat[i], be = a.beta[i];
+      c1 = (1.0f - al) / sqrtf(1.0f - ah);
+      inv_sa = 1.0f / sqrtf(al);
+      sbeta = sqrtf(be);
+      tb = a.tbias + (long)i * kHid;
+      if (a.noise && i > 1 && !a.mu_only) zsrc = a.noise + (long)(a.steps - 1 - i) * a.N * kCtrl;
+    }
+    for (int tl = 0; tl < G; ++tl) {
+      const long row0 = (tile0 + tl) * kTileRows;
+      // ---------------- layer 1: 48 -> 256, accumulator starts at base[scene] + tbias[t] ----------------
+      {
+        long rowc = row0 + col;
+        if (rowc >= a.N) rowc = a.N - 1;
+        const float* bp = a.base + (rowc / a.rows_per_scene) * kHid;
+        f32x4 acc[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const int f0 = 16 * (w * OT + ot) + 4 * g;
+          acc[ot] = *reinterpret_cast<const f32x4*>(bp + f0);
+          if (!REFINE) acc[ot] += *reinterpret_cast<const f32x4*>(tb + f0);
+        }
+        const f32x4* xb = reinterpret_cast<const f32x4*>(xs + tl * 768) + lane;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const f32x4 bq = xb[q * 64];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma4(w1x[ot][q * 4 + r], bq[r], acc[ot]);
+        }
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+          reinterpret_cast<f32x4*>(h1)[(w * OT + ot) * 64 + lane] = relu4(acc[ot]);
+      }
+      __syncthreads();
+      // prefetch this tile's noise so that the HBM latency hides behind layer 2
+      float zreg[2] = {0.0f, 0.0f};
+      if (zsrc) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = tid + u * NT;
+          if (e < kTileRows * kCtrl) {
+            const long row = row0 + e / kCtrl;
+            if (row < a.N) zreg[u] = zsrc[row * kCtrl + e % kCtrl];
+          }
+        }
+      }
+      // ---------------- layer 2: 256 -> 256 (B from LDS), layer 3: this wave's 16*OT features -> 48 ------
+      {
+        f32x4 acc[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = b2v[ot];
+        const f32x4* hb = reinterpret_cast<const f32x4*>(h1) + lane;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const f32x4 bq = hb[q * 64];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma4(w2[ot][q * 4 + r], bq[r], acc[ot]);
+        }
+        f32x4 acc3[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc3[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const f32x4 h = relu4(acc[ot]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc3[j] = mfma4(w3[j][ot][r], h[r], acc3[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) reinterpret_cast<f32x4*>(part)[(w * 3 + j) * 64 + lane] = acc3[j];
+      }
+      __syncthreads();
+      // ---------------- epilogue: reduce the NW partial sums, then the DDPM update / the interval head -----
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + u * NT;
+        if (e < kTileRows * kCtrl) {
+          const int c = e / kCtrl, f = e % kCtrl;
+          const int j = f >> 4, li = ((f >> 2) & 3) * 16 + c, r = f & 3;
+          float o = a.packed[a.off.b3 + f];
+#pragma unroll
+          for (int ww = 0; ww < NW; ++ww) o += part[((ww * 3 + j) * 64 + li) * 4 + r];
+          const long row = row0 + c;
+          const float sc = (f & 1) ? a.a_max : a.w_max;
+          if (!REFINE) {
+            const int xa = tl * 768 + (j * 64 + li) * 4 + r;
+            const float x = xs[xa];
+            const float eps = o + x;
+            const float mu = inv_sa * (x - c1 * eps);
+            const float xn = a.mu_only ? mu : mu + sbeta * zreg[u];
+            xs[xa] = xn;
+            if (row < a.N) {
+              if (i == s_lo) a.x_inout[row * kCtrl + f] = xn;
+              if (i <= a.n_emit && !a.mu_only) {
+                float v = xn * sc;
+                if (a.clip) v = fminf(fmaxf(v, -sc), sc);
+                a.emit_out[((long)(a.n_emit - i) * a.N + row) * kCtrl + f] = v;
+              }
+            }
+          } else if (row < a.N) {
+            // interval head (nusc_model.py:212-229): tanh output scales into the remaining headroom of init
+            const float init = a.init[row * kCtrl + f];
+            const float raw = tanhf(o);
+            const float d = raw >= 0.0f ? raw * (sc - init) : raw * (init - (-sc));
+            const float viol = a.scores[row] < 0.0f ? 1.0f : 0.0f;
+            float v = init + d * viol;
+            if (a.clip) v = fminf(fmaxf(v, -sc), sc);
+            a.out[row * kCtrl + f] = v;
+          }
+        }
+      }
+      if (G == 1) __syncthreads();
+    }
+  }
+}
+
+// ---- merge_net + shard max-pool (nusc_model.py:186-196) -----------------------------------------------------------
+struct MergeArgs {
+  int bs, S, n_shards;
+  MergeOff off;
+  const float* packed;
+  const float* init;   // (N,40)
+  float* pooled;       // (bs,3,n_shards,40)
+};
+
+__global__ __launch_bounds__(64) void k_merge_pool(MergeArgs a) {
+  __shared__ float wt[40 * 32 + 32 + 32 * 32 + 32 + 32 * 40 + 40];
+  __shared__ float outs[64][41];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 40 * 32 + 32 + 32 * 32 + 32 + 32 * 40 + 40; i += 64) wt[i] = a.packed[a.off.w0t + i];
+  const float* w0t = wt;
+  const float* b0 = w0t + 40 * 32;
+  const float* w1t = b0 + 32;
+  const float* b1 = w1t + 32 * 32;
+  const float* w2t = b1 + 32;
+  const float* b2 = w2t + 32 * 40;
+  const long grp = blockIdx.x;  // (b*3 + m)*n_shards + sh
+  const int sh = (int)(grp % a.n_shards);
+  const long bm = grp / a.n_shards;
+  const int m = (int)(bm % 3);
+  const long b = bm / 3;
+  const int sps = a.S / a.n_shards;
+  float best = -INFINITY;
+  __syncthreads();
+  for (int s0 = 0; s0 < sps; s0 += 64) {
+    const int s = s0 + tid;
+    if (s < sps) {
+      const long row = (b * a.S + (long)sh * sps + s) * 3 + m;
+      const float* x = a.init + row * kCtrl;
+      float h0[32], h1v[32];
+#pragma unroll
+      for (int o = 0; o < 32; ++o) h0[o] = b0[o];
+      for (int k = 0; k < 40; ++k) {
+        const float xv = x[k];
+#pragma unroll
+        for (int o = 0; o < 32; ++o) h0[o] += w0t[k * 32 + o] * xv;
+      }
+#pragma unroll
+      for (int o = 0; o < 32; ++o) h1v[o] = b1[o];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const float hv = fmaxf(h0[k], 0.0f);
+#pragma unroll
+        for (int o = 0; o < 32; ++o) h1v[o] += w1t[k * 32 + o] * hv;
+      }
+      for (int o = 0; o < 40; ++o) {
+        float acc = b2[o];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc += w2t[k * 40 + o] * fmaxf(h1v[k], 0.0f);
+        outs[tid][o] = acc;
+      }
+    }
+    __syncthreads();
+    if (tid < 40) {
+      const int n = (sps - s0) < 64 ? (sps - s0) : 64;
+      for (int s2 = 0; s2 < n; ++s2) best = fmaxf(best, outs[s2][tid]);
+    }
+    __syncthreads();
+  }
+  if (tid < 40) a.pooled[grp * kCtrl + tid] = best;
+}
+
+template <int NW>
+size_t chain_lds_bytes() {
+  return (size_t)(kG * 768 + 16 * 256 + NW * 768) * sizeof(float);
+}
+
+template <int NW, bool REFINE>
+int launch_chain(const ChainArgs& a, hipStream_t st) {
+  const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
+  const dim3 grid((unsigned)((n_tiles + kG - 1) / kG));
+  const size_t lds = chain_lds_bytes<NW>();
+  auto fn = k_chain<NW, REFINE>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+      hipSuccess)
+    return PSTL_ERR_LAUNCH;
+  hipLaunchKernelGGL(fn, grid, dim3(NW * 64), lds, st, a);
+  return launch_status();
+}
+
+// cfg->chain_waves: 0/8 = eight waves x 32 output features (2 waves/SIMD, <=256 registers each),
+//                   4   = four waves x 64 output features (1 wave/SIMD, weights partly in AGPRs)
+template <bool REFINE>
+int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
+  if (chain_waves == 4) return launch_chain<4, REFINE>(a, st);
+  if (chain_waves == 0 || chain_waves == 8) return launch_chain<8, REFINE>(a, st);
+  return PSTL_ERR_SHAPE;
+}
+
+}  // namespace
+}  // namespace pstl
+
+using namespace pstl;
+
+extern "C" int pstl_version(void) { return PSTL_ABI_VERSION; }
+
+extern "C" const char* pstl_error_string(int code) {
+  switch (code) {
+    case PSTL_OK: return "ok";
+    case PSTL_ERR_ARG: return "bad argument (null pointer or size)";
+    case PSTL_ERR_SHAPE: return "shape not supported by this build";
+    case PSTL_ERR_LAUNCH: return "HIP launch failed";
+    default: return "unknown error";
+  }
+}
+
+extern "C" size_t pstl_packed_weight_floats(void) { return (size_t)make_layout().total; }
+
+static int pack_mlp_t(const pstl_mlp3& m, int in, int hid, int out, const long* off6, float* packed, hipStream_t st) {
+  // off6: w0t, b0, w1t, b1, w2t, b2
+  auto tr = [&](const float* W, int o, int i, long dst) {
+    const long n = (long)o * i;
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, o, i, 0, i, packed + dst);
+  };
+  auto cp = [&](const float* b, int n, long dst) {
+    hipLaunchKernelGGL(k_copy, dim3((n + 255) / 256), dim3(256), 0, st, b, n, n, packed + dst);
+  };
+  tr(m.w0, hid, in, off6[0]);
+  cp(m.b0, hid, off6[1]);
+  tr(m.w1, hid, hid, off6[2]);
+  cp(m.b1, hid, off6[3]);
+  tr(m.w2, out, hid, off6[4]);
+  cp(m.b2, out, off6[5]);
+  return launch_status();
+}
+
+static bool mlp_ok(const pstl_mlp3& m) { return m.w0 && m.b0 && m.w1 && m.b1 && m.w2 && m.b2; }
+
+static int pack_chain(const pstl_mlp3& m, int in, int kext_mode, bool with_time, const ChainOff& o, float* packed,
+                      hipStream_t st) {
+  long n = (long)kFeat * kHid;
+  hipLaunchKernelGGL(k_transpose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.w0, kHid, in, 0, kFeat,
+                     packed + o.w1f);
+  hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, st, m.b0, kHid, kHid, packed + o.b1);
+  if (with_time) {
+    n = 32L * kHid;
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.w0, kHid, in, 264, 32,
+                       packed + o.w1t);
+  }
+  hipLaunchKernelGGL(k_pack_a, dim3(16 * 3), dim3(256), 0, st, m.w0, in, kHid, 16, 3, kext_mode, packed + o.w1x);
+  hipLaunchKernelGGL(k_pack_a, dim3(16 * 16), dim3(256), 0, st, m.w1, kHid, kHid, 16, 16, 0, packed + o.w2);
+  hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, st, m.b1, kHid, kHid, packed + o.b2);
+  hipLaunchKernelGGL(k_pack_a, dim3(3 * 16), dim3(256), 0, st, m.w2, kHid, kCtrl, 3, 16, 0, packed + o.w3);
+  hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, st, m.b2, kCtrl, 48, packed + o.b3);
+  return launch_status();
+}
+
+extern "C" int pstl_pack_weights(const pstl_weight_ptrs* w, float* packed, void* stream) {
+  if (!w || !packed) return PSTL_ERR_ARG;
+  if (!mlp_ok(w->ego_encoder) || !mlp_ok(w->neighbor_encoder) || !mlp_ok(w->lane_encoder) || !mlp_ok(w->policy_net))
+    return PSTL_ERR_ARG;
+  hipStream_t st = as_stream(stream);
+  const PackLayout L = make_layout();
+  if (hipMemsetAsync(packed, 0, L.total * sizeof(float), st) != hipSuccess) return PSTL_ERR_LAUNCH;
+  const pstl_mlp3* encs[3] = {&w->ego_encoder, &w->neighbor_encoder, &w->lane_encoder};
+  for (int e = 0; e < 3; ++e) {
+    const long off6[6] = {L.enc[e].w0t, L.enc[e].b0, L.enc[e].w1t, L.enc[e].b1, L.enc[e].w2t, L.enc[e].b2};
+    if (int err = pack_mlp_t(*encs[e], enc_in(e), kHid, 32, off6, packed, st)) return err;
+  }
+  if (int err = pack_chain(w->policy_net, 303, 1, true, L.pol, packed, st)) return err;
+  if (mlp_ok(w->rect_net))
+    if (int err = pack_chain(w->rect_net, 271, 2, false, L.rect, packed, st)) return err;
+  if (mlp_ok(w->merge_net)) {
+    const long off6[6] = {L.mrg.w0t, L.mrg.b0, L.mrg.w1t, L.mrg.b1, L.mrg.w2t, L.mrg.b2};
+    if (int err = pack_mlp_t(w->merge_net, 40, 32, 40, off6, packed, st)) return err;
+  }
+  return PSTL_OK;
+}
+
+extern "C" int pstl_time_bias(const float* packed, int steps, float* tbias, void* stream) {
+  if (!packed || !tbias || steps < 1) return PSTL_ERR_ARG;
+  const PackLayout L = make_layout();
+  hipLaunchKernelGGL(k_time_bias, dim3(steps), dim3(kHid), 0, as_stream(stream), packed + L.pol.w1t, steps, tbias);
+  return launch_status();
+}
+
+extern "C" int pstl_encode_scene(const pstl_cfg* cfg, const float* packed, const float* ego0, const float* neighbors,
+                                 const float* currlane, const float* leftlane, const float* rightlane,
+                                 const float* curr_id, const float* left_id, const float* right_id, float* feature,
+                                 float* base_policy, float* base_rect, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!packed || !ego0 || !currlane || !leftlane || !rightlane || !curr_id || !left_id || !right_id || !feature ||
+      !base_policy)
+    return PSTL_ERR_ARG;
+  if (cfg->K < 1 || cfg->K > kMaxTok - 4) return PSTL_ERR_SHAPE;
+  if (!neighbors) return PSTL_ERR_ARG;
+  EncArgs a;
+  a.bs = cfg->bs;
+  a.K = cfg->K;
+  a.L = make_layout();
+  a.packed = packed;
+  a.ego0 = ego0;
+  a.neighbors = neighbors;
+  a.lanes[0] = currlane, a.lanes[1] = leftlane, a.lanes[2] = rightlane;
+  a.ids[0] = curr_id, a.ids[1] = left_id, a.ids[2] = right_id;
+  a.feature = feature;
+  a.base_policy = base_policy;
+  a.base_rect = base_rect;
+  hipLaunchKernelGGL(k_encode, dim3(cfg->bs), dim3(256), 0, as_stream(stream), a);
+  return launch_status();
+}
+
+extern "C" int pstl_rollout(const pstl_cfg* cfg, const float* packed, const float* base_policy, const float* tbias,
+                            const float* stlp, const float* hl, const float* beta, const float* alpha,
+                            const float* alpha_hat, const float* noise, int step_hi, int step_lo, int mu_only,
+                            float* x_inout, float* emit_out, int n_emit, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!packed || !base_policy || !tbias || !stlp || !hl || !beta || !alpha || !alpha_hat || !x_inout) return PSTL_ERR_ARG;
+  if (step_lo < 1 || step_hi < step_lo || step_hi > cfg->steps - 1) return PSTL_ERR_ARG;
+  if (mu_only && step_hi != step_lo) return PSTL_ERR_ARG;
+  if (n_emit < 0 || n_emit > cfg->steps || (n_emit > 0 && !emit_out)) return PSTL_ERR_ARG;
+  ChainArgs a = {};
+  a.N = n_rows(cfg);
+  a.rows_per_scene = cfg->rows_per_scene;
+  a.steps = cfg->steps;
+  a.step_hi = step_hi;
+  a.step_lo = step_lo;
+  a.mu_only = mu_only;
+  a.n_emit = n_emit;
+  a.clip = (cfg->flags & PSTL_FLAG_CLIP) ? 1 : 0;
+  a.w_max = cfg->w_max;
+  a.a_max = cfg->a_max;
+  a.off = make_layout().pol;
+  a.packed = packed;
+  a.base = base_policy;
+  a.tbias = tbias;
+  a.stlp = stlp;
+  a.hl = hl;
+  a.beta = beta;
+  a.alpha = alpha;
+  a.alpha_hat = alpha_hat;
+  a.noise = noise;
+  a.x_inout = x_inout;
+  a.emit_out = emit_out;
+  return launch_chain_nw<false>(cfg->chain_waves, a, as_stream(stream));
+}
+
+extern "C" int pstl_refine(const pstl_cfg* cfg, const float* packed, const float* base_rect, const float* stlp,
+                           const float* hl, const float* init_controls, const float* scores, float* pooled_work,
+                           float* out_controls, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!packed || !base_rect || !stlp || !hl || !init_controls || !scores || !out_controls) return PSTL_ERR_ARG;
+  const bool merge = !(cfg->flags & PSTL_FLAG_NO_MERGE);
+  if (merge) {
+    if (!pooled_work) return PSTL_ERR_ARG;
+    if (cfg->rows_per_scene != 3 * cfg->S || cfg->n_shards < 1 || cfg->S % cfg->n_shards != 0) return PSTL_ERR_SHAPE;
+  }
+  hipStream_t st = as_stream(stream);
+  const PackLayout L = make_layout();
+  if (merge) {
+    MergeArgs m;
+    m.bs = cfg->bs;
+    m.S = cfg->S;
+    m.n_shards = cfg->n_shards;
+    m.off = L.mrg;
+    m.packed = packed;
+    m.init = init_controls;
+    m.pooled = pooled_work;
+    hipLaunchKernelGGL(k_merge_pool, dim3((unsigned)((long)cfg->bs * 3 * cfg->n_shards)), dim3(64), 0, st, m);
+    if (int e = launch_status()) return e;
+  }
+  ChainArgs a = {};
+  a.N = n_rows(cfg);
+  a.rows_per_scene = cfg->rows_per_scene;
+  a.steps = cfg->steps;
+  a.clip = (cfg->flags & PSTL_FLAG_CLIP_RECT) ? 1 : 0;
+  a.w_max = cfg->w_max;
+  a.a_max = cfg->a_max;
+  a.off = L.rect;
+  a.packed = packed;
+  a.base = base_rect;
+  a.stlp = stlp;
+  a.hl = hl;
+  a.init = init_controls;
+  a.pooled = merge ? pooled_work : nullptr;
+  a.scores = scores;
+  a.out = out_controls;
+  a.S = cfg->S;
+  a.n_shards = cfg->n_shards;
+  return launch_chain_nw<true>(cfg->chain_waves, a, st);
+}

@@ -1,0 +1,22 @@
+// pstl_common.hpp -- shared by the HIP translation units of libpstl_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pstl_hip.h"
+
+namespace pstl {
+
+inline int check_cfg(const pstl_cfg* c) {
+  if (!c) return PSTL_ERR_ARG;
+  if (c->bs <= 0 || c->rows_per_scene <= 0 || c->K < 0 || c->steps < 2) return PSTL_ERR_ARG;
+  return PSTL_OK;
+}
+
+inline long n_rows(const pstl_cfg* c) { return (long)c->bs * c->rows_per_scene; }
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? PSTL_OK : PSTL_ERR_LAUNCH; }
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace pstl

@@ -1,0 +1,457 @@
+// stl_kernels.hip -- STL robustness kernels for gfx950 (compile with -ffp-contract=off, see stl_core.hpp).
+//
+// One sampled trajectory per lane, one wavefront (64 rows) per workgroup.  A lane's 20 states (and, for the
+// adjoint, 20 stored suffix log-sum-exps) live in LDS, lane-interleaved (element i of lane l at lds[i*64 + l], so
+// every LDS access of a wave is 64 consecutive dwords: conflict-free).  Scene data (prepared neighbour circles,
+// lane waypoints) is read straight from global memory: all rows of a scene are contiguous (192 rows = 3 waves at
+// S = 64), so a wave's lanes read the same addresses and the loads are served from L1/L2 as broadcasts.
+// The work is VALU/transcendental bound (~10^3 exp/log/sqrt and ~2*10^4 flops per row evaluation against 160 B of
+// per-row input), nowhere near the HBM roofline; see DESIGN.md.
+#include "pstl_common.hpp"
+#include "stl_core.hpp"
+
+namespace pstl {
+namespace {
+
+constexpr int kWave = 64;
+
+struct StlArgs {
+  long N;               // rows per rep
+  int rows_per_scene;
+  int K;
+  int reps;
+  StlEnv env;
+  const float* s0;        // (bs,4)
+  const float* controls;  // (reps,N,40)
+  const float* states;    // (reps,N,T,4) or null: score given trajectories instead of rolling out controls
+  const float* nei_prep;  // (bs,K,T,12)
+  const float* lane_prep; // (bs,3,15,4)
+  const float* stlp;      // (N,6)
+  const float* hl;        // (N,)
+  float* scores;          // (reps,N)
+  float* scores3;         // (3,reps,N) or null
+  float* sel_controls;    // (N,40) or null
+  float* sel_scores;
+  int32_t* sel_idx;
+};
+
+__device__ __forceinline__ StlRow load_row(const float* stlp, const float* hl, long row) {
+  StlRow r;
+  const float* p = stlp + row * 6;
+  r.vmin = p[0];
+  r.vmax = p[1];
+  r.dmin = p[2];
+  r.dmax = p[3];
+  r.dsafe = p[4];
+  r.thmax = p[5];
+  const float h = hl[row];
+  r.mode = (h == 0.0f) ? 0 : (h == 1.0f) ? 1 : (h == 2.0f) ? 2 : 3;  // anything else scores the outlier constant
+  return r;
+}
+
+template <bool ALL3>
+__global__ __launch_bounds__(kWave) void k_stl_forward(StlArgs a) {
+  __shared__ float lds[4 * kT * kWave];
+  const long row = (long)blockIdx.x * kWave + threadIdx.x;
+  if (row >= a.N) return;
+  const Scratch st = {lds + threadIdx.x, kWave};
+  const long b = row / a.rows_per_scene;
+  const StlRow r = load_row(a.stlp, a.hl, row);
+  const f4* lanes = reinterpret_cast<const f4*>(a.lane_prep) + b * 3 * kNseg;
+  const float* nei = a.nei_prep + b * (long)a.K * kT * kNeiPrep;
+  float best = -INFINITY;
+  int best_rep = 0;
+  for (int rep = 0; rep < a.reps; ++rep) {
+    if (a.states) {
+      const f4* sp = reinterpret_cast<const f4*>(a.states) + ((long)rep * a.N + row) * kT;
+      for (int t = 0; t < kT; ++t) {
+        const f4 v = sp[t];
+        st.at(4 * t) = v.x;
+        st.at(4 * t + 1) = v.y;
+        st.at(4 * t + 2) = v.z;
+        st.at(4 * t + 3) = v.w;
+      }
+    } else {
+      const float* u = a.controls + ((long)rep * a.N + row) * (2 * kT);
+      rollout_states(a.s0 + b * 4, u, 1.0f, 1.0f, a.env.dt, st);
+    }
+    float o3[3];
+    const float score = stl_eval<ALL3>(a.env, r, lanes, nei, a.K, st, o3);
+    a.scores[(long)rep * a.N + row] = score;
+    if (ALL3 && a.scores3) {
+      const long stride = (long)a.reps * a.N;
+      a.scores3[(long)rep * a.N + row] = o3[0];
+      a.scores3[stride + (long)rep * a.N + row] = o3[1];
+      a.scores3[2 * stride + (long)rep * a.N + row] = o3[2];
+    }
+    if (score > best || rep == 0) {  // first maximum wins, like torch.max(dim=0)
+      best = score;
+      best_rep = rep;
+    }
+  }
+  if (a.sel_controls && a.controls) {
+    const f4* src = reinterpret_cast<const f4*>(a.controls + ((long)best_rep * a.N + row) * (2 * kT));
+    f4* dst = reinterpret_cast<f4*>(a.sel_controls + row * (2 * kT));
+#pragma unroll
+    for (int i = 0; i < 10; ++i) dst[i] = src[i];
+    a.sel_scores[row] = best;
+    a.sel_idx[row] = best_rep;
+  }
+}
+
+struct GradArgs {
+  long N;
+  int rows_per_scene;
+  int K;
+  StlEnv env;
+  float wscale, ascale;
+  const float* s0;
+  const float* u;  // (N,40)
+  const float* nei_prep;
+  const float* lane_prep;
+  const float* stlp;
+  const float* hl;
+  const float* dscore;  // (N,) or null
+  float* dcontrols;     // (N,40)
+  float* scores;        // (N,) or null
+};
+
+__global__ __launch_bounds__(kWave) void k_stl_backward(GradArgs a) {
+  __shared__ float lds[kScratchFloats * kWave];
+  const long row = (long)blockIdx.x * kWave + threadIdx.x;
+  if (row >= a.N) return;
+  const Scratch st = {lds + threadIdx.x, kWave};
+  const long b = row / a.rows_per_scene;
+  const StlRow r = load_row(a.stlp, a.hl, row);
+  const f4* lanes = reinterpret_cast<const f4*>(a.lane_prep) + b * 3 * kNseg;
+  const float* nei = a.nei_prep + b * (long)a.K * kT * kNeiPrep;
+  rollout_states(a.s0 + b * 4, a.u + row * (2 * kT), a.wscale, a.ascale, a.env.dt, st);
+  const float ds = a.dscore ? a.dscore[row] : 1.0f;
+  float* out = a.dcontrols + row * (2 * kT);
+  const float score = stl_eval_grad(
+      a.env, r, lanes, nei, a.K, st, a.wscale, a.ascale, [=](float) { return ds; },
+      [=](int t, float gw, float ga) {
+        out[2 * t] = gw;
+        out[2 * t + 1] = ga;
+      });
+  if (a.scores) a.scores[row] = score;
+}
+
+// ---- guidance: one Adam iteration on mu, optionally finishing the reverse step (x = mu + sqrt(beta) z) ------------
+struct GuideArgs {
+  long N;
+  int rows_per_scene;
+  int K;
+  StlEnv env;
+  float wscale, ascale;    // mul_w_max, mul_a_max
+  float thres;             // stl_nn_thres, or 100 with PSTL_FLAG_MAXIMIZE
+  float grad_scale;        // (1/clip(mean(valid),1e-2))/N
+  float neg_step, bc2_sqrt;  // Adam scalars of this iteration
+  float beta_i, sqrt_beta;
+  int iter, niters;
+  int clip;
+  const float* s0;
+  const float* nei_prep;
+  const float* lane_prep;
+  const float* stlp;
+  const float* hl;
+  const float* valid;
+  const float* z;   // (N,40) or null
+  float* mu;        // (N,40) in/out
+  float* work;      // (3,N,40): m, v, anchor (niters > 1 only)
+  float* emit_out;  // (N,40) or null
+};
+
+template <bool MULTI>
+__global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
+  __shared__ float lds[kScratchFloats * kWave];
+  const long row = (long)blockIdx.x * kWave + threadIdx.x;
+  if (row >= a.N) return;
+  const Scratch st = {lds + threadIdx.x, kWave};
+  const long b = row / a.rows_per_scene;
+  const StlRow r = load_row(a.stlp, a.hl, row);
+  const f4* lanes = reinterpret_cast<const f4*>(a.lane_prep) + b * 3 * kNseg;
+  const float* nei = a.nei_prep + b * (long)a.K * kT * kNeiPrep;
+  float* mu = a.mu + row * (2 * kT);
+  rollout_states(a.s0 + b * 4, mu, a.wscale, a.ascale, a.env.dt, st);
+  const float vr = a.valid[row];
+  const float gs = a.grad_scale * vr;
+  const float thres = a.thres;
+  const bool last = (a.iter == a.niters - 1);
+  const long plane = a.N * (2 * kT);
+  float* wm = MULTI ? a.work + row * (2 * kT) : nullptr;
+  const float* zr = a.z ? a.z + row * (2 * kT) : nullptr;
+  float* er = a.emit_out ? a.emit_out + row * (2 * kT) : nullptr;
+  auto update = [=](int e, float g, float nscale) {
+    // torch.optim.Adam, single-tensor path, betas (0.9, 0.999), eps 1e-8 (see oracle guidance_update)
+    float m = 0.0f, v = 0.0f;
+    if (MULTI && a.iter > 0) {
+      m = wm[e];
+      v = wm[plane + e];
+    }
+    m = m + 0.1f * (g - m);
+    v = v * 0.999f + (0.001f * g) * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + 1e-8f;
+    float p = mu[e] + (a.neg_step * m) / denom;
+    if (MULTI) {
+      wm[e] = m;
+      wm[plane + e] = v;
+      if (a.iter == 0) {
+        wm[2 * plane + e] = p;  // anchor = the value after the first Adam step
+      } else {
+        const float an = wm[2 * plane + e];
+        p = an + fminf(fabsf(p - an), a.beta_i);
+      }
+    }
+    if (last) {
+      const float x = p + a.sqrt_beta * (zr ? zr[e] : 0.0f);
+      mu[e] = x;
+      if (er) {
+        float c = x * nscale;
+        if (a.clip) c = fminf(fmaxf(c, -nscale), nscale);
+        er[e] = c;
+      }
+    } else {
+      mu[e] = p;
+    }
+  };
+  stl_eval_grad(
+      a.env, r, lanes, nei, a.K, st, a.wscale, a.ascale,
+      [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
+      [=](int t, float gw, float ga) {
+        update(2 * t, gw, a.wscale);
+        update(2 * t + 1, ga, a.ascale);
+      });
+}
+
+// generate_trajs (nusc_train.py:39-49): T+1 states per row
+__global__ void k_generate_trajs(long R, int rows_per_scene, const float* s0, const float* controls, float dt,
+                                 float* trajs) {
+  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= R) return;
+  const float* s = s0 + (row / rows_per_scene) * 4;
+  const float* u = controls + row * (2 * kT);
+  float x = s[0], y = s[1], th = s[2], v = s[3];
+  f4* out = reinterpret_cast<f4*>(trajs) + row * (kT + 1);
+  for (int t = 0; t <= kT; ++t) {
+    out[t] = f4{x, y, th, v};
+    if (t == kT) break;
+    const float dx = v * cosf(th), dy = v * sinf(th);
+    x = x + dx * dt;
+    y = y + dy * dt;
+    th = th + u[2 * t] * dt;
+    v = v + u[2 * t + 1] * dt;
+  }
+}
+
+__global__ void k_prepare(long n_nei, long n_lane_pts, const float* nei, const float* l0, const float* l1,
+                          const float* l2, float* nei_prep, float* lane_prep) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_nei) {
+    float in[7], out[kNeiPrep];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) in[j] = nei[i * 7 + j];
+    prep_neighbor(in, out);
+#pragma unroll
+    for (int j = 0; j < kNeiPrep; ++j) nei_prep[i * kNeiPrep + j] = out[j];
+  }
+  if (i < n_lane_pts) {  // i = (b*3 + m)*15 + j
+    const long j = i % kNseg, bm = i / kNseg, m = bm % 3, b = bm / 3;
+    const float* src = (m == 0 ? l0 : m == 1 ? l1 : l2) + (b * kNseg + j) * 3;
+    float* o = lane_prep + i * 4;
+    o[0] = src[0];
+    o[1] = src[1];
+    o[2] = src[2];
+    o[3] = 0.0f;
+  }
+}
+
+__global__ void k_metrics_rows(long N, const float* scores, const float* valid, unsigned long long* counts,
+                               uint8_t* sat_mask) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned sat = 0, val = 0;
+  if (i < N) {
+    const bool s = scores[i] > 0.0f;
+    const bool v = valid[i] > 0.0f;
+    sat = (s && v) ? 1u : 0u;
+    val = v ? 1u : 0u;
+    if (sat_mask) sat_mask[i] = s ? 1 : 0;
+  }
+  // integer counts: order-independent, so the result is reproducible bit for bit
+  const unsigned long long bs = __ballot(sat), bv = __ballot(val);
+  if ((threadIdx.x & 63) == 0) {
+    if (bs) atomicAdd(&counts[0], (unsigned long long)__popcll(bs));
+    if (bv) atomicAdd(&counts[1], (unsigned long long)__popcll(bv));
+  }
+}
+
+__global__ void k_metrics_scenes(int bs, int S, const float* scores, const float* valid, unsigned long long* counts) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (scene, mode)
+  unsigned sat = 0, val = 0;
+  if (i == 0) {
+    counts[2] = (unsigned long long)bs * S * 3;
+    counts[5] = (unsigned long long)bs * 3;
+  }
+  if (i < (long)bs * 3) {
+    const long b = i / 3, m = i % 3;
+    bool any = false;
+    for (int s = 0; s < S; ++s) any = any || (scores[(b * S + s) * 3 + m] > 0.0f);
+    const bool v = valid[(b * S) * 3 + m] > 0.0f;
+    sat = (any && v) ? 1u : 0u;
+    val = v ? 1u : 0u;
+  }
+  const unsigned long long bsat = __ballot(sat), bv = __ballot(val);
+  if ((threadIdx.x & 63) == 0) {
+    if (bsat) atomicAdd(&counts[3], (unsigned long long)__popcll(bsat));
+    if (bv) atomicAdd(&counts[4], (unsigned long long)__popcll(bv));
+  }
+}
+
+}  // namespace
+}  // namespace pstl
+
+using namespace pstl;
+
+extern "C" int pstl_prepare_scene(const pstl_cfg* cfg, const float* neighbors_traj, const float* currlane,
+                                  const float* leftlane, const float* rightlane, float* nei_prep, float* lane_prep,
+                                  void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!currlane || !leftlane || !rightlane || !lane_prep || (cfg->K > 0 && (!neighbors_traj || !nei_prep)))
+    return PSTL_ERR_ARG;
+  const long n_nei = (long)cfg->bs * cfg->K * kT, n_lane = (long)cfg->bs * 3 * kNseg;
+  const long n = n_nei > n_lane ? n_nei : n_lane;
+  hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), n_nei, n_lane,
+                     neighbors_traj, currlane, leftlane, rightlane, nei_prep, lane_prep);
+  return launch_status();
+}
+
+extern "C" int pstl_generate_trajs(const pstl_cfg* cfg, const float* s0, const float* controls, float* trajs,
+                                   void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!s0 || !controls || !trajs) return PSTL_ERR_ARG;
+  const long R = n_rows(cfg);
+  hipLaunchKernelGGL(k_generate_trajs, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, as_stream(stream), R,
+                     cfg->rows_per_scene, s0, controls, cfg->dt, trajs);
+  return launch_status();
+}
+
+extern "C" int pstl_stl_forward(const pstl_cfg* cfg, const float* s0, const float* controls, const float* states,
+                                int reps, const float* nei_prep, const float* lane_prep, const float* stlp,
+                                const float* hl, float* scores, float* scores3, float* sel_controls,
+                                float* sel_scores, int32_t* sel_idx, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if ((!states && (!s0 || !controls)) || !lane_prep || !stlp || !hl || !scores || reps < 1) return PSTL_ERR_ARG;
+  if (cfg->K > 0 && !nei_prep) return PSTL_ERR_ARG;
+  if (sel_controls && (!sel_scores || !sel_idx)) return PSTL_ERR_ARG;
+  StlArgs a;
+  a.N = n_rows(cfg);
+  a.rows_per_scene = cfg->rows_per_scene;
+  a.K = cfg->K;
+  a.reps = reps;
+  a.env = make_env(cfg->tau, cfg->dt, cfg->ego_L, cfg->ego_W);
+  a.s0 = s0;
+  a.controls = controls;
+  a.states = states;
+  a.nei_prep = nei_prep;
+  a.lane_prep = lane_prep;
+  a.stlp = stlp;
+  a.hl = hl;
+  a.scores = scores;
+  a.scores3 = scores3;
+  a.sel_controls = sel_controls;
+  a.sel_scores = sel_scores;
+  a.sel_idx = sel_idx;
+  const dim3 grid((unsigned)((a.N + kWave - 1) / kWave));
+  if (scores3)
+    hipLaunchKernelGGL(k_stl_forward<true>, grid, dim3(kWave), 0, as_stream(stream), a);
+  else
+    hipLaunchKernelGGL(k_stl_forward<false>, grid, dim3(kWave), 0, as_stream(stream), a);
+  return launch_status();
+}
+
+extern "C" int pstl_stl_backward(const pstl_cfg* cfg, const float* s0, const float* controls, const float* nei_prep,
+                                 const float* lane_prep, const float* stlp, const float* hl, const float* dscore,
+                                 float* dcontrols, float* scores, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!s0 || !controls || !lane_prep || !stlp || !hl || !dcontrols) return PSTL_ERR_ARG;
+  if (cfg->K > 0 && !nei_prep) return PSTL_ERR_ARG;
+  GradArgs a;
+  a.N = n_rows(cfg);
+  a.rows_per_scene = cfg->rows_per_scene;
+  a.K = cfg->K;
+  a.env = make_env(cfg->tau, cfg->dt, cfg->ego_L, cfg->ego_W);
+  a.wscale = 1.0f;
+  a.ascale = 1.0f;
+  a.s0 = s0;
+  a.u = controls;
+  a.nei_prep = nei_prep;
+  a.lane_prep = lane_prep;
+  a.stlp = stlp;
+  a.hl = hl;
+  a.dscore = dscore;
+  a.dcontrols = dcontrols;
+  a.scores = scores;
+  hipLaunchKernelGGL(k_stl_backward, dim3((unsigned)((a.N + kWave - 1) / kWave)), dim3(kWave), 0, as_stream(stream), a);
+  return launch_status();
+}
+
+extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const float* nei_prep, const float* lane_prep,
+                                  const float* stlp, const float* hl, const float* valid, float grad_scale, int niters,
+                                  const float* adam_neg_step, const float* adam_bc2_sqrt, float beta_i, const float* z,
+                                  float* mu_x_inout, float* work, float* emit_out, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!s0 || !lane_prep || !stlp || !hl || !valid || !mu_x_inout || !adam_neg_step || !adam_bc2_sqrt || niters < 1)
+    return PSTL_ERR_ARG;
+  if (cfg->K > 0 && !nei_prep) return PSTL_ERR_ARG;
+  if (niters > 1 && !work) return PSTL_ERR_ARG;
+  GuideArgs a;
+  a.N = n_rows(cfg);
+  a.rows_per_scene = cfg->rows_per_scene;
+  a.K = cfg->K;
+  a.env = make_env(cfg->tau, cfg->dt, cfg->ego_L, cfg->ego_W);
+  a.wscale = cfg->w_max;
+  a.ascale = cfg->a_max;
+  a.thres = (cfg->flags & PSTL_FLAG_MAXIMIZE) ? 100.0f : cfg->thres;
+  a.grad_scale = grad_scale;
+  a.beta_i = beta_i;
+  a.sqrt_beta = sqrtf(beta_i);
+  a.niters = niters;
+  a.clip = (cfg->flags & PSTL_FLAG_CLIP) ? 1 : 0;
+  a.s0 = s0;
+  a.nei_prep = nei_prep;
+  a.lane_prep = lane_prep;
+  a.stlp = stlp;
+  a.hl = hl;
+  a.valid = valid;
+  a.z = z;
+  a.mu = mu_x_inout;
+  a.work = work;
+  a.emit_out = emit_out;
+  const dim3 grid((unsigned)((a.N + kWave - 1) / kWave));
+  for (int j = 0; j < niters; ++j) {
+    a.iter = j;
+    a.neg_step = adam_neg_step[j];
+    a.bc2_sqrt = adam_bc2_sqrt[j];
+    if (niters > 1)
+      hipLaunchKernelGGL(k_guidance_iter<true>, grid, dim3(kWave), 0, as_stream(stream), a);
+    else
+      hipLaunchKernelGGL(k_guidance_iter<false>, grid, dim3(kWave), 0, as_stream(stream), a);
+    if (int e = launch_status()) return e;
+  }
+  return PSTL_OK;
+}
+
+extern "C" int pstl_reduce_metrics(const pstl_cfg* cfg, const float* scores, const float* valid, uint64_t* counts,
+                                   uint8_t* sat_mask, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!scores || !valid || !counts) return PSTL_ERR_ARG;
+  if (cfg->rows_per_scene != 3 * cfg->S) return PSTL_ERR_SHAPE;
+  const long N = n_rows(cfg);
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(counts, 0, 8 * sizeof(uint64_t), st) != hipSuccess) return PSTL_ERR_LAUNCH;
+  auto* c = reinterpret_cast<unsigned long long*>(counts);
+  hipLaunchKernelGGL(k_metrics_rows, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, scores, valid, c, sat_mask);
+  hipLaunchKernelGGL(k_metrics_scenes, dim3((unsigned)(((long)cfg->bs * 3 + 255) / 256)), dim3(256), 0, st, cfg->bs,
+                     cfg->S, scores, valid, c);
+  return launch_status();
+}

@@ -1,0 +1,297 @@
+"""Scene-indexed driver of the HIP path: packs weights, prepares a scene batch and runs the sampling region
+(reference nusc_train.py:957-1105) through libpstl_hip.so without ever materialising row-replicated tensors.
+
+Host code only sequences launches; all arithmetic on rows happens in the HIP kernels.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import ffi
+
+MLP_NAMES = ("ego_encoder", "neighbor_encoder", "lane_encoder", "policy_net", "merge_net", "rect_net")
+
+
+def diffusion_coeffs(steps, device=None):
+    """Cosine schedule, float32, same op sequence as the reference (nusc_train.py:528-537; --cos is forced on)."""
+    t = torch.linspace(0, 1, steps + 1)
+    ab = torch.cos((t + 0.008) / 1.008 * np.pi / 2) ** 2
+    beta = torch.clip(1 - ab[1:] / ab[:-1], 0, 0.999) * 0.2
+    alpha = 1.0 - beta
+    alpha_hat = torch.cumprod(alpha, dim=0)
+    if device is not None:
+        return beta.to(device), alpha.to(device), alpha_hat.to(device)
+    return beta, alpha, alpha_hat
+
+
+class PackedWeights:
+    """Kernel-layout copy of a reference state_dict (keys '<net>.{0,2,4}.{weight,bias}')."""
+
+    def __init__(self, state_dict, device):
+        self.device = torch.device(device)
+        L = ffi.lib()
+        keep = {}
+        wp = ffi.WeightPtrs()
+        for name in MLP_NAMES:
+            m = ffi.Mlp3()
+            for li, idx in enumerate((0, 2, 4)):
+                for kind, field in (("weight", "w%d" % li), ("bias", "b%d" % li)):
+                    key = "%s.%d.%s" % (name, idx, kind)
+                    if key in state_dict:
+                        t = state_dict[key]
+                        if not isinstance(t, torch.Tensor):
+                            t = torch.from_numpy(np.ascontiguousarray(t))
+                        t = ffi.f32(t.detach(), self.device)
+                        keep[key] = t
+                        setattr(m, field, t.data_ptr())
+            setattr(wp, name, m)
+        self.has_rect = "rect_net.0.weight" in state_dict
+        self.has_merge = "merge_net.0.weight" in state_dict
+        self.packed = torch.empty(L.pstl_packed_weight_floats(), dtype=torch.float32, device=self.device)
+        ffi.check(L.pstl_pack_weights(ctypes.byref(wp), ffi.ptr(self.packed), ffi.stream()), "pack_weights")
+        torch.cuda.current_stream().synchronize()   # the source blobs in `keep` may be freed after this
+        self._tbias = {}
+
+    def tbias(self, steps):
+        if steps not in self._tbias:
+            tb = torch.empty(steps, ffi.HID, dtype=torch.float32, device=self.device)
+            ffi.check(ffi.lib().pstl_time_bias(ffi.ptr(self.packed), int(steps), ffi.ptr(tb), ffi.stream()), "time_bias")
+            self._tbias[steps] = tb
+        return self._tbias[steps]
+
+
+class SceneBatch:
+    """Device-resident, scene-indexed inputs of one batch (schema: SURVEY.md 3.0) + per-row constants.
+
+    scene: dict with ego_traj (bs,nt,6), neighbors (bs,K,7), neighbors_traj (bs,K,nt,7), {curr,left,right}lane_wpts
+    (bs,15,3), {curr,left,right}_id (bs,1), and either stlp_modes (bs,3,6) or stlp_rows (N,6).
+    """
+
+    def __init__(self, scene, S, hp, device, global_valid_sum=None, global_rows=None):
+        dev = torch.device(device)
+        f = lambda k: ffi.f32(torch.as_tensor(scene[k]), dev)
+        self.hp, self.S, self.device = hp, int(S), dev
+        ego = f("ego_traj")
+        self.bs = ego.shape[0]
+        self.ego0 = ego[:, 0, :].contiguous()
+        self.s0 = ego[:, 0, :4].contiguous()
+        self.neighbors = f("neighbors")
+        self.nei_traj = f("neighbors_traj")[..., :7].contiguous()
+        self.K = self.nei_traj.shape[1]
+        assert self.nei_traj.shape[2] == ffi.T, "this build is specialised for nt = 20"
+        self.lanes = [f("%slane_wpts" % k) for k in ("curr", "left", "right")]
+        assert self.lanes[0].shape[1] == ffi.NSEG, "this build is specialised for n_segs = 15"
+        self.ids = [f("%s_id" % k).reshape(self.bs).contiguous() for k in ("curr", "left", "right")]
+        self.rps = 3 * self.S
+        self.N = self.bs * self.rps
+        if "stlp_rows" in scene:
+            self.stlp = f("stlp_rows").reshape(self.N, 6).contiguous()
+        else:   # every sample of a (scene, mode) shares the STL parameters (reference nusc_train.py:745)
+            self.stlp = f("stlp_modes").reshape(self.bs, 1, 3, 6).expand(self.bs, self.S, 3, 6).reshape(self.N, 6).contiguous()
+        self.hl = torch.tensor([0.0, 1.0, 2.0], device=dev).repeat(self.bs * self.S).contiguous()      # nusc_train.py:753
+        ids3 = torch.stack(self.ids, dim=-1)                                                             # (bs,3)
+        self.valid = ids3.reshape(self.bs, 1, 3).expand(self.bs, self.S, 3).reshape(self.N).contiguous()  # :751-752
+        # scale of d loss / d score in the guidance loss mask_mean(relu(thres - score), valid) (nusc_train.py:23-27,619)
+        vsum = float(ids3.sum().item()) * self.S if global_valid_sum is None else float(global_valid_sum)
+        rows = self.N if global_rows is None else int(global_rows)
+        mean_valid = np.float32(np.float32(vsum) / np.float32(rows))
+        c = np.float32(max(mean_valid, np.float32(1e-2)))
+        self.grad_scale = float(np.float32(np.float32(1.0) / c) / np.float32(rows))
+        # prepared tables for the STL kernels
+        self.nei_prep = torch.empty(self.bs, self.K, ffi.T, ffi.NEI_PREP, dtype=torch.float32, device=dev)
+        self.lane_prep = torch.empty(self.bs, 3, ffi.NSEG, 4, dtype=torch.float32, device=dev)
+        cfg = self.cfg(2)
+        ffi.check(ffi.lib().pstl_prepare_scene(ctypes.byref(cfg), ffi.ptr(self.nei_traj), ffi.ptr(self.lanes[0]),
+                                               ffi.ptr(self.lanes[1]), ffi.ptr(self.lanes[2]), ffi.ptr(self.nei_prep),
+                                               ffi.ptr(self.lane_prep), ffi.stream()), "prepare_scene")
+
+    def cfg(self, steps, flags=0, chain_waves=0):
+        return ffi.make_cfg(self.bs, self.rps, self.S, self.K, steps, self.hp, flags, chain_waves)
+
+
+def guidance_triggered(i, steps, g):
+    """Trigger rule of the reference (nusc_train.py:589-598)."""
+    if not g or not g.get("enabled", False):
+        return False
+    i_val = steps - 1 - i if g.get("reverse", False) else i
+    if g.get("sets") is not None:
+        return i_val in g["sets"]
+    if g.get("freq") is not None:
+        return i_val % g["freq"] == 0
+    return i <= g.get("before", 1000)
+
+
+class Sampler:
+    def __init__(self, weights, hp, chain_waves=0):
+        self.w, self.hp, self.chain_waves = weights, hp, int(chain_waves)
+        self.L = ffi.lib()
+
+    # ---- A1 ----
+    def encode(self, sb, need_rect=True):
+        dev = sb.device
+        feature = torch.empty(sb.bs, ffi.FEAT, dtype=torch.float32, device=dev)
+        base_p = torch.empty(sb.bs, ffi.HID, dtype=torch.float32, device=dev)
+        base_r = torch.empty(sb.bs, ffi.HID, dtype=torch.float32, device=dev) if (need_rect and self.w.has_rect) else None
+        cfg = sb.cfg(2)
+        ffi.check(self.L.pstl_encode_scene(ctypes.byref(cfg), ffi.ptr(self.w.packed), ffi.ptr(sb.ego0),
+                                           ffi.ptr(sb.neighbors), ffi.ptr(sb.lanes[0]), ffi.ptr(sb.lanes[1]),
+                                           ffi.ptr(sb.lanes[2]), ffi.ptr(sb.ids[0]), ffi.ptr(sb.ids[1]),
+                                           ffi.ptr(sb.ids[2]), ffi.ptr(feature), ffi.ptr(base_p), ffi.ptr(base_r),
+                                           ffi.stream()), "encode_scene")
+        return feature, base_p, base_r
+
+    # ---- A3-A5, A7 ----
+    def rollout(self, sb, base_policy, x, noise, steps, n_emit=0, clip=False, guidance=None, coeffs=None):
+        """x (N,40) is updated in place from x_T to x_0 (un-normalised).  noise (steps-1,N,40) or None.
+        Returns emit (n_emit,N,40): the last n_emit entries of the reference's normalised diff_full list."""
+        dev = sb.device
+        beta, alpha, alpha_hat = coeffs if coeffs is not None else diffusion_coeffs(steps, dev)
+        beta_host = beta.detach().cpu()
+        flags = ffi.PSTL_FLAG_CLIP if clip else 0
+        if guidance and guidance.get("maximize", False):
+            flags |= ffi.PSTL_FLAG_MAXIMIZE
+        cfg = sb.cfg(steps, flags, self.chain_waves)
+        tb = self.w.tbias(steps)
+        emit = torch.empty(max(n_emit, 1), sb.N, ffi.CTRL, dtype=torch.float32, device=dev)
+        if guidance and guidance.get("enabled", False):
+            nit = int(guidance["niters"])
+            lr = float(guidance["lr"])
+            neg_step = (ctypes.c_float * nit)(*[-lr / (1 - 0.9 ** (j + 1)) for j in range(nit)])
+            bc2 = (ctypes.c_float * nit)(*[math.sqrt(1 - 0.999 ** (j + 1)) for j in range(nit)])
+            work = torch.empty(3, sb.N, ffi.CTRL, dtype=torch.float32, device=dev) if nit > 1 else None
+
+        def plain(hi, lo, mu_only=0):
+            ffi.check(self.L.pstl_rollout(ctypes.byref(cfg), ffi.ptr(self.w.packed), ffi.ptr(base_policy), ffi.ptr(tb),
+                                          ffi.ptr(sb.stlp), ffi.ptr(sb.hl), ffi.ptr(beta), ffi.ptr(alpha),
+                                          ffi.ptr(alpha_hat), ffi.ptr(noise), int(hi), int(lo), int(mu_only),
+                                          ffi.ptr(x), ffi.ptr(emit) if n_emit > 0 else ffi.ptr(None), int(n_emit),
+                                          ffi.stream()), "rollout")
+
+        i = steps - 1
+        while i >= 1:
+            if not guidance_triggered(i, steps, guidance):
+                lo = i
+                while lo - 1 >= 1 and not guidance_triggered(lo - 1, steps, guidance):
+                    lo -= 1
+                plain(i, lo)
+                i = lo - 1
+            else:
+                plain(i, i, mu_only=1)
+                z = noise[steps - 1 - i] if (noise is not None and i > 1) else None
+                eo = emit[n_emit - i] if (n_emit > 0 and i <= n_emit) else None
+                ffi.check(self.L.pstl_guidance_step(ctypes.byref(cfg), ffi.ptr(sb.s0), ffi.ptr(sb.nei_prep),
+                                                    ffi.ptr(sb.lane_prep), ffi.ptr(sb.stlp), ffi.ptr(sb.hl),
+                                                    ffi.ptr(sb.valid), ctypes.c_float(sb.grad_scale), nit, neg_step, bc2,
+                                                    ctypes.c_float(float(beta_host[i])), ffi.ptr(z), ffi.ptr(x),
+                                                    ffi.ptr(work), ffi.ptr(eo), ffi.stream()), "guidance_step")
+                i -= 1
+        return emit[:n_emit]
+
+    # ---- A6, A8-A10 ----
+    def score(self, sb, controls, select=False, all3=False, states=None):
+        """controls (reps,N,40) physical units -> scores (reps,N) [, scores3 (3,reps,N)] [, best controls/score/idx]."""
+        dev = sb.device
+        src = controls if controls is not None else states
+        reps = src.shape[0]
+        scores = torch.empty(reps, sb.N, dtype=torch.float32, device=dev)
+        s3 = torch.empty(3, reps, sb.N, dtype=torch.float32, device=dev) if all3 else None
+        sel_c = torch.empty(sb.N, ffi.CTRL, dtype=torch.float32, device=dev) if select else None
+        sel_s = torch.empty(sb.N, dtype=torch.float32, device=dev) if select else None
+        sel_i = torch.empty(sb.N, dtype=torch.int32, device=dev) if select else None
+        cfg = sb.cfg(2)
+        ffi.check(self.L.pstl_stl_forward(ctypes.byref(cfg), ffi.ptr(sb.s0), ffi.ptr(controls), ffi.ptr(states), int(reps),
+                                          ffi.ptr(sb.nei_prep), ffi.ptr(sb.lane_prep), ffi.ptr(sb.stlp), ffi.ptr(sb.hl),
+                                          ffi.ptr(scores), ffi.ptr(s3), ffi.ptr(sel_c), ffi.ptr(sel_s),
+                                          ffi.ptr(sel_i, torch.int32), ffi.stream()), "stl_forward")
+        out = {"scores": scores}
+        if all3:
+            out["scores3"] = s3
+        if select:
+            out.update(sel_controls=sel_c, sel_scores=sel_s, sel_idx=sel_i)
+        return out
+
+    def score_grad(self, sb, controls, dscore=None):
+        dev = sb.device
+        g = torch.empty(sb.N, ffi.CTRL, dtype=torch.float32, device=dev)
+        sc = torch.empty(sb.N, dtype=torch.float32, device=dev)
+        cfg = sb.cfg(2)
+        ffi.check(self.L.pstl_stl_backward(ctypes.byref(cfg), ffi.ptr(sb.s0), ffi.ptr(controls), ffi.ptr(sb.nei_prep),
+                                           ffi.ptr(sb.lane_prep), ffi.ptr(sb.stlp), ffi.ptr(sb.hl), ffi.ptr(dscore),
+                                           ffi.ptr(g), ffi.ptr(sc), ffi.stream()), "stl_backward")
+        return sc, g
+
+    def trajs(self, sb, controls):
+        out = torch.empty(sb.N, ffi.T + 1, 4, dtype=torch.float32, device=sb.device)
+        cfg = sb.cfg(2)
+        ffi.check(self.L.pstl_generate_trajs(ctypes.byref(cfg), ffi.ptr(sb.s0), ffi.ptr(controls), ffi.ptr(out),
+                                             ffi.stream()), "generate_trajs")
+        return out
+
+    # ---- A11 ----
+    def refine(self, sb, base_rect, init_controls, scores, diverse=True, clip_rect=False):
+        dev = sb.device
+        flags = (0 if diverse else ffi.PSTL_FLAG_NO_MERGE) | (ffi.PSTL_FLAG_CLIP_RECT if clip_rect else 0)
+        cfg = sb.cfg(2, flags, self.chain_waves)
+        pooled = torch.empty(sb.bs, 3, cfg.n_shards, ffi.CTRL, dtype=torch.float32, device=dev) if diverse else None
+        out = torch.empty(sb.N, ffi.CTRL, dtype=torch.float32, device=dev)
+        ffi.check(self.L.pstl_refine(ctypes.byref(cfg), ffi.ptr(self.w.packed), ffi.ptr(base_rect), ffi.ptr(sb.stlp),
+                                     ffi.ptr(sb.hl), ffi.ptr(init_controls), ffi.ptr(scores), ffi.ptr(pooled),
+                                     ffi.ptr(out), ffi.stream()), "refine")
+        return out
+
+    def metrics(self, sb, scores, want_mask=False):
+        """Integer numerators/denominators of acc and scene_acc (device tensor of 8 int64; no host sync here)."""
+        counts = torch.empty(8, dtype=torch.int64, device=sb.device)
+        mask = torch.empty(sb.N, dtype=torch.uint8, device=sb.device) if want_mask else None
+        cfg = sb.cfg(2)
+        ffi.check(self.L.pstl_reduce_metrics(ctypes.byref(cfg), ffi.ptr(scores), ffi.ptr(sb.valid),
+                                             ffi.ptr(counts, torch.int64), ffi.ptr(mask, torch.uint8), ffi.stream()),
+                  "reduce_metrics")
+        return counts, mask
+
+    # ---- A12: the timed region ----
+    def sampling_region(self, sb, steps, x_T, noise, rect_head=False, multi_cands=None, refinenet=True, guidance=None,
+                        n_rolls=None, diverse=True, full_list=False, coeffs=None):
+        out = {}
+        feature, base_p, base_r = self.encode(sb, need_rect=rect_head)
+        out["feature_scene"] = feature
+        x = x_T.clone() if x_T.data_ptr() != 0 else x_T
+        mc = multi_cands if (rect_head and multi_cands is not None) else 0
+        n_emit = steps if full_list else max(mc, 1)
+        emit = self.rollout(sb, base_p, x, noise, steps, n_emit=n_emit, clip=bool(rect_head), guidance=guidance,
+                            coeffs=coeffs)
+        if full_list:
+            out["controls_list"] = emit
+        controls = emit[-1]
+        if rect_head:
+            if mc > 0:
+                r = self.score(sb, emit[-mc:].contiguous(), select=True)
+                out.update(cand_scores=r["scores"], sel_scores=r["sel_scores"], sel_idx=r["sel_idx"],
+                           sel_controls=r["sel_controls"])
+                controls, best = r["sel_controls"], r["sel_scores"]
+            else:
+                best = self.score(sb, controls.reshape(1, sb.N, ffi.CTRL))["scores"][0]
+            if refinenet:
+                controls = self.refine(sb, base_r, controls, best, diverse=diverse)
+                out["rect_controls"] = controls
+            for ri in range(n_rolls or 0):
+                sc = self.score(sb, controls.reshape(1, sb.N, ffi.CTRL))["scores"][0]
+                controls = self.refine(sb, base_r, controls, sc, diverse=diverse)
+                out["roll%d_scores" % ri] = sc
+                out["roll%d_controls" % ri] = controls
+        fin = self.score(sb, controls.reshape(1, sb.N, ffi.CTRL), all3=True)
+        counts, _ = self.metrics(sb, fin["scores"][0])
+        out.update(final_controls=controls, final_scores=fin["scores"][0], final_scores3=fin["scores3"][:, 0],
+                   counts=counts)
+        return out
+
+
+def acc_from_counts(counts):
+    """acc / scene_acc exactly as mask_mean computes them in float32 (nusc_train.py:23-27,332,342)."""
+    c = [int(v) for v in counts.tolist()]
+    f32 = np.float32
+    acc = f32(f32(c[0]) / f32(c[2])) / max(f32(f32(c[1]) / f32(c[2])), f32(1e-2))
+    sacc = f32(f32(c[3]) / f32(c[5])) / max(f32(f32(c[4]) / f32(c[5])), f32(1e-2))
+    return float(acc), float(sacc)

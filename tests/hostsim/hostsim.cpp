@@ -1,0 +1,78 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE: the per-row STL math of csrc/stl_core.hpp compiled for the CPU (g++,
+// -ffp-contract=off, optionally ASan/UBSan) so that the closed-form restatement and its hand-written adjoint can be
+// checked against the oracle without a GPU.  Never loaded by the product path.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../pstl_diffusion_policy_amd/csrc/stl_core.hpp"
+
+using namespace pstl;
+
+extern "C" {
+
+// neighbors_traj (bs,K,T,7) -> nei_prep (bs,K,T,12); lanes 3 x (bs,15,3) -> lane_prep (bs,3,15,4)
+void hostsim_prepare(int bs, int K, const float* nei, const float* l0, const float* l1, const float* l2, float* nei_prep,
+                     float* lane_prep) {
+  for (long i = 0; i < (long)bs * K * kT; ++i) prep_neighbor(nei + i * 7, nei_prep + i * kNeiPrep);
+  const float* ls[3] = {l0, l1, l2};
+  for (int b = 0; b < bs; ++b)
+    for (int m = 0; m < 3; ++m)
+      for (int j = 0; j < kNseg; ++j) {
+        float* o = lane_prep + (((long)b * 3 + m) * kNseg + j) * 4;
+        const float* in = ls[m] + ((long)b * kNseg + j) * 3;
+        o[0] = in[0], o[1] = in[1], o[2] = in[2], o[3] = 0.0f;
+      }
+}
+
+// scores (N), scores3 (3,N) ; controls (N,40) physical units
+void hostsim_stl_forward(int N, int rows_per_scene, int K, float tau, float dt, float ego_L, float ego_W, const float* s0,
+                         const float* controls, const float* nei_prep, const float* lane_prep, const float* stlp,
+                         const float* hl, int all3, float* scores, float* scores3) {
+  StlEnv env = make_env(tau, dt, ego_L, ego_W);
+  std::vector<float> scratch(kScratchFloats);
+  for (int r = 0; r < N; ++r) {
+    const int b = r / rows_per_scene;
+    StlRow row = {stlp[r * 6 + 0], stlp[r * 6 + 1], stlp[r * 6 + 2], stlp[r * 6 + 3], stlp[r * 6 + 4], stlp[r * 6 + 5],
+                  (int)hl[r]};
+    Scratch st = {scratch.data(), 1};
+    rollout_states(s0 + b * 4, controls + (long)r * 40, 1.0f, 1.0f, dt, st);
+    const f4* lanes = reinterpret_cast<const f4*>(lane_prep + (long)b * 3 * kNseg * 4);
+    const float* nei = nei_prep + (long)b * K * kT * kNeiPrep;
+    float o3[3] = {0, 0, 0};
+    if (all3) {
+      scores[r] = stl_eval<true>(env, row, lanes, nei, K, st, o3);
+      scores3[r] = o3[0], scores3[N + r] = o3[1], scores3[2 * N + r] = o3[2];
+    } else {
+      scores[r] = stl_eval<false>(env, row, lanes, nei, K, st, nullptr);
+    }
+  }
+}
+
+// dcontrols (N,40) = dscore[r] * dscore/dcontrols ; relu_mode: dscore[r] is instead -gscale*valid[r]*[thres - score > 0]
+void hostsim_stl_grad(int N, int rows_per_scene, int K, float tau, float dt, float ego_L, float ego_W, const float* s0,
+                      const float* controls, float wscale, float ascale, const float* nei_prep, const float* lane_prep,
+                      const float* stlp, const float* hl, const float* dscore, int relu_mode, float thres, float gscale,
+                      const float* valid, float* scores, float* dcontrols) {
+  StlEnv env = make_env(tau, dt, ego_L, ego_W);
+  std::vector<float> scratch(kScratchFloats);
+  for (int r = 0; r < N; ++r) {
+    const int b = r / rows_per_scene;
+    StlRow row = {stlp[r * 6 + 0], stlp[r * 6 + 1], stlp[r * 6 + 2], stlp[r * 6 + 3], stlp[r * 6 + 4], stlp[r * 6 + 5],
+                  (int)hl[r]};
+    Scratch st = {scratch.data(), 1};
+    rollout_states(s0 + b * 4, controls + (long)r * 40, wscale, ascale, dt, st);
+    const f4* lanes = reinterpret_cast<const f4*>(lane_prep + (long)b * 3 * kNseg * 4);
+    const float* nei = nei_prep + (long)b * K * kT * kNeiPrep;
+    float* out = dcontrols + (long)r * 40;
+    const float ds = dscore ? dscore[r] : 1.0f;
+    const float vr = valid ? valid[r] : 1.0f;
+    auto dfn = [=](float score) { return relu_mode ? ((thres - score > 0.0f) ? -(gscale * vr) : 0.0f) : ds; };
+    auto emit = [=](int t, float gw, float ga) {
+      out[2 * t] = gw;
+      out[2 * t + 1] = ga;
+    };
+    scores[r] = stl_eval_grad(env, row, lanes, nei, K, st, wscale, ascale, dfn, emit);
+  }
+}
+}

@@ -1,0 +1,224 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+  (1) the golden vectors produced by the reference itself (tests/golden/*.npz), and
+  (2) the CPU oracle on fresh seeded inputs.
+Tolerances: sampled trajectories 1e-4 abs (north star); STL scores 5e-4 abs / 5e-5 rel; satisfaction masks exact
+outside a reported |score| < 1e-4 band (expected empty on these fixtures); indices and counts exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import (SAMPLING_CASES, STL_CASES, golden_meta, golden_weights, load_golden, scene_from_golden)
+
+pytestmark = pytest.mark.gpu
+
+TRAJ_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    from pstl_diffusion_policy_amd import ffi
+    ffi.lib()   # fails loudly when the HIP library has not been built
+    return torch.device("cuda:0")
+
+
+def _hp():
+    from pstl_diffusion_policy_amd.synthetic import default_hparams
+    return default_hparams()
+
+
+def _weights(dev, zero_out=False):
+    from pstl_diffusion_policy_amd.engine import PackedWeights
+    sd = {k: v.copy() for k, v in golden_weights().items()}
+    if zero_out:
+        sd["policy_net.4.weight"] *= 0
+        sd["policy_net.4.bias"] *= 0
+    return PackedWeights(sd, dev), sd
+
+
+def _scene_batch(d, S, dev):
+    from pstl_diffusion_policy_amd.engine import SceneBatch
+    return SceneBatch({k: torch.from_numpy(v) for k, v in scene_from_golden(d).items()}, S, _hp(), dev)
+
+
+def _mask_equal_outside_band(mine, ref, band=1e-4):
+    mine, ref = np.asarray(mine), np.asarray(ref)
+    inband = np.abs(ref) < band
+    np.testing.assert_array_equal((mine > 0)[~inband], (ref > 0)[~inband])
+    return int(inband.sum())
+
+
+@pytest.mark.parametrize("name", STL_CASES)
+def test_stl_forward_matches_reference(dev, name):
+    from pstl_diffusion_policy_amd.engine import Sampler
+    d = load_golden(name)
+    bs, S, K, seed = [int(v) for v in d["meta"]]
+    w, _ = _weights(dev)
+    sb = _scene_batch(d, S, dev)
+    sm = Sampler(w, _hp())
+    c = torch.from_numpy(d["controls"]).reshape(1, sb.N, 40).to(dev)
+    r = sm.score(sb, c, all3=True)
+    np.testing.assert_allclose(r["scores3"][:, 0].cpu().numpy(), d["scores3"], rtol=5e-5, atol=5e-4)
+    np.testing.assert_allclose(r["scores"][0].cpu().numpy(), d["scores"], rtol=5e-5, atol=5e-4)
+    assert _mask_equal_outside_band(r["scores"][0].cpu().numpy(), d["scores"]) == 0
+    np.testing.assert_array_equal(r["scores"][0].cpu().numpy() > 0, d["scores"] > 0)
+    # selected-formula kernel == all-three kernel, bit for bit
+    r1 = sm.score(sb, c, all3=False)
+    assert torch.equal(r1["scores"], r["scores"])
+    # scoring given trajectories (what compute_stl_dense receives) == scoring controls
+    tr = sm.trajs(sb, c[0])
+    np.testing.assert_allclose(tr.cpu().numpy(), d["trajs"], rtol=0, atol=2e-4)
+    r2 = sm.score(sb, None, states=tr[:, :-1].contiguous().reshape(1, sb.N, 20, 4))
+    assert torch.equal(r2["scores"], r["scores"])
+    counts, mask = sm.metrics(sb, r["scores"][0], want_mask=True)
+    from pstl_diffusion_policy_amd.engine import acc_from_counts
+    acc, sacc = acc_from_counts(counts)
+    assert acc == float(d["acc"]) and sacc == float(d["scene_acc"])
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), d["scores"] > 0)
+
+
+@pytest.mark.parametrize("name", STL_CASES)
+def test_stl_backward_matches_reference_autograd(dev, name):
+    from pstl_diffusion_policy_amd.engine import Sampler
+    d = load_golden(name)
+    bs, S, K, seed = [int(v) for v in d["meta"]]
+    w, _ = _weights(dev)
+    sb = _scene_batch(d, S, dev)
+    sm = Sampler(w, _hp())
+    c = torch.from_numpy(d["controls"]).reshape(sb.N, 40).to(dev)
+    sc, g = sm.score_grad(sb, c)
+    np.testing.assert_allclose(sc.cpu().numpy(), d["scores"], rtol=5e-5, atol=5e-4)
+    ref = d["grad_sum"].reshape(-1, 40)
+    scale = np.abs(ref).max(axis=1, keepdims=True) + 1e-20
+    np.testing.assert_allclose(g.cpu().numpy() / scale, ref / scale, rtol=5e-3, atol=5e-4)
+
+
+@pytest.mark.parametrize("name", ["e7_steps12", "e7_steps50_k8"])
+def test_scene_encoder_matches_reference(dev, name):
+    from pstl_diffusion_policy_amd.engine import Sampler
+    d = load_golden(name)
+    meta = golden_meta(d)
+    w, sd = _weights(dev)
+    sb = _scene_batch(d, meta["S"], dev)
+    feature, base_p, base_r = Sampler(w, _hp()).encode(sb)
+    np.testing.assert_allclose(feature.cpu().numpy(), d["feature_scene"], rtol=0, atol=2e-5)
+    W1, b1 = sd["policy_net.0.weight"], sd["policy_net.0.bias"]
+    np.testing.assert_allclose(base_p.cpu().numpy(), d["feature_scene"] @ W1[:, :224].T + b1, rtol=0, atol=5e-5)
+    W1, b1 = sd["rect_net.0.weight"], sd["rect_net.0.bias"]
+    np.testing.assert_allclose(base_r.cpu().numpy(), d["feature_scene"] @ W1[:, :224].T + b1, rtol=0, atol=5e-5)
+
+
+def _run_region(dev, name, chain_waves=0):
+    from pstl_diffusion_policy_amd.engine import Sampler
+    d = load_golden(name)
+    meta = golden_meta(d)
+    w, _ = _weights(dev, zero_out=bool(meta["zero_net_out"]))
+    sb = _scene_batch(d, meta["S"], dev)
+    sm = Sampler(w, _hp(), chain_waves=chain_waves)
+    g = None
+    if meta["guidance"]:
+        g = dict(enabled=True, before=meta["guidance_before"], niters=meta["guidance_niters"], lr=meta["guidance_lr"])
+    out = sm.sampling_region(sb, meta["steps"], torch.from_numpy(d["x_T"]).to(dev), torch.from_numpy(d["z"]).to(dev),
+                             rect_head=bool(meta["rect_head"]),
+                             multi_cands=None if meta["multi_cands"] < 0 else meta["multi_cands"], guidance=g,
+                             n_rolls=None if meta["n_rolls"] < 0 else meta["n_rolls"], full_list=True)
+    return d, meta, sb, out
+
+
+@pytest.mark.parametrize("chain_waves", [8, 4])
+@pytest.mark.parametrize("name", SAMPLING_CASES)
+def test_sampling_region_matches_reference(dev, name, chain_waves):
+    from pstl_diffusion_policy_amd.engine import acc_from_counts
+    d, meta, sb, out = _run_region(dev, name, chain_waves)
+    N = sb.N
+    cl = out["controls_list"].reshape(meta["steps"], N, 20, 2).cpu().numpy()
+    err = np.abs(cl - d["controls_list"]).reshape(meta["steps"], -1).max(axis=1)
+    assert err.max() <= TRAJ_TOL, "per-step max |delta| of the sampled controls: %s" % err
+    np.testing.assert_allclose(out["final_controls"].reshape(N, 20, 2).cpu().numpy(), d["final_controls"], rtol=0,
+                               atol=TRAJ_TOL)
+    if "sel_idx" in d:
+        np.testing.assert_allclose(out["cand_scores"].cpu().numpy(), d["cand_scores"], rtol=5e-5, atol=1e-3)
+        # candidate choice: exact unless two candidates score within the arithmetic noise of each other
+        top2 = np.sort(d["cand_scores"], axis=0)[-2:]
+        clear = (top2[1] - top2[0]) > 1e-3
+        np.testing.assert_array_equal(out["sel_idx"].cpu().numpy()[clear], d["sel_idx"][clear])
+        np.testing.assert_allclose(out["sel_controls"].reshape(N, 20, 2).cpu().numpy()[clear], d["sel_controls"][clear],
+                                   rtol=0, atol=TRAJ_TOL)
+    for k in ["rect_controls", "roll0_controls", "roll1_controls"]:
+        if k in d:
+            np.testing.assert_allclose(out[k].reshape(N, 20, 2).cpu().numpy(), d[k], rtol=0, atol=TRAJ_TOL, err_msg=k)
+    np.testing.assert_allclose(out["final_scores"].cpu().numpy(), d["final_scores"], rtol=1e-4, atol=2e-3)
+    assert _mask_equal_outside_band(out["final_scores"].cpu().numpy(), d["final_scores"], band=1e-3) == 0
+    acc, sacc = acc_from_counts(out["counts"])
+    assert abs(acc - float(d["final_acc"])) <= 0.005 and abs(sacc - float(d["final_scene_acc"])) <= 0.005
+    assert acc == float(d["final_acc"]) and sacc == float(d["final_scene_acc"])
+
+
+def test_run_to_run_determinism(dev):
+    _, _, _, a = _run_region(dev, "e7_wide")
+    _, _, _, b = _run_region(dev, "e7_wide")
+    for k in ["controls_list", "final_controls", "final_scores", "counts", "sel_idx", "rect_controls"]:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_against_oracle_on_fresh_scenes(dev):
+    """No fixture involved: seeded scenes, weights and noise; oracle on the CPU vs HIP, e7 + guidance."""
+    from oracle import pstl_oracle as orc
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler, acc_from_counts
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    bs, S, K, steps = 6, 16, 5, 14
+    scene = make_scene_batch(bs, K=K, S=S, seed=4242, invalid_lane_frac=0.3, stlp_mode="wide")
+    sd = golden_weights()
+    g = torch.Generator().manual_seed(7)
+    N = bs * S * 3
+    x_T = torch.randn(N, 40, generator=g)
+    z = torch.randn(steps - 1, N, 40, generator=g)
+    guid = dict(enabled=True, before=3, niters=2, lr=0.01)
+    ref = orc.sampling_region(sd, {k: v.numpy() for k, v in scene.items()}, S, steps, hp, x_T, z, rect_head=True,
+                              multi_cands=5, guidance=guid, n_rolls=1)
+    sm = Sampler(PackedWeights(sd, dev), hp)
+    sb = SceneBatch(scene, S, hp, dev)
+    out = sm.sampling_region(sb, steps, x_T.to(dev), z.to(dev), rect_head=True, multi_cands=5, guidance=guid, n_rolls=1,
+                             full_list=True)
+    cl = out["controls_list"].reshape(steps, N, 20, 2).cpu()
+    assert (cl - ref["controls_list"]).abs().max().item() <= TRAJ_TOL
+    assert (out["final_controls"].reshape(N, 20, 2).cpu() - ref["final_controls"]).abs().max().item() <= TRAJ_TOL
+    np.testing.assert_allclose(out["final_scores"].cpu().numpy(), ref["final_scores"].numpy(), rtol=1e-4, atol=2e-3)
+    nband = _mask_equal_outside_band(out["final_scores"].cpu().numpy(), ref["final_scores"].numpy(), band=1e-3)
+    acc, sacc = acc_from_counts(out["counts"])
+    assert abs(acc - float(ref["final_acc"])) <= 0.005, (acc, float(ref["final_acc"]), nband)
+    assert abs(sacc - float(ref["final_scene_acc"])) <= 0.005
+
+
+def test_shard_invariance_and_outlier_rows(dev):
+    """Size-independent properties at a larger size: (a) evaluating a contiguous block of scenes alone gives exactly the
+    rows of the full evaluation (what multi-GPU sharding relies on); (b) duplicated scenes with duplicated noise give
+    duplicated results; (c) rows whose high-level index is 3 score the constant 1."""
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    bs, S, K, steps = 96, 64, 4, 6
+    scene = make_scene_batch(bs, K=K, S=S, seed=5, invalid_lane_frac=0.2, stlp_mode="wide")
+    for k in scene:                      # (b): second half duplicates the first half
+        scene[k][bs // 2:] = scene[k][:bs // 2]
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    N = bs * S * 3
+    g = torch.Generator().manual_seed(11)
+    x_T = torch.randn(N // 2, 40, generator=g).repeat(2, 1).to(dev)
+    z = torch.randn(steps - 1, N // 2, 40, generator=g).repeat(1, 2, 1).to(dev)
+    full = sm.sampling_region(SceneBatch(scene, S, hp, dev), steps, x_T, z, rect_head=True, multi_cands=3)
+    h = N // 2
+    assert torch.equal(full["final_controls"][:h], full["final_controls"][h:])
+    assert torch.equal(full["final_scores"][:h], full["final_scores"][h:])
+    lo, hi = 16, 40                      # (a): scenes [16,40) alone
+    sub = {k: v[lo:hi].clone() for k, v in scene.items()}
+    r0, r1 = lo * S * 3, hi * S * 3
+    part = sm.sampling_region(SceneBatch(sub, S, hp, dev), steps, x_T[r0:r1].contiguous(), z[:, r0:r1].contiguous(),
+                              rect_head=True, multi_cands=3)
+    assert torch.equal(part["final_controls"], full["final_controls"][r0:r1])
+    assert torch.equal(part["final_scores"], full["final_scores"][r0:r1])
+    sb = SceneBatch(sub, S, hp, dev)     # (c)
+    sb.hl = torch.full_like(sb.hl, 3.0)
+    sc = sm.score(sb, part["final_controls"].reshape(1, -1, 40), all3=True)["scores"]
+    assert torch.equal(sc, torch.ones_like(sc))

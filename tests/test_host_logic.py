@@ -1,0 +1,90 @@
+"""CPU tests of the host side: library export table vs the header, schedule, guidance trigger, metric arithmetic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, golden_meta
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from pstl_diffusion_policy_amd import build, ffi
+    build.build(verbose=False)
+    L = ffi.lib()
+    assert L.pstl_version() == 1
+    header = open(os.path.join(ROOT, "include", "pstl_hip.h")).read()
+    declared = sorted(set(re.findall(r"^(?:int|size_t|const char\*)\s+(pstl_\w+)\s*\(", header, flags=re.M)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(ffi.EXPORTS) == declared
+    assert L.pstl_packed_weight_floats() > 540952          # at least the reference parameter count
+    assert L.pstl_error_string(-2).decode().startswith("shape")
+    assert ctypes.sizeof(ffi.PstlCfg) == 64
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from pstl_diffusion_policy_amd import ffi
+    monkeypatch.setattr(ffi, "_lib", None)
+    monkeypatch.setattr(ffi, "LIB_PATH", "/nonexistent/libpstl_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ffi.lib()
+
+
+def test_null_and_bad_arguments_are_rejected_without_a_gpu():
+    from pstl_diffusion_policy_amd import ffi
+    from pstl_diffusion_policy_amd.synthetic import default_hparams
+    L = ffi.lib()
+    cfg = ffi.make_cfg(2, 24, 8, 3, 10, default_hparams())
+    null = ctypes.c_void_p(0)
+    assert L.pstl_rollout(ctypes.byref(cfg), null, null, null, null, null, null, null, null, null, 9, 1, 0, null, null, 0,
+                          null) == -1
+    assert L.pstl_stl_forward(ctypes.byref(cfg), null, null, null, 1, null, null, null, null, null, null, null, null,
+                              null, null) == -1
+    assert L.pstl_pack_weights(null, null, null) == -1
+
+
+def test_schedule_is_bit_identical_to_the_reference():
+    from pstl_diffusion_policy_amd.engine import diffusion_coeffs
+    for name in ["e5_steps10", "e5_steps100", "e7_steps50_k8"]:
+        d = load_golden(name)
+        b, a, ah = diffusion_coeffs(golden_meta(d)["steps"])
+        np.testing.assert_array_equal(b.numpy(), d["coef_beta"])
+        np.testing.assert_array_equal(a.numpy(), d["coef_alpha"])
+        np.testing.assert_array_equal(ah.numpy(), d["coef_alpha_hat"])
+
+
+def test_guidance_trigger_rule():
+    from pstl_diffusion_policy_amd.engine import guidance_triggered as trig
+    steps = 100
+    assert not trig(5, steps, None)
+    g = dict(enabled=True, before=10)
+    assert [i for i in range(1, steps) if trig(i, steps, g)] == list(range(1, 11))
+    g = dict(enabled=True, freq=25)
+    assert [i for i in range(1, steps) if trig(i, steps, g)] == [25, 50, 75]
+    g = dict(enabled=True, sets=[3, 7], before=1000)
+    assert [i for i in range(1, steps) if trig(i, steps, g)] == [3, 7]
+    g = dict(enabled=True, sets=[0, 1], reverse=True)
+    assert [i for i in range(1, steps) if trig(i, steps, g)] == [98, 99]
+    assert all(trig(i, steps, dict(enabled=True)) for i in range(1, steps))     # reference default: before=1000
+
+
+def test_metric_arithmetic_matches_mask_mean():
+    from oracle import pstl_oracle as orc
+    from pstl_diffusion_policy_amd.engine import acc_from_counts
+    g = torch.Generator().manual_seed(0)
+    bs, S = 7, 8
+    scores = torch.randn(bs * S * 3, generator=g)
+    ids = (torch.rand(bs, 3, generator=g) < 0.7).float()
+    valid = ids[:, None].repeat(1, S, 1).reshape(-1)
+    acc, sacc = orc.stl_metrics(scores, valid, S)
+    sat = ((scores > 0) & (valid > 0)).sum().item()
+    cube = scores.reshape(bs, S, 3)
+    ssat = (((cube.max(dim=1)[0] > 0)) & (ids > 0)).sum().item()
+    counts = torch.tensor([sat, int(valid.sum()), bs * S * 3, ssat, int(ids.sum()), bs * 3, 0, 0])
+    a, s = acc_from_counts(counts)
+    assert a == float(acc) and s == float(scene_acc) if False else True
+    assert a == float(acc) and s == float(sacc)

@@ -1,0 +1,135 @@
+"""The per-row STL arithmetic the HIP kernels run (csrc/stl_core.hpp), compiled for the CPU with g++ and checked
+against the golden vectors and the oracle's autograd gradients.  CPU-only: validates the closed-form restatement
+(running log-sum-exp, hand-written adjoint) before it ever reaches a GPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, STL_CASES, SAMPLING_CASES, load_golden, scene_from_golden, golden_meta
+from oracle import pstl_oracle as orc
+from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+
+HS_DIR = os.path.join(ROOT, "tests", "hostsim")
+F = ctypes.POINTER(ctypes.c_float)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(F)
+
+
+@pytest.fixture(scope="module")
+def hs():
+    so = os.path.join(HS_DIR, "libpstl_hostsim.so")
+    src = os.path.join(HS_DIR, "hostsim.cpp")
+    core = os.path.join(ROOT, "pstl_diffusion_policy_amd", "csrc", "stl_core.hpp")
+    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core)):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                               "-Wno-unknown-pragmas", src, "-o", so])
+    return ctypes.CDLL(so)
+
+
+class HostRows:
+    def __init__(self, hs, scene, S, hp):
+        self.hs, self.hp, self.S = hs, hp, S
+        f = lambda k: np.ascontiguousarray(np.asarray(scene[k], dtype=np.float32))
+        nei = f("neighbors_traj")
+        self.bs, self.K = nei.shape[0], nei.shape[1]
+        self.nei_prep = np.zeros((self.bs, self.K, 20, 12), np.float32)
+        self.lane_prep = np.zeros((self.bs, 3, 15, 4), np.float32)
+        hs.hostsim_prepare(self.bs, self.K, _ptr(nei), _ptr(f("currlane_wpts")), _ptr(f("leftlane_wpts")),
+                           _ptr(f("rightlane_wpts")), _ptr(self.nei_prep), _ptr(self.lane_prep))
+        self.s0 = np.ascontiguousarray(f("ego_traj")[:, 0, :4])
+        self.N = self.bs * 3 * S
+        sm = f("stlp_modes")
+        self.stlp = np.ascontiguousarray(np.repeat(sm[:, None], S, axis=1).reshape(self.N, 6))
+        self.hl = np.tile(np.array([0, 1, 2], np.float32), self.bs * S)
+
+    def forward(self, controls, all3=True):
+        c = np.ascontiguousarray(controls.reshape(self.N, 40), dtype=np.float32)
+        scores = np.zeros(self.N, np.float32)
+        s3 = np.zeros((3, self.N), np.float32)
+        hp = self.hp
+        self.hs.hostsim_stl_forward(self.N, 3 * self.S, self.K, ctypes.c_float(hp["smoothing_factor"]),
+                                    ctypes.c_float(hp["dt"]), ctypes.c_float(hp["ego_L"]), ctypes.c_float(hp["ego_W"]),
+                                    _ptr(self.s0), _ptr(c), _ptr(self.nei_prep), _ptr(self.lane_prep), _ptr(self.stlp),
+                                    _ptr(self.hl), int(all3), _ptr(scores), _ptr(s3))
+        return scores, s3
+
+    def grad(self, controls, wscale=1.0, ascale=1.0, dscore=None, relu=False, thres=0.0, gscale=0.0, valid=None):
+        c = np.ascontiguousarray(controls.reshape(self.N, 40), dtype=np.float32)
+        scores = np.zeros(self.N, np.float32)
+        g = np.zeros((self.N, 40), np.float32)
+        hp = self.hp
+        self.hs.hostsim_stl_grad(self.N, 3 * self.S, self.K, ctypes.c_float(hp["smoothing_factor"]),
+                                 ctypes.c_float(hp["dt"]), ctypes.c_float(hp["ego_L"]), ctypes.c_float(hp["ego_W"]),
+                                 _ptr(self.s0), _ptr(c), ctypes.c_float(wscale), ctypes.c_float(ascale),
+                                 _ptr(self.nei_prep), _ptr(self.lane_prep), _ptr(self.stlp), _ptr(self.hl),
+                                 _ptr(dscore), int(relu), ctypes.c_float(thres), ctypes.c_float(gscale), _ptr(valid),
+                                 _ptr(scores), _ptr(g))
+        return scores, g
+
+
+@pytest.mark.parametrize("name", STL_CASES)
+def test_scores_match_reference_golden(hs, name):
+    d = load_golden(name)
+    bs, S, K, seed = [int(v) for v in d["meta"]]
+    rows = HostRows(hs, scene_from_golden(d), S, default_hparams())
+    scores, s3 = rows.forward(d["controls"], all3=True)
+    np.testing.assert_allclose(s3, d["scores3"], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(scores, d["scores"], rtol=2e-5, atol=2e-4)
+    np.testing.assert_array_equal(scores > 0, d["scores"] > 0)            # satisfaction mask: exact
+    sel, _ = rows.forward(d["controls"], all3=False)
+    np.testing.assert_array_equal(sel, scores)                             # selected-formula path is the same arithmetic
+
+
+@pytest.mark.parametrize("name", ["e7_wide", "e7_steps50_k8", "e7_steps12"])
+def test_final_scores_of_sampling_goldens(hs, name):
+    d = load_golden(name)
+    meta = golden_meta(d)
+    rows = HostRows(hs, scene_from_golden(d), meta["S"], default_hparams())
+    scores, s3 = rows.forward(d["final_controls"], all3=True)
+    np.testing.assert_allclose(s3, d["final_scores3"], rtol=5e-5, atol=5e-4)
+    np.testing.assert_array_equal(scores > 0, d["final_scores"] > 0)
+
+
+@pytest.mark.parametrize("name", STL_CASES)
+def test_adjoint_matches_reference_autograd(hs, name):
+    d = load_golden(name)
+    bs, S, K, seed = [int(v) for v in d["meta"]]
+    hp = default_hparams()
+    rows = HostRows(hs, scene_from_golden(d), S, hp)
+    scores, g = rows.grad(d["controls"])
+    ref = d["grad_sum"].reshape(-1, 40)
+    scale = np.abs(ref).max(axis=1, keepdims=True) + 1e-20
+    np.testing.assert_allclose(g / scale, ref / scale, rtol=2e-3, atol=2e-4)
+    # guidance-loss gradient: mask_mean(relu(thres - score), valid)
+    valid = d["in_valids_dense"].reshape(-1).astype(np.float32)
+    N = valid.shape[0]
+    gscale = np.float32(np.float32(1.0) / np.float32(max(valid.mean(dtype=np.float32), np.float32(1e-2)))) / np.float32(N)
+    _, gl = rows.grad(d["controls"], relu=True, thres=hp["stl_nn_thres"], gscale=float(gscale), valid=valid)
+    refl = d["grad_loss"].reshape(-1, 40)
+    scale = np.abs(refl).max() + 1e-30
+    np.testing.assert_allclose(gl / scale, refl / scale, rtol=2e-3, atol=2e-5)
+
+
+def test_adjoint_vs_oracle_autograd_on_fresh_scenes(hs):
+    """Independent of the fixtures: random scenes, guidance-style scaled inputs (mu * (w_max, a_max))."""
+    hp = default_hparams()
+    S = 4
+    scene = {k: v.numpy() for k, v in make_scene_batch(5, K=5, S=S, seed=99, invalid_lane_frac=0.3).items()}
+    orows = orc.Rows(scene, S, hp)
+    g = torch.Generator().manual_seed(3)
+    mu = (torch.randn(orows.N, 20, 2, generator=g) * 0.05).requires_grad_()
+    scale = torch.tensor([hp["mul_w_max"], hp["mul_a_max"]])
+    _, score, _ = orows.score(mu * scale)
+    gref, = torch.autograd.grad(score.sum(), mu)
+    rows = HostRows(hs, scene, S, hp)
+    sc, gmine = rows.grad(mu.detach().numpy(), wscale=hp["mul_w_max"], ascale=hp["mul_a_max"])
+    np.testing.assert_allclose(sc, score.detach().numpy(), rtol=2e-5, atol=2e-4)
+    ref = gref.numpy().reshape(-1, 40)
+    sc_ = np.abs(ref).max(axis=1, keepdims=True) + 1e-20
+    np.testing.assert_allclose(gmine / sc_, ref / sc_, rtol=2e-3, atol=2e-4)
