@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the DDPM-sampling + STL hot path on MI355X (contract: see the round prompt).
+
+A "step" is one pass of the timed region of the reference's sampling harness (nusc_train.py:957-1105) over one
+synthetic batch already resident in HBM: row constants, scene preparation, scene encoder, noise generation,
+`diffusion_steps-1` denoiser evaluations (+ STL guidance on the last `guidance_before` steps), candidate scoring +
+selection, RefineNet, final STL scoring and the satisfaction counts (+ one RCCL all-gather of 8 counters when N > 1).
+Unit: sampled trajectories per second = rows (scenes x sampling_size x 3 modes) / wall time, whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_STEP_MIN = 2 * (40 * 256 + 256 * 256 + 256 * 40)   # algorithmic FLOP per row per denoiser evaluation
+PEAK_FP32_MATRIX_TFLOPS = 157.3                       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--workload", default="e7_guid", choices=["e5", "e7", "e7_guid"])
+    p.add_argument("--scenes", type=int, default=4096, help="scenes per GPU (weak scaling)")
+    p.add_argument("--sampling_size", type=int, default=64)
+    p.add_argument("--neighbors", type=int, default=2)
+    p.add_argument("--diffusion_steps", type=int, default=50)
+    p.add_argument("--multi_cands", type=int, default=5)
+    p.add_argument("--chain_waves", type=int, default=0)
+    p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--cpu_scenes", type=int, default=24)
+    return p.parse_args()
+
+
+def cpu_baseline(a, hp, sd, guidance, rect_head):
+    """The CPU oracle (a float32 torch restatement of the reference path; the reference itself cannot travel to the
+    GPU box) timed on the host cores on a bounded sample of the same workload."""
+    from oracle import pstl_oracle as orc
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    bs, S, steps = a.cpu_scenes, a.sampling_size, a.diffusion_steps
+    scene = {k: v.numpy() for k, v in make_scene_batch(bs, K=a.neighbors, S=S, seed=77, stlp_mode="wide").items()}
+    N = bs * S * 3
+    g = torch.Generator().manual_seed(5)
+    sdn = {k: v.cpu().numpy() for k, v in sd.items()}
+    t0 = time.time()
+    x_T = torch.randn(N, 40, generator=g)
+    z = torch.randn(steps - 1, N, 40, generator=g)
+    orc.sampling_region(sdn, scene, S, steps, hp, x_T, z, rect_head=rect_head,
+                        multi_cands=a.multi_cands if rect_head else None, guidance=guidance)
+    dt = time.time() - t0
+    return {"value": N / dt, "unit": "trajectories/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%s, %d scenes x %d samples x 3 modes = %d rows, %d diffusion steps, K=%d, %.1f s, torch %s CPU"
+                      % (a.workload, bs, S, N, steps, a.neighbors, dt, torch.__version__)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from pstl_diffusion_policy_amd.engine import (PackedWeights, SceneBatch, Sampler, acc_from_counts,
+                                                  diffusion_coeffs)
+    from pstl_diffusion_policy_amd.nusc_model import init_state_dict
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+
+    hp = default_hparams()
+    rect_head = a.workload != "e5"
+    guidance = dict(enabled=True, before=10, niters=1, lr=0.01) if a.workload == "e7_guid" else None
+    sd = init_state_dict(1007)     # random init as in the reference under seed 1007 (no checkpoints offline)
+    S, steps, bs = a.sampling_size, a.diffusion_steps, a.scenes
+    # every rank owns its own contiguous block of scenes (seeded by the global scene offset); no data-path collective
+    scene = make_scene_batch(bs, K=a.neighbors, S=S, seed=1000 + rank, invalid_lane_frac=0.2, stlp_mode="wide")
+    scene = {k: v.to(dev) for k, v in scene.items() if k not in ("params", "pre_stlp", "tj_scores_prior")}
+    sampler = Sampler(PackedWeights(sd, dev), hp, chain_waves=a.chain_waves)
+    coeffs = diffusion_coeffs(steps, dev)
+    N = bs * S * 3
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    gathered = [torch.zeros(8, dtype=torch.int64, device=dev) for _ in range(world)]
+    vstat = torch.zeros(2, dtype=torch.float64, device=dev)
+
+    def one_step():
+        # global mean(valid) of the guidance loss (one tiny all-reduce; the shard split must not change results)
+        ids = torch.stack([scene["curr_id"], scene["left_id"], scene["right_id"]]).sum()
+        vstat[0], vstat[1] = ids * S, float(N)
+        if world > 1:
+            dist.all_reduce(vstat)
+        vs = vstat.tolist()
+        sb = SceneBatch(scene, S, hp, dev, global_valid_sum=vs[0], global_rows=int(vs[1]))
+        x_T = torch.randn(N, 40, device=dev, generator=gen)
+        z = torch.randn(steps - 1, N, 40, device=dev, generator=gen)
+        out = sampler.sampling_region(sb, steps, x_T, z, rect_head=rect_head,
+                                      multi_cands=a.multi_cands if rect_head else None, guidance=guidance, coeffs=coeffs)
+        if world > 1:   # the only exchange of the path: 8 counters per rank (RCCL all-gather over xGMI)
+            dist.all_gather(gathered, out["counts"])
+            return torch.stack(gathered).sum(dim=0)
+        return out["counts"]
+
+    for _ in range(a.warmup):
+        counts = one_step()
+    sampler.trace = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        counts = one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # dominant kernel (k_chain, the multi-step denoiser launch): HIP events on the launch stream
+    ms = [e0.elapsed_time(e1) for (e0, e1, _, _) in sampler.trace]
+    nst, nrows = sampler.trace[0][2], sampler.trace[0][3]
+    k_ms = float(np.mean(ms))
+    flop = float(nrows) * nst * F_STEP_MIN
+    achieved = flop / (k_ms * 1e-3) / 1e12
+    acc, sacc = acc_from_counts(counts)
+    line = None
+    if rank == 0:
+        line = {
+            "metric": "sampled trajectories/sec (%d DDPM steps, multi_cands=%d) + STL-sat rate" % (steps, a.multi_cands),
+            "value": world * N * a.steps / dt, "unit": "trajectories/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d scenes/GPU x sampling_size %d x 3 modes = %d rows/GPU, T=20, K=%d neighbours, "
+                                   "diffusion_steps=%d (%d denoiser evals), multi_cands=%s, guidance=%s, RefineNet=%s, "
+                                   "random-init weights (seed 1007)"
+                                   % (a.workload, bs, S, N, a.neighbors, steps, steps - 1,
+                                      a.multi_cands if rect_head else None,
+                                      "before=10,niters=1,lr=0.01" if guidance else None, rect_head),
+                       "rows_per_gpu": N, "parallelism": "scene shards x%d, no data-path collective" % world,
+                       "chain_waves": a.chain_waves or 8},
+            "stl_sat_rate": acc, "scene_sat_rate": sacc,
+            "roofline": {"bound": "mfma", "kernel": "k_chain (denoiser MLP chain, %d reverse steps per launch)" % nst,
+                         "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "kernel_ms": k_ms, "flop_per_launch": flop,
+                         "note": "algorithmic FLOP = rows x steps x 172032 (hoisted layer-1 columns not counted)"},
+        }
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a, hp, sd, guidance, rect_head)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,8 +113,9 @@ int pstl_encode_scene(const pstl_cfg* cfg, const float* packed, const float* ego
 /* Runs reverse steps i = step_hi ... step_lo (step_hi >= step_lo >= 1) of diffusion_rollout (nusc_train.py:568-630)
  * for all N rows in ONE launch:  eps = policy_net(...) + x ; mu = (x - (1-a_i)/sqrt(1-ah_i) eps)/sqrt(a_i) ;
  * x <- mu + sqrt(b_i) z.   noise (steps-1, N, 40): noise[k] is used at step i = steps-1-k and ignored at i == 1
- * (the reference draws zeros there).  If mu_only != 0 (requires step_hi == step_lo) x_inout receives mu and no
- * noise is added (the guidance kernel finishes the step).
+ * (the reference draws zeros there).  mu_only (requires step_hi == step_lo): 1 = x_inout receives mu and no noise
+ * is added (the guidance kernel finishes the step); 2 = x_inout receives the predicted noise eps itself, i.e. one
+ * Net.forward evaluation (nusc_model.py:159-162).
  * emit: for every step with i <= n_emit the new state, normalised (x * (w_max,a_max), clipped iff PSTL_FLAG_CLIP), is
  * written to emit_out[n_emit - i] (N,40) -- i.e. the last n_emit entries of the reference's diff_full list
  * (nusc_train.py:633-634); n_emit may be 0. */

@@ -313,6 +313,7 @@ template <int NW, bool REFINE>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   constexpr int OT = 16 / NW;       // 16-feature output tiles per wave
   constexpr int NT = NW * 64;
+  constexpr int NE = (kTileRows * kCtrl + NT - 1) / NT;  // epilogue elements per thread
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                          // [kG][3][64][4]
   float* h1 = xs + kG * 768;                // [16][64][4]
@@ -429,10 +430,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       }
       __syncthreads();
       // prefetch this tile's noise so that the HBM latency hides behind layer 2
-      float zreg[2] = {0.0f, 0.0f};
+      float zreg[NE];
+#pragma unroll
+      for (int u = 0; u < NE; ++u) zreg[u] = 0.0f;
       if (zsrc) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NE; ++u) {
           const int e = tid + u * NT;
           if (e < kTileRows * kCtrl) {
             const long row = row0 + e / kCtrl;
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       __syncthreads();
       // ---------------- epilogue: reduce the NW partial sums, then the DDPM update / the interval head -----
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < NE; ++u) {
         const int e = tid + u * NT;
         if (e < kTileRows * kCtrl) {
           const int c = e / kCtrl, f = e % kCtrl;
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
             const float x = xs[xa];
             const float eps = o + x;
             const float mu = inv_sa * (x - c1 * eps);
-            const float xn = a.mu_only ? mu : mu + sbeta * zreg[u];
+            const float xn = a.mu_only == 2 ? eps : a.mu_only ? mu : mu + sbeta * zreg[u];
             xs[xa] = xn;
             if (row < a.N) {
               if (i == s_lo) a.x_inout[row * kCtrl + f] = xn;

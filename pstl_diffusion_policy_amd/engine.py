@@ -127,6 +127,9 @@ class Sampler:
     def __init__(self, weights, hp, chain_waves=0):
         self.w, self.hp, self.chain_waves = weights, hp, int(chain_waves)
         self.L = ffi.lib()
+        # when set to a list, every multi-step rollout launch appends (start_event, end_event, n_steps, n_rows):
+        # HIP events recorded on the launch stream, used by bench.py to time the dominant kernel live
+        self.trace = None
 
     # ---- A1 ----
     def encode(self, sb, need_rect=True):
@@ -163,6 +166,16 @@ class Sampler:
             work = torch.empty(3, sb.N, ffi.CTRL, dtype=torch.float32, device=dev) if nit > 1 else None
 
         def plain(hi, lo, mu_only=0):
+            ev = None
+            if self.trace is not None and hi > lo:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            _launch(hi, lo, mu_only)
+            if ev is not None:
+                ev[1].record()
+                self.trace.append((ev[0], ev[1], hi - lo + 1, sb.N))
+
+        def _launch(hi, lo, mu_only):
             ffi.check(self.L.pstl_rollout(ctypes.byref(cfg), ffi.ptr(self.w.packed), ffi.ptr(base_policy), ffi.ptr(tb),
                                           ffi.ptr(sb.stlp), ffi.ptr(sb.hl), ffi.ptr(beta), ffi.ptr(alpha),
                                           ffi.ptr(alpha_hat), ffi.ptr(noise), int(hi), int(lo), int(mu_only),

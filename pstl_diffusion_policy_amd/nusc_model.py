@@ -1,0 +1,188 @@
+"""Host-side mirror of the reference model surface for the hot path (reference: nusc_model.py).
+
+`Net` keeps the reference constructor, sub-module names and therefore `state_dict()` keys
+({ego,neighbor,lane}_encoder / policy_net / merge_net / rect_net .{0,2,4}.{weight,bias}), so reference checkpoints
+load unchanged (`load_state_dict(torch.load(...), strict=not args.rect_head)`, reference nusc_train.py:1215).
+The torch modules only HOLD the parameters; `encode_feat`, `forward` (diffusion branch) and `rect_forward` run the
+HIP kernels of libpstl_hip.so.  Inference only (the reference runs this path under no_grad / net.eval()).
+
+Scope: the diffusion branch (`--diffusion`, multi-sample rows).  The VAE / BC / gt_data_training branches of the
+reference Net.forward (nusc_model.py:128-154) are baselines outside the hot path and raise NotImplementedError.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import ffi
+from .engine import PackedWeights
+
+
+def build_relu_nn(input_dim, output_dim, hiddens):
+    """Linear -> ReLU -> ... -> Linear, same layer indices as the reference builder (utils.py:91-101)."""
+    dims = [input_dim] + list(hiddens) + [output_dim]
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2:
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+class SceneFeature(torch.Tensor):
+    """The (N,224) feature tensor the reference passes around, carrying the per-scene layer-1 partials the kernels use."""
+    @staticmethod
+    def wrap(dense, feature_scene, base_policy, base_rect, rows_per_scene):
+        t = dense.as_subclass(SceneFeature)
+        t.pstl = dict(feature_scene=feature_scene, base_policy=base_policy, base_rect=base_rect,
+                      rows_per_scene=rows_per_scene)
+        return t
+
+
+class Net(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        if not getattr(args, "diffusion", False):
+            raise NotImplementedError("only the --diffusion model family is on the MI355X hot path")
+        if list(args.hiddens) != [256, 256] or args.nt != 20 or args.n_segs != 15:
+            raise NotImplementedError("libpstl_hip is specialised for hiddens=[256,256], nt=20, n_segs=15")
+        self.output_dim = args.nt * 2
+        self.feat_dim = feat_dim = 32
+        self.stlp_dim = stlp_dim = 6
+        self.time_dim = 32
+        self.ego_encoder = build_relu_nn(6, feat_dim, args.hiddens)
+        self.neighbor_encoder = build_relu_nn(7, feat_dim, args.hiddens)
+        self.lane_encoder = build_relu_nn(args.n_segs * 3, feat_dim, args.hiddens)
+        latent_dim = args.nt * 2 + self.time_dim + 1 + stlp_dim
+        if getattr(args, "use_init_hint", False):
+            raise NotImplementedError("--use_init_hint is a VAE/BC baseline option")
+        self.policy_net = build_relu_nn(latent_dim + feat_dim * 7, args.nt * 2, args.hiddens)
+        if getattr(args, "rect_head", False):
+            if getattr(args, "diverse_loss", False):
+                if not getattr(args, "no_arch", False) and getattr(args, "diverse_fuse_type", "add") != "add":
+                    raise NotImplementedError("only diverse_fuse_type='add' (the reference default)")
+                self.merge_net = build_relu_nn(args.nt * 2, args.nt * 2, [32, 32])
+            if list(getattr(args, "rect_hiddens", [256, 256])) != [256, 256]:
+                raise NotImplementedError("rect_hiddens must be [256,256]")
+            self.rect_net = build_relu_nn(latent_dim - self.time_dim + feat_dim * 7, args.nt * 2, [256, 256])
+        self._packed = None
+        self._packed_key = None
+
+    # ---- kernel-layout weights, re-packed whenever a parameter changed (load_state_dict, optimiser step) ----
+    def packed(self):
+        ps = list(self.parameters())
+        key = (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
+        if self._packed is None or key != self._packed_key:
+            if not ps[0].is_cuda:
+                raise RuntimeError("Net must be on the GPU (net.cuda()) before the HIP path can run")
+            self._packed = PackedWeights({k: v for k, v in self.state_dict().items()}, ps[0].device)
+            self._packed_key = key
+        return self._packed
+
+    def hparams(self):
+        a = self.args
+        return dict(nt=a.nt, dt=a.dt, mul_w_max=a.mul_w_max, mul_a_max=a.mul_a_max,
+                    smoothing_factor=a.smoothing_factor, stl_nn_thres=a.stl_nn_thres, ego_L=a.ego_L, ego_W=a.ego_W,
+                    refined_nL=a.refined_nL, refined_nW=a.refined_nW, n_segs=a.n_segs, n_shards=a.n_shards)
+
+    def _encode(self, nn_input):
+        pw = self.packed()
+        dev = pw.device
+        ego0 = ffi.f32(nn_input["ego_traj"][:, 0], dev)
+        bs = ego0.shape[0]
+        nei = ffi.f32(nn_input["neighbors"], dev)
+        lanes = [ffi.f32(nn_input["%slane_wpts" % k], dev) for k in ("curr", "left", "right")]
+        ids = [ffi.f32(nn_input["%s_id" % k].reshape(bs), dev) for k in ("curr", "left", "right")]
+        feature = torch.empty(bs, ffi.FEAT, dtype=torch.float32, device=dev)
+        base_p = torch.empty(bs, ffi.HID, dtype=torch.float32, device=dev)
+        base_r = torch.empty(bs, ffi.HID, dtype=torch.float32, device=dev) if pw.has_rect else None
+        cfg = ffi.make_cfg(bs, 1, 1, nei.shape[1], 2, self.hparams())
+        ffi.check(ffi.lib().pstl_encode_scene(ctypes.byref(cfg), ffi.ptr(pw.packed), ffi.ptr(ego0), ffi.ptr(nei),
+                                              ffi.ptr(lanes[0]), ffi.ptr(lanes[1]), ffi.ptr(lanes[2]), ffi.ptr(ids[0]),
+                                              ffi.ptr(ids[1]), ffi.ptr(ids[2]), ffi.ptr(feature), ffi.ptr(base_p),
+                                              ffi.ptr(base_r), ffi.stream()), "encode_scene")
+        return feature, base_p, base_r
+
+    def encode_feat(self, nn_input, ext=None):
+        """(bs,224) scene feature (reference nusc_model.py:55-95)."""
+        return self._encode(nn_input)[0]
+
+    def scene_feature(self, nn_input, n_rep):
+        """Dense (bs*n_rep,224) feature as the reference returns it (nusc_model.py:104-110), tagged with the per-scene
+        layer-1 partials so that later calls do not recompute or re-read it."""
+        f, bp, br = self._encode(nn_input)
+        bs, k = f.shape
+        dense = f.reshape(bs, 1, k).expand(bs, n_rep, k).reshape(-1, k)
+        return SceneFeature.wrap(dense, f, bp, br, n_rep)
+
+    def _bases_of(self, feature, nn_input=None):
+        if isinstance(feature, SceneFeature) and hasattr(feature, "pstl"):
+            return feature.pstl
+        raise ValueError("pass the feature object returned by this Net (forward(get_feature=True) / scene_feature)")
+
+    def forward(self, nn_input, ext=None, get_feature=False, prev_feature=None, sample=False, n_randoms=None):
+        """One denoiser evaluation: predicted noise (N,nt,2) = policy_net([feature|x|pe(t)|hl|stlp]) + x
+        (reference nusc_model.py:97-180, diffusion branch with multi-sample rows)."""
+        a = self.args
+        if getattr(a, "gt_data_training", False):
+            raise NotImplementedError("gt_data_training (e4_ddpm_mono) rows are outside the hot path")
+        if n_randoms is None:
+            n_randoms = a.n_randoms
+        feature = prev_feature if prev_feature is not None else self.scene_feature(nn_input, n_randoms * 3)
+        info = self._bases_of(feature)
+        pw = self.packed()
+        dev = pw.device
+        x = ffi.f32(ext["noise"], dev).clone()
+        N = x.shape[0]
+        t = int(ext["timestep"].reshape(-1)[0].item())
+        steps = max(int(a.diffusion_steps), t + 1)
+        stlp = ffi.f32(nn_input["stlp_dense"][:, 0], dev)
+        hl = ffi.f32(ext["highlevel"].reshape(N), dev)
+        rps = info["rows_per_scene"]
+        cfg = ffi.make_cfg(N // rps, rps, max(rps // 3, 1), 1, steps, self.hparams())
+        from .engine import diffusion_coeffs
+        beta, alpha, alpha_hat = diffusion_coeffs(steps, dev)
+        ffi.check(ffi.lib().pstl_rollout(ctypes.byref(cfg), ffi.ptr(pw.packed), ffi.ptr(info["base_policy"]),
+                                         ffi.ptr(pw.tbias(steps)), ffi.ptr(stlp), ffi.ptr(hl), ffi.ptr(beta),
+                                         ffi.ptr(alpha), ffi.ptr(alpha_hat), ffi.ptr(None), t, t, 2, ffi.ptr(x),
+                                         ffi.ptr(None), 0, ffi.stream()), "rollout(eps)")
+        controls = x.reshape(N, a.nt, 2)
+        return (controls, feature) if get_feature else controls
+
+    def rect_forward(self, feature, highlevel, stlp_dense_feat, init_controls, scores, extras=None):
+        """RefineNet head (reference nusc_model.py:182-235) with --interval (forced on by --rect_head)."""
+        a = self.args
+        info = self._bases_of(feature)
+        pw = self.packed()
+        dev = pw.device
+        N = init_controls.shape[0]
+        rps = info["rows_per_scene"]
+        diverse = bool(getattr(a, "diverse_loss", False)) and not getattr(a, "no_arch", False)
+        flags = (0 if diverse else ffi.PSTL_FLAG_NO_MERGE) | (ffi.PSTL_FLAG_CLIP_RECT if getattr(a, "clip_rect", False) else 0)
+        cfg = ffi.make_cfg(N // rps, rps, rps // 3, 1, 2, self.hparams(), flags)
+        if diverse and rps // 3 != a.n_randoms:
+            raise ValueError("merge_net pooling needs sampling_size == n_randoms (reference nusc_model.py:187-196)")
+        init = ffi.f32(init_controls.reshape(N, -1), dev)
+        pooled = torch.empty(N // rps, 3, cfg.n_shards, ffi.CTRL, dtype=torch.float32, device=dev) if diverse else None
+        out = torch.empty(N, ffi.CTRL, dtype=torch.float32, device=dev)
+        ffi.check(ffi.lib().pstl_refine(ctypes.byref(cfg), ffi.ptr(pw.packed), ffi.ptr(info["base_rect"]),
+                                        ffi.ptr(ffi.f32(stlp_dense_feat, dev)), ffi.ptr(ffi.f32(highlevel.reshape(N), dev)),
+                                        ffi.ptr(init), ffi.ptr(ffi.f32(scores.reshape(N), dev)), ffi.ptr(pooled),
+                                        ffi.ptr(out), ffi.stream()), "refine")
+        return out.reshape(N, a.nt, 2)
+
+
+def init_state_dict(seed=1007, rect_head=True, diverse_loss=True):
+    """Random-init weights exactly as `torch.manual_seed(seed); Net(args)` gives them in the reference (same layer
+    construction order, hence the same RNG consumption).  Used for synthetic benchmarks: real checkpoints are not
+    available offline."""
+    import types
+    args = types.SimpleNamespace(diffusion=True, hiddens=[256, 256], nt=20, n_segs=15, rect_head=rect_head,
+                                 diverse_loss=diverse_loss, no_arch=False, diverse_fuse_type="add",
+                                 rect_hiddens=[256, 256], use_init_hint=False)
+    rng = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    net = Net(args)
+    torch.random.set_rng_state(rng)
+    return {k: v.detach().clone() for k, v in net.state_dict().items()}
