@@ -91,25 +91,19 @@ def main():
     coeffs = diffusion_coeffs(steps, dev)
     N = bs * S * 3
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    gathered = [torch.zeros(8, dtype=torch.int64, device=dev) for _ in range(world)]
-    vstat = torch.zeros(2, dtype=torch.float64, device=dev)
+    from pstl_diffusion_policy_amd.shard import gather_counts, global_valid_stats
 
     def one_step():
         # global mean(valid) of the guidance loss (one tiny all-reduce; the shard split must not change results)
-        ids = torch.stack([scene["curr_id"], scene["left_id"], scene["right_id"]]).sum()
-        vstat[0], vstat[1] = ids * S, float(N)
-        if world > 1:
-            dist.all_reduce(vstat)
-        vs = vstat.tolist()
-        sb = SceneBatch(scene, S, hp, dev, global_valid_sum=vs[0], global_rows=int(vs[1]))
+        ids = torch.stack([scene["curr_id"], scene["left_id"], scene["right_id"]]).sum().item()
+        vsum, vrows = global_valid_stats(ids * S, N, dev)
+        sb = SceneBatch(scene, S, hp, dev, global_valid_sum=vsum, global_rows=vrows)
         x_T = torch.randn(N, 40, device=dev, generator=gen)
         z = torch.randn(steps - 1, N, 40, device=dev, generator=gen)
         out = sampler.sampling_region(sb, steps, x_T, z, rect_head=rect_head,
                                       multi_cands=a.multi_cands if rect_head else None, guidance=guidance, coeffs=coeffs)
-        if world > 1:   # the only exchange of the path: 8 counters per rank (RCCL all-gather over xGMI)
-            dist.all_gather(gathered, out["counts"])
-            return torch.stack(gathered).sum(dim=0)
-        return out["counts"]
+        # the only exchange after the rollout: 8 counters per rank (RCCL all-gather over xGMI when N > 1)
+        return gather_counts(out["counts"])
 
     for _ in range(a.warmup):
         counts = one_step()

@@ -1,0 +1,522 @@
+"""Host-side mirror of the reference's sampling surface (reference: nusc_train.py), calling libpstl_hip.so.
+
+Same function names, argument meaning and return structure as the reference for the hot path:
+  generate_parser (:1635) . get_diffusion_coeffs (:528) . dup (:20) . mask_mean (:23) . generate_trajs (:39) .
+  build_stl_cache (:95) . augment_batch_data (:724) . pre_prepare_stl_cache (:258) . compute_stl_dense (:318) .
+  diffusion_rollout (:557) . normalize_diff (:647) . run_sampling_test (:890) . main (:1185)
+and the same CLI flags (--diffusion --guidance* --run_sampling_test --multi_cands --rect_head --no_refinenet
+--diffusion_steps --sampling_size --n_rolls --time_profile ...), including the reference's post-parse overrides.
+
+Differences that are deliberate:
+  * batches carry a scene-indexed side channel (`batch["_pstl"]`, an engine.SceneBatch) so that nothing is replicated
+    per row; the reference's dense keys (`neighbors_dense`, ...) are only materialised with `dense=True`.
+    `compute_stl_dense` also accepts a purely dense `stl_input` (rows_per_scene = 1) as the reference passes it.
+  * data comes from the seeded synthetic scene generator (synthetic.py): the nuScenes cache / devkit are out of scope.
+  * metrics that the reference computes on the CPU after its timer stops (diversity std / hull volume / entropy,
+    ADE/FDE) are outside this path and printed as nan.
+"""
+import argparse
+import ctypes
+import time
+
+import numpy as np
+import torch
+
+from . import ffi
+from .engine import Sampler, SceneBatch, acc_from_counts, diffusion_coeffs
+from .nusc_model import Net
+from .synthetic import make_scene_batch
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# small helpers with the reference's names
+# ---------------------------------------------------------------------------------------------------------------
+def dup(x, m):
+    """(N, ...) -> (N*m, ...), each row repeated m times contiguously."""
+    return x.unsqueeze(1).repeat((1, m) + tuple(1 for _ in x.shape[1:])).reshape((-1,) + x.shape[1:])
+
+
+def mask_mean(loss, mask, dim=None):
+    if dim is not None:
+        return torch.mean(loss * mask, dim=dim) / torch.clip(torch.mean(mask, dim=dim), 1e-2)
+    return torch.mean(loss * mask) / torch.clip(torch.mean(mask), 1e-2)
+
+
+def get_diffusion_coeffs(args):
+    """(beta, alpha, alpha_hat) on the GPU; cosine schedule (the reference forces --cos on, nusc_train.py:1782)."""
+    if not getattr(args, "cos", True):
+        raise NotImplementedError("the reference forces the cosine schedule (nusc_train.py:1782)")
+    return diffusion_coeffs(args.diffusion_steps, torch.device("cuda"))
+
+
+def normalize_diff(x, n, nt, w_max, a_max, clip):
+    x = x.reshape(n, nt, 2)
+    w = x[..., 0] * w_max
+    a = x[..., 1] * a_max
+    if clip:
+        w = torch.clip(w, -w_max, w_max)
+        a = torch.clip(a, -a_max, a_max)
+    return torch.stack([w, a], dim=-1)
+
+
+def _hp(args):
+    return dict(nt=args.nt, dt=args.dt, mul_w_max=args.mul_w_max, mul_a_max=args.mul_a_max,
+                smoothing_factor=args.smoothing_factor, stl_nn_thres=args.stl_nn_thres, ego_L=args.ego_L,
+                ego_W=args.ego_W, refined_nL=args.refined_nL, refined_nW=args.refined_nW, n_segs=args.n_segs,
+                n_shards=args.n_shards)
+
+
+def generate_trajs(s, us, dt):
+    """(..., 4) x (..., T, 2) -> (..., T+1, 4): unicycle Euler rollout on the GPU (one row per lane)."""
+    assert s.shape[-1] == 4 and us.shape[-1] == 2 and us.shape[:-2] == s.shape[:-1]
+    assert us.shape[-2] == ffi.T, "libpstl_hip is specialised for nt = 20"
+    lead = us.shape[:-2]
+    dev = us.device
+    s0 = ffi.f32(s.reshape(-1, 4), dev)
+    u = ffi.f32(us.reshape(-1, ffi.CTRL), dev)
+    R = u.shape[0]
+    out = torch.empty(R, ffi.T + 1, 4, dtype=torch.float32, device=dev)
+    hp = dict(smoothing_factor=1.0, stl_nn_thres=0.0, mul_w_max=1.0, mul_a_max=1.0, dt=float(dt), ego_L=1.0, ego_W=1.0)
+    cfg = ffi.make_cfg(R, 1, 1, 0, 2, hp)
+    ffi.check(ffi.lib().pstl_generate_trajs(ctypes.byref(cfg), ffi.ptr(s0), ffi.ptr(u), ffi.ptr(out), ffi.stream()),
+              "generate_trajs")
+    return out.reshape(lead + (ffi.T + 1, 4))
+
+
+class StlFormula:
+    """Descriptor of one of the three fixed formulas of the path (reference build_stl_cache, nusc_train.py:95-140).
+    The robustness itself is evaluated by the fused HIP kernel in compute_stl_dense, not by composing Python objects."""
+    def __init__(self, name, text):
+        self.name, self.text = name, text
+
+    def __str__(self):
+        return self.text
+
+
+def build_stl_cache(args):
+    if getattr(args, "norm_stl", False):
+        raise NotImplementedError("--norm_stl is not on the hot path")
+    nt = args.nt
+    keep = "G[0:%d](v>=vmin) & G(v<=vmax)" % nt
+    safe = "G(d_nei>=d_safe)"
+    return [StlFormula("stl_curr", "%s & G(dmin<=d_curr<=dmax) & G(th_curr<=thmax) & %s" % (keep, safe)),
+            StlFormula("stl_left", "%s & F[0:%d]G(dmin<=d_left<=dmax) & F[0:%d]G(th_left<=thmax) & %s" % (keep, nt // 2, nt // 2, safe)),
+            StlFormula("stl_right", "%s & F[0:%d]G(dmin<=d_right<=dmax) & F[0:%d]G(th_right<=thmax) & %s" % (keep, nt // 2, nt // 2, safe))]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# batch construction
+# ---------------------------------------------------------------------------------------------------------------
+def augment_batch_data(batch, the_stlp, args, n_randoms=None, stlp_dense=None, dense=False):
+    """Adds the per-row constants of the sampling harness (reference nusc_train.py:724-754).  `batch["_pstl"]` holds
+    the scene-indexed device tensors the kernels read; dense replicas are only built with dense=True."""
+    if n_randoms is None:
+        new_sample = False
+        n_randoms = args.n_randoms
+    else:
+        new_sample = True
+    m = n_randoms * 3
+    bs = batch["currlane_wpts"].shape[0]
+    dev = batch["currlane_wpts"].device
+    batch["stlp"] = the_stlp.unsqueeze(-2)
+    if stlp_dense is not None:
+        batch["stlp_dense"] = stlp_dense
+    elif args.load_stlp:
+        if new_sample:
+            batch["stlp_dense"] = batch["pre_stlp"].reshape(bs, -1, 3, 6)[:, 0:1].repeat(1, n_randoms, 1, 1).reshape(bs * m, 1, 6)
+        else:
+            batch["stlp_dense"] = batch["pre_stlp"].reshape(bs * m, 1, 6)
+    else:
+        raise NotImplementedError("sampling test runs with --load_stlp (README commands); get_dense_stlp is data tooling")
+    valids = torch.cat([batch["curr_id"], batch["left_id"], batch["right_id"]], dim=-1)
+    batch["valids_dense"] = dup(valids, n_randoms).reshape(bs * n_randoms, 3)
+    batch["highlevel_dense"] = torch.tensor([0, 1.0, 2.0], device=dev).reshape(1, 3, 1).repeat(bs * n_randoms, 1, 1).reshape(bs * m, 1)
+    scene = {k: batch[k] for k in ("ego_traj", "neighbors", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
+                                   "curr_id", "left_id", "right_id")}
+    scene["neighbors_traj"] = batch["neighbor_trajs_aug"]
+    scene["stlp_rows"] = batch["stlp_dense"][:, 0]
+    batch["_pstl"] = SceneBatch(scene, n_randoms, _hp(args), dev)
+    if dense:
+        batch["neighbors_dense"] = dup(batch["neighbor_trajs_aug"], m)
+        for k in ("curr", "left", "right"):
+            batch["%slane_wpts_dense" % k] = dup(batch["%slane_wpts" % k], m)
+    return batch
+
+
+def pre_prepare_stl_cache(batch_cuda, dense_trajs=None, detach=False, repeat_n=None, mono=False, mono_n=None, gt_stlp=None):
+    if mono:
+        raise NotImplementedError("mono (gt_data_training) rows are outside the hot path")
+    stl_input = {"stlp": batch_cuda["stlp_dense"], "dense_valids": batch_cuda["valids_dense"],
+                 "gt_high_level": batch_cuda["gt_high_level"]}
+    if repeat_n is not None:
+        stl_input = {k: v.repeat(repeat_n, *[1] * (v.dim() - 1)) for k, v in stl_input.items()}
+    for k in ("neighbors_dense", "currlane_wpts_dense", "leftlane_wpts_dense", "rightlane_wpts_dense"):
+        if k in batch_cuda:
+            v = batch_cuda[k]
+            stl_input[k.replace("_dense", "")] = v if repeat_n is None else v.repeat(repeat_n, *[1] * (v.dim() - 1))
+    stl_input["_pstl"] = batch_cuda.get("_pstl")
+    stl_input["_pstl_reps"] = repeat_n or 1
+    if dense_trajs is not None:
+        stl_input["ego_traj"] = dense_trajs.detach() if detach else dense_trajs
+    return stl_input
+
+
+def compute_stl_dense(stl_input, stls_cac, stl_idx, mask, args, debug=False, tj_scores=None, scene=False):
+    """Scores trajectories stl_input["ego_traj"] (R,T,4) (reference nusc_train.py:318-345).
+    Returns (scores_list [curr, left, right, ones], scores (R,), acc[, scene_acc])."""
+    traj = stl_input["ego_traj"]
+    dev = traj.device
+    R = traj.shape[0]
+    states = ffi.f32(traj[..., :4], dev).reshape(R, ffi.T, 4)
+    hp = _hp(args)
+    sb = stl_input.get("_pstl")
+    reps = stl_input.get("_pstl_reps", 1)
+    if sb is not None and sb.N * reps == R:
+        n_per, s0 = sb.N, sb.s0
+        nei_prep, lane_prep, stlp = sb.nei_prep, sb.lane_prep, sb.stlp
+        hl = ffi.f32(stl_idx.reshape(reps, n_per)[0], dev)
+        cfg = sb.cfg(2)
+        states = states.reshape(reps, n_per, ffi.T, 4)
+    else:   # the reference's dense layout: every row carries its own scene tensors
+        nei = ffi.f32(stl_input["neighbors"][..., :7], dev)
+        lanes = [ffi.f32(stl_input["%slane_wpts" % k], dev) for k in ("curr", "left", "right")]
+        K = nei.shape[1]
+        cfg = ffi.make_cfg(R, 1, 1, K, 2, hp)
+        nei_prep = torch.empty(R, K, ffi.T, ffi.NEI_PREP, dtype=torch.float32, device=dev)
+        lane_prep = torch.empty(R, 3, ffi.NSEG, 4, dtype=torch.float32, device=dev)
+        ffi.check(ffi.lib().pstl_prepare_scene(ctypes.byref(cfg), ffi.ptr(nei), ffi.ptr(lanes[0]), ffi.ptr(lanes[1]),
+                                               ffi.ptr(lanes[2]), ffi.ptr(nei_prep), ffi.ptr(lane_prep), ffi.stream()),
+                  "prepare_scene")
+        stlp = ffi.f32(stl_input["stlp"].reshape(R, 6), dev)
+        hl = ffi.f32(stl_idx.reshape(R), dev)
+        reps, n_per, s0 = 1, R, None
+        states = states.reshape(1, R, ffi.T, 4)
+    scores = torch.empty(reps, n_per, dtype=torch.float32, device=dev)
+    s3 = torch.empty(3, reps, n_per, dtype=torch.float32, device=dev)
+    ffi.check(ffi.lib().pstl_stl_forward(ctypes.byref(cfg), ffi.ptr(s0), ffi.ptr(None), ffi.ptr(states), int(reps),
+                                         ffi.ptr(nei_prep), ffi.ptr(lane_prep), ffi.ptr(stlp), ffi.ptr(hl),
+                                         ffi.ptr(scores), ffi.ptr(s3), ffi.ptr(None), ffi.ptr(None),
+                                         ffi.ptr(None, torch.int32), ffi.stream()), "stl_forward")
+    scores = scores.reshape(R)
+    scores_list = [s3[0].reshape(R), s3[1].reshape(R), s3[2].reshape(R)]
+    scores_list.append(torch.ones_like(scores))
+    mask_flat = mask.reshape(-1).to(scores.dtype)
+    if getattr(args, "oracle_filter", False) and tj_scores is not None:
+        cube = torch.max(tj_scores.reshape(-1, args.n_randoms, 3), dim=1, keepdim=True)[0]
+        mask_flat = mask_flat * (cube > 0).float().repeat(1, args.n_randoms, 1).reshape(-1)
+    acc = mask_mean((scores > 0).float(), mask_flat)
+    if debug:
+        return scores_list, scores, acc, stl_input
+    if scene:
+        cube = scores.reshape(-1, args.n_randoms, 3)
+        mcube = mask.reshape(-1, args.n_randoms, 3)
+        scene_acc = mask_mean((torch.max(cube, dim=1)[0] > 0).float(), mcube[:, 0, :])
+        return scores_list, scores, acc, scene_acc
+    return scores_list, scores, acc
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reverse diffusion
+# ---------------------------------------------------------------------------------------------------------------
+def diffusion_rollout(noise, net, batch_cuda, highlevel_dense, feature, args, coeffs=None, fastforward=False,
+                      n_randoms=None, return_feature=False, mono=False, tmp_stlp=None, guidance_extras=None,
+                      maximize=False):
+    """Reference nusc_train.py:557-645.  `noise` only provides the shape (as in the reference); x_T and the per-step
+    noise are drawn from torch's global generator in the reference's order."""
+    if mono:
+        raise NotImplementedError("mono (gt_data_training) rows are outside the hot path")
+    n = noise.shape[0]
+    net.eval()
+    steps = args.diffusion_steps
+    dev = noise.device
+    if n_randoms is None:
+        n_randoms = args.n_randoms
+    if feature is None:
+        feature = net.scene_feature(batch_cuda, n_randoms * 3)
+    sb = batch_cuda["_pstl"]
+    assert sb.N == n, "batch rows and noise rows disagree"
+    with torch.no_grad():
+        x = torch.randn_like(noise).float().contiguous()
+        zs = torch.empty(max(steps - 1, 1), n, ffi.CTRL, dtype=torch.float32, device=dev)
+        if not fastforward:
+            for k, i in enumerate(reversed(range(1, steps))):
+                if i > 1:
+                    zs[k] = torch.randn_like(x)
+        guidance = None
+        if args.guidance and guidance_extras is not None:
+            guidance = dict(enabled=True, before=args.guidance_before, niters=args.guidance_niters,
+                            lr=args.guidance_lr, reverse=args.guidance_reverse, sets=args.guidance_sets,
+                            freq=args.guidance_freq, maximize=maximize)
+        sm = Sampler(net.packed(), net.hparams())
+        n_emit = steps if args.diff_full else 1
+        if fastforward:
+            emit = normalize_diff(x, n, args.nt, args.mul_w_max, args.mul_a_max, args.diffusion_clip).reshape(1, n, -1)
+        else:
+            emit = sm.rollout(sb, feature.pstl["base_policy"], x, zs, steps, n_emit=n_emit, clip=args.diffusion_clip,
+                              guidance=guidance, coeffs=coeffs)
+    diffused_result = emit[-1].reshape(n, args.nt, 2)
+    if args.diff_full:
+        final_list = [e.reshape(n, args.nt, 2) for e in emit]
+        return (diffused_result, feature, final_list) if return_feature else (diffused_result, final_list)
+    return (diffused_result, feature) if return_feature else diffused_result
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the sampling harness
+# ---------------------------------------------------------------------------------------------------------------
+class MyTimer:
+    """Named wall-clock marks (reference utils.py:112-147), with a device sync so that GPU time is attributed."""
+    def __init__(self):
+        self.marks, self.acc, self.count = [], {}, 0
+
+    def add(self, key):
+        torch.cuda.synchronize()
+        now = time.time()
+        if self.marks:
+            name = "%s-%s" % (key, self.marks[-1][0])
+            self.acc[name] = self.acc.get(name, 0.0) + now - self.marks[-1][1]
+        self.marks.append((key, now))
+
+    def next_batch(self):
+        self.marks = []
+        self.count += 1
+
+    def print_profile(self):
+        print(" ".join("%s:%.3f" % (k, v / max(self.count, 1)) for k, v in self.acc.items()))
+
+
+class MeterDict:
+    def __init__(self):
+        self.sum, self.cnt, self.last = {}, {}, {}
+
+    def update(self, k, v):
+        self.sum[k] = self.sum.get(k, 0.0) + v
+        self.cnt[k] = self.cnt.get(k, 0) + 1
+        self.last[k] = v
+
+    def __getitem__(self, k):
+        return self.last.get(k, float("nan"))
+
+    def __call__(self, k):
+        return self.sum[k] / self.cnt[k] if k in self.sum else float("nan")
+
+
+class SyntheticLoader:
+    """Stand-in for the nuScenes DataLoader: seeded synthetic scenes with the dataset's output schema."""
+    def __init__(self, args, n_batches=None):
+        self.args = args
+        self.n_batches = n_batches if n_batches is not None else min(args.n_trials + 1, 3)
+
+    def __len__(self):
+        return self.n_batches
+
+    def __iter__(self):
+        a = self.args
+        for bi in range(self.n_batches):
+            yield make_scene_batch(a.batch_size, K=a.n_neighbors, nt=a.nt, n_segs=a.n_segs, S=a.n_randoms,
+                                   seed=a.seed + bi, dt=a.dt, invalid_lane_frac=0.2, stlp_mode="wide")
+
+
+def dict_to_cuda(batch):
+    return {k: (v.cuda() if hasattr(v, "device") else v) for k, v in batch.items()}
+
+
+def run_sampling_test(stls_cac, data_loader, net, coeffs, args, result_queue=None, thread_nusc=None):
+    """Reference nusc_train.py:890-1183, the neural-sampling half (the traj-opt 'TJ' reference numbers need the
+    dataset's traj-opt parameters and are printed as nan)."""
+    md = MeterDict()
+    myt = MyTimer() if args.time_profile else None
+    for bi, batch in enumerate(data_loader):
+        if bi > args.n_trials:
+            continue
+        batch_cuda = dict_to_cuda(batch)
+        gt_trajs = batch_cuda["ego_traj"][..., :4]
+        states = gt_trajs[..., 0, :4]
+        bs = states.shape[0]
+        gt_stlp = batch_cuda["stlp_modes"][:, 0]
+        N = bs * args.sampling_size * 3
+        torch.cuda.synchronize()
+        tttt1 = time.time()
+        if myt:
+            myt.next_batch()
+        new_batch = {k: batch_cuda[k] for k in ("ego_traj", "neighbors", "currlane_wpts", "leftlane_wpts",
+                                                "rightlane_wpts", "curr_id", "left_id", "right_id", "gt_high_level",
+                                                "pre_stlp")}
+        new_batch["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
+        new_batch = augment_batch_data(new_batch, gt_stlp, args, n_randoms=args.sampling_size)
+        highlevel_new = new_batch["highlevel_dense"]
+        states_flat_new = states.unsqueeze(1).unsqueeze(1).repeat(1, args.sampling_size, 3, 1).reshape(N, 4)
+        noise = torch.empty(N, args.nt * 2, device=states.device)
+        guidance_extras = (new_batch, states_flat_new, stls_cac) if args.guidance else None
+        if myt:
+            myt.add("start_diffusion")
+        res = diffusion_rollout(noise, net, new_batch, highlevel_new, None, args, coeffs, fastforward=False,
+                                n_randoms=args.sampling_size, return_feature=True, guidance_extras=guidance_extras)
+        if myt:
+            myt.add("end_diffusion")
+        if args.diff_full:
+            nn_controls, feature, nn_controls_list = res
+        else:
+            nn_controls, feature = res
+            nn_controls_list = None
+        sb = new_batch["_pstl"]
+        sm = Sampler(net.packed(), net.hparams())
+        if args.rect_head and not args.not_use_rect:
+            if args.multi_cands is not None:
+                cands = torch.stack(nn_controls_list[-args.multi_cands:], dim=0).reshape(args.multi_cands, N, -1).contiguous()
+                r = sm.score(sb, cands, select=True)
+                nn_controls, prev_scores = r["sel_controls"].reshape(N, args.nt, 2), r["sel_scores"]
+                if myt:
+                    myt.add("selected_stl_max")
+            else:
+                prev_scores = sm.score(sb, nn_controls.reshape(1, N, -1).contiguous())["scores"][0]
+            if not args.no_refinenet:
+                nn_controls = net.rect_forward(feature, highlevel_new, new_batch["stlp_dense"][:, 0], nn_controls, prev_scores)
+            if myt:
+                myt.add("rect_forward()")
+            for _ in range(args.n_rolls or 0):
+                sc = sm.score(sb, nn_controls.reshape(1, N, -1).contiguous())["scores"][0]
+                nn_controls = net.rect_forward(feature, highlevel_new, new_batch["stlp_dense"][:, 0], nn_controls, sc)
+        nn_trajs = generate_trajs(states_flat_new, nn_controls, args.dt).reshape(N, args.nt + 1, 4)
+        stl_input = pre_prepare_stl_cache(new_batch, dense_trajs=nn_trajs[:, :-1])
+        scores_list, scores, acc, scene_acc = compute_stl_dense(stl_input, stls_cac, new_batch["highlevel_dense"],
+                                                                stl_input["dense_valids"], args, scene=True)
+        torch.cuda.synchronize()
+        tttt2 = time.time()
+        md.update("acc", acc.item())
+        md.update("scene_acc", scene_acc.item())
+        md.update("time", tttt2 - tttt1)
+        nan = float("nan")
+        print("###[%02d] TJ acc:%.3f scene_acc:%.3f ade:%.3f fde:%.3f std:%.3f vol:%.3f area:%.3f s:%.3f u:%.3f| "
+              "NN acc:%.3f scene_acc:%.3f ade:%.3f fde:%.3f std:%.3f vol:%.3f area:%.3f s:%.3f u:%.3f ||| T:%.3f" % (
+                  bi, nan, nan, nan, nan, nan, nan, nan, nan, nan, md("acc"), md("scene_acc"), nan, nan, nan, nan, nan,
+                  nan, nan, md("time")))
+    if myt:
+        myt.print_profile()
+    return md
+
+
+def generate_parser(argv=None):
+    """The reference's flags and post-parse overrides (nusc_train.py:1635-1814)."""
+    parser = argparse.ArgumentParser("")
+    add = parser.add_argument
+    add("--seed", type=int, default=1007)
+    add("--exp_name", "-e", type=str, default=None)
+    add("--gpus", type=str, default="0")
+    add("--epochs", type=int, default=500)
+    add("--test", action="store_true", default=False)
+    add("--net_pretrained_path", "-P", type=str, default=None)
+    add("--num_workers", type=int, default=8)
+    add("--batch_size", "-b", type=int, default=128)
+    add("--lr", type=float, default=3e-4)
+    add("--hiddens", type=int, nargs="+", default=[256, 256])
+    add("--mini", action="store_true", default=False)
+    add("--n_neighbors", "-N", type=int, default=8)
+    add("--n_randoms", type=int, default=64)
+    add("--n_segs", type=int, default=15)
+    add("--ego_L", type=float, default=4.084)
+    add("--ego_W", type=float, default=1.730)
+    add("--refined_nL", type=int, default=4)
+    add("--refined_nW", type=int, default=1)
+    add("--nt", type=int, default=20)
+    add("--dt", type=float, default=0.5)
+    add("--mul_w_max", type=float, default=0.5)
+    add("--mul_a_max", type=float, default=5.0)
+    add("--smoothing_factor", type=float, default=100.0)
+    add("--skip_nusc_load", action="store_true", default=False)
+    add("--clip_dist", action="store_true", default=False)
+    add("--stl_nn_thres", type=float, default=0.0005)
+    add("--inline", action="store_true", default=False)
+    add("--use_init_hint", action="store_true", default=False)
+    add("--norm_stl", action="store_true", default=False)
+    add("--flex", action="store_true", default=False)
+    add("--load_stlp", action="store_true", default=False)
+    add("--load_tj", action="store_true", default=False)
+    add("--stl_weight", type=float, default=1.0)
+    add("--bc", action="store_true", default=False)
+    add("--vae", action="store_true", default=False)
+    add("--diffusion", action="store_true", default=False)
+    add("--diffusion_steps", type=int, default=100)
+    add("--beta_start", type=float, default=1e-4)
+    add("--beta_end", type=float, default=0.02)
+    add("--cos", action="store_true", default=False)
+    add("--grad_rollout", action="store_true", default=False)
+    add("--rect_head", action="store_true", default=False)
+    add("--rect_hiddens", type=int, nargs="+", default=[256, 256])
+    add("--not_use_rect", action="store_true", default=False)
+    add("--measure_diversity", action="store_true", default=False)
+    add("--extra_diversity", action="store_true", default=False)
+    add("--viz_correct", action="store_true", default=False)
+    add("--run_sampling_test", action="store_true", default=False)
+    add("--sampling_size", type=int, default=64)
+    add("--n_trials", type=int, default=100)
+    add("--diff_full", action="store_true", default=False)
+    add("--diverse_loss", action="store_true", default=False)
+    add("--no_arch", action="store_true", default=False)
+    add("--n_shards", type=int, default=4)
+    add("--diverse_fuse_type", type=str, default="add")
+    add("--interval", action="store_true", default=False)
+    add("--diffusion_clip", action="store_true", default=False)
+    add("--multi_cands", type=int, default=None)
+    add("--gt_data_training", action="store_true", default=False)
+    add("--collision_loss", type=float, default=None)
+    add("--guidance", action="store_true", default=False)
+    add("--guidance_niters", type=int, default=3)
+    add("--guidance_before", type=int, default=1000)
+    add("--guidance_lr", type=float, default=0.01)
+    add("--guidance_reverse", action="store_true", default=False)
+    add("--guidance_sets", nargs="+", type=int, default=None)
+    add("--guidance_freq", type=int, default=None)
+    add("--oracle_filter", action="store_true", default=False)
+    add("--clip_rect", action="store_true", default=False)
+    add("--ego", action="store_true", default=False)
+    add("--other", action="store_true", default=False)
+    add("--n_rolls", type=int, default=None)
+    add("--suffix", type=str, default=None)
+    add("--no_refinenet", action="store_true", default=False)
+    add("--time_profile", action="store_true", default=False)
+    args = parser.parse_args(argv)
+    args.cos = True
+    args.measure_diversity = True
+    if args.run_sampling_test:
+        args.test = True
+        args.extra_diversity = True
+    if args.load_stlp:
+        args.load_tj = True
+    if args.rect_head:
+        args.interval = True
+        args.diffusion_clip = True
+        args.diff_full = True
+    if args.test:
+        args.epochs = 1
+    return args
+
+
+def main(argv=None):
+    args = generate_parser(argv)
+    if not args.run_sampling_test:
+        raise SystemExit("only --run_sampling_test (the sampling + STL hot path) is implemented on MI355X")
+    if args.sampling_size != args.n_randoms:
+        raise SystemExit("--sampling_size must equal --n_randoms (merge_net pooling, reference nusc_model.py:187-196)")
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    loader = SyntheticLoader(args)
+    stls_cac = build_stl_cache(args)
+    net = Net(args).cuda()
+    if args.net_pretrained_path is not None:
+        import os
+        path = args.net_pretrained_path
+        if not os.path.isfile(path):
+            path = os.path.join("exps", path, "models", "model_last.ckpt")
+        if os.path.isfile(path):
+            net.load_state_dict(torch.load(path, map_location="cuda"), strict=(not args.rect_head))
+        else:
+            print("checkpoint %s not found: running with random-init weights (seed %d)" % (path, args.seed))
+    coeffs = get_diffusion_coeffs(args)
+    return run_sampling_test(stls_cac, loader, net, coeffs, args, None, None)
+
+
+if __name__ == "__main__":
+    t1 = time.time()
+    main()
+    print("Finished in %.3f seconds" % (time.time() - t1))

@@ -1,0 +1,73 @@
+"""N > 1 path on the CPU: two gloo processes, each owning a contiguous block of scenes.  Checks that the exchanged
+quantities (global valid statistics before the rollout, satisfaction counters after the final scoring) reproduce the
+single-process result exactly, using the CPU oracle as the per-shard scorer."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _counts_from_scores(scores, valid, bs, S):
+    sat = int(((scores > 0) & (valid > 0)).sum())
+    cube = scores.reshape(bs, S, 3)
+    v0 = valid.reshape(bs, S, 3)[:, 0, :]
+    ssat = int(((cube.max(dim=1)[0] > 0) & (v0 > 0)).sum())
+    return torch.tensor([sat, int(valid.sum()), bs * S * 3, ssat, int(v0.sum()), bs * 3, 0, 0], dtype=torch.int64)
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pstl_oracle as orc
+    from pstl_diffusion_policy_amd.shard import gather_counts, global_valid_stats, shard_range
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    hp = default_hparams()
+    bs, S, K = 7, 4, 3
+    scene = make_scene_batch(bs, K=K, S=S, seed=31, invalid_lane_frac=0.4, stlp_mode="wide")
+    lo, hi = shard_range(bs, rank, world)
+    sub = {k: v[lo:hi].numpy() for k, v in scene.items()}
+    rows = orc.Rows(sub, S, hp)
+    g = torch.Generator().manual_seed(9)
+    u_all = torch.randn(bs * S * 3, 20, 2, generator=g) * torch.tensor([0.05, 0.5])
+    u = u_all[lo * S * 3:hi * S * 3]
+    vsum, vrows = global_valid_stats(float(rows.valid.sum()), rows.N, torch.device("cpu"))
+    _, score, _ = rows.score(u)
+    counts = gather_counts(_counts_from_scores(score, rows.valid, hi - lo, S))
+    if rank == 0:
+        torch.save({"vsum": vsum, "vrows": vrows, "counts": counts}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_shards_reproduce_the_single_process_numbers(tmp_path):
+    from oracle import pstl_oracle as orc
+    from pstl_diffusion_policy_amd.engine import acc_from_counts
+    from pstl_diffusion_policy_amd.shard import shard_range
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    assert [shard_range(7, r, 2) for r in range(2)] == [(0, 4), (4, 7)]
+    assert [shard_range(4096, r, 8) for r in range(8)][-1] == (3584, 4096)
+    out_path = str(tmp_path / "r0.pt")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out_path), nprocs=2, join=True)
+    got = torch.load(out_path)
+    hp = default_hparams()
+    bs, S, K = 7, 4, 3
+    scene = {k: v.numpy() for k, v in make_scene_batch(bs, K=K, S=S, seed=31, invalid_lane_frac=0.4, stlp_mode="wide").items()}
+    rows = orc.Rows(scene, S, hp)
+    g = torch.Generator().manual_seed(9)
+    u = torch.randn(bs * S * 3, 20, 2, generator=g) * torch.tensor([0.05, 0.5])
+    _, score, _ = rows.score(u)
+    want = _counts_from_scores(score, rows.valid, bs, S)
+    assert got["vsum"] == float(rows.valid.sum()) and got["vrows"] == rows.N
+    assert torch.equal(got["counts"], want)
+    acc, sacc = orc.stl_metrics(score, rows.valid, S)
+    a, s = acc_from_counts(got["counts"])
+    assert a == float(acc) and s == float(sacc)
