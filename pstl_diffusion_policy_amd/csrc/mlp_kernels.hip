@@ -27,6 +27,7 @@ constexpr int kCtrl = PSTL_CTRL;   // 40
 constexpr int kKx = 48;            // per-row input columns of layer 1 (40 + 1 + 6, padded to 48)
 constexpr int kTileRows = 16;
 constexpr int kG = 12;             // tiles per workgroup
+constexpr int kMaxLaunchSteps = 128;  // reverse steps per launch (longer segments are split by pstl_rollout)
 
 // ---- packed weight buffer (float offsets) -----------------------------------------------------------------------
 struct EncOff {
@@ -309,24 +310,34 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // LDS address (in floats) of activation element k (0..47) of tile column c in the B-operand image [q][lane][r]
 __device__ __forceinline__ int xs_addr(int k, int c) { return (((k >> 4) * 64) + (((k >> 2) & 3) * 16 + c)) * 4 + (k & 3); }
 
-template <int NW, bool REFINE>
+// ABL != 0 are timing-only ablation builds (wrong results by construction; selected with cfg->chain_waves = 8 + 100*ABL
+// and used only to attribute the kernel's time): 1 = no epilogue, 2 = also no layer 1, 3 = also no barrier,
+// 5 = no epilogue and only waves 0..NW/2-1 issue MFMAs (what one wave per SIMD sustains alone).
+template <int NW, bool REFINE, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   constexpr int OT = 16 / NW;       // 16-feature output tiles per wave
   constexpr int NT = NW * 64;
-  constexpr int NE = (kTileRows * kCtrl + NT - 1) / NT;  // epilogue elements per thread
+  constexpr int NCW = NW == 4 ? 3 : NW / 2;  // the last NCW waves also run the epilogue (8 waves: one partner per SIMD)
+  constexpr int NCT = NCW * 64;     // >= 160 epilogue threads are needed (4 outputs each)
+  static_assert(NCT >= 160, "epilogue needs 160 threads");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xs = lds;                          // [kG][3][64][4]
-  float* h1 = xs + kG * 768;                // [16][64][4]
-  float* part = h1 + 16 * 256;              // [NW][3][64][4]
+  float* xs = lds;                          // [kG][3][64][4]      activations of layer 1, B-operand order
+  float* h1 = xs + kG * 768;                // [2][16][64][4]      layer-1 output (double buffered)
+  float* part = h1 + 2 * 16 * 256;          // [2][NW][3][64][4]   layer-3 partial sums (double buffered)
+  float* b2s = part + 2 * NW * 768;         // [256] layer-2 bias, [48] layer-3 bias
+  float* b3s = b2s + 256;
+  float* coef = b3s + 48;                   // [kMaxLaunchSteps][4] c1, 1/sqrt(alpha), sqrt(beta) of step s_hi - n
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
   const long tile0 = (long)blockIdx.x * kG;
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
-  const int G = (int)((n_tiles - tile0) < kG ? (n_tiles - tile0) : kG);
+  int G = (int)((n_tiles - tile0) < kG ? (n_tiles - tile0) : kG);
+  // The deferred epilogue needs >= 3 tiles in flight (see the hazard note below); short tail blocks process
+  // phantom tiles whose rows are clamped on load and masked on store.
+  if (G < 3) G = 3;
 
   // ---- weights -> registers (A operands), once per launch ----
   float w1x[OT][12], w2[OT][64], w3[3][OT][4];
-  f32x4 b2v[OT];
   {
     const float* p1 = a.packed + a.off.w1x;
     const float* p2 = a.packed + a.off.w2;
@@ -342,7 +353,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) w3[j][ot][r] = p3[(((long)j * 16 + T) * 4 + r) * 64 + lane];
-      b2v[ot] = *reinterpret_cast<const f32x4*>(a.packed + a.off.b2 + 16 * T + 4 * g);
+    }
+    if (tid < 256) b2s[tid] = a.packed[a.off.b2 + tid];
+    if (tid < 48) b3s[tid] = a.packed[a.off.b3 + tid];
+    if (!REFINE && tid <= a.step_hi - a.step_lo) {   // reverse-step coefficients (nusc_train.py:580-587), once per launch
+      const int i = a.step_hi - tid;
+      const float al = a.alpha[i], ah = a.alpha_hat[i], be = a.beta[i];
+      coef[4 * tid + 0] = (1.0f - al) / sqrtf(1.0f - ah);
+      coef[4 * tid + 1] = 1.0f / sqrtf(al);
+      coef[4 * tid + 2] = sqrtf(be);
+      coef[4 * tid + 3] = 0.0f;
     }
   }
 
@@ -389,131 +409,173 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   __syncthreads();
 
   const int s_hi = REFINE ? 1 : a.step_hi, s_lo = REFINE ? 1 : a.step_lo;
-  for (int i = s_hi; i >= s_lo; --i) {
+  const int total = (s_hi - s_lo + 1) * G;  // tile-steps of this workgroup; tile-step `it` = (step s_hi - it/G, tile it%G)
+
+  // ---- layer 1 of tile-step `it`: 48 -> 256, result (after ReLU) into h1[it & 1] --------------------------------
+  auto layer1 = [&](int it) {
+    const int tl = it % G, i = s_hi - it / G;
+    long rowc = (tile0 + tl) * kTileRows + col;
+    if (rowc >= a.N) rowc = a.N - 1;
+    const float* bp = a.base + (rowc / a.rows_per_scene) * kHid;
+    // the scene/timestep constant part of the pre-activation: loaded now, added after the MFMAs (latency hidden)
+    f32x4 cst[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      const int f0 = 16 * (w * OT + ot) + 4 * g;
+      cst[ot] = *reinterpret_cast<const f32x4*>(bp + f0);
+      if (!REFINE) cst[ot] += *reinterpret_cast<const f32x4*>(a.tbias + (long)i * kHid + f0);
+    }
+    f32x4 acc[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) acc[ot] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4* xb = reinterpret_cast<const f32x4*>(xs + tl * 768) + lane;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const f32x4 bq = xb[q * 64];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma4(w1x[ot][q * 4 + r], bq[r], acc[ot]);
+    }
+    f32x4* hw = reinterpret_cast<f32x4*>(h1 + (it & 1) * 4096);
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) hw[(w * OT + ot) * 64 + lane] = relu4(acc[ot] + cst[ot]);
+  };
+
+  // ---- epilogue of tile-step `it` (run by the second half of the waves, one tile-step late) ---------------------
+  // Hazards: it reads part[it & 1] (complete since the barrier that ended iteration `it`; rewritten only in iteration
+  // it + 2, after another barrier) and rewrites xs[tile], which layer1 reads again G - 1 iterations later -- at least
+  // one barrier later as long as G >= 3.
+  auto epilogue = [&](int it, const f32x4& z4) {
+    const int tl = it % G, i = s_hi - it / G;
+    const long row0 = (tile0 + tl) * kTileRows;
     float c1 = 0.0f, inv_sa = 0.0f, sbeta = 0.0f;
-    const float* tb = nullptr;
-    const float* zsrc = nullptr;
     if (!REFINE) {
-      const float al = a.alpha[i], ah = a.alpha_hat[i], be = a.beta[i];
-      c1 = (1.0f - al) / sqrtf(1.0f - ah);
-      inv_sa = 1.0f / sqrtf(al);
-      sbeta = sqrtf(be);
-      tb = a.tbias + (long)i * kHid;
-      if (a.noise && i > 1 && !a.mu_only) zsrc = a.noise + (long)(a.steps - 1 - i) * a.N * kCtrl;
+      const f32x4 cf = reinterpret_cast<const f32x4*>(coef)[it / G];
+      c1 = cf.x;
+      inv_sa = cf.y;
+      sbeta = cf.z;
     }
-    for (int tl = 0; tl < G; ++tl) {
-      const long row0 = (tile0 + tl) * kTileRows;
-      // ---------------- layer 1: 48 -> 256, accumulator starts at base[scene] + tbias[t] ----------------
-      {
-        long rowc = row0 + col;
-        if (rowc >= a.N) rowc = a.N - 1;
-        const float* bp = a.base + (rowc / a.rows_per_scene) * kHid;
-        f32x4 acc[OT];
+    // thread et < 160 owns outputs f0..f0+3 of tile column c: 16-byte LDS accesses at consecutive slots (no bank
+    // conflicts), 16-byte global accesses (4 lanes cover one 64-byte piece of a row)
+    const int et = tid - (NT - NCT);
+    if (et < 160) {
+      const int qd = et >> 4, c = et & 15;
+      const int j = qd >> 2, gq = qd & 3, slot = gq * 16 + c, f0 = 4 * qd;
+      const f32x4* pp = reinterpret_cast<const f32x4*>(part + (it & 1) * (NW * 768));
+      f32x4 o = reinterpret_cast<const f32x4*>(b3s)[qd];
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-          const int f0 = 16 * (w * OT + ot) + 4 * g;
-          acc[ot] = *reinterpret_cast<const f32x4*>(bp + f0);
-          if (!REFINE) acc[ot] += *reinterpret_cast<const f32x4*>(tb + f0);
-        }
-        const f32x4* xb = reinterpret_cast<const f32x4*>(xs + tl * 768) + lane;
+      for (int ww = 0; ww < NW; ++ww) o += pp[(ww * 3 + j) * 64 + slot];
+      const long row = row0 + c;
+      const f32x4 sc = f32x4{a.w_max, a.a_max, a.w_max, a.a_max};
+      if (!REFINE) {
+        f32x4* xp = reinterpret_cast<f32x4*>(xs + tl * 768) + j * 64 + slot;
+        const f32x4 x = *xp;
+        const f32x4 eps = o + x;
+        const f32x4 mu = inv_sa * (x - c1 * eps);
+        const f32x4 xn = a.mu_only == 2 ? eps : a.mu_only ? mu : mu + sbeta * z4;
+        *xp = xn;
+        if (row < a.N) {
+          if (i == s_lo) *reinterpret_cast<f32x4*>(a.x_inout + row * kCtrl + f0) = xn;
+          if (i <= a.n_emit && !a.mu_only) {
+            f32x4 v = xn * sc;
+            if (a.clip) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const f32x4 bq = xb[q * 64];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma4(w1x[ot][q * 4 + r], bq[r], acc[ot]);
-        }
-#pragma unroll
-        for (int ot = 0; ot < OT; ++ot)
-          reinterpret_cast<f32x4*>(h1)[(w * OT + ot) * 64 + lane] = relu4(acc[ot]);
-      }
-      __syncthreads();
-      // prefetch this tile's noise so that the HBM latency hides behind layer 2
-      float zreg[NE];
-#pragma unroll
-      for (int u = 0; u < NE; ++u) zreg[u] = 0.0f;
-      if (zsrc) {
-#pragma unroll
-        for (int u = 0; u < NE; ++u) {
-          const int e = tid + u * NT;
-          if (e < kTileRows * kCtrl) {
-            const long row = row0 + e / kCtrl;
-            if (row < a.N) zreg[u] = zsrc[row * kCtrl + e % kCtrl];
-          }
-        }
-      }
-      // ---------------- layer 2: 256 -> 256 (B from LDS), layer 3: this wave's 16*OT features -> 48 ------
-      {
-        f32x4 acc[OT];
-#pragma unroll
-        for (int ot = 0; ot < OT; ++ot) acc[ot] = b2v[ot];
-        const f32x4* hb = reinterpret_cast<const f32x4*>(h1) + lane;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const f32x4 bq = hb[q * 64];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma4(w2[ot][q * 4 + r], bq[r], acc[ot]);
-        }
-        f32x4 acc3[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc3[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-          const f32x4 h = relu4(acc[ot]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc3[j] = mfma4(w3[j][ot][r], h[r], acc3[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) reinterpret_cast<f32x4*>(part)[(w * 3 + j) * 64 + lane] = acc3[j];
-      }
-      __syncthreads();
-      // ---------------- epilogue: reduce the NW partial sums, then the DDPM update / the interval head -----
-#pragma unroll
-      for (int u = 0; u < NE; ++u) {
-        const int e = tid + u * NT;
-        if (e < kTileRows * kCtrl) {
-          const int c = e / kCtrl, f = e % kCtrl;
-          const int j = f >> 4, li = ((f >> 2) & 3) * 16 + c, r = f & 3;
-          float o = a.packed[a.off.b3 + f];
-#pragma unroll
-          for (int ww = 0; ww < NW; ++ww) o += part[((ww * 3 + j) * 64 + li) * 4 + r];
-          const long row = row0 + c;
-          const float sc = (f & 1) ? a.a_max : a.w_max;
-          if (!REFINE) {
-            const int xa = tl * 768 + (j * 64 + li) * 4 + r;
-            const float x = xs[xa];
-            const float eps = o + x;
-            const float mu = inv_sa * (x - c1 * eps);
-            const float xn = a.mu_only == 2 ? eps : a.mu_only ? mu : mu + sbeta * zreg[u];
-            xs[xa] = xn;
-            if (row < a.N) {
-              if (i == s_lo) a.x_inout[row * kCtrl + f] = xn;
-              if (i <= a.n_emit && !a.mu_only) {
-                float v = xn * sc;
-                if (a.clip) v = fminf(fmaxf(v, -sc), sc);
-                a.emit_out[((long)(a.n_emit - i) * a.N + row) * kCtrl + f] = v;
-              }
+              for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], -sc[r]), sc[r]);
             }
-          } else if (row < a.N) {
-            // interval head (nusc_model.py:212-229): tanh output scales into the remaining headroom of init
-            const float init = a.init[row * kCtrl + f];
-            const float raw = tanhf(o);
-            const float d = raw >= 0.0f ? raw * (sc - init) : raw * (init - (-sc));
-            const float viol = a.scores[row] < 0.0f ? 1.0f : 0.0f;
-            float v = init + d * viol;
-            if (a.clip) v = fminf(fmaxf(v, -sc), sc);
-            a.out[row * kCtrl + f] = v;
+            *reinterpret_cast<f32x4*>(a.emit_out + ((long)(a.n_emit - i) * a.N + row) * kCtrl + f0) = v;
           }
         }
+      } else if (row < a.N) {
+        // interval head (nusc_model.py:212-229): tanh output scales into the remaining headroom of init
+        const f32x4 init = *reinterpret_cast<const f32x4*>(a.init + row * kCtrl + f0);
+        const float viol = a.scores[row] < 0.0f ? 1.0f : 0.0f;
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float raw = tanhf(o[r]);
+          const float d = raw >= 0.0f ? raw * (sc[r] - init[r]) : raw * (init[r] - (-sc[r]));
+          v[r] = init[r] + d * viol;
+          if (a.clip) v[r] = fminf(fmaxf(v[r], -sc[r]), sc[r]);
+        }
+        *reinterpret_cast<f32x4*>(a.out + row * kCtrl + f0) = v;
       }
-      if (G == 1) __syncthreads();
     }
+  };
+
+  // noise of tile-step `it`, fetched one iteration before its epilogue runs
+  auto fetch_noise = [&](int it, f32x4& z4) {
+    z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (REFINE || !a.noise || a.mu_only) return;
+    const int tl = it % G, i = s_hi - it / G;
+    if (i <= 1) return;  // the reference adds zeros at the last step
+    const int et = tid - (NT - NCT);
+    if (et < 160) {
+      const long row = (tile0 + tl) * kTileRows + (et & 15);
+      if (row < a.N)
+        z4 = *reinterpret_cast<const f32x4*>(a.noise + ((long)(a.steps - 1 - i) * a.N + row) * kCtrl + 4 * (et >> 4));
+    }
+  };
+
+  const bool epi_wave = (w >= NW - NCW);  // wave-uniform
+  f32x4 zreg = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  layer1(0);
+  __syncthreads();
+  for (int it = 0; it < total; ++it) {
+    if (epi_wave && ABL == 0) {
+      // While this half finishes the previous tile-step, the partner wave on the same SIMD already issues MFMAs: the
+      // matrix pipe never waits for the epilogue (the stagger of MI355X_MICROARCH.md "Two waves per SIMD", item 9).
+      const f32x4 zprev = zreg;
+      fetch_noise(it, zreg);               // HBM read of this tile-step's noise first: a full iteration to land
+      if (it > 0) epilogue(it - 1, zprev);
+    }
+    if (ABL == 5 && w >= NW / 2) {  // solo-rate probe: one wave per SIMD issues MFMAs, its partner only joins barriers
+      __syncthreads();
+      continue;
+    }
+    // ---------------- layer 2: 256 -> 256 (B from LDS), layer 3: this wave's 16*OT features -> 48 ----------------
+    f32x4 acc[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) acc[ot] = reinterpret_cast<const f32x4*>(b2s)[(w * OT + ot) * 4 + g];
+    const f32x4* hb = reinterpret_cast<const f32x4*>(h1 + (it & 1) * 4096) + lane;
+    f32x4 bq = hb[0];
+    __builtin_amdgcn_sched_barrier(0);  // the pipelined region starts here
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      f32x4 bn = bq;
+      if (q < 15) bn = hb[(q + 1) * 64];  // next B fragment in flight while this one feeds 4*OT MFMAs
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma4(w2[ot][q * 4 + r], bq[r], acc[ot]);
+      bq = bn;
+      // issue order: the LDS read of fragment q+1, then the 4*OT MFMAs of fragment q (left alone, the scheduler puts
+      // the read behind the MFMAs and exposes its latency)
+      if (q < 15) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * OT, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc3[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc3[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      const f32x4 h = relu4(acc[ot]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc3[j] = mfma4(w3[j][ot][r], h[r], acc3[j]);
+    }
+    f32x4* pw = reinterpret_cast<f32x4*>(part + (it & 1) * (NW * 768));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) pw[(w * 3 + j) * 64 + lane] = acc3[j];
+    // ---------------- layer 1 of the NEXT tile-step, so that one barrier per tile-step is enough ------------------
+    if (it + 1 < total && (ABL < 2 || ABL == 5)) layer1(it + 1);
+    if (ABL < 3 || ABL == 5) __syncthreads();
   }
+  if (epi_wave && ABL == 0) epilogue(total - 1, zreg);
+  if (ABL != 0 && a.N < 0) epilogue(0, zreg);  // keep the code reachable for the compiler, never executed
 }
 
 // ---- merge_net + shard max-pool (nusc_model.py:186-196) -----------------------------------------------------------
@@ -584,15 +646,15 @@ __global__ __launch_bounds__(64) void k_merge_pool(MergeArgs a) {
 
 template <int NW>
 size_t chain_lds_bytes() {
-  return (size_t)(kG * 768 + 16 * 256 + NW * 768) * sizeof(float);
+  return (size_t)(kG * 768 + 2 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps) * sizeof(float);
 }
 
-template <int NW, bool REFINE>
+template <int NW, bool REFINE, int ABL = 0>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
   const dim3 grid((unsigned)((n_tiles + kG - 1) / kG));
   const size_t lds = chain_lds_bytes<NW>();
-  auto fn = k_chain<NW, REFINE>;
+  auto fn = k_chain<NW, REFINE, ABL>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return PSTL_ERR_LAUNCH;
@@ -606,6 +668,11 @@ template <bool REFINE>
 int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   if (chain_waves == 4) return launch_chain<4, REFINE>(a, st);
   if (chain_waves == 0 || chain_waves == 8) return launch_chain<8, REFINE>(a, st);
+  if (!REFINE && chain_waves == 108) return launch_chain<8, false, 1>(a, st);
+  if (!REFINE && chain_waves == 208) return launch_chain<8, false, 2>(a, st);
+  if (!REFINE && chain_waves == 308) return launch_chain<8, false, 3>(a, st);
+  if (!REFINE && chain_waves == 508) return launch_chain<8, false, 5>(a, st);
+  if (REFINE && chain_waves > 100) return launch_chain<8, true>(a, st);
   return PSTL_ERR_SHAPE;
 }
 
@@ -754,7 +821,13 @@ extern "C" int pstl_rollout(const pstl_cfg* cfg, const float* packed, const floa
   a.noise = noise;
   a.x_inout = x_inout;
   a.emit_out = emit_out;
-  return launch_chain_nw<false>(cfg->chain_waves, a, as_stream(stream));
+  // one launch covers at most kMaxLaunchSteps reverse steps (the per-step coefficients sit in LDS)
+  for (int hi = step_hi; hi >= step_lo; hi -= kMaxLaunchSteps) {
+    a.step_hi = hi;
+    a.step_lo = (hi - kMaxLaunchSteps + 1 > step_lo) ? hi - kMaxLaunchSteps + 1 : step_lo;
+    if (int e = launch_chain_nw<false>(cfg->chain_waves, a, as_stream(stream))) return e;
+  }
+  return PSTL_OK;
 }
 
 extern "C" int pstl_refine(const pstl_cfg* cfg, const float* packed, const float* base_rect, const float* stlp,
