@@ -101,7 +101,8 @@ def main():
         x_T = torch.randn(N, 40, device=dev, generator=gen)
         z = torch.randn(steps - 1, N, 40, device=dev, generator=gen)
         out = sampler.sampling_region(sb, steps, x_T, z, rect_head=rect_head,
-                                      multi_cands=a.multi_cands if rect_head else None, guidance=guidance, coeffs=coeffs)
+                                      multi_cands=a.multi_cands if rect_head else None, guidance=guidance, coeffs=coeffs,
+                                      want_scores3=False)
         # the only exchange after the rollout: 8 counters per rank (RCCL all-gather over xGMI when N > 1)
         return gather_counts(out["counts"])
 

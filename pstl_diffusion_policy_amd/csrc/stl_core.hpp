@@ -27,13 +27,29 @@
 #define PSTL_NOUNROLL
 #endif
 
+// exp/log of the soft-min/soft-max operators.  On the device these are the hardware v_exp_f32 / v_log_f32 forms
+// (about 1 ulp; arguments here are <= 0 and results are divided by tau = 100 afterwards, so a robustness score moves
+// by ~1e-8): they are ~5x cheaper than the correctly rounded library calls and there are ~300 of them per row.
+// Trigonometric functions, divisions and square roots stay exact (positions integrate over 20 steps).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PSTL_EXP(x) __expf(x)
+#define PSTL_LOG(x) __logf(x)
+#else
+#define PSTL_EXP(x) expf(x)
+#define PSTL_LOG(x) logf(x)
+#endif
+
 namespace pstl {
 
 constexpr int kT = 20;        // horizon nt
 constexpr int kNseg = 15;     // lane waypoints
 constexpr int kFwin = 10;     // Eventually(0, nt//2)
 constexpr int kNeiPrep = 12;  // floats per prepared (neighbour, t)
-constexpr int kScratchFloats = 4 * kT + 2 * kFwin;  // states + the two stored suffix tables of the backward pass
+// per-lane scratch floats: forward needs the first 10 values of the two "reach" signals per evaluated side lane;
+// the adjoint additionally keeps x_t, y_t (heading and speed are re-derived from the controls, see stl_eval_grad)
+constexpr int kScratchFwd = 2 * kFwin;       // selected formula only
+constexpr int kScratchFwd3 = 4 * kFwin;      // all three formulas (left and right lane)
+constexpr int kScratchGrad = 2 * kT + 2 * kFwin;
 
 struct alignas(16) f4 {
   float x, y, z, w;
@@ -105,38 +121,16 @@ struct Lse {
   }
   PSTL_HD void add(float a) {
     const float hi = fmaxf(a, m);
-    const float e = expf(fminf(a, m) - hi);  // exp(-|a-m|); exp(-inf) = 0 on the first add
+    const float e = PSTL_EXP(fminf(a, m) - hi);  // exp(-|a-m|); exp(-inf) = 0 on the first add
     s = (a > m) ? (s * e + 1.0f) : (s + e);
     m = hi;
   }
-  PSTL_HD float value() const { return logf(s) + m; }
+  PSTL_HD float value() const { return PSTL_LOG(s) + m; }
 };
 
 PSTL_HD float lse2(float a, float b) {
   const float m = fmaxf(a, b);
-  return logf(expf(a - m) + expf(b - m)) + m;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// A6  unicycle states 0..T-1 into scratch[4*t + {0,1,2,3}]
-// ---------------------------------------------------------------------------------------------------------------
-PSTL_HD void rollout_states(const float* s0, const float* u, float wscale, float ascale, float dt, Scratch st) {
-  float x = s0[0], y = s0[1], th = s0[2], v = s0[3];
-  PSTL_NOUNROLL
-  for (int t = 0; t < kT; ++t) {
-    st.at(4 * t + 0) = x;
-    st.at(4 * t + 1) = y;
-    st.at(4 * t + 2) = th;
-    st.at(4 * t + 3) = v;
-    const float w = u[2 * t] * wscale;
-    const float a = u[2 * t + 1] * ascale;
-    const float dx = v * cosf(th);
-    const float dy = v * sinf(th);
-    x = x + dx * dt;
-    y = y + dy * dt;
-    th = th + w * dt;
-    v = v + a * dt;
-  }
+  return PSTL_LOG(PSTL_EXP(a - m) + PSTL_EXP(b - m)) + m;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -206,8 +200,8 @@ struct ClearHit {
 };
 
 template <bool GRAD>
-PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, float x, float y, float th, ClearHit& h) {
-  const float c = cosf(th), s = sinf(th);
+PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, float x, float y, float c, float s,
+                            ClearHit& h) {
   float ex[4], ey[4];
   PSTL_UNROLL
   for (int i = 0; i < 4; ++i) {
@@ -266,45 +260,83 @@ PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, f
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// A8  formulas.  Time runs backwards (t = T-1 ... 0) so that every suffix soft-min G s[t] = softmin(s[t:T]) is a
-//     running log-sum-exp; F10 G s = softmax over t < 10 of those suffix values is a second running log-sum-exp.
+// State sources: the unicycle driven by the row's controls (A6, nusc_train.py:29-49), or trajectories handed in by the
+// caller (what compute_stl_dense receives).  get() returns state t and cos/sin of its heading (shared by the dynamics
+// and by the ego circle row).
 // ---------------------------------------------------------------------------------------------------------------
-struct LaneAcc {
-  Lse g1, g2, g3;  // keep-lane terms: G(d - dmin), G(dmax - d), G((thmax - th)/thmax)
-  Lse gb;          // suffix soft-min of the band term softmin2(d - dmin, dmax - d)
-  Lse fb, ft;      // F10 over G(band)[t] and over G(th-term)[t]
+struct DynSrc {
+  float x, y, th, v;
+  const float* u;
+  float ws, as, dt;
+  PSTL_HD DynSrc(const float* s0, const float* u_, float ws_, float as_, float dt_)
+      : x(s0[0]), y(s0[1]), th(s0[2]), v(s0[3]), u(u_), ws(ws_), as(as_), dt(dt_) {}
+  PSTL_HD void get(int t, float& X, float& Y, float& TH, float& V, float& c, float& s) {
+    X = x, Y = y, TH = th, V = v;
+    c = cosf(th);
+    s = sinf(th);
+    const float w = u[2 * t] * ws;
+    const float a = u[2 * t + 1] * as;
+    const float dx = v * c;
+    const float dy = v * s;
+    x = x + dx * dt;
+    y = y + dy * dt;
+    th = th + w * dt;
+    v = v + a * dt;
+  }
+};
+
+struct GivenSrc {
+  const f4* p;  // (T,4) states of this row
+  PSTL_HD void get(int t, float& X, float& Y, float& TH, float& V, float& c, float& s) const {
+    const f4 q = p[t];
+    X = q.x, Y = q.y, TH = q.z, V = q.w;
+    c = cosf(q.z);
+    s = sinf(q.z);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// A8  formulas, evaluated in ONE forward sweep over time.
+//   "Always" at time 0 (G s[0] = softmin over all t) is an order-independent running log-sum-exp.
+//   "Eventually(0,10, Always(...))" needs the suffix soft-mins G s[k] = softmin(s[k:T]) for k < 10: the sweep keeps
+//   the tail t >= 10 as one running log-sum-exp and parks the first 10 values of the signal in scratch; a 10-step
+//   backward scan then yields every suffix value, which feeds the outer soft-max.  The 405 torch.logsumexp calls of
+//   the reference per evaluation become ~100 exp and ~30 log per row.
+// ---------------------------------------------------------------------------------------------------------------
+struct ReachAcc {  // one "reach the side lane" pair: band = softmin2(d - dmin, dmax - d) and the heading term
+  Lse tailb, tailt;
   PSTL_HD void init() {
-    g1.init();
-    g2.init();
-    g3.init();
-    gb.init();
+    tailb.init();
+    tailt.init();
+  }
+  PSTL_HD void step(float tau, int t, float s1, float s2, float a3, Scratch st, int base) {
+    const float band = -(lse2(-s1 * tau, -s2 * tau) / tau);
+    const float ab = -band * tau;
+    if (t < kFwin) {
+      st.at(base + t) = ab;
+      st.at(base + kFwin + t) = a3;
+    } else {
+      tailb.add(ab);
+      tailt.add(a3);
+    }
+  }
+  // suffix scan: leaves L_k = logsumexp(a[k:T]) in scratch (the adjoint needs them) and returns the two F10 values
+  PSTL_HD void finish(float tau, Scratch st, int base, float& Lfb, float& Lft) {
+    Lse fb, ft;
     fb.init();
     ft.init();
-  }
-  // KEEP: accumulate the keep-lane family; REACH: the reach family (shares g3)
-  template <bool KEEP, bool REACH>
-  PSTL_HD void step(const StlRow& r, float tau, int t, float d, float th, float* lb_store, float* lt_store) {
-    const float s1 = d - r.dmin;
-    const float s2 = -d + r.dmax;
-    const float s3 = (r.thmax - th) / r.thmax;
-    g3.add(-s3 * tau);
-    if (KEEP) {
-      g1.add(-s1 * tau);
-      g2.add(-s2 * tau);
+    PSTL_NOUNROLL
+    for (int k = kFwin - 1; k >= 0; --k) {
+      tailb.add(st.at(base + k));
+      tailt.add(st.at(base + kFwin + k));
+      const float lb = tailb.value(), lt = tailt.value();
+      st.at(base + k) = lb;
+      st.at(base + kFwin + k) = lt;
+      fb.add(-(lb / tau) * tau);
+      ft.add(-(lt / tau) * tau);
     }
-    if (REACH) {
-      const float band = -(lse2(-s1 * tau, -s2 * tau) / tau);
-      gb.add(-band * tau);
-      if (t < kFwin) {
-        const float lb = gb.value(), lt = g3.value();
-        fb.add(-(lb / tau) * tau);
-        ft.add(-(lt / tau) * tau);
-        if (lb_store) {
-          *lb_store = lb;
-          *lt_store = lt;
-        }
-      }
-    }
+    Lfb = fb.value();
+    Lft = ft.value();
   }
 };
 
@@ -318,61 +350,82 @@ PSTL_HD float conj6(const float* v, int n, float tau) {  // softmin over n <= 6 
   }
   float s = 0.0f;
   PSTL_UNROLL
-  for (int i = 0; i < 6; ++i) s += (i < n) ? expf(a[i] - m) : 0.0f;
-  return -((logf(s) + m) / tau);
+  for (int i = 0; i < 6; ++i) s += (i < n) ? PSTL_EXP(a[i] - m) : 0.0f;
+  return -((PSTL_LOG(s) + m) / tau);
 }
 
-// Evaluates the formulas of one row whose states are already in scratch.
-//   ALL3 = true : all three formulas -> out3[0..2]; returns the mode-selected score
-//   ALL3 = false: only the formula of r.mode
-template <bool ALL3>
-PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Scratch st,
-                       float* out3) {
+struct FwdOut {  // what the adjoint needs from the forward sweep
+  float Lv1, Lv2, Ls, L1, L2, L3, Lfb, Lft, score;
+};
+
+// Evaluates the formulas of one row.
+//   ALL3 = true : all three formulas -> out3[0..2]; returns the mode-selected score   (scratch: kScratchFwd3)
+//   ALL3 = false: only the formula of r.mode                                           (scratch: kScratchFwd)
+//   XY != -1    : additionally parks x_t, y_t at scratch[XY + t], scratch[XY + T + t]  (adjoint)
+template <bool ALL3, int XY, class Src>
+PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Src src, Scratch st,
+                       int tab, float* out3, FwdOut* fo) {
   const float tau = env.tau;
-  Lse gv1, gv2, gsafe;
+  Lse gv1, gv2, gsafe, g1, g2, g3;
   gv1.init();
   gv2.init();
   gsafe.init();
-  LaneAcc L0, L1, L2;
-  L0.init();
-  L1.init();
-  L2.init();
+  g1.init();
+  g2.init();
+  g3.init();
+  ReachAcc R1, R2;
+  R1.init();
+  R2.init();
   const int mode = r.mode;
   const f4* sel_lane = lanes + (mode < 3 ? mode : 0) * kNseg;
   PSTL_NOUNROLL
-  for (int t = kT - 1; t >= 0; --t) {
-    const float x = st.at(4 * t), y = st.at(4 * t + 1), th = st.at(4 * t + 2), v = st.at(4 * t + 3);
+  for (int t = 0; t < kT; ++t) {
+    float x, y, th, v, c, s;
+    src.get(t, x, y, th, v, c, s);
+    if (XY >= 0) {
+      st.at(XY + t) = x;
+      st.at(XY + kT + t) = y;
+    }
     gv1.add(-(v - r.vmin) * tau);
     gv2.add(-(-v + r.vmax) * tau);
     ClearHit ch;
-    clearance_eval<false>(env, nei, K, t, x, y, th, ch);
+    clearance_eval<false>(env, nei, K, t, x, y, c, s, ch);
     gsafe.add(-(ch.dn - r.dsafe) * tau);
     LaneHit h;
+    lane_eval<false>(ALL3 ? lanes : sel_lane, x, y, th, h);
+    {
+      const float s1 = h.d - r.dmin, s2 = -h.d + r.dmax, a3 = -((r.thmax - h.th) / r.thmax) * tau;
+      g1.add(-s1 * tau);
+      g2.add(-s2 * tau);
+      g3.add(a3);
+      if (!ALL3) R1.step(tau, t, s1, s2, a3, st, tab);
+    }
     if (ALL3) {
-      lane_eval<false>(lanes, x, y, th, h);
-      L0.step<true, false>(r, tau, t, h.d, h.th, nullptr, nullptr);
       lane_eval<false>(lanes + kNseg, x, y, th, h);
-      L1.step<false, true>(r, tau, t, h.d, h.th, nullptr, nullptr);
+      R1.step(tau, t, h.d - r.dmin, -h.d + r.dmax, -((r.thmax - h.th) / r.thmax) * tau, st, tab);
       lane_eval<false>(lanes + 2 * kNseg, x, y, th, h);
-      L2.step<false, true>(r, tau, t, h.d, h.th, nullptr, nullptr);
-    } else {
-      lane_eval<false>(sel_lane, x, y, th, h);
-      L0.step<true, true>(r, tau, t, h.d, h.th, nullptr, nullptr);
+      R2.step(tau, t, h.d - r.dmin, -h.d + r.dmax, -((r.thmax - h.th) / r.thmax) * tau, st, tab + 2 * kFwin);
     }
   }
-  const float Vv1 = -(gv1.value() / tau), Vv2 = -(gv2.value() / tau), Vs = -(gsafe.value() / tau);
+  const float Lv1 = gv1.value(), Lv2 = gv2.value(), Ls = gsafe.value();
+  const float Vv1 = -(Lv1 / tau), Vv2 = -(Lv2 / tau), Vs = -(Ls / tau);
+  const float L1 = g1.value(), L2 = g2.value(), L3 = g3.value();
+  float Lfb = 0.0f, Lft = 0.0f;
   float sc[3] = {0.0f, 0.0f, 0.0f};
   if (ALL3 || mode == 0) {
-    const float v[6] = {Vv1, Vv2, -(L0.g1.value() / tau), -(L0.g2.value() / tau), -(L0.g3.value() / tau), Vs};
-    sc[0] = conj6(v, 6, tau);
+    const float v6[6] = {Vv1, Vv2, -(L1 / tau), -(L2 / tau), -(L3 / tau), Vs};
+    sc[0] = conj6(v6, 6, tau);
   }
   if (ALL3) {
-    const float v1[5] = {Vv1, Vv2, L1.fb.value() / tau, L1.ft.value() / tau, Vs};
+    R1.finish(tau, st, tab, Lfb, Lft);
+    const float v1[5] = {Vv1, Vv2, Lfb / tau, Lft / tau, Vs};
     sc[1] = conj6(v1, 5, tau);
-    const float v2[5] = {Vv1, Vv2, L2.fb.value() / tau, L2.ft.value() / tau, Vs};
+    R2.finish(tau, st, tab + 2 * kFwin, Lfb, Lft);
+    const float v2[5] = {Vv1, Vv2, Lfb / tau, Lft / tau, Vs};
     sc[2] = conj6(v2, 5, tau);
   } else if (mode == 1 || mode == 2) {
-    const float v1[5] = {Vv1, Vv2, L0.fb.value() / tau, L0.ft.value() / tau, Vs};
+    R1.finish(tau, st, tab, Lfb, Lft);
+    const float v1[5] = {Vv1, Vv2, Lfb / tau, Lft / tau, Vs};
     sc[mode] = conj6(v1, 5, tau);
   }
   if (ALL3 && out3) {
@@ -380,23 +433,33 @@ PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, cons
     out3[1] = sc[1];
     out3[2] = sc[2];
   }
-  // get_stl_scores (nusc_train.py:150-151): masked sum of the three formulas plus the constant 1 for outliers
+  float score;
   if (ALL3) {
-    return sc[0] * (mode == 0 ? 1.0f : 0.0f) + sc[1] * (mode == 1 ? 1.0f : 0.0f) + sc[2] * (mode == 2 ? 1.0f : 0.0f) +
-           1.0f * (mode == 3 ? 1.0f : 0.0f);
+    // get_stl_scores (nusc_train.py:150-151): masked sum of the three formulas plus the constant 1 for outliers
+    score = sc[0] * (mode == 0 ? 1.0f : 0.0f) + sc[1] * (mode == 1 ? 1.0f : 0.0f) + sc[2] * (mode == 2 ? 1.0f : 0.0f) +
+            1.0f * (mode == 3 ? 1.0f : 0.0f);
+  } else {
+    score = mode == 3 ? 1.0f : sc[mode];
   }
-  return mode == 3 ? 1.0f : sc[mode];
+  if (fo) {
+    fo->Lv1 = Lv1, fo->Lv2 = Lv2, fo->Ls = Ls, fo->L1 = L1, fo->L2 = L2, fo->L3 = L3, fo->Lfb = Lfb, fo->Lft = Lft;
+    fo->score = score;
+  }
+  return score;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Forward + adjoint of one row: returns the score and calls emit(t, gw, ga) once for every t in [0,T) with
-// (gw, ga) = dscore_fn(score) * d score / d (u[2t], u[2t+1])  (u = the 40 control values that rollout_states
-// multiplied by wscale/ascale).  Only the formula of r.mode carries gradient (the others are multiplied by a 0 mask
-// in the reference).  Scratch must hold kScratchFloats floats per lane.
+// (gw, ga) = dscore_fn(score) * d score / d (u[2t], u[2t+1])  (u = the 40 control values, scaled by wscale/ascale
+// inside the dynamics).  Only the formula of r.mode carries gradient (the others are multiplied by a 0 mask in the
+// reference).  Scratch: kScratchGrad floats per lane = x_t, y_t (2T) + the two suffix tables (2*10).  Heading and
+// speed at time t are re-derived from the controls by the very same chain of additions the forward sweep performed
+// (O(T^2) = 190 cheap steps per row), which keeps them bit-identical without storing them -- 40 % less LDS per
+// wavefront, i.e. more resident wavefronts.
 // ---------------------------------------------------------------------------------------------------------------
 template <class DScoreFn, class EmitFn>
-PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Scratch st,
-                            float wscale, float ascale, DScoreFn dscore_fn, EmitFn emit) {
+PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, const float* s0,
+                            const float* u, Scratch st, float wscale, float ascale, DScoreFn dscore_fn, EmitFn emit) {
   const float tau = env.tau;
   const int mode = r.mode;
   if (mode >= 3) {
@@ -405,64 +468,63 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     return 1.0f;
   }
   const f4* lane = lanes + mode * kNseg;
-  const int LB = 4 * kT, LT = 4 * kT + kFwin;
-  // ---- pass 2: values -----------------------------------------------------------------------------------------
-  Lse gv1, gv2, gsafe;
-  gv1.init();
-  gv2.init();
-  gsafe.init();
-  LaneAcc A;
-  A.init();
-  PSTL_NOUNROLL
-  for (int t = kT - 1; t >= 0; --t) {
-    const float x = st.at(4 * t), y = st.at(4 * t + 1), th = st.at(4 * t + 2), v = st.at(4 * t + 3);
-    gv1.add(-(v - r.vmin) * tau);
-    gv2.add(-(-v + r.vmax) * tau);
-    ClearHit ch;
-    clearance_eval<false>(env, nei, K, t, x, y, th, ch);
-    gsafe.add(-(ch.dn - r.dsafe) * tau);
-    LaneHit h;
-    lane_eval<false>(lane, x, y, th, h);
-    float lb = 0.0f, lt = 0.0f;
-    A.step<true, true>(r, tau, t, h.d, h.th, &lb, &lt);
-    if (t < kFwin) {
-      st.at(LB + t) = lb;
-      st.at(LT + t) = lt;
-    }
-  }
-  const float Lv1 = gv1.value(), Lv2 = gv2.value(), Ls = gsafe.value();
-  const float Vv1 = -(Lv1 / tau), Vv2 = -(Lv2 / tau), Vs = -(Ls / tau);
-  const float L1 = A.g1.value(), L2 = A.g2.value(), L3 = A.g3.value();
-  const float Lfb = A.fb.value(), Lft = A.ft.value();
+  const int XY = 0, LB = 2 * kT, LT = 2 * kT + kFwin;
+  // ---- forward sweep ------------------------------------------------------------------------------------------
+  FwdOut fo;
+  const float score = stl_eval<false, 0>(env, r, lanes, nei, K, DynSrc(s0, u, wscale, ascale, env.dt), st, LB, nullptr, &fo);
+  const float Lv1 = fo.Lv1, Lv2 = fo.Lv2, Ls = fo.Ls, L1 = fo.L1, L2 = fo.L2, L3 = fo.L3, Lfb = fo.Lfb, Lft = fo.Lft;
   float V[6];
   int n;
   if (mode == 0) {
-    V[0] = Vv1, V[1] = Vv2, V[2] = -(L1 / tau), V[3] = -(L2 / tau), V[4] = -(L3 / tau), V[5] = Vs;
+    V[0] = -(Lv1 / tau), V[1] = -(Lv2 / tau), V[2] = -(L1 / tau), V[3] = -(L2 / tau), V[4] = -(L3 / tau), V[5] = -(Ls / tau);
     n = 6;
   } else {
-    V[0] = Vv1, V[1] = Vv2, V[2] = Lfb / tau, V[3] = Lft / tau, V[4] = Vs;
+    V[0] = -(Lv1 / tau), V[1] = -(Lv2 / tau), V[2] = Lfb / tau, V[3] = Lft / tau, V[4] = -(Ls / tau);
     n = 5;
   }
-  const float score = conj6(V, n, tau);
   const float Lout = -score * tau;  // logsumexp of (-V_i tau)
   const float dscore_in = dscore_fn(score);
   float om[6];
   PSTL_UNROLL
-  for (int i = 0; i < 6; ++i) om[i] = i < n ? expf(-V[i] * tau - Lout) * dscore_in : 0.0f;  // d score / d V_i
+  for (int i = 0; i < 6; ++i) om[i] = i < n ? PSTL_EXP(-V[i] * tau - Lout) * dscore_in : 0.0f;  // d score / d V_i
   const float o_v1 = om[0], o_v2 = om[1], o_s = (mode == 0) ? om[5] : om[4];
   emit(kT - 1, 0.0f, 0.0f);  // the last control never reaches a scored state
-  // ---- pass 3: adjoint, backwards in time ---------------------------------------------------------------------
+  if (mode != 0) {
+    // d F10(G s) / d s_u = sum_{k <= m} q_k exp(a_u - L_k), m = min(u, 9), q_k = exp(tau g_k - Lf).  With
+    // S_m = sum_{k<=m} q_k exp(L_m - L_k) (a 10-step recurrence; L_k decreases with k so every exponent is <= 0)
+    // this is exp(a_u - Lambda_m), Lambda_m = L_m - log S_m: one exp per time step instead of one per (u, k).
+    float sb = 0.0f, sth = 0.0f, lb_prev = 0.0f, lt_prev = 0.0f;
+    PSTL_NOUNROLL
+    for (int k = 0; k < kFwin; ++k) {
+      const float lb = st.at(LB + k), lt = st.at(LT + k);
+      const float qb = PSTL_EXP(-(lb / tau) * tau - Lfb), qt = PSTL_EXP(-(lt / tau) * tau - Lft);
+      sb = (k == 0) ? qb : sb * PSTL_EXP(lb - lb_prev) + qb;
+      sth = (k == 0) ? qt : sth * PSTL_EXP(lt - lt_prev) + qt;
+      st.at(LB + k) = lb - PSTL_LOG(sb);
+      st.at(LT + k) = lt - PSTL_LOG(sth);
+      lb_prev = lb;
+      lt_prev = lt;
+    }
+  }
+  // ---- adjoint, backwards in time -----------------------------------------------------------------------------
   float lx = 0.0f, ly = 0.0f, lth = 0.0f, lv = 0.0f;  // lambda_{t+1}
   const float dt = env.dt;
   PSTL_NOUNROLL
   for (int t = kT - 1; t >= 1; --t) {
-    const float x = st.at(4 * t), y = st.at(4 * t + 1), th = st.at(4 * t + 2), v = st.at(4 * t + 3);
+    const float x = st.at(XY + t), y = st.at(XY + kT + t);
+    float th = s0[2], v = s0[3];
+    PSTL_NOUNROLL
+    for (int q = 0; q < t; ++q) {  // the forward sweep's own additions, replayed
+      th = th + (u[2 * q] * wscale) * dt;
+      v = v + (u[2 * q + 1] * ascale) * dt;
+    }
+    const float c = cosf(th), s = sinf(th);
     // direct partials of the score w.r.t. state t
     float gx, gy, gth, gv;
-    gv = o_v1 * expf(-(v - r.vmin) * tau - Lv1) - o_v2 * expf(-(-v + r.vmax) * tau - Lv2);
+    gv = o_v1 * PSTL_EXP(-(v - r.vmin) * tau - Lv1) - o_v2 * PSTL_EXP(-(-v + r.vmax) * tau - Lv2);
     ClearHit ch;
-    clearance_eval<true>(env, nei, K, t, x, y, th, ch);
-    const float gs = o_s * expf(-(ch.dn - r.dsafe) * tau - Ls);
+    clearance_eval<true>(env, nei, K, t, x, y, c, s, ch);
+    const float gs = o_s * PSTL_EXP(-(ch.dn - r.dsafe) * tau - Ls);
     gx = gs * ch.d_dx;
     gy = gs * ch.d_dy;
     gth = gs * ch.d_dth;
@@ -471,29 +533,23 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     const float s1 = h.d - r.dmin, s2 = -h.d + r.dmax, s3 = (r.thmax - h.th) / r.thmax;
     float gd, gsth;  // d score / d d_t , d score / d s3_t
     if (mode == 0) {
-      gd = om[2] * expf(-s1 * tau - L1) - om[3] * expf(-s2 * tau - L2);
-      gsth = om[4] * expf(-s3 * tau - L3);
+      gd = om[2] * PSTL_EXP(-s1 * tau - L1) - om[3] * PSTL_EXP(-s2 * tau - L2);
+      gsth = om[4] * PSTL_EXP(-s3 * tau - L3);
     } else {
       const float a1 = -s1 * tau, a2 = -s2 * tau;
       const float lp = lse2(a1, a2);
       const float band = -(lp / tau);
       const float ab = -band * tau, a3 = -s3 * tau;
-      float wb = 0.0f, wt = 0.0f;
-      const int tmax = t < kFwin - 1 ? t : kFwin - 1;
-      PSTL_NOUNROLL
-      for (int k = 0; k <= tmax; ++k) {
-        const float lb = st.at(LB + k), lt = st.at(LT + k);
-        wb += expf(-(lb / tau) * tau - Lfb) * expf(ab - lb);
-        wt += expf(-(lt / tau) * tau - Lft) * expf(a3 - lt);
-      }
-      gd = om[2] * wb * (expf(a1 - lp) - expf(a2 - lp));
+      const int m = t < kFwin - 1 ? t : kFwin - 1;
+      const float wb = PSTL_EXP(ab - st.at(LB + m));
+      const float wt = PSTL_EXP(a3 - st.at(LT + m));
+      gd = om[2] * wb * (PSTL_EXP(a1 - lp) - PSTL_EXP(a2 - lp));
       gsth = om[3] * wt;
     }
     gx += gd * h.dd_dx;
     gy += gd * h.dd_dy;
     gth += gsth * (-1.0f / r.thmax) * h.dth_dth;
     // lambda_t = direct_t + J_t^T lambda_{t+1}
-    const float c = cosf(th), s = sinf(th);
     const float nlth = gth + lth + lx * (-(v * s) * dt) + ly * ((v * c) * dt);
     const float nlv = gv + lv + lx * (c * dt) + ly * (s * dt);
     lx = gx + lx;

@@ -49,34 +49,59 @@ __device__ __forceinline__ StlRow load_row(const float* stlp, const float* hl, l
   return r;
 }
 
-template <bool ALL3>
+// Scene tables of the row.  STAGED (host picks it when rows_per_scene % 64 == 0, so that the 64 rows of a workgroup
+// share one scene): the wave copies the scene's lane waypoints and prepared neighbour circles into LDS once, and every
+// later read is an LDS broadcast instead of a latency-bound global load.  Otherwise they are read from global memory.
+// Dynamic LDS layout: [scratch: n_scratch x 64 floats][lanes: 3*15 float4][neighbours: K*20*12 floats].
+template <bool STAGED>
+__device__ __forceinline__ void scene_tables(float* lds, int n_scratch, const float* lane_prep, const float* nei_prep,
+                                             int K, int rows_per_scene, long row, const f4*& lanes, const float*& nei) {
+  if (STAGED) {
+    const long b = ((long)blockIdx.x * kWave) / rows_per_scene;  // uniform over the workgroup
+    f4* sl = reinterpret_cast<f4*>(lds + n_scratch * kWave);
+    f4* sn = sl + 3 * kNseg + 3;  // keep 16-byte alignment and a little padding
+    const f4* gl = reinterpret_cast<const f4*>(lane_prep) + b * 3 * kNseg;
+    const f4* gn = reinterpret_cast<const f4*>(nei_prep + b * (long)K * kT * kNeiPrep);
+    for (int i = threadIdx.x; i < 3 * kNseg; i += kWave) sl[i] = gl[i];
+    for (int i = threadIdx.x; i < K * kT * 3; i += kWave) sn[i] = gn[i];
+    __syncthreads();
+    lanes = sl;
+    nei = reinterpret_cast<const float*>(sn);
+  } else {
+    const long b = row / rows_per_scene;
+    lanes = reinterpret_cast<const f4*>(lane_prep) + b * 3 * kNseg;
+    nei = nei_prep + b * (long)K * kT * kNeiPrep;
+  }
+}
+
+inline size_t stl_lds_bytes(int n_scratch, int K, bool staged) {
+  return ((size_t)n_scratch * kWave + (staged ? (size_t)(3 * kNseg + 3) * 4 + (size_t)K * kT * kNeiPrep : 0)) * sizeof(float);
+}
+
+template <bool ALL3, bool STAGED, bool GIVEN>
 __global__ __launch_bounds__(kWave) void k_stl_forward(StlArgs a) {
-  __shared__ float lds[4 * kT * kWave];
-  const long row = (long)blockIdx.x * kWave + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NS = ALL3 ? kScratchFwd3 : kScratchFwd;
+  long row = (long)blockIdx.x * kWave + threadIdx.x;
+  const f4* lanes;
+  const float* nei;
+  scene_tables<STAGED>(lds, NS, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes, nei);
   if (row >= a.N) return;
   const Scratch st = {lds + threadIdx.x, kWave};
   const long b = row / a.rows_per_scene;
   const StlRow r = load_row(a.stlp, a.hl, row);
-  const f4* lanes = reinterpret_cast<const f4*>(a.lane_prep) + b * 3 * kNseg;
-  const float* nei = a.nei_prep + b * (long)a.K * kT * kNeiPrep;
   float best = -INFINITY;
   int best_rep = 0;
   for (int rep = 0; rep < a.reps; ++rep) {
-    if (a.states) {
-      const f4* sp = reinterpret_cast<const f4*>(a.states) + ((long)rep * a.N + row) * kT;
-      for (int t = 0; t < kT; ++t) {
-        const f4 v = sp[t];
-        st.at(4 * t) = v.x;
-        st.at(4 * t + 1) = v.y;
-        st.at(4 * t + 2) = v.z;
-        st.at(4 * t + 3) = v.w;
-      }
-    } else {
-      const float* u = a.controls + ((long)rep * a.N + row) * (2 * kT);
-      rollout_states(a.s0 + b * 4, u, 1.0f, 1.0f, a.env.dt, st);
-    }
     float o3[3];
-    const float score = stl_eval<ALL3>(a.env, r, lanes, nei, a.K, st, o3);
+    float score;
+    if (GIVEN) {
+      const GivenSrc src = {reinterpret_cast<const f4*>(a.states) + ((long)rep * a.N + row) * kT};
+      score = stl_eval<ALL3, -1>(a.env, r, lanes, nei, a.K, src, st, 0, o3, nullptr);
+    } else {
+      const DynSrc src(a.s0 + b * 4, a.controls + ((long)rep * a.N + row) * (2 * kT), 1.0f, 1.0f, a.env.dt);
+      score = stl_eval<ALL3, -1>(a.env, r, lanes, nei, a.K, src, st, 0, o3, nullptr);
+    }
     a.scores[(long)rep * a.N + row] = score;
     if (ALL3 && a.scores3) {
       const long stride = (long)a.reps * a.N;
@@ -116,20 +141,22 @@ struct GradArgs {
   float* scores;        // (N,) or null
 };
 
+template <bool STAGED>
 __global__ __launch_bounds__(kWave) void k_stl_backward(GradArgs a) {
-  __shared__ float lds[kScratchFloats * kWave];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const long row = (long)blockIdx.x * kWave + threadIdx.x;
+  const f4* lanes;
+  const float* nei;
+  scene_tables<STAGED>(lds, kScratchGrad, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes,
+                       nei);
   if (row >= a.N) return;
   const Scratch st = {lds + threadIdx.x, kWave};
   const long b = row / a.rows_per_scene;
   const StlRow r = load_row(a.stlp, a.hl, row);
-  const f4* lanes = reinterpret_cast<const f4*>(a.lane_prep) + b * 3 * kNseg;
-  const float* nei = a.nei_prep + b * (long)a.K * kT * kNeiPrep;
-  rollout_states(a.s0 + b * 4, a.u + row * (2 * kT), a.wscale, a.ascale, a.env.dt, st);
   const float ds = a.dscore ? a.dscore[row] : 1.0f;
   float* out = a.dcontrols + row * (2 * kT);
   const float score = stl_eval_grad(
-      a.env, r, lanes, nei, a.K, st, a.wscale, a.ascale, [=](float) { return ds; },
+      a.env, r, lanes, nei, a.K, a.s0 + b * 4, a.u + row * (2 * kT), st, a.wscale, a.ascale, [=](float) { return ds; },
       [=](int t, float gw, float ga) {
         out[2 * t] = gw;
         out[2 * t + 1] = ga;
@@ -162,18 +189,19 @@ struct GuideArgs {
   float* emit_out;  // (N,40) or null
 };
 
-template <bool MULTI>
+template <bool MULTI, bool STAGED>
 __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
-  __shared__ float lds[kScratchFloats * kWave];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const long row = (long)blockIdx.x * kWave + threadIdx.x;
+  const f4* lanes;
+  const float* nei;
+  scene_tables<STAGED>(lds, kScratchGrad, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes,
+                       nei);
   if (row >= a.N) return;
   const Scratch st = {lds + threadIdx.x, kWave};
   const long b = row / a.rows_per_scene;
   const StlRow r = load_row(a.stlp, a.hl, row);
-  const f4* lanes = reinterpret_cast<const f4*>(a.lane_prep) + b * 3 * kNseg;
-  const float* nei = a.nei_prep + b * (long)a.K * kT * kNeiPrep;
   float* mu = a.mu + row * (2 * kT);
-  rollout_states(a.s0 + b * 4, mu, a.wscale, a.ascale, a.env.dt, st);
   const float vr = a.valid[row];
   const float gs = a.grad_scale * vr;
   const float thres = a.thres;
@@ -215,8 +243,10 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
       mu[e] = p;
     }
   };
+  // mu[2t], mu[2t+1] are rewritten by emit(t) while the adjoint walks t = T-1 ... 0; the sweep re-reads only entries
+  // of earlier time steps, which are still the original values
   stl_eval_grad(
-      a.env, r, lanes, nei, a.K, st, a.wscale, a.ascale,
+      a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
       [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
       [=](int t, float gw, float ga) {
         update(2 * t, gw, a.wscale);
@@ -312,6 +342,15 @@ __global__ void k_metrics_scenes(int bs, int S, const float* scores, const float
 
 using namespace pstl;
 
+// the 64 rows of every workgroup share one scene (and the staged tables fit comfortably in LDS)
+static bool scene_staged(const pstl_cfg* cfg) { return cfg->rows_per_scene % kWave == 0 && cfg->K <= 16; }
+
+static int allow_lds(const void* fn, size_t bytes) {
+  if (bytes <= 48 * 1024) return PSTL_OK;
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? PSTL_OK
+                                                                                                        : PSTL_ERR_LAUNCH;
+}
+
 extern "C" int pstl_prepare_scene(const pstl_cfg* cfg, const float* neighbors_traj, const float* currlane,
                                   const float* leftlane, const float* rightlane, float* nei_prep, float* lane_prep,
                                   void* stream) {
@@ -362,10 +401,17 @@ extern "C" int pstl_stl_forward(const pstl_cfg* cfg, const float* s0, const floa
   a.sel_scores = sel_scores;
   a.sel_idx = sel_idx;
   const dim3 grid((unsigned)((a.N + kWave - 1) / kWave));
-  if (scores3)
-    hipLaunchKernelGGL(k_stl_forward<true>, grid, dim3(kWave), 0, as_stream(stream), a);
+  const bool staged = scene_staged(cfg);
+  const size_t lds = stl_lds_bytes(scores3 ? kScratchFwd3 : kScratchFwd, cfg->K, staged);
+  void (*fn)(StlArgs);
+  if (states)
+    fn = scores3 ? (staged ? k_stl_forward<true, true, true> : k_stl_forward<true, false, true>)
+                 : (staged ? k_stl_forward<false, true, true> : k_stl_forward<false, false, true>);
   else
-    hipLaunchKernelGGL(k_stl_forward<false>, grid, dim3(kWave), 0, as_stream(stream), a);
+    fn = scores3 ? (staged ? k_stl_forward<true, true, false> : k_stl_forward<true, false, false>)
+                 : (staged ? k_stl_forward<false, true, false> : k_stl_forward<false, false, false>);
+  if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
+  hipLaunchKernelGGL(fn, grid, dim3(kWave), lds, as_stream(stream), a);
   return launch_status();
 }
 
@@ -391,7 +437,11 @@ extern "C" int pstl_stl_backward(const pstl_cfg* cfg, const float* s0, const flo
   a.dscore = dscore;
   a.dcontrols = dcontrols;
   a.scores = scores;
-  hipLaunchKernelGGL(k_stl_backward, dim3((unsigned)((a.N + kWave - 1) / kWave)), dim3(kWave), 0, as_stream(stream), a);
+  const bool staged = scene_staged(cfg);
+  const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged);
+  void (*fn)(GradArgs) = staged ? k_stl_backward<true> : k_stl_backward<false>;
+  if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
+  hipLaunchKernelGGL(fn, dim3((unsigned)((a.N + kWave - 1) / kWave)), dim3(kWave), lds, as_stream(stream), a);
   return launch_status();
 }
 
@@ -428,14 +478,16 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
   a.work = work;
   a.emit_out = emit_out;
   const dim3 grid((unsigned)((a.N + kWave - 1) / kWave));
+  const bool staged = scene_staged(cfg);
+  const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged);
+  void (*fn)(GuideArgs) = niters > 1 ? (staged ? k_guidance_iter<true, true> : k_guidance_iter<true, false>)
+                                     : (staged ? k_guidance_iter<false, true> : k_guidance_iter<false, false>);
+  if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
   for (int j = 0; j < niters; ++j) {
     a.iter = j;
     a.neg_step = adam_neg_step[j];
     a.bc2_sqrt = adam_bc2_sqrt[j];
-    if (niters > 1)
-      hipLaunchKernelGGL(k_guidance_iter<true>, grid, dim3(kWave), 0, as_stream(stream), a);
-    else
-      hipLaunchKernelGGL(k_guidance_iter<false>, grid, dim3(kWave), 0, as_stream(stream), a);
+    hipLaunchKernelGGL(fn, grid, dim3(kWave), lds, as_stream(stream), a);
     if (int e = launch_status()) return e;
   }
   return PSTL_OK;

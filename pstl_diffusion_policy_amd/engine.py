@@ -266,7 +266,7 @@ class Sampler:
 
     # ---- A12: the timed region ----
     def sampling_region(self, sb, steps, x_T, noise, rect_head=False, multi_cands=None, refinenet=True, guidance=None,
-                        n_rolls=None, diverse=True, full_list=False, coeffs=None):
+                        n_rolls=None, diverse=True, full_list=False, coeffs=None, want_scores3=True):
         out = {}
         feature, base_p, base_r = self.encode(sb, need_rect=rect_head)
         out["feature_scene"] = feature
@@ -294,10 +294,11 @@ class Sampler:
                 controls = self.refine(sb, base_r, controls, sc, diverse=diverse)
                 out["roll%d_scores" % ri] = sc
                 out["roll%d_controls" % ri] = controls
-        fin = self.score(sb, controls.reshape(1, sb.N, ffi.CTRL), all3=True)
+        fin = self.score(sb, controls.reshape(1, sb.N, ffi.CTRL), all3=want_scores3)
         counts, _ = self.metrics(sb, fin["scores"][0])
-        out.update(final_controls=controls, final_scores=fin["scores"][0], final_scores3=fin["scores3"][:, 0],
-                   counts=counts)
+        out.update(final_controls=controls, final_scores=fin["scores"][0], counts=counts)
+        if want_scores3:   # the three formulas before mode selection (what compute_stl_dense returns as scores_list)
+            out["final_scores3"] = fin["scores3"][:, 0]
         return out
 
 

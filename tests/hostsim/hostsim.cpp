@@ -30,21 +30,21 @@ void hostsim_stl_forward(int N, int rows_per_scene, int K, float tau, float dt, 
                          const float* controls, const float* nei_prep, const float* lane_prep, const float* stlp,
                          const float* hl, int all3, float* scores, float* scores3) {
   StlEnv env = make_env(tau, dt, ego_L, ego_W);
-  std::vector<float> scratch(kScratchFloats);
+  std::vector<float> scratch(kScratchFwd3);
   for (int r = 0; r < N; ++r) {
     const int b = r / rows_per_scene;
     StlRow row = {stlp[r * 6 + 0], stlp[r * 6 + 1], stlp[r * 6 + 2], stlp[r * 6 + 3], stlp[r * 6 + 4], stlp[r * 6 + 5],
                   (int)hl[r]};
     Scratch st = {scratch.data(), 1};
-    rollout_states(s0 + b * 4, controls + (long)r * 40, 1.0f, 1.0f, dt, st);
+    DynSrc src(s0 + b * 4, controls + (long)r * 40, 1.0f, 1.0f, dt);
     const f4* lanes = reinterpret_cast<const f4*>(lane_prep + (long)b * 3 * kNseg * 4);
     const float* nei = nei_prep + (long)b * K * kT * kNeiPrep;
     float o3[3] = {0, 0, 0};
     if (all3) {
-      scores[r] = stl_eval<true>(env, row, lanes, nei, K, st, o3);
+      scores[r] = stl_eval<true, -1>(env, row, lanes, nei, K, src, st, 0, o3, nullptr);
       scores3[r] = o3[0], scores3[N + r] = o3[1], scores3[2 * N + r] = o3[2];
     } else {
-      scores[r] = stl_eval<false>(env, row, lanes, nei, K, st, nullptr);
+      scores[r] = stl_eval<false, -1>(env, row, lanes, nei, K, src, st, 0, nullptr, nullptr);
     }
   }
 }
@@ -55,13 +55,12 @@ void hostsim_stl_grad(int N, int rows_per_scene, int K, float tau, float dt, flo
                       const float* stlp, const float* hl, const float* dscore, int relu_mode, float thres, float gscale,
                       const float* valid, float* scores, float* dcontrols) {
   StlEnv env = make_env(tau, dt, ego_L, ego_W);
-  std::vector<float> scratch(kScratchFloats);
+  std::vector<float> scratch(kScratchGrad);
   for (int r = 0; r < N; ++r) {
     const int b = r / rows_per_scene;
     StlRow row = {stlp[r * 6 + 0], stlp[r * 6 + 1], stlp[r * 6 + 2], stlp[r * 6 + 3], stlp[r * 6 + 4], stlp[r * 6 + 5],
                   (int)hl[r]};
     Scratch st = {scratch.data(), 1};
-    rollout_states(s0 + b * 4, controls + (long)r * 40, wscale, ascale, dt, st);
     const f4* lanes = reinterpret_cast<const f4*>(lane_prep + (long)b * 3 * kNseg * 4);
     const float* nei = nei_prep + (long)b * K * kT * kNeiPrep;
     float* out = dcontrols + (long)r * 40;
@@ -72,7 +71,7 @@ void hostsim_stl_grad(int N, int rows_per_scene, int K, float tau, float dt, flo
       out[2 * t] = gw;
       out[2 * t + 1] = ga;
     };
-    scores[r] = stl_eval_grad(env, row, lanes, nei, K, st, wscale, ascale, dfn, emit);
+    scores[r] = stl_eval_grad(env, row, lanes, nei, K, s0 + b * 4, controls + (long)r * 40, st, wscale, ascale, dfn, emit);
   }
 }
 }
