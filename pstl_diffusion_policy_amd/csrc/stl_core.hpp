@@ -34,9 +34,15 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PSTL_EXP(x) __expf(x)
 #define PSTL_LOG(x) __logf(x)
+// 1-ulp hardware square root: ONLY for ranking the 14 waypoint pairs of a lane (the winner's distance itself is
+// computed with exact arithmetic afterwards); a different winner needs two pair sums within 1 ulp of each other
+#define PSTL_SQRT_RANK(x) __builtin_amdgcn_sqrtf(x)
+#define PSTL_SINCOS(x, s, c) sincosf((x), (s), (c))
 #else
 #define PSTL_EXP(x) expf(x)
 #define PSTL_LOG(x) logf(x)
+#define PSTL_SQRT_RANK(x) sqrtf(x)
+#define PSTL_SINCOS(x, s, c) (*(s) = sinf(x), *(c) = cosf(x))
 #endif
 
 namespace pstl {
@@ -145,25 +151,23 @@ template <bool GRAD>
 PSTL_HD void lane_eval(const f4* lane, float px, float py, float pth, LaneHit& h) {
   f4 p = lane[0];
   float ex = px - p.x, ey = py - p.y;
-  float prev = sqrtf(ex * ex + ey * ey);
+  float prev = PSTL_SQRT_RANK(ex * ex + ey * ey);
   float best = INFINITY;
-  f4 p2 = p, p3 = p;
-  f4 q = p;
+  int jb = 0;
   PSTL_UNROLL
   for (int j = 0; j < kNseg - 1; ++j) {
     const f4 n = lane[j + 1];
     ex = px - n.x;
     ey = py - n.y;
-    const float cur = sqrtf(ex * ex + ey * ey);
+    const float cur = PSTL_SQRT_RANK(ex * ex + ey * ey);
     const float s = prev + cur;
     if (s < best) {  // strict: lowest index wins ties, like torch.argmin
       best = s;
-      p2 = q;
-      p3 = n;
+      jb = j;
     }
     prev = cur;
-    q = n;
   }
+  const f4 p2 = lane[jb], p3 = lane[jb + 1];
   const float area = px * (p2.y - p3.y) + p2.x * (p3.y - py) + p3.x * (py - p2.y);
   const float sx = p2.x - p3.x, sy = p2.y - p3.y;
   const float bl = sqrtf(sx * sx + sy * sy);
@@ -174,7 +178,13 @@ PSTL_HD void lane_eval(const f4* lane, float px, float py, float pth, LaneHit& h
   const float cbl = fmaxf(bl, 1e-7f);
   h.d = normal ? area / cbl : l2;
   const float du = p2.z - pth;
-  h.th = 1.0f - cosf(du);
+  float sdu = 0.0f, cdu;
+  if (GRAD) {
+    PSTL_SINCOS(du, &sdu, &cdu);
+  } else {
+    cdu = cosf(du);
+  }
+  h.th = 1.0f - cdu;
   if (GRAD) {
     if (normal) {
       h.dd_dx = (p2.y - p3.y) / cbl;
@@ -186,7 +196,7 @@ PSTL_HD void lane_eval(const f4* lane, float px, float py, float pth, LaneHit& h
       h.dd_dx = 0.0f;
       h.dd_dy = 0.0f;
     }
-    h.dth_dth = -sinf(du);
+    h.dth_dth = -sdu;
   }
 }
 
@@ -272,8 +282,7 @@ struct DynSrc {
       : x(s0[0]), y(s0[1]), th(s0[2]), v(s0[3]), u(u_), ws(ws_), as(as_), dt(dt_) {}
   PSTL_HD void get(int t, float& X, float& Y, float& TH, float& V, float& c, float& s) {
     X = x, Y = y, TH = th, V = v;
-    c = cosf(th);
-    s = sinf(th);
+    PSTL_SINCOS(th, &s, &c);
     const float w = u[2 * t] * ws;
     const float a = u[2 * t + 1] * as;
     const float dx = v * c;
@@ -290,8 +299,7 @@ struct GivenSrc {
   PSTL_HD void get(int t, float& X, float& Y, float& TH, float& V, float& c, float& s) const {
     const f4 q = p[t];
     X = q.x, Y = q.y, TH = q.z, V = q.w;
-    c = cosf(q.z);
-    s = sinf(q.z);
+    PSTL_SINCOS(q.z, &s, &c);
   }
 };
 
@@ -518,7 +526,8 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
       th = th + (u[2 * q] * wscale) * dt;
       v = v + (u[2 * q + 1] * ascale) * dt;
     }
-    const float c = cosf(th), s = sinf(th);
+    float c, s;
+    PSTL_SINCOS(th, &s, &c);
     // direct partials of the score w.r.t. state t
     float gx, gy, gth, gv;
     gv = o_v1 * PSTL_EXP(-(v - r.vmin) * tau - Lv1) - o_v2 * PSTL_EXP(-(-v + r.vmax) * tau - Lv2);
