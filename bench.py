@@ -67,9 +67,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # PSTL_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs than ranks (ranks then
+    # share devices); the real runs use nccl (= RCCL over xGMI), one process per GPU.
+    backend = os.environ.get("PSTL_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

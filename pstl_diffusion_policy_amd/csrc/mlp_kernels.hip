@@ -313,7 +313,8 @@ __device__ __forceinline__ int xs_addr(int k, int c) { return (((k >> 4) * 64) +
 // ABL != 0 are timing-only ablation builds (wrong results by construction; selected with cfg->chain_waves = 8 + 100*ABL
 // and used only to attribute the kernel's time): 1 = no epilogue, 2 = also no layer 1, 3 = also no barrier,
 // 5 = no epilogue and only waves 0..NW/2-1 issue MFMAs (what one wave per SIMD sustains alone).
-template <int NW, bool REFINE, int ABL = 0>
+// EPI_FIRST: the epilogue runs on waves 0..3 (the older wave of each SIMD pair; measured 1.8 % faster than 4..7).
+template <int NW, bool REFINE, int ABL = 0, bool EPI_FIRST = true>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   constexpr int OT = 16 / NW;       // 16-feature output tiles per wave
   constexpr int NT = NW * 64;
@@ -322,8 +323,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   static_assert(NCT >= 160, "epilogue needs 160 threads");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                          // [kG][3][64][4]      activations of layer 1, B-operand order
-  float* h1 = xs + kG * 768;                // [2][16][64][4]      layer-1 output (double buffered)
-  float* part = h1 + 2 * 16 * 256;          // [2][NW][3][64][4]   layer-3 partial sums (double buffered)
+  float* h1 = xs + kG * 768;                // [3][16][64][4]      layer-1 output (triple buffered: written two ahead)
+  float* part = h1 + 3 * 16 * 256;          // [2][NW][3][64][4]   layer-3 partial sums (double buffered)
   float* b2s = part + 2 * NW * 768;         // [256] layer-2 bias, [48] layer-3 bias
   float* b3s = b2s + 256;
   float* coef = b3s + 48;                   // [kMaxLaunchSteps][4] c1, 1/sqrt(alpha), sqrt(beta) of step s_hi - n
@@ -332,9 +333,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   const long tile0 = (long)blockIdx.x * kG;
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
   int G = (int)((n_tiles - tile0) < kG ? (n_tiles - tile0) : kG);
-  // The deferred epilogue needs >= 3 tiles in flight (see the hazard note below); short tail blocks process
-  // phantom tiles whose rows are clamped on load and masked on store.
-  if (G < 3) G = 3;
+  // Layer 1 runs two tile-steps ahead and the epilogue one behind, so >= 4 tiles must be in flight (see the hazard
+  // notes below); short tail blocks process phantom tiles whose rows are clamped on load and masked on store.
+  if (G < 4) G = 4;
 
   // ---- weights -> registers (A operands), once per launch ----
   float w1x[OT][12], w2[OT][64], w3[3][OT][4];
@@ -411,8 +412,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   const int s_hi = REFINE ? 1 : a.step_hi, s_lo = REFINE ? 1 : a.step_lo;
   const int total = (s_hi - s_lo + 1) * G;  // tile-steps of this workgroup; tile-step `it` = (step s_hi - it/G, tile it%G)
 
-  // ---- layer 1 of tile-step `it`: 48 -> 256, result (after ReLU) into h1[it & 1] --------------------------------
-  auto layer1 = [&](int it) {
+  // ---- layer 1 of tile-step `it`: 48 -> 256, result (after ReLU) into h1[it % 3] --------------------------------
+  // It is issued two iterations before layer 2 consumes it, at the START of an iteration: its LDS write has long
+  // landed when the barrier comes, and its own operand latencies hide under the neighbouring MFMAs.
+  // Hazards: it overwrites the buffer layer 2 read in the previous iteration (a barrier ago), and it reads xs[tile],
+  // which the epilogue of tile-step it - G rewrote in iteration it - G + 1 <= it - 3 (G >= 4).
+  auto layer1 = [&](int it, int buf) {
     const int tl = it % G, i = s_hi - it / G;
     long rowc = (tile0 + tl) * kTileRows + col;
     if (rowc >= a.N) rowc = a.N - 1;
@@ -437,15 +442,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma4(w1x[ot][q * 4 + r], bq[r], acc[ot]);
     }
-    f32x4* hw = reinterpret_cast<f32x4*>(h1 + (it & 1) * 4096);
+    f32x4* hw = reinterpret_cast<f32x4*>(h1 + buf * 4096);
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) hw[(w * OT + ot) * 64 + lane] = relu4(acc[ot] + cst[ot]);
   };
 
   // ---- epilogue of tile-step `it` (run by the second half of the waves, one tile-step late) ---------------------
   // Hazards: it reads part[it & 1] (complete since the barrier that ended iteration `it`; rewritten only in iteration
-  // it + 2, after another barrier) and rewrites xs[tile], which layer1 reads again G - 1 iterations later -- at least
-  // one barrier later as long as G >= 3.
+  // it + 2, after another barrier) and rewrites xs[tile], which layer1 reads again G - 3 iterations later -- at least
+  // one barrier later as long as G >= 4.
   auto epilogue = [&](int it, const f32x4& z4) {
     const int tl = it % G, i = s_hi - it / G;
     const long row0 = (tile0 + tl) * kTileRows;
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
     // thread et < 160 owns outputs f0..f0+3 of tile column c: 16-byte LDS accesses at consecutive slots (no bank
     // conflicts), 16-byte global accesses (4 lanes cover one 64-byte piece of a row)
-    const int et = tid - (NT - NCT);
+    const int et = EPI_FIRST ? tid : tid - (NT - NCT);
     if (et < 160) {
       const int qd = et >> 4, c = et & 15;
       const int j = qd >> 2, gq = qd & 3, slot = gq * 16 + c, f0 = 4 * qd;
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     if (REFINE || !a.noise || a.mu_only) return;
     const int tl = it % G, i = s_hi - it / G;
     if (i <= 1) return;  // the reference adds zeros at the last step
-    const int et = tid - (NT - NCT);
+    const int et = EPI_FIRST ? tid : tid - (NT - NCT);
     if (et < 160) {
       const long row = (tile0 + tl) * kTileRows + (et & 15);
       if (row < a.N)
@@ -517,11 +522,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
   };
 
-  const bool epi_wave = (w >= NW - NCW);  // wave-uniform
+  const bool epi_wave = EPI_FIRST ? (w < NCW) : (w >= NW - NCW);  // wave-uniform
   f32x4 zreg = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-  layer1(0);
+  layer1(0, 0);
+  if (total > 1) layer1(1, 1);
   __syncthreads();
+  int hbuf = 0;  // it % 3
   for (int it = 0; it < total; ++it) {
     if (epi_wave && ABL == 0) {
       // While this half finishes the previous tile-step, the partner wave on the same SIMD already issues MFMAs: the
@@ -532,13 +539,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
     if (ABL == 5 && w >= NW / 2) {  // solo-rate probe: one wave per SIMD issues MFMAs, its partner only joins barriers
       __syncthreads();
+      hbuf = hbuf == 2 ? 0 : hbuf + 1;
       continue;
     }
+    // ---------------- layer 1 of tile-step it + 2 (two ahead) ------------------------------------------------------
+    if (it + 2 < total && (ABL < 2 || ABL == 5)) layer1(it + 2, hbuf == 0 ? 2 : hbuf - 1);
     // ---------------- layer 2: 256 -> 256 (B from LDS), layer 3: this wave's 16*OT features -> 48 ----------------
     f32x4 acc[OT];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) acc[ot] = reinterpret_cast<const f32x4*>(b2s)[(w * OT + ot) * 4 + g];
-    const f32x4* hb = reinterpret_cast<const f32x4*>(h1 + (it & 1) * 4096) + lane;
+    const f32x4* hb = reinterpret_cast<const f32x4*>(h1 + hbuf * 4096) + lane;
     f32x4 bq = hb[0];
     __builtin_amdgcn_sched_barrier(0);  // the pipelined region starts here
 #pragma unroll
@@ -570,9 +580,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     f32x4* pw = reinterpret_cast<f32x4*>(part + (it & 1) * (NW * 768));
 #pragma unroll
     for (int j = 0; j < 3; ++j) pw[(w * 3 + j) * 64 + lane] = acc3[j];
-    // ---------------- layer 1 of the NEXT tile-step, so that one barrier per tile-step is enough ------------------
-    if (it + 1 < total && (ABL < 2 || ABL == 5)) layer1(it + 1);
     if (ABL < 3 || ABL == 5) __syncthreads();
+    hbuf = hbuf == 2 ? 0 : hbuf + 1;
   }
   if (epi_wave && ABL == 0) epilogue(total - 1, zreg);
   if (ABL != 0 && a.N < 0) epilogue(0, zreg);  // keep the code reachable for the compiler, never executed
@@ -646,15 +655,15 @@ __global__ __launch_bounds__(64) void k_merge_pool(MergeArgs a) {
 
 template <int NW>
 size_t chain_lds_bytes() {
-  return (size_t)(kG * 768 + 2 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps) * sizeof(float);
+  return (size_t)(kG * 768 + 3 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps) * sizeof(float);
 }
 
-template <int NW, bool REFINE, int ABL = 0>
+template <int NW, bool REFINE, int ABL = 0, bool EPI_FIRST = true>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
   const dim3 grid((unsigned)((n_tiles + kG - 1) / kG));
   const size_t lds = chain_lds_bytes<NW>();
-  auto fn = k_chain<NW, REFINE, ABL>;
+  auto fn = k_chain<NW, REFINE, ABL, EPI_FIRST>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return PSTL_ERR_LAUNCH;
@@ -672,6 +681,7 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   if (!REFINE && chain_waves == 208) return launch_chain<8, false, 2>(a, st);
   if (!REFINE && chain_waves == 308) return launch_chain<8, false, 3>(a, st);
   if (!REFINE && chain_waves == 508) return launch_chain<8, false, 5>(a, st);
+  if (!REFINE && chain_waves == 608) return launch_chain<8, false, 0, false>(a, st);
   if (REFINE && chain_waves > 100) return launch_chain<8, true>(a, st);
   return PSTL_ERR_SHAPE;
 }
