@@ -35,6 +35,8 @@ def parse():
     p.add_argument("--diffusion_steps", type=int, default=50)
     p.add_argument("--multi_cands", type=int, default=5)
     p.add_argument("--chain_waves", type=int, default=0)
+    p.add_argument("--noise", default="kernel", choices=["kernel", "torch"],
+                   help="kernel: Philox noise drawn inside the HIP kernels; torch: torch.randn tensors (parity mode)")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_scenes", type=int, default=24)
     return p.parse_args()
@@ -99,17 +101,24 @@ def main():
     N = bs * S * 3
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     from pstl_diffusion_policy_amd.shard import gather_counts, global_valid_stats
+    call = [0]
 
     def one_step():
         # global mean(valid) of the guidance loss (one tiny all-reduce; the shard split must not change results)
         ids = torch.stack([scene["curr_id"], scene["left_id"], scene["right_id"]]).sum().item()
         vsum, vrows = global_valid_stats(ids * S, N, dev)
-        sb = SceneBatch(scene, S, hp, dev, global_valid_sum=vsum, global_rows=vrows)
-        x_T = torch.randn(N, 40, device=dev, generator=gen)
-        z = torch.randn(steps - 1, N, 40, device=dev, generator=gen)
+        sb = SceneBatch(scene, S, hp, dev, global_valid_sum=vsum, global_rows=vrows, row_offset=rank * N)
+        if a.noise == "torch":
+            x_T = torch.randn(N, 40, device=dev, generator=gen)
+            z = torch.randn(steps - 1, N, 40, device=dev, generator=gen)
+            seed = None
+        else:
+            x_T = z = None
+            call[0] += 1
+            seed = 987654321 + call[0]
         out = sampler.sampling_region(sb, steps, x_T, z, rect_head=rect_head,
                                       multi_cands=a.multi_cands if rect_head else None, guidance=guidance, coeffs=coeffs,
-                                      want_scores3=False)
+                                      want_scores3=False, seed=seed)
         # the only exchange after the rollout: 8 counters per rank (RCCL all-gather over xGMI when N > 1)
         return gather_counts(out["counts"])
 
@@ -152,7 +161,8 @@ def main():
                                       a.multi_cands if rect_head else None,
                                       "before=10,niters=1,lr=0.01" if guidance else None, rect_head),
                        "rows_per_gpu": N, "parallelism": "scene shards x%d, no data-path collective" % world,
-                       "chain_waves": a.chain_waves or 8},
+                       "chain_waves": a.chain_waves or 8,
+                       "noise": "in-kernel Philox4x32-10" if a.noise == "kernel" else "torch.randn tensors"},
             "stl_sat_rate": acc, "scene_sat_rate": sacc,
             "roofline": {"bound": "mfma", "kernel": "k_chain (denoiser MLP chain, %d reverse steps per launch)" % nst,
                          "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",

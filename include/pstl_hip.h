@@ -46,7 +46,9 @@ enum {
   PSTL_FLAG_CLIP = 1,       /* clip normalised controls to +-max  (--diffusion_clip, nusc_train.py:651-653) */
   PSTL_FLAG_MAXIMIZE = 2,   /* guidance loss relu(100 - score)     (nusc_train.py:616-617)                 */
   PSTL_FLAG_CLIP_RECT = 4,  /* --clip_rect (nusc_model.py:230-233)                                         */
-  PSTL_FLAG_NO_MERGE = 8    /* rect_forward without merge_net pooling (not diverse_loss / --no_arch)       */
+  PSTL_FLAG_NO_MERGE = 8,   /* rect_forward without merge_net pooling (not diverse_loss / --no_arch)       */
+  PSTL_FLAG_RNG = 16        /* kernels draw the diffusion noise themselves (cfg.seed, cfg.row_offset); the  */
+                            /* `noise` / `z` pointer arguments are then ignored                              */
 };
 
 typedef struct pstl_cfg {
@@ -64,6 +66,9 @@ typedef struct pstl_cfg {
   float dt;                /* --dt                                                        */
   float ego_L, ego_W;      /* --ego_L, --ego_W                                            */
   float reserved_f;
+  uint64_t seed;           /* PSTL_FLAG_RNG: noise stream                                 */
+  int64_t row_offset;      /* PSTL_FLAG_RNG: global index of this shard's first row, so that the noise of a row */
+                           /* does not depend on how the batch is split over GPUs                                */
 } pstl_cfg;
 
 /* state_dict blobs of the reference Net (nusc_model.py:20-46; keys "<net>.{0,2,4}.{weight,bias}").
@@ -124,6 +129,11 @@ int pstl_rollout(const pstl_cfg* cfg, const float* packed, const float* base_pol
                  const float* alpha_hat, const float* noise, int step_hi, int step_lo, int mu_only,
                  float* x_inout /* (N,40) */, float* emit_out, int n_emit, void* stream);
 
+/* out (N,40) = the N(0,1) values the kernels draw under PSTL_FLAG_RNG for reverse step `step` (step == cfg->steps
+ * is the stream of the initial state x_T, reference nusc_train.py:563).  Philox4x32-10 + Box-Muller, a pure function of
+ * (cfg->seed, cfg->row_offset + row, column, step). */
+int pstl_fill_normal(const pstl_cfg* cfg, int step, float* out, void* stream);
+
 /* ---- dynamics + STL robustness ------------------------------------------------------------------------------- */
 /* generate_trajs (nusc_train.py:29-49): trajs (N,21,4) from s0 (bs,4) and controls (N,40) in physical units. */
 int pstl_generate_trajs(const pstl_cfg* cfg, const float* s0, const float* controls, float* trajs, void* stream);
@@ -151,11 +161,12 @@ int pstl_stl_backward(const pstl_cfg* cfg, const float* s0, const float* control
  * (see oracle/pstl_oracle.py:guidance_update): iteration 0 is a plain Adam step; later iterations are
  * anchor + clip(|mu - anchor|, -beta_i, beta_i).  valid (N,) 0/1; grad_scale = (1/clip(mean(valid),1e-2))/N_global.
  * adam_neg_step / adam_bc2_sqrt: host arrays [niters] = float(-lr/(1-0.9^j)), float(sqrt(1-0.999^j)), j=1..niters.
- * work (3,N,40) scratch (m, v, anchor), only touched when niters > 1.  z (N,40) or null (= zeros, the i == 1 step).
+ * work (3,N,40) scratch (m, v, anchor), only touched when niters > 1.  z (N,40) or null (= zeros, the i == 1 step);
+ * under PSTL_FLAG_RNG z is ignored and the noise of reverse step `step` is drawn in the kernel (none at step 1).
  * emit_out (N,40) or null: normalised new state, as in pstl_rollout. */
 int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const float* nei_prep, const float* lane_prep,
                        const float* stlp, const float* hl, const float* valid, float grad_scale, int niters,
-                       const float* adam_neg_step, const float* adam_bc2_sqrt, float beta_i, const float* z,
+                       const float* adam_neg_step, const float* adam_bc2_sqrt, float beta_i, int step, const float* z,
                        float* mu_x_inout /* (N,40): mu in, x out */, float* work, float* emit_out, void* stream);
 
 /* ---- RefineNet ------------------------------------------------------------------------------------------------ */

@@ -15,6 +15,7 @@
 //    LDS between steps; HBM traffic is the noise read (parity mode) and the emitted candidates.
 //  * f32 MFMA is bit-for-bit a k-ordered fmaf chain, so results match an fp32 torch path to rounding (1e-4 gate).
 #include "pstl_common.hpp"
+#include "rng.hpp"
 
 namespace pstl {
 namespace {
@@ -284,6 +285,9 @@ struct ChainArgs {
   const float* alpha;
   const float* alpha_hat;
   const float* noise;    // (steps-1,N,40) or null
+  int rng;               // draw the noise in the kernel (seed, row_offset)
+  unsigned long long seed;
+  long row_offset;
   float* x_inout;        // (N,40)
   float* emit_out;       // (n_emit,N,40)
   // refine
@@ -511,14 +515,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // noise of tile-step `it`, fetched one iteration before its epilogue runs
   auto fetch_noise = [&](int it, f32x4& z4) {
     z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (REFINE || !a.noise || a.mu_only) return;
+    if (REFINE || (!a.noise && !a.rng) || a.mu_only) return;
     const int tl = it % G, i = s_hi - it / G;
     if (i <= 1) return;  // the reference adds zeros at the last step
     const int et = EPI_FIRST ? tid : tid - (NT - NCT);
     if (et < 160) {
       const long row = (tile0 + tl) * kTileRows + (et & 15);
-      if (row < a.N)
-        z4 = *reinterpret_cast<const f32x4*>(a.noise + ((long)(a.steps - 1 - i) * a.N + row) * kCtrl + 4 * (et >> 4));
+      if (row < a.N) {
+        if (a.rng) {
+          float z[4];
+          normal4(a.seed, a.row_offset + row, et >> 4, i, z);
+          z4 = f32x4{z[0], z[1], z[2], z[3]};
+        } else {
+          z4 = *reinterpret_cast<const f32x4*>(a.noise + ((long)(a.steps - 1 - i) * a.N + row) * kCtrl + 4 * (et >> 4));
+        }
+      }
     }
   };
 
@@ -607,18 +618,18 @@ __global__ __launch_bounds__(64) void k_merge_pool(MergeArgs a) {
   const float* b1 = w1t + 32 * 32;
   const float* w2t = b1 + 32;
   const float* b2 = w2t + 32 * 40;
-  const long grp = blockIdx.x;  // (b*3 + m)*n_shards + sh
-  const int sh = (int)(grp % a.n_shards);
-  const long bm = grp / a.n_shards;
+  // one workgroup per (scene, mode); the S samples are walked 64 at a time (all lanes busy when S >= 64); the running
+  // maximum of every shard is kept by the 40 x n_shards threads that own one (shard, output) pair each
+  const long bm = blockIdx.x;
   const int m = (int)(bm % 3);
   const long b = bm / 3;
   const int sps = a.S / a.n_shards;
-  float best = -INFINITY;
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // up to 4 (shard, output) pairs per thread
   __syncthreads();
-  for (int s0 = 0; s0 < sps; s0 += 64) {
+  for (int s0 = 0; s0 < a.S; s0 += 64) {
     const int s = s0 + tid;
-    if (s < sps) {
-      const long row = (b * a.S + (long)sh * sps + s) * 3 + m;
+    if (s < a.S) {
+      const long row = (b * a.S + s) * 3 + m;
       const float* x = a.init + row * kCtrl;
       float h0[32], h1v[32];
 #pragma unroll
@@ -644,13 +655,33 @@ __global__ __launch_bounds__(64) void k_merge_pool(MergeArgs a) {
       }
     }
     __syncthreads();
-    if (tid < 40) {
-      const int n = (sps - s0) < 64 ? (sps - s0) : 64;
-      for (int s2 = 0; s2 < n; ++s2) best = fmaxf(best, outs[s2][tid]);
+    const int n = (a.S - s0) < 64 ? (a.S - s0) : 64;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = tid + 64 * u;               // (shard, output) pair
+      if (p < a.n_shards * 40) {
+        const int sh = p / 40, o = p % 40;
+        for (int s2 = 0; s2 < n; ++s2)
+          if ((s0 + s2) / sps == sh) best[u] = fmaxf(best[u], outs[s2][o]);
+      }
     }
     __syncthreads();
   }
-  if (tid < 40) a.pooled[grp * kCtrl + tid] = best;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int p = tid + 64 * u;
+    if (p < a.n_shards * 40) a.pooled[bm * a.n_shards * kCtrl + p] = best[u];
+  }
+}
+
+__global__ void k_fill_normal(long N, unsigned long long seed, long row_offset, int step, float* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (row, quad)
+  if (i >= N * 10) return;
+  const long row = i / 10;
+  const int quad = (int)(i % 10);
+  float z[4];
+  normal4(seed, row_offset + row, quad, step, z);
+  *reinterpret_cast<f32x4*>(out + row * kCtrl + 4 * quad) = f32x4{z[0], z[1], z[2], z[3]};
 }
 
 template <int NW>
@@ -766,6 +797,15 @@ extern "C" int pstl_pack_weights(const pstl_weight_ptrs* w, float* packed, void*
   return PSTL_OK;
 }
 
+extern "C" int pstl_fill_normal(const pstl_cfg* cfg, int step, float* out, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!out || step < 0) return PSTL_ERR_ARG;
+  const long N = n_rows(cfg);
+  hipLaunchKernelGGL(k_fill_normal, dim3((unsigned)((N * 10 + 255) / 256)), dim3(256), 0, as_stream(stream), N,
+                     (unsigned long long)cfg->seed, (long)cfg->row_offset, step, out);
+  return launch_status();
+}
+
 extern "C" int pstl_time_bias(const float* packed, int steps, float* tbias, void* stream) {
   if (!packed || !tbias || steps < 1) return PSTL_ERR_ARG;
   const PackLayout L = make_layout();
@@ -829,6 +869,9 @@ extern "C" int pstl_rollout(const pstl_cfg* cfg, const float* packed, const floa
   a.alpha = alpha;
   a.alpha_hat = alpha_hat;
   a.noise = noise;
+  a.rng = (cfg->flags & PSTL_FLAG_RNG) ? 1 : 0;
+  a.seed = cfg->seed;
+  a.row_offset = (long)cfg->row_offset;
   a.x_inout = x_inout;
   a.emit_out = emit_out;
   // one launch covers at most kMaxLaunchSteps reverse steps (the per-step coefficients sit in LDS)
@@ -848,7 +891,8 @@ extern "C" int pstl_refine(const pstl_cfg* cfg, const float* packed, const float
   const bool merge = !(cfg->flags & PSTL_FLAG_NO_MERGE);
   if (merge) {
     if (!pooled_work) return PSTL_ERR_ARG;
-    if (cfg->rows_per_scene != 3 * cfg->S || cfg->n_shards < 1 || cfg->S % cfg->n_shards != 0) return PSTL_ERR_SHAPE;
+    if (cfg->rows_per_scene != 3 * cfg->S || cfg->n_shards < 1 || cfg->S % cfg->n_shards != 0 || cfg->n_shards * 40 > 256)
+      return PSTL_ERR_SHAPE;
   }
   hipStream_t st = as_stream(stream);
   const PackLayout L = make_layout();
@@ -861,7 +905,7 @@ extern "C" int pstl_refine(const pstl_cfg* cfg, const float* packed, const float
     m.packed = packed;
     m.init = init_controls;
     m.pooled = pooled_work;
-    hipLaunchKernelGGL(k_merge_pool, dim3((unsigned)((long)cfg->bs * 3 * cfg->n_shards)), dim3(64), 0, st, m);
+    hipLaunchKernelGGL(k_merge_pool, dim3((unsigned)((long)cfg->bs * 3)), dim3(64), 0, st, m);
     if (int e = launch_status()) return e;
   }
   ChainArgs a = {};

@@ -1,0 +1,57 @@
+// rng.hpp -- counter-based normal noise for the reverse diffusion (Philox4x32-10 + Box-Muller).
+//
+// The reference draws its noise from torch's global generator (nusc_train.py:563,584), which cannot be reproduced
+// bit for bit on another device; parity tests therefore pass the noise in.  In production ("PSTL_FLAG_RNG") the
+// kernels draw it themselves: the four values of outputs f0..f0+3 of GLOBAL row R at reverse step i are a pure function
+// of (seed, R, f0/4, i), so results do not depend on tiling, launch segmentation or how scenes are sharded over GPUs.
+#pragma once
+#include <stdint.h>
+
+namespace pstl {
+
+struct u32x4 {
+  uint32_t x, y, z, w;
+};
+
+__host__ __device__ inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c.x, p1 = (uint64_t)M1 * c.z;
+    u32x4 n;
+    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (uint32_t)p0;
+    c = n;
+    k0 += W0;
+    k1 += W1;
+  }
+  return c;
+}
+
+// four independent N(0,1) values for (global row, quad = f0/4, step)
+// (contraction is switched off inside: the function is compiled into two translation units with different
+// -ffp-contract settings and must give the same bits in both)
+__device__ inline void normal4(uint64_t seed, int64_t row, int quad, int step, float* out) {
+#pragma clang fp contract(off)
+  const uint64_t e = (uint64_t)row * 10u + (uint64_t)quad;
+  const u32x4 r = philox4x32_10(u32x4{(uint32_t)e, (uint32_t)(e >> 32), (uint32_t)step, 0x5053544Cu}, (uint32_t)seed,
+                                (uint32_t)(seed >> 32));
+  const float k = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = ((float)r.x + 1.0f) * k, u1 = (float)r.y * k;   // u0 in (0,1], u1 in [0,1]
+  const float u2 = ((float)r.z + 1.0f) * k, u3 = (float)r.w * k;
+  // single hardware instructions only (v_log_f32 = log2, v_sqrt_f32, v_sin/v_cos): library expansions of log/sqrt
+  // depend on the translation unit's contraction setting, and both units must draw identical bits.
+  // -2 ln(u) = (-2 ln 2) log2(u)
+  const float c2 = -1.3862943611198906f;
+  const float r0 = __builtin_amdgcn_sqrtf(c2 * __builtin_amdgcn_logf(u0));
+  const float r1 = __builtin_amdgcn_sqrtf(c2 * __builtin_amdgcn_logf(u2));
+  // v_sin_f32 / v_cos_f32 take their argument in revolutions: exactly the uniform variate
+  out[0] = r0 * __builtin_amdgcn_cosf(u1);
+  out[1] = r0 * __builtin_amdgcn_sinf(u1);
+  out[2] = r1 * __builtin_amdgcn_cosf(u3);
+  out[3] = r1 * __builtin_amdgcn_sinf(u3);
+}
+
+}  // namespace pstl

@@ -8,6 +8,7 @@
 // The work is VALU/transcendental bound (~10^3 exp/log/sqrt and ~2*10^4 flops per row evaluation against 160 B of
 // per-row input), nowhere near the HBM roofline; see DESIGN.md.
 #include "pstl_common.hpp"
+#include "rng.hpp"
 #include "stl_core.hpp"
 
 namespace pstl {
@@ -184,6 +185,9 @@ struct GuideArgs {
   const float* hl;
   const float* valid;
   const float* z;   // (N,40) or null
+  int rng, step;    // PSTL_FLAG_RNG: draw z for reverse step `step` in the kernel
+  unsigned long long seed;
+  long row_offset;
   float* mu;        // (N,40) in/out
   float* work;      // (3,N,40): m, v, anchor (niters > 1 only)
   float* emit_out;  // (N,40) or null
@@ -232,7 +236,13 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
       }
     }
     if (last) {
-      const float x = p + a.sqrt_beta * (zr ? zr[e] : 0.0f);
+      float zv = zr ? zr[e] : 0.0f;
+      if (a.rng && a.step > 1) {
+        float z4[4];
+        normal4(a.seed, a.row_offset + row, e >> 2, a.step, z4);
+        zv = z4[e & 3];
+      }
+      const float x = p + a.sqrt_beta * zv;
       mu[e] = x;
       if (er) {
         float c = x * nscale;
@@ -296,22 +306,33 @@ __global__ void k_prepare(long n_nei, long n_lane_pts, const float* nei, const f
   }
 }
 
-__global__ void k_metrics_rows(long N, const float* scores, const float* valid, unsigned long long* counts,
-                               uint8_t* sat_mask) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned sat = 0, val = 0;
-  if (i < N) {
+// grid-stride row counts; one pair of 64-bit atomics per workgroup (a few hundred in total instead of one per wave on
+// two addresses).  Integer counts are order-independent, so the result is reproducible bit for bit.
+__global__ __launch_bounds__(256) void k_metrics_rows(long N, const float* scores, const float* valid,
+                                                      unsigned long long* counts, uint8_t* sat_mask) {
+  __shared__ unsigned int s_sat[4], s_val[4];
+  unsigned int sat = 0, val = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
     const bool s = scores[i] > 0.0f;
     const bool v = valid[i] > 0.0f;
-    sat = (s && v) ? 1u : 0u;
-    val = v ? 1u : 0u;
+    sat += (s && v) ? 1u : 0u;
+    val += v ? 1u : 0u;
     if (sat_mask) sat_mask[i] = s ? 1 : 0;
   }
-  // integer counts: order-independent, so the result is reproducible bit for bit
-  const unsigned long long bs = __ballot(sat), bv = __ballot(val);
-  if ((threadIdx.x & 63) == 0) {
-    if (bs) atomicAdd(&counts[0], (unsigned long long)__popcll(bs));
-    if (bv) atomicAdd(&counts[1], (unsigned long long)__popcll(bv));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sat += __shfl_down(sat, o);
+    val += __shfl_down(val, o);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    s_sat[w] = sat;
+    s_val[w] = val;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&counts[0], (unsigned long long)(s_sat[0] + s_sat[1] + s_sat[2] + s_sat[3]));
+    atomicAdd(&counts[1], (unsigned long long)(s_val[0] + s_val[1] + s_val[2] + s_val[3]));
   }
 }
 
@@ -447,8 +468,8 @@ extern "C" int pstl_stl_backward(const pstl_cfg* cfg, const float* s0, const flo
 
 extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const float* nei_prep, const float* lane_prep,
                                   const float* stlp, const float* hl, const float* valid, float grad_scale, int niters,
-                                  const float* adam_neg_step, const float* adam_bc2_sqrt, float beta_i, const float* z,
-                                  float* mu_x_inout, float* work, float* emit_out, void* stream) {
+                                  const float* adam_neg_step, const float* adam_bc2_sqrt, float beta_i, int step,
+                                  const float* z, float* mu_x_inout, float* work, float* emit_out, void* stream) {
   if (int e = check_cfg(cfg)) return e;
   if (!s0 || !lane_prep || !stlp || !hl || !valid || !mu_x_inout || !adam_neg_step || !adam_bc2_sqrt || niters < 1)
     return PSTL_ERR_ARG;
@@ -474,6 +495,10 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
   a.hl = hl;
   a.valid = valid;
   a.z = z;
+  a.rng = (cfg->flags & PSTL_FLAG_RNG) ? 1 : 0;
+  a.step = step;
+  a.seed = cfg->seed;
+  a.row_offset = (long)cfg->row_offset;
   a.mu = mu_x_inout;
   a.work = work;
   a.emit_out = emit_out;
@@ -502,7 +527,9 @@ extern "C" int pstl_reduce_metrics(const pstl_cfg* cfg, const float* scores, con
   hipStream_t st = as_stream(stream);
   if (hipMemsetAsync(counts, 0, 8 * sizeof(uint64_t), st) != hipSuccess) return PSTL_ERR_LAUNCH;
   auto* c = reinterpret_cast<unsigned long long*>(counts);
-  hipLaunchKernelGGL(k_metrics_rows, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, scores, valid, c, sat_mask);
+  const long nb = (N + 255) / 256;
+  hipLaunchKernelGGL(k_metrics_rows, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, st, N, scores, valid, c,
+                     sat_mask);
   hipLaunchKernelGGL(k_metrics_scenes, dim3((unsigned)(((long)cfg->bs * 3 + 255) / 256)), dim3(256), 0, st, cfg->bs,
                      cfg->S, scores, valid, c);
   return launch_status();

@@ -69,8 +69,9 @@ class SceneBatch:
     (bs,15,3), {curr,left,right}_id (bs,1), and either stlp_modes (bs,3,6) or stlp_rows (N,6).
     """
 
-    def __init__(self, scene, S, hp, device, global_valid_sum=None, global_rows=None):
+    def __init__(self, scene, S, hp, device, global_valid_sum=None, global_rows=None, row_offset=0):
         dev = torch.device(device)
+        self.row_offset = int(row_offset)   # global index of the first row (in-kernel noise is keyed by global row)
         f = lambda k: ffi.f32(torch.as_tensor(scene[k]), dev)
         self.hp, self.S, self.device = hp, int(S), dev
         ego = f("ego_traj")
@@ -107,8 +108,8 @@ class SceneBatch:
                                                ffi.ptr(self.lanes[1]), ffi.ptr(self.lanes[2]), ffi.ptr(self.nei_prep),
                                                ffi.ptr(self.lane_prep), ffi.stream()), "prepare_scene")
 
-    def cfg(self, steps, flags=0, chain_waves=0):
-        return ffi.make_cfg(self.bs, self.rps, self.S, self.K, steps, self.hp, flags, chain_waves)
+    def cfg(self, steps, flags=0, chain_waves=0, seed=0):
+        return ffi.make_cfg(self.bs, self.rps, self.S, self.K, steps, self.hp, flags, chain_waves, seed, self.row_offset)
 
 
 def guidance_triggered(i, steps, g):
@@ -146,8 +147,17 @@ class Sampler:
         return feature, base_p, base_r
 
     # ---- A3-A5, A7 ----
-    def rollout(self, sb, base_policy, x, noise, steps, n_emit=0, clip=False, guidance=None, coeffs=None):
-        """x (N,40) is updated in place from x_T to x_0 (un-normalised).  noise (steps-1,N,40) or None.
+    def fill_normal(self, sb, steps, step, seed, out=None):
+        """The N(0,1) values the kernels draw for reverse step `step` under in-kernel noise (step == steps: x_T)."""
+        if out is None:
+            out = torch.empty(sb.N, ffi.CTRL, dtype=torch.float32, device=sb.device)
+        cfg = sb.cfg(steps, 0, 0, seed)
+        ffi.check(self.L.pstl_fill_normal(ctypes.byref(cfg), int(step), ffi.ptr(out), ffi.stream()), "fill_normal")
+        return out
+
+    def rollout(self, sb, base_policy, x, noise, steps, n_emit=0, clip=False, guidance=None, coeffs=None, seed=None):
+        """x (N,40) is updated in place from x_T to x_0 (un-normalised).  noise (steps-1,N,40) supplied by the caller,
+        or seed != None: the kernels draw the noise themselves (Philox keyed by seed and global row).
         Returns emit (n_emit,N,40): the last n_emit entries of the reference's normalised diff_full list."""
         dev = sb.device
         beta, alpha, alpha_hat = coeffs if coeffs is not None else diffusion_coeffs(steps, dev)
@@ -155,7 +165,10 @@ class Sampler:
         flags = ffi.PSTL_FLAG_CLIP if clip else 0
         if guidance and guidance.get("maximize", False):
             flags |= ffi.PSTL_FLAG_MAXIMIZE
-        cfg = sb.cfg(steps, flags, self.chain_waves)
+        if seed is not None:
+            flags |= ffi.PSTL_FLAG_RNG
+            noise = None
+        cfg = sb.cfg(steps, flags, self.chain_waves, seed or 0)
         tb = self.w.tbias(steps)
         emit = torch.empty(max(n_emit, 1), sb.N, ffi.CTRL, dtype=torch.float32, device=dev)
         if guidance and guidance.get("enabled", False):
@@ -197,7 +210,7 @@ class Sampler:
                 ffi.check(self.L.pstl_guidance_step(ctypes.byref(cfg), ffi.ptr(sb.s0), ffi.ptr(sb.nei_prep),
                                                     ffi.ptr(sb.lane_prep), ffi.ptr(sb.stlp), ffi.ptr(sb.hl),
                                                     ffi.ptr(sb.valid), ctypes.c_float(sb.grad_scale), nit, neg_step, bc2,
-                                                    ctypes.c_float(float(beta_host[i])), ffi.ptr(z), ffi.ptr(x),
+                                                    ctypes.c_float(float(beta_host[i])), int(i), ffi.ptr(z), ffi.ptr(x),
                                                     ffi.ptr(work), ffi.ptr(eo), ffi.stream()), "guidance_step")
                 i -= 1
         return emit[:n_emit]
@@ -266,15 +279,20 @@ class Sampler:
 
     # ---- A12: the timed region ----
     def sampling_region(self, sb, steps, x_T, noise, rect_head=False, multi_cands=None, refinenet=True, guidance=None,
-                        n_rolls=None, diverse=True, full_list=False, coeffs=None, want_scores3=True):
+                        n_rolls=None, diverse=True, full_list=False, coeffs=None, want_scores3=True, seed=None):
+        """x_T (N,40) and noise (steps-1,N,40) supplied by the caller (parity), or seed != None: x_T and all noise are
+        drawn by the kernels (x_T / noise arguments ignored)."""
         out = {}
         feature, base_p, base_r = self.encode(sb, need_rect=rect_head)
         out["feature_scene"] = feature
-        x = x_T.clone() if x_T.data_ptr() != 0 else x_T
+        if seed is not None:
+            x = self.fill_normal(sb, steps, steps, seed)
+        else:
+            x = x_T.clone()
         mc = multi_cands if (rect_head and multi_cands is not None) else 0
         n_emit = steps if full_list else max(mc, 1)
         emit = self.rollout(sb, base_p, x, noise, steps, n_emit=n_emit, clip=bool(rect_head), guidance=guidance,
-                            coeffs=coeffs)
+                            coeffs=coeffs, seed=seed)
         if full_list:
             out["controls_list"] = emit
         controls = emit[-1]

@@ -15,6 +15,7 @@ PSTL_FLAG_CLIP = 1
 PSTL_FLAG_MAXIMIZE = 2
 PSTL_FLAG_CLIP_RECT = 4
 PSTL_FLAG_NO_MERGE = 8
+PSTL_FLAG_RNG = 16
 
 T = 20
 NSEG = 15
@@ -24,6 +25,7 @@ FEAT = 224
 NEI_PREP = 12
 
 EXPORTS = ["pstl_version", "pstl_error_string", "pstl_packed_weight_floats", "pstl_pack_weights", "pstl_time_bias",
+           "pstl_fill_normal",
            "pstl_prepare_scene", "pstl_encode_scene", "pstl_rollout", "pstl_generate_trajs", "pstl_stl_forward",
            "pstl_stl_backward", "pstl_guidance_step", "pstl_refine", "pstl_reduce_metrics"]
 
@@ -34,7 +36,8 @@ class PstlCfg(ctypes.Structure):
                 ("flags", ctypes.c_int32), ("chain_waves", ctypes.c_int32),
                 ("tau", ctypes.c_float), ("thres", ctypes.c_float), ("w_max", ctypes.c_float),
                 ("a_max", ctypes.c_float), ("dt", ctypes.c_float), ("ego_L", ctypes.c_float),
-                ("ego_W", ctypes.c_float), ("reserved_f", ctypes.c_float)]
+                ("ego_W", ctypes.c_float), ("reserved_f", ctypes.c_float),
+                ("seed", ctypes.c_uint64), ("row_offset", ctypes.c_int64)]
 
 
 class Mlp3(ctypes.Structure):
@@ -89,12 +92,12 @@ def ptr(t, dtype=torch.float32):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def make_cfg(bs, rows_per_scene, S, K, steps, hp, flags=0, chain_waves=0):
+def make_cfg(bs, rows_per_scene, S, K, steps, hp, flags=0, chain_waves=0, seed=0, row_offset=0):
     return PstlCfg(bs=int(bs), rows_per_scene=int(rows_per_scene), S=int(S), K=int(K), steps=int(steps),
                    n_shards=int(hp.get("n_shards", 4)), flags=int(flags), chain_waves=int(chain_waves),
                    tau=float(hp["smoothing_factor"]), thres=float(hp["stl_nn_thres"]), w_max=float(hp["mul_w_max"]),
                    a_max=float(hp["mul_a_max"]), dt=float(hp["dt"]), ego_L=float(hp["ego_L"]),
-                   ego_W=float(hp["ego_W"]), reserved_f=0.0)
+                   ego_W=float(hp["ego_W"]), reserved_f=0.0, seed=int(seed) & (2 ** 64 - 1), row_offset=int(row_offset))
 
 
 def f32(x, device):

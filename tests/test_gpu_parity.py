@@ -224,3 +224,38 @@ def test_shard_invariance_and_outlier_rows(dev):
     sb.hl = torch.full_like(sb.hl, 3.0)
     sc = sm.score(sb, part["final_controls"].reshape(1, -1, 40), all3=True)["scores"]
     assert torch.equal(sc, torch.ones_like(sc))
+
+
+def test_in_kernel_noise(dev):
+    """PSTL_FLAG_RNG: (1) the draws are standard normal and differ between steps/seeds; (2) a rollout that draws its own
+    noise equals, bit for bit, the same rollout fed with pstl_fill_normal's tensors (so the parity-mode tests cover the
+    arithmetic of the production mode too), guided steps included; (3) a block of scenes evaluated alone with the right
+    row_offset reproduces its rows of the full batch."""
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    bs, S, K, steps, seed = 48, 64, 3, 9, 20240229
+    scene = make_scene_batch(bs, K=K, S=S, seed=8, invalid_lane_frac=0.2, stlp_mode="wide")
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    sb = SceneBatch(scene, S, hp, dev)
+    z = torch.stack([sm.fill_normal(sb, steps, i, seed) for i in range(steps - 1, 0, -1)])   # z[k] <-> step steps-1-k
+    x_T = sm.fill_normal(sb, steps, steps, seed)
+    allz = torch.cat([z.reshape(-1), x_T.reshape(-1)]).double()
+    n = allz.numel()
+    assert abs(allz.mean().item()) < 5 / n ** 0.5 and abs(allz.var().item() - 1) < 10 / n ** 0.5
+    assert abs((allz ** 3).mean().item()) < 10 / n ** 0.5 and abs((allz ** 4).mean().item() - 3) < 30 / n ** 0.5
+    assert not torch.equal(z[0], z[1]) and not torch.equal(z[0], sm.fill_normal(sb, steps, steps - 1, seed + 1))
+    assert torch.equal(z[0], sm.fill_normal(sb, steps, steps - 1, seed))
+    guid = dict(enabled=True, before=3, niters=2, lr=0.01)
+    a = sm.sampling_region(sb, steps, None, None, rect_head=True, multi_cands=4, guidance=guid, seed=seed, full_list=True)
+    b = sm.sampling_region(sb, steps, x_T, z, rect_head=True, multi_cands=4, guidance=guid, full_list=True)
+    for k in ["controls_list", "final_controls", "final_scores", "counts"]:
+        assert torch.equal(a[k], b[k]), k
+    lo, hi = 10, 31
+    sub = {k: v[lo:hi].clone() for k, v in scene.items()}
+    part = sm.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=lo * S * 3, global_valid_sum=float(sb.valid.sum()),
+                                         global_rows=sb.N), steps, None, None, rect_head=True, multi_cands=4,
+                              guidance=guid, seed=seed)
+    r0, r1 = lo * S * 3, hi * S * 3
+    assert torch.equal(part["final_controls"], a["final_controls"][r0:r1])
+    assert torch.equal(part["final_scores"], a["final_scores"][r0:r1])

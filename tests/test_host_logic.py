@@ -23,7 +23,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert sorted(ffi.EXPORTS) == declared
     assert L.pstl_packed_weight_floats() > 540952          # at least the reference parameter count
     assert L.pstl_error_string(-2).decode().startswith("shape")
-    assert ctypes.sizeof(ffi.PstlCfg) == 64
+    assert ctypes.sizeof(ffi.PstlCfg) == 80
 
 
 def test_missing_library_fails_loudly(monkeypatch):
