@@ -26,8 +26,8 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3                       # MI355X_MICROARCH.md: v_m
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--workload", default="e7_guid", choices=["e5", "e7", "e7_guid"])
     p.add_argument("--scenes", type=int, default=4096, help="scenes per GPU (weak scaling)")
     p.add_argument("--sampling_size", type=int, default=64)
@@ -147,6 +147,14 @@ def main():
     flop = float(nrows) * nst * F_STEP_MIN
     achieved = flop / (k_ms * 1e-3) / 1e12
     acc, sacc = acc_from_counts(counts)
+    # HBM bytes of that launch from the committed PMC passes (FETCH_SIZE/WRITE_SIZE cannot be read inside this process);
+    # only quoted when this run is the configuration those passes were collected on
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")
+    is_default = (a.workload == "e7_guid" and bs == 4096 and S == 64 and a.neighbors == 2 and steps == 50
+                  and a.noise == "kernel" and not a.chain_waves)
+    if is_default and os.path.exists(pmc):
+        traffic = json.load(open(pmc))["summary_dominant_kernel"]["hbm_bytes_per_launch_corrected"]
     line = None
     if rank == 0:
         line = {
@@ -166,7 +174,9 @@ def main():
             "stl_sat_rate": acc, "scene_sat_rate": sacc,
             "roofline": {"bound": "mfma", "kernel": "k_chain (denoiser MLP chain, %d reverse steps per launch)" % nst,
                          "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
+                         "traffic_source": "profiles/r1/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
+                                           if traffic else None,
                          "kernel_ms": k_ms, "flop_per_launch": flop,
                          "note": "algorithmic FLOP = rows x steps x 172032 (hoisted layer-1 columns not counted)"},
         }

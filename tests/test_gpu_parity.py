@@ -259,3 +259,46 @@ def test_in_kernel_noise(dev):
     r0, r1 = lo * S * 3, hi * S * 3
     assert torch.equal(part["final_controls"], a["final_controls"][r0:r1])
     assert torch.equal(part["final_scores"], a["final_scores"][r0:r1])
+
+
+def test_full_size_properties(dev):
+    """BASELINE.json's single-GPU size (4096 scenes x 64 samples x 3 modes = 786432 rows, 50 diffusion steps, e7 +
+    guidance), checked through size-independent properties: the two halves of the batch evaluated on their own (as two
+    GPUs would) reproduce the full run bit for bit and their counters add up; every control respects the clip range;
+    the counters agree with the scores; rows of invalid lanes never count."""
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler, acc_from_counts
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    bs, S, K, steps, seed = 4096, 64, 2, 50, 7
+    scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=K, S=S, seed=3, invalid_lane_frac=0.2, stlp_mode="wide").items()
+             if k not in ("params", "pre_stlp", "tj_scores_prior")}
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    guid = dict(enabled=True, before=10, niters=1, lr=0.01)
+    sb = SceneBatch(scene, S, hp, dev)
+    full = sm.sampling_region(sb, steps, None, None, rect_head=True, multi_cands=5, guidance=guid, seed=seed,
+                              want_scores3=False)
+    N = sb.N
+    assert N == 786432
+    c = full["final_controls"].reshape(N, 20, 2)
+    assert torch.isfinite(c).all() and torch.isfinite(full["final_scores"]).all()
+    assert c[..., 0].abs().max().item() <= hp["mul_w_max"] and c[..., 1].abs().max().item() <= hp["mul_a_max"]
+    cnt = full["counts"].tolist()
+    sat = (full["final_scores"] > 0) & (sb.valid > 0)
+    assert cnt[0] == int(sat.sum()) and cnt[1] == int(sb.valid.sum()) and cnt[2] == N and cnt[5] == 3 * bs
+    scene_sat = sat.reshape(bs, S, 3).any(dim=1)
+    assert cnt[3] == int(scene_sat.sum()) and cnt[4] == int(sb.valid.reshape(bs, S, 3)[:, 0].sum())
+    total = torch.zeros(8, dtype=torch.int64, device=dev)
+    vsum = float(sb.valid.sum())
+    for half in range(2):
+        lo, hi = half * bs // 2, (half + 1) * bs // 2
+        sub = {k: v[lo:hi].contiguous() for k, v in scene.items()}
+        part = sm.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=lo * S * 3, global_valid_sum=vsum, global_rows=N),
+                                  steps, None, None, rect_head=True, multi_cands=5, guidance=guid, seed=seed,
+                                  want_scores3=False)
+        r0, r1 = lo * S * 3, hi * S * 3
+        assert torch.equal(part["final_controls"], full["final_controls"][r0:r1])
+        assert torch.equal(part["final_scores"], full["final_scores"][r0:r1])
+        total += part["counts"]
+    assert torch.equal(total, full["counts"])
+    acc, sacc = acc_from_counts(full["counts"])
+    assert 0.0 < acc < 1.0 and 0.0 < sacc <= 1.0
