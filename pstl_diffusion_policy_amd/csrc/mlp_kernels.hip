@@ -316,14 +316,20 @@ __device__ __forceinline__ int xs_addr(int k, int c) { return (((k >> 4) * 64) +
 
 // ABL != 0 are timing-only ablation builds (wrong results by construction; selected with cfg->chain_waves = 8 + 100*ABL
 // and used only to attribute the kernel's time): 1 = no epilogue, 2 = also no layer 1, 3 = also no barrier,
-// 5 = no epilogue and only waves 0..NW/2-1 issue MFMAs (what one wave per SIMD sustains alone).
+// 5 = no epilogue and only waves 0..NW/2-1 issue MFMAs (what one wave per SIMD sustains alone),
+// 7 = full kernel with s_memtime stamps of workgroup 7, iterations 64..95, every wave, written as 64-bit ticks to the
+//     buffer passed as emit_out (n_emit must be 0): [it-64][wave][slot], slots 0 start, 1 after epilogue, 2 after
+//     layer 1, 3 after layer 2, 4 after layer 3 + partial-sum write, 5 after the barrier.
 // EPI_FIRST: the epilogue runs on waves 0..3 (the older wave of each SIMD pair; measured 1.8 % faster than 4..7).
-template <int NW, bool REFINE, int ABL = 0, bool EPI_FIRST = true>
+template <int NW, bool REFINE, int ABL = 0, bool EPI_FIRST = true, int PRIO = 0, bool UT = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   constexpr int OT = 16 / NW;       // 16-feature output tiles per wave
   constexpr int NT = NW * 64;
   constexpr int NCW = NW == 4 ? 3 : NW / 2;  // the last NCW waves also run the epilogue (8 waves: one partner per SIMD)
   constexpr int NCT = NCW * 64;     // >= 160 epilogue threads are needed (4 outputs each)
+  // wave that issues the direct-to-LDS loads of the constant rows: with 8 waves, wave 3 belongs to the epilogue group
+  // but owns no epilogue rows (160 threads = 2.5 waves), so it has the slack
+  constexpr int kStager = (EPI_FIRST && NCT - 160 >= 64) ? NCW - 1 : NW - 1;
   static_assert(NCT >= 160, "epilogue needs 160 threads");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                          // [kG][3][64][4]      activations of layer 1, B-operand order
@@ -332,6 +338,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   float* b2s = part + 2 * NW * 768;         // [256] layer-2 bias, [48] layer-3 bias
   float* b3s = b2s + 256;
   float* coef = b3s + 48;                   // [kMaxLaunchSteps][4] c1, 1/sqrt(alpha), sqrt(beta) of step s_hi - n
+  float* crow = coef + 4 * kMaxLaunchSteps; // [3][2][256] UT only: base[scene] row and tbias[step] row of a tile-step
+  float* zbuf = crow + 3 * 512;             // [2][160][4] noise of a tile-step, produced by the non-epilogue waves
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
   const long tile0 = (long)blockIdx.x * kG;
@@ -411,8 +419,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       }
     }
   }
-  __syncthreads();
-
   const int s_hi = REFINE ? 1 : a.step_hi, s_lo = REFINE ? 1 : a.step_lo;
   const int total = (s_hi - s_lo + 1) * G;  // tile-steps of this workgroup; tile-step `it` = (step s_hi - it/G, tile it%G)
 
@@ -421,18 +427,44 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // landed when the barrier comes, and its own operand latencies hide under the neighbouring MFMAs.
   // Hazards: it overwrites the buffer layer 2 read in the previous iteration (a barrier ago), and it reads xs[tile],
   // which the epilogue of tile-step it - G rewrote in iteration it - G + 1 <= it - 3 (G >= 4).
+  // UT (all 16 rows of a tile share one scene: rows_per_scene % 16 == 0): the scene row of `base` and the step row of
+  // `tbias` that layer 1 adds are brought into a 3-slot LDS ring by direct-to-LDS loads (global_load_lds, no
+  // registers), issued by one wave a whole iteration before layer 1 needs them.  A plain global load here costs every
+  // wave ~1400 stalled cycles per tile-step (measured with the stamp build), because nothing else of the wave can
+  // issue while it waits.
+  auto stage_cst = [&](int j) {
+    const int tl = j % G, i = s_hi - j / G;
+    long row = (tile0 + tl) * kTileRows;
+    if (row >= a.N) row = a.N - 1;
+    float* dst = crow + (j % 3) * 512;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    __builtin_amdgcn_global_load_lds((glb_ptr)(a.base + (row / a.rows_per_scene) * kHid + lane * 4), (lds_ptr)dst, 16, 0, 0);
+    if (!REFINE)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(a.tbias + (long)i * kHid + lane * 4), (lds_ptr)(dst + 256), 16, 0, 0);
+  };
+
   auto layer1 = [&](int it, int buf) {
     const int tl = it % G, i = s_hi - it / G;
-    long rowc = (tile0 + tl) * kTileRows + col;
-    if (rowc >= a.N) rowc = a.N - 1;
-    const float* bp = a.base + (rowc / a.rows_per_scene) * kHid;
-    // the scene/timestep constant part of the pre-activation: loaded now, added after the MFMAs (latency hidden)
+    // the scene/timestep constant part of the pre-activation: fetched now, added after the MFMAs
     f32x4 cst[OT];
+    if (UT) {
+      const f32x4* cb = reinterpret_cast<const f32x4*>(crow + (it % 3) * 512);
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) {
-      const int f0 = 16 * (w * OT + ot) + 4 * g;
-      cst[ot] = *reinterpret_cast<const f32x4*>(bp + f0);
-      if (!REFINE) cst[ot] += *reinterpret_cast<const f32x4*>(a.tbias + (long)i * kHid + f0);
+      for (int ot = 0; ot < OT; ++ot) {
+        cst[ot] = cb[4 * (w * OT + ot) + g];
+        if (!REFINE) cst[ot] += cb[64 + 4 * (w * OT + ot) + g];
+      }
+    } else {
+      long rowc = (tile0 + tl) * kTileRows + col;
+      if (rowc >= a.N) rowc = a.N - 1;
+      const float* bp = a.base + (rowc / a.rows_per_scene) * kHid;
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const int f0 = 16 * (w * OT + ot) + 4 * g;
+        cst[ot] = *reinterpret_cast<const f32x4*>(bp + f0);
+        if (!REFINE) cst[ot] += *reinterpret_cast<const f32x4*>(a.tbias + (long)i * kHid + f0);
+      }
     }
     f32x4 acc[OT];
 #pragma unroll
@@ -513,12 +545,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   };
 
   // noise of tile-step `it`, fetched one iteration before its epilogue runs
-  auto fetch_noise = [&](int it, f32x4& z4) {
+  // PRODUCER: the waves that do not run the epilogue (they reach the barrier thousands of cycles early) prepare the
+  // noise of tile-step `it` -- Philox + Box-Muller, or the caller's tensor -- and pass it through LDS, which takes
+  // ~1000 cycles off the epilogue waves' critical path.  With too few such threads (4-wave variant) the epilogue
+  // threads fetch it themselves.
+  // Measured (stamp build): with "older wave first" arbitration of both the matrix pipe and VALU issue, noise drawn by
+  // the younger waves is starved behind their partners' MFMA streams (+1000 cycles per tile-step) wherever it is placed,
+  // whereas drawn by the older epilogue waves at the top of the iteration it overlaps the partners' MFMAs.  Kept off.
+  constexpr bool PRODUCER = false;
+  auto fetch_noise = [&](int it, int et, f32x4& z4) {
     z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (REFINE || (!a.noise && !a.rng) || a.mu_only) return;
     const int tl = it % G, i = s_hi - it / G;
     if (i <= 1) return;  // the reference adds zeros at the last step
-    const int et = EPI_FIRST ? tid : tid - (NT - NCT);
     if (et < 160) {
       const long row = (tile0 + tl) * kTileRows + (et & 15);
       if (row < a.N) {
@@ -533,28 +572,68 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
   };
 
+  if (UT && w == kStager) {
+    for (int j = 0; j < 3 && j < total; ++j) stage_cst(j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();  // xs image, bias/coefficient tables and the first three constant rows are in LDS
+
   const bool epi_wave = EPI_FIRST ? (w < NCW) : (w >= NW - NCW);  // wave-uniform
   f32x4 zreg = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.emit_out);
+#define PSTL_STAMP(slot)                                                                        \
+  if (ABL == 7 && blockIdx.x == 7 && it >= 64 && it < 96) {                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    unsigned long long t_;                                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+    if (lane == 0) dbg[((it - 64) * NW + w) * 8 + (slot)] = t_;                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  }
+
+  // static issue priority for one wave of each SIMD pair (PRIO 1: the epilogue waves, 2: their partners)
+  if (PRIO == 1 && epi_wave) __builtin_amdgcn_s_setprio(1);
+  if (PRIO == 2 && !epi_wave) __builtin_amdgcn_s_setprio(1);
 
   layer1(0, 0);
   if (total > 1) layer1(1, 1);
   __syncthreads();
   int hbuf = 0;  // it % 3
   for (int it = 0; it < total; ++it) {
-    if (epi_wave && ABL == 0) {
+    PSTL_STAMP(0)
+    if (UT && w == kStager && it + 3 < total) stage_cst(it + 3);
+    if (epi_wave && (ABL == 0 || ABL == 7)) {
       // While this half finishes the previous tile-step, the partner wave on the same SIMD already issues MFMAs: the
       // matrix pipe never waits for the epilogue (the stagger of MI355X_MICROARCH.md "Two waves per SIMD", item 9).
-      const f32x4 zprev = zreg;
-      fetch_noise(it, zreg);               // HBM read of this tile-step's noise first: a full iteration to land
-      if (it > 0) epilogue(it - 1, zprev);
+      const int et = EPI_FIRST ? tid : tid - (NT - NCT);
+      if (PRODUCER) {
+        if (it > 0) {
+          f32x4 zprev = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          if (et < 160) zprev = reinterpret_cast<const f32x4*>(zbuf)[((it - 1) & 1) * 160 + et];
+          epilogue(it - 1, zprev);
+        }
+      } else {
+        const f32x4 zprev = zreg;
+        fetch_noise(it, et, zreg);           // HBM read of this tile-step's noise first: a full iteration to land
+        if (it > 0) epilogue(it - 1, zprev);
+      }
     }
+    const int pt = EPI_FIRST ? tid - NCT : tid;   // producer thread index (non-epilogue waves)
+    if (PRODUCER && !epi_wave && !a.rng && (ABL == 0 || ABL == 7)) fetch_noise(it, pt, zreg);   // tensor: load early
     if (ABL == 5 && w >= NW / 2) {  // solo-rate probe: one wave per SIMD issues MFMAs, its partner only joins barriers
       __syncthreads();
       hbuf = hbuf == 2 ? 0 : hbuf + 1;
       continue;
     }
+    PSTL_STAMP(1)
     // ---------------- layer 1 of tile-step it + 2 (two ahead) ------------------------------------------------------
-    if (it + 2 < total && (ABL < 2 || ABL == 5)) layer1(it + 2, hbuf == 0 ? 2 : hbuf - 1);
+    if (it + 2 < total && (ABL < 2 || ABL == 5 || ABL == 7)) layer1(it + 2, hbuf == 0 ? 2 : hbuf - 1);
+    if (PRODUCER && !epi_wave && a.rng && (ABL == 0 || ABL == 7)) {
+      // Philox + Box-Muller for tile-step `it`, placed where the older partner wave (now past its epilogue) wins the
+      // matrix-pipe arbitration anyway, so these VALU cycles cost the pair nothing
+      fetch_noise(it, pt, zreg);
+      if (pt < 160) reinterpret_cast<f32x4*>(zbuf)[(it & 1) * 160 + pt] = zreg;
+    }
+    PSTL_STAMP(2)
     // ---------------- layer 2: 256 -> 256 (B from LDS), layer 3: this wave's 16*OT features -> 48 ----------------
     f32x4 acc[OT];
 #pragma unroll
@@ -577,6 +656,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * OT, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    PSTL_STAMP(3)
     f32x4 acc3[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc3[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -591,10 +671,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     f32x4* pw = reinterpret_cast<f32x4*>(part + (it & 1) * (NW * 768));
 #pragma unroll
     for (int j = 0; j < 3; ++j) pw[(w * 3 + j) * 64 + lane] = acc3[j];
-    if (ABL < 3 || ABL == 5) __syncthreads();
+    if (PRODUCER && !epi_wave && !a.rng && (ABL == 0 || ABL == 7)) {
+      if (pt < 160) reinterpret_cast<f32x4*>(zbuf)[(it & 1) * 160 + pt] = zreg;   // the tensor values loaded at the top
+    }
+    PSTL_STAMP(4)
+    if (UT && w == kStager) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged rows have landed
+    if (ABL < 3 || ABL == 5 || ABL == 7) __syncthreads();
+    PSTL_STAMP(5)
     hbuf = hbuf == 2 ? 0 : hbuf + 1;
   }
-  if (epi_wave && ABL == 0) epilogue(total - 1, zreg);
+  if (epi_wave && (ABL == 0 || ABL == 7)) {
+    const int et = EPI_FIRST ? tid : tid - (NT - NCT);
+    if (PRODUCER && et < 160) zreg = reinterpret_cast<const f32x4*>(zbuf)[((total - 1) & 1) * 160 + et];
+    epilogue(total - 1, zreg);
+  }
   if (ABL != 0 && a.N < 0) epilogue(0, zreg);  // keep the code reachable for the compiler, never executed
 }
 
@@ -686,15 +776,16 @@ __global__ void k_fill_normal(long N, unsigned long long seed, long row_offset, 
 
 template <int NW>
 size_t chain_lds_bytes() {
-  return (size_t)(kG * 768 + 3 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps) * sizeof(float);
+  return (size_t)(kG * 768 + 3 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps + 3 * 512 + 2 * 640) *
+         sizeof(float);
 }
 
-template <int NW, bool REFINE, int ABL = 0, bool EPI_FIRST = true>
+template <int NW, bool REFINE, int ABL = 0, bool EPI_FIRST = true, int PRIO = 0, bool UT = false>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
   const dim3 grid((unsigned)((n_tiles + kG - 1) / kG));
   const size_t lds = chain_lds_bytes<NW>();
-  auto fn = k_chain<NW, REFINE, ABL, EPI_FIRST>;
+  auto fn = k_chain<NW, REFINE, ABL, EPI_FIRST, PRIO, UT>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return PSTL_ERR_LAUNCH;
@@ -707,12 +798,19 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
 template <bool REFINE>
 int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   if (chain_waves == 4) return launch_chain<4, REFINE>(a, st);
-  if (chain_waves == 0 || chain_waves == 8) return launch_chain<8, REFINE>(a, st);
+  const bool ut = (a.rows_per_scene % kTileRows == 0);  // every 16-row tile lies inside one scene
+  if (chain_waves == 0 || chain_waves == 8)
+    return ut ? launch_chain<8, REFINE, 0, true, 0, true>(a, st) : launch_chain<8, REFINE>(a, st);
+  if (!REFINE && chain_waves == 1008) return launch_chain<8, false>(a, st);           // force the general path
+  if (!REFINE && chain_waves == 1108 && ut) return launch_chain<8, false, 7, true, 0, true>(a, st);  // stamps, UT
   if (!REFINE && chain_waves == 108) return launch_chain<8, false, 1>(a, st);
   if (!REFINE && chain_waves == 208) return launch_chain<8, false, 2>(a, st);
   if (!REFINE && chain_waves == 308) return launch_chain<8, false, 3>(a, st);
   if (!REFINE && chain_waves == 508) return launch_chain<8, false, 5>(a, st);
   if (!REFINE && chain_waves == 608) return launch_chain<8, false, 0, false>(a, st);
+  if (!REFINE && chain_waves == 708) return launch_chain<8, false, 7>(a, st);
+  if (!REFINE && chain_waves == 808) return launch_chain<8, false, 0, true, 1>(a, st);
+  if (!REFINE && chain_waves == 908) return launch_chain<8, false, 0, true, 2>(a, st);
   if (REFINE && chain_waves > 100) return launch_chain<8, true>(a, st);
   return PSTL_ERR_SHAPE;
 }

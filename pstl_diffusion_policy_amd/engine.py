@@ -131,6 +131,7 @@ class Sampler:
         # when set to a list, every multi-step rollout launch appends (start_event, end_event, n_steps, n_rows):
         # HIP events recorded on the launch stream, used by bench.py to time the dominant kernel live
         self.trace = None
+        self.debug_buf = None   # diagnostic builds only (chain_waves 708): receives the kernel's cycle stamps
 
     # ---- A1 ----
     def encode(self, sb, need_rect=True):
@@ -192,7 +193,7 @@ class Sampler:
             ffi.check(self.L.pstl_rollout(ctypes.byref(cfg), ffi.ptr(self.w.packed), ffi.ptr(base_policy), ffi.ptr(tb),
                                           ffi.ptr(sb.stlp), ffi.ptr(sb.hl), ffi.ptr(beta), ffi.ptr(alpha),
                                           ffi.ptr(alpha_hat), ffi.ptr(noise), int(hi), int(lo), int(mu_only),
-                                          ffi.ptr(x), ffi.ptr(emit) if n_emit > 0 else ffi.ptr(None), int(n_emit),
+                                          ffi.ptr(x), ffi.ptr(emit) if n_emit > 0 else ffi.ptr(self.debug_buf), int(n_emit),
                                           ffi.stream()), "rollout")
 
         i = steps - 1
