@@ -178,6 +178,30 @@ int pstl_refine(const pstl_cfg* cfg, const float* packed, const float* base_rect
                 const float* init_controls /* (N,40) */, const float* scores /* (N,) */, float* pooled_work,
                 float* out_controls /* (N,40) */, void* stream);
 
+/* ---- RefineNet training step (config 5, nusc_train.py:1400-1427,1522-1525) ----------------------- */
+/* pstl_refine with the activations kept for the backward pass: h1_save, h2_save (N,256) = relu of layers 1, 2;
+ * pre_save (N,40) = layer-3 output before tanh. */
+int pstl_refine_train_forward(const pstl_cfg* cfg, const float* packed, const float* base_rect, const float* stlp,
+                              const float* hl, const float* init_controls, const float* scores, float* pooled_work,
+                              float* out_controls, float* h1_save, float* h2_save, float* pre_save, void* stream);
+/* Loss mask_mean(relu(thres - score), valid) (compute_policy_loss :411): dscore[r] = -grad_scale*valid[r]*[thres-score>0]
+ * (grad_scale as in pstl_guidance_step); loss_parts[256] partial sums of relu(thres - score)*valid (host adds them and
+ * divides by N * clip(mean(valid), 1e-2)). */
+int pstl_loss_grad(const pstl_cfg* cfg, const float* scores, const float* valid, float grad_scale, float* dscore,
+                   float* loss_parts, void* stream);
+/* Context of the backward pass (a rocBLAS handle for its five plain fp32 GEMMs). */
+int pstl_train_create(void** ctx);
+int pstl_train_destroy(void* ctx);
+size_t pstl_train_work_floats(const pstl_cfg* cfg);
+/* d loss / d rect_net parameters given dcontrols = d loss / d out_controls (from pstl_stl_backward).  w2, w3: the
+ * reference-layout weights rect_net.2.weight (256,256), rect_net.4.weight (40,256).  Gradients in the reference layout:
+ * dw1 (256,271), db1 (256), dw2 (256,256), db2 (256), dw3 (40,256), db3 (40).  Gradients w.r.t. the scene feature
+ * (needed only with --joint) are not produced.  work: pstl_train_work_floats(cfg) floats. */
+int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float* w2, const float* w3, const float* feature,
+                         const float* stlp, const float* hl, const float* init_controls, const float* prev_scores,
+                         const float* h1, const float* h2, const float* pre, const float* dcontrols, float* work,
+                         float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, void* stream);
+
 /* ---- metrics --------------------------------------------------------------------------------------------------- */
 /* counts[0] = #rows with score>0 and valid, counts[1] = #valid rows, counts[2] = #rows,
  * counts[3] = #(scene,mode) with any sample score>0 and valid, counts[4] = #valid (scene,mode), counts[5] = 3*bs.

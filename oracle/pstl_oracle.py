@@ -426,3 +426,27 @@ def sampling_region(sd, scene, S, steps, hp, x_T, z, rect_head=False, multi_cand
                    final_scene_acc=scene_acc, signals=sig,
                    final_trajs=unicycle_rollout(rows.s0, controls, hp["dt"]))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# N1  training step of RefineNet under the STL loss (reference nusc_train.py:1400-1427, compute_policy_loss
+#     :370-478 with rect_head and no diverse_loss, optimizer :1233,1522-1525)
+# ------------------------------------------------------------------------------------------------
+def rect_train_step(sd, scene, S, hp, init_controls, prev_scores, lr, diverse=False, n_shards=4):
+    """loss = mask_mean(relu(thres - score(rect_controls)), valid) (+ zero-weight regularisers); returns the loss, the
+    gradients of the six rect_net tensors and the tensors after one Adam step (fresh optimiser state)."""
+    rows = Rows(scene, S, hp)
+    params = {k: _t(v).clone().requires_grad_() for k, v in sd.items() if k.startswith("rect_net.")}
+    sd_live = {k: (params[k] if k in params else _t(v)) for k, v in sd.items()}
+    feature = encode_feat(sd_live, scene).detach()
+    rect = rect_forward(sd_live, feature, rows, _t(init_controls), _t(prev_scores), n_shards, diverse)
+    _, score, _ = rows.score(rect)
+    loss = mask_mean(torch.relu(hp["stl_nn_thres"] - score), rows.valid)
+    names = sorted(params)
+    grads = torch.autograd.grad(loss, [params[k] for k in names])
+    opt = torch.optim.Adam([params[k] for k in names], lr=lr)
+    for k, g in zip(names, grads):
+        params[k].grad = g
+    opt.step()
+    return dict(loss=loss.detach(), rect_controls=rect.detach(), scores=score.detach(),
+                grads={k: g for k, g in zip(names, grads)}, after={k: params[k].detach() for k in names})

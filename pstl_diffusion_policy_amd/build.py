@@ -9,7 +9,9 @@ LIB = os.path.join(HERE, "libpstl_hip.so")
 ARCH = "gfx950"
 
 # (source, extra flags).  stl_kernels must not contract mul+add into fma: see csrc/stl_core.hpp.
-UNITS = [("stl_kernels.hip", ["-ffp-contract=off"]), ("mlp_kernels.hip", [])]
+UNITS = [("stl_kernels.hip", ["-ffp-contract=off"]), ("mlp_kernels.hip", []), ("train_kernels.hip", [])]
+# rocBLAS only serves the plain fp32 GEMMs of the RefineNet backward pass (train_kernels.hip)
+LINK_LIBS = ["-lrocblas"]
 
 
 def _newer(target, deps):
@@ -34,7 +36,7 @@ def build(force=False, verbose=True):
             subprocess.check_call(cmd)
         objs.append(o)
     if force or _newer(LIB, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB]
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + LINK_LIBS + ["-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

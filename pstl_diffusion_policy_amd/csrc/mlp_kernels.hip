@@ -296,6 +296,10 @@ struct ChainArgs {
   const float* scores;   // (N,)
   float* out;            // (N,40)
   int S, n_shards;
+  // training (N1): activations of rect_net kept for the backward pass; null = inference
+  float* h1_save;        // (N,256) relu(layer 1)
+  float* h2_save;        // (N,256) relu(layer 2)
+  float* pre_save;       // (N,40)  layer-3 output before tanh
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -480,7 +484,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
     f32x4* hw = reinterpret_cast<f32x4*>(h1 + buf * 4096);
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) hw[(w * OT + ot) * 64 + lane] = relu4(acc[ot] + cst[ot]);
+    for (int ot = 0; ot < OT; ++ot) {
+      const f32x4 hv = relu4(acc[ot] + cst[ot]);
+      hw[(w * OT + ot) * 64 + lane] = hv;
+      if (REFINE && a.h1_save) {
+        const long row = (tile0 + tl) * kTileRows + col;
+        if (row < a.N) *reinterpret_cast<f32x4*>(a.h1_save + row * kHid + 16 * (w * OT + ot) + 4 * g) = hv;
+      }
+    }
   };
 
   // ---- epilogue of tile-step `it` (run by the second half of the waves, one tile-step late) ---------------------
@@ -530,6 +541,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       } else if (row < a.N) {
         // interval head (nusc_model.py:212-229): tanh output scales into the remaining headroom of init
         const f32x4 init = *reinterpret_cast<const f32x4*>(a.init + row * kCtrl + f0);
+        if (a.pre_save) *reinterpret_cast<f32x4*>(a.pre_save + row * kCtrl + f0) = o;
         const float viol = a.scores[row] < 0.0f ? 1.0f : 0.0f;
         f32x4 v;
 #pragma unroll
@@ -663,6 +675,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
       const f32x4 h = relu4(acc[ot]);
+      if (REFINE && a.h2_save) {
+        const long row = (tile0 + it % G) * kTileRows + col;
+        if (row < a.N) *reinterpret_cast<f32x4*>(a.h2_save + row * kHid + 16 * (w * OT + ot) + 4 * g) = h;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -981,9 +997,29 @@ extern "C" int pstl_rollout(const pstl_cfg* cfg, const float* packed, const floa
   return PSTL_OK;
 }
 
+static int refine_impl(const pstl_cfg* cfg, const float* packed, const float* base_rect, const float* stlp,
+                       const float* hl, const float* init_controls, const float* scores, float* pooled_work,
+                       float* out_controls, float* h1_save, float* h2_save, float* pre_save, void* stream);
+
 extern "C" int pstl_refine(const pstl_cfg* cfg, const float* packed, const float* base_rect, const float* stlp,
                            const float* hl, const float* init_controls, const float* scores, float* pooled_work,
                            float* out_controls, void* stream) {
+  return refine_impl(cfg, packed, base_rect, stlp, hl, init_controls, scores, pooled_work, out_controls, nullptr, nullptr,
+                     nullptr, stream);
+}
+
+extern "C" int pstl_refine_train_forward(const pstl_cfg* cfg, const float* packed, const float* base_rect,
+                                         const float* stlp, const float* hl, const float* init_controls,
+                                         const float* scores, float* pooled_work, float* out_controls, float* h1_save,
+                                         float* h2_save, float* pre_save, void* stream) {
+  if (!h1_save || !h2_save || !pre_save) return PSTL_ERR_ARG;
+  return refine_impl(cfg, packed, base_rect, stlp, hl, init_controls, scores, pooled_work, out_controls, h1_save, h2_save,
+                     pre_save, stream);
+}
+
+static int refine_impl(const pstl_cfg* cfg, const float* packed, const float* base_rect, const float* stlp,
+                       const float* hl, const float* init_controls, const float* scores, float* pooled_work,
+                       float* out_controls, float* h1_save, float* h2_save, float* pre_save, void* stream) {
   if (int e = check_cfg(cfg)) return e;
   if (!packed || !base_rect || !stlp || !hl || !init_controls || !scores || !out_controls) return PSTL_ERR_ARG;
   const bool merge = !(cfg->flags & PSTL_FLAG_NO_MERGE);
@@ -1024,5 +1060,8 @@ extern "C" int pstl_refine(const pstl_cfg* cfg, const float* packed, const float
   a.out = out_controls;
   a.S = cfg->S;
   a.n_shards = cfg->n_shards;
+  a.h1_save = h1_save;
+  a.h2_save = h2_save;
+  a.pre_save = pre_save;
   return launch_chain_nw<true>(cfg->chain_waves, a, st);
 }

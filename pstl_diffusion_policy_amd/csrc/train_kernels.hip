@@ -1,0 +1,193 @@
+// train_kernels.hip -- backward pass of RefineNet under the STL loss (the training step of
+// config 5, reference nusc_train.py:1400-1427,1522-1525 and compute_policy_loss :370-478).
+//
+//   forward (pstl_refine_train_forward, mlp_kernels.hip) keeps h1 = relu(L1), h2 = relu(L2), pre = L3 output.
+//   d loss / d rect_controls comes from pstl_stl_backward (the STL adjoint already used by guidance).
+//   here: interval/tanh head backward (fused elementwise kernel), ReLU masks + column sums (fused, deterministic
+//   two-stage reduction), per-scene reduction for the 224 scene-constant input columns, and five PLAIN fp32 GEMMs
+//   (dH2 = dO W3, dW3 = dO^T h2, dH1 = dH2 W2, dW2 = dH2^T h1, dW1 = dH1^T [feature|hl|stlp|init]) which go to rocBLAS.
+#include <rocblas/rocblas.h>
+
+#include "pstl_common.hpp"
+
+namespace pstl {
+namespace {
+
+constexpr int kHid = PSTL_HID, kCtrl = PSTL_CTRL, kFeat = PSTL_FEAT;
+constexpr int kX47 = 47;   // hl 1 | stlp 6 | init 40  = input columns 224..270 of rect_net layer 1
+constexpr int kIn = kFeat + kX47;  // 271
+
+struct TrainCtx {
+  rocblas_handle h;
+};
+
+// dO = dcontrols * [prev_score < 0] * d interval / d raw * (1 - raw^2), raw = tanh(pre)   (nusc_model.py:212-229)
+// x47 = [hl | stlp | init]
+__global__ void k_head_bwd(long N, float w_max, float a_max, const float* dctrl, const float* pre, const float* init,
+                           const float* prev_scores, const float* hl, const float* stlp, float* dO, float* x47) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * kCtrl) return;
+  const long row = i / kCtrl;
+  const int f = (int)(i % kCtrl);
+  const float sc = (f & 1) ? a_max : w_max;
+  const float raw = tanhf(pre[i]);
+  const float in0 = init[i];
+  const float slope = raw >= 0.0f ? (sc - in0) : (in0 - (-sc));
+  const float viol = prev_scores[row] < 0.0f ? 1.0f : 0.0f;
+  dO[i] = dctrl[i] * viol * slope * (1.0f - raw * raw);
+  x47[row * kX47 + 7 + f] = in0;
+  if (f == 0) x47[row * kX47] = hl[row];
+  if (f < 6) x47[row * kX47 + 1 + f] = stlp[row * 6 + f];
+}
+
+// G *= [H > 0] (in place, skipped when H == nullptr) and partial[b][c] = sum over the block's rows of G[.][c]
+__global__ void k_mask_colsum(long N, int ncol, float* G, const float* H, float* partial) {
+  const int c = threadIdx.x;
+  if (c >= ncol) return;
+  const long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+  const long r0 = blockIdx.x * rows_per_block, r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
+  float acc = 0.0f;
+  for (long r = r0; r < r1; ++r) {
+    float g = G[r * ncol + c];
+    if (H) {
+      g = H[r * ncol + c] > 0.0f ? g : 0.0f;
+      G[r * ncol + c] = g;
+    }
+    acc += g;
+  }
+  partial[(long)blockIdx.x * ncol + c] = acc;
+}
+
+__global__ void k_colsum_final(int nblocks, int ncol, const float* partial, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncol) return;
+  float acc = 0.0f;
+  for (int b = 0; b < nblocks; ++b) acc += partial[(long)b * ncol + c];
+  out[c] = acc;
+}
+
+// S[scene][f] = sum over the scene's rows of G[row][f]
+__global__ void k_scene_sum(int rows_per_scene, const float* G, float* S) {
+  const long b = blockIdx.x;
+  const int f = threadIdx.x;
+  float acc = 0.0f;
+  for (int r = 0; r < rows_per_scene; ++r) acc += G[(b * rows_per_scene + r) * kHid + f];
+  S[b * kHid + f] = acc;
+}
+
+// dscore[r] = -grad_scale * valid[r] * [thres - score[r] > 0] ; loss_parts[block] = sum relu(thres - score) * valid
+__global__ void k_loss_grad(long N, const float* scores, const float* valid, float thres, float grad_scale, float* dscore,
+                            float* loss_parts) {
+  __shared__ float red[256];
+  float acc = 0.0f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+    const float m = thres - scores[i];
+    const float v = valid[i];
+    dscore[i] = m > 0.0f ? -(grad_scale * v) : 0.0f;
+    acc += fmaxf(m, 0.0f) * v;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_parts[blockIdx.x] = red[0];
+}
+
+// row-major C(m x n) = op(A) op(B) through column-major rocBLAS
+int gemm_rm(rocblas_handle h, bool ta, bool tb, int m, int n, long k, const float* A, int lda, const float* B, int ldb,
+            float* C, int ldc) {
+  const float one = 1.0f, zero = 0.0f;
+  const rocblas_status st =
+      rocblas_sgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
+                    ta ? rocblas_operation_transpose : rocblas_operation_none, n, m, (rocblas_int)k, &one, B, ldb, A, lda,
+                    &zero, C, ldc);
+  return st == rocblas_status_success ? PSTL_OK : PSTL_ERR_LAUNCH;
+}
+
+constexpr int kRedBlocks = 512;
+
+}  // namespace
+}  // namespace pstl
+
+using namespace pstl;
+
+extern "C" int pstl_train_create(void** ctx) {
+  if (!ctx) return PSTL_ERR_ARG;
+  TrainCtx* c = new TrainCtx();
+  if (rocblas_create_handle(&c->h) != rocblas_status_success) {
+    delete c;
+    return PSTL_ERR_LAUNCH;
+  }
+  *ctx = c;
+  return PSTL_OK;
+}
+
+extern "C" int pstl_train_destroy(void* ctx) {
+  if (!ctx) return PSTL_ERR_ARG;
+  TrainCtx* c = static_cast<TrainCtx*>(ctx);
+  rocblas_destroy_handle(c->h);
+  delete c;
+  return PSTL_OK;
+}
+
+extern "C" size_t pstl_train_work_floats(const pstl_cfg* cfg) {
+  if (check_cfg(cfg)) return 0;
+  const long N = n_rows(cfg);
+  return (size_t)(N * (kCtrl + kX47 + 2L * kHid) + (long)cfg->bs * kHid + (long)kRedBlocks * kHid + 64);
+}
+
+extern "C" int pstl_loss_grad(const pstl_cfg* cfg, const float* scores, const float* valid, float grad_scale, float* dscore,
+                              float* loss_parts /* 256 floats */, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!scores || !valid || !dscore || !loss_parts) return PSTL_ERR_ARG;
+  const float thres = (cfg->flags & PSTL_FLAG_MAXIMIZE) ? 100.0f : cfg->thres;
+  hipLaunchKernelGGL(k_loss_grad, dim3(256), dim3(256), 0, as_stream(stream), n_rows(cfg), scores, valid, thres, grad_scale,
+                     dscore, loss_parts);
+  return launch_status();
+}
+
+extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float* w2 /* (256,256) */,
+                                    const float* w3 /* (40,256) */, const float* feature /* (bs,224) */, const float* stlp,
+                                    const float* hl, const float* init_controls, const float* prev_scores,
+                                    const float* h1, const float* h2, const float* pre, const float* dcontrols,
+                                    float* work, float* dw1 /* (256,271) */, float* db1, float* dw2, float* db2,
+                                    float* dw3 /* (40,256) */, float* db3, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!ctx || !w2 || !w3 || !feature || !stlp || !hl || !init_controls || !prev_scores || !h1 || !h2 || !pre ||
+      !dcontrols || !work || !dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3)
+    return PSTL_ERR_ARG;
+  if (cfg->flags & PSTL_FLAG_CLIP_RECT) return PSTL_ERR_SHAPE;  // the reference trains without --clip_rect
+  TrainCtx* c = static_cast<TrainCtx*>(ctx);
+  hipStream_t st = as_stream(stream);
+  if (rocblas_set_stream(c->h, st) != rocblas_status_success) return PSTL_ERR_LAUNCH;
+  const long N = n_rows(cfg);
+  float* dO = work;                       // (N,40)
+  float* x47 = dO + N * kCtrl;            // (N,47)
+  float* dH2 = x47 + N * kX47;            // (N,256)
+  float* dH1 = dH2 + N * kHid;            // (N,256)
+  float* S = dH1 + N * kHid;              // (bs,256)
+  float* part = S + (long)cfg->bs * kHid; // (kRedBlocks,256)
+  const int nb = (int)(N < kRedBlocks ? N : kRedBlocks);
+
+  hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)((N * kCtrl + 255) / 256)), dim3(256), 0, st, N, cfg->w_max, cfg->a_max,
+                     dcontrols, pre, init_controls, prev_scores, hl, stlp, dO, x47);
+  // layer 3
+  hipLaunchKernelGGL(k_mask_colsum, dim3(nb), dim3(64), 0, st, N, kCtrl, dO, (const float*)nullptr, part);
+  hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(64), 0, st, nb, kCtrl, part, db3);
+  if (int e = gemm_rm(c->h, true, false, kCtrl, kHid, N, dO, kCtrl, h2, kHid, dw3, kHid)) return e;   // dW3 = dO^T h2
+  if (int e = gemm_rm(c->h, false, false, (int)N, kHid, kCtrl, dO, kCtrl, w3, kHid, dH2, kHid)) return e;  // dH2 = dO W3
+  // layer 2
+  hipLaunchKernelGGL(k_mask_colsum, dim3(nb), dim3(256), 0, st, N, kHid, dH2, h2, part);
+  hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(256), 0, st, nb, kHid, part, db2);
+  if (int e = gemm_rm(c->h, true, false, kHid, kHid, N, dH2, kHid, h1, kHid, dw2, kHid)) return e;    // dW2 = dH2^T h1
+  if (int e = gemm_rm(c->h, false, false, (int)N, kHid, kHid, dH2, kHid, w2, kHid, dH1, kHid)) return e;  // dH1 = dH2 W2
+  // layer 1
+  hipLaunchKernelGGL(k_mask_colsum, dim3(nb), dim3(256), 0, st, N, kHid, dH1, h1, part);
+  hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(256), 0, st, nb, kHid, part, db1);
+  hipLaunchKernelGGL(k_scene_sum, dim3(cfg->bs), dim3(256), 0, st, cfg->rows_per_scene, dH1, S);
+  if (int e = gemm_rm(c->h, true, false, kHid, kFeat, cfg->bs, S, kHid, feature, kFeat, dw1, kIn)) return e;
+  if (int e = gemm_rm(c->h, true, false, kHid, kX47, N, dH1, kHid, x47, kX47, dw1 + kFeat, kIn)) return e;
+  return launch_status();
+}

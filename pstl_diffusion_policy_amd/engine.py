@@ -328,3 +328,64 @@ def acc_from_counts(counts):
     acc = f32(f32(c[0]) / f32(c[2])) / max(f32(f32(c[1]) / f32(c[2])), f32(1e-2))
     sacc = f32(f32(c[3]) / f32(c[5])) / max(f32(f32(c[4]) / f32(c[5])), f32(1e-2))
     return float(acc), float(sacc)
+
+
+class RectTrainer:
+    """RefineNet training step under the STL loss (reference nusc_train.py:1400-1427,1522-1525 with
+    compute_policy_loss :370-478 for --rect_head without --diverse_loss): forward with saved activations, STL adjoint,
+    head/MLP backward -> gradients of the six rect_net tensors in the reference layout.  The optimiser itself stays the
+    caller's torch.optim.Adam over `net.rect_net.parameters()`, exactly as in the reference."""
+
+    NAMES = ("rect_net.0.weight", "rect_net.0.bias", "rect_net.2.weight", "rect_net.2.bias", "rect_net.4.weight",
+             "rect_net.4.bias")
+
+    def __init__(self, sampler):
+        self.sm = sampler
+        self.L = sampler.L
+        self.ctx = ctypes.c_void_p()
+        ffi.check(self.L.pstl_train_create(ctypes.byref(self.ctx)), "train_create")
+
+    def __del__(self):
+        try:
+            if self.ctx:
+                self.L.pstl_train_destroy(self.ctx)
+        except Exception:
+            pass
+
+    def loss_and_grads(self, sb, feature, base_rect, w2, w3, init_controls, prev_scores):
+        """init_controls (N,40) physical units, prev_scores (N,) (both detached in the reference).  w2, w3: the live
+        rect_net.2.weight / rect_net.4.weight tensors.  Returns (loss tensor, rect_controls, scores, {name: grad})."""
+        dev = sb.device
+        N = sb.N
+        cfg = sb.cfg(2, ffi.PSTL_FLAG_NO_MERGE, self.sm.chain_waves)
+        h1 = torch.empty(N, ffi.HID, dtype=torch.float32, device=dev)
+        h2 = torch.empty(N, ffi.HID, dtype=torch.float32, device=dev)
+        pre = torch.empty(N, ffi.CTRL, dtype=torch.float32, device=dev)
+        rect = torch.empty(N, ffi.CTRL, dtype=torch.float32, device=dev)
+        ffi.check(self.L.pstl_refine_train_forward(ctypes.byref(cfg), ffi.ptr(self.sm.w.packed), ffi.ptr(base_rect),
+                                                   ffi.ptr(sb.stlp), ffi.ptr(sb.hl), ffi.ptr(init_controls),
+                                                   ffi.ptr(prev_scores), ffi.ptr(None), ffi.ptr(rect), ffi.ptr(h1),
+                                                   ffi.ptr(h2), ffi.ptr(pre), ffi.stream()), "refine_train_forward")
+        scores = self.sm.score(sb, rect.reshape(1, N, ffi.CTRL))["scores"][0]
+        dscore = torch.empty(N, dtype=torch.float32, device=dev)
+        parts = torch.empty(256, dtype=torch.float32, device=dev)
+        ffi.check(self.L.pstl_loss_grad(ctypes.byref(cfg), ffi.ptr(scores), ffi.ptr(sb.valid),
+                                        ctypes.c_float(sb.grad_scale), ffi.ptr(dscore), ffi.ptr(parts), ffi.stream()),
+                  "loss_grad")
+        _, dctrl = self.sm.score_grad(sb, rect, dscore=dscore)
+        work = torch.empty(self.L.pstl_train_work_floats(ctypes.byref(cfg)), dtype=torch.float32, device=dev)
+        shapes = {"rect_net.0.weight": (ffi.HID, ffi.FEAT + 47), "rect_net.0.bias": (ffi.HID,),
+                  "rect_net.2.weight": (ffi.HID, ffi.HID), "rect_net.2.bias": (ffi.HID,),
+                  "rect_net.4.weight": (ffi.CTRL, ffi.HID), "rect_net.4.bias": (ffi.CTRL,)}
+        g = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in self.NAMES}
+        ffi.check(self.L.pstl_refine_backward(ctypes.byref(cfg), self.ctx, ffi.ptr(ffi.f32(w2.detach(), dev)),
+                                              ffi.ptr(ffi.f32(w3.detach(), dev)), ffi.ptr(feature), ffi.ptr(sb.stlp),
+                                              ffi.ptr(sb.hl), ffi.ptr(init_controls), ffi.ptr(prev_scores), ffi.ptr(h1),
+                                              ffi.ptr(h2), ffi.ptr(pre), ffi.ptr(dctrl), ffi.ptr(work),
+                                              ffi.ptr(g["rect_net.0.weight"]), ffi.ptr(g["rect_net.0.bias"]),
+                                              ffi.ptr(g["rect_net.2.weight"]), ffi.ptr(g["rect_net.2.bias"]),
+                                              ffi.ptr(g["rect_net.4.weight"]), ffi.ptr(g["rect_net.4.bias"]),
+                                              ffi.stream()), "refine_backward")
+        # loss = mean(relu(thres - score) * valid) / clip(mean(valid), 1e-2): grad_scale is exactly (1/clip)/N
+        loss = parts.sum() * sb.grad_scale
+        return loss, rect, scores, g

@@ -27,7 +27,9 @@ NEI_PREP = 12
 EXPORTS = ["pstl_version", "pstl_error_string", "pstl_packed_weight_floats", "pstl_pack_weights", "pstl_time_bias",
            "pstl_fill_normal",
            "pstl_prepare_scene", "pstl_encode_scene", "pstl_rollout", "pstl_generate_trajs", "pstl_stl_forward",
-           "pstl_stl_backward", "pstl_guidance_step", "pstl_refine", "pstl_reduce_metrics"]
+           "pstl_stl_backward", "pstl_guidance_step", "pstl_refine", "pstl_reduce_metrics",
+           "pstl_refine_train_forward", "pstl_loss_grad", "pstl_train_create", "pstl_train_destroy",
+           "pstl_train_work_floats", "pstl_refine_backward"]
 
 
 class PstlCfg(ctypes.Structure):
@@ -67,6 +69,7 @@ def lib():
         L.pstl_packed_weight_floats.restype = ctypes.c_size_t
         for name in EXPORTS[3:]:
             getattr(L, name).restype = ctypes.c_int
+        L.pstl_train_work_floats.restype = ctypes.c_size_t
         _lib = L
     return _lib
 

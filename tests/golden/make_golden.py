@@ -224,5 +224,100 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--train" not in sys.argv:
     main()
+
+
+def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4):
+    """One training step of config 5 (e8_ours_ablation: --rect_head, STL loss through RefineNet; reference
+    nusc_train.py:1365-1427 + compute_policy_loss :370-478 + optimizer :1522-1525), driven through the reference's own
+    functions.  Stored: inputs, every noise draw, the loss, d loss / d rect_net parameters and the parameters after
+    one Adam step."""
+    nt = ref.nusc_train
+    argv = ["--diffusion", "--stl_weight", "1.0", "--load_stlp", "--load_tj", "--rect_head", "--flex",
+            "--diversity_weight", "0.0", "--n_shards", "4", "--interval", "--multi_cands", "5", "--diff_full",
+            "--diffusion_steps", str(steps), "--n_randoms", str(S), "--sampling_size", str(S), "--n_neighbors", str(K),
+            "--lr", str(lr)]
+    args = ref_harness.parse_reference_args(argv)
+    args.measure_diversity = False        # CPU-side metric (scipy hull), not part of the loss
+    net = ref.nusc_model.Net(args)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items() if not k.startswith("merge_net")}, strict=True)
+    optimizer = torch.optim.Adam(net.rect_net.parameters(), lr=args.lr)   # reference :1233 (no --joint)
+    coeffs = nt.get_diffusion_coeffs(args)
+    stls = nt.build_stl_cache(args)
+    batch = make_scene_batch(bs, K=K, S=S, seed=seed, invalid_lane_frac=0.25, stlp_mode="wide")
+    batch_cuda = dict(batch)
+    gt_trajs = batch_cuda["ego_traj"][..., :4]
+    states = gt_trajs[..., 0, :4]
+    batch_cuda["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
+    gt_stlp = batch_cuda["stlp_modes"][:, 0]
+    batch_cuda = nt.augment_batch_data(batch_cuda, gt_stlp, args)
+    n = bs * S * 3
+    dense_states_flat = states.unsqueeze(1).unsqueeze(1).repeat(1, S, 3, 1).reshape(n, 4)
+    hl = batch_cuda["highlevel_dense"]
+    dense_controls = batch_cuda["params"]
+    dense_trajs = nt.generate_trajs(states.unsqueeze(1).unsqueeze(1).repeat(1, S, 3, 1), dense_controls, args.dt)
+    dense_scores = batch_cuda["tj_scores_prior"].reshape(bs * S, 3)
+    dense_valids = batch_cuda["valids_dense"]
+    torch.manual_seed(seed + 3)
+    noise, tsteps, _, noised_b = nt.diffusion_prep(dense_controls, n_randoms=S, coeffs=coeffs)
+    net.train()
+    ext = {"timestep": tsteps, "highlevel": hl, "noise": noised_b}
+    est_a, feature = net(batch_cuda, ext=ext, get_feature=True)
+    est_a = est_a.reshape(n, args.nt * 2)
+    draws = []
+    with ref_harness.record_randn_like(draws):
+        nn_controls, clist = nt.diffusion_rollout(noise, net, batch_cuda, hl, feature, args, coeffs, fastforward=False)
+    mc = args.multi_cands
+    states_mul = dense_states_flat.repeat(mc, 1)
+    ctrls_mul = torch.cat(clist[-mc:], dim=0)
+    trajs_mul = nt.generate_trajs(states_mul, ctrls_mul, args.dt)
+    prev_in = nt.pre_prepare_stl_cache(batch_cuda, dense_trajs=trajs_mul[:, :-1], repeat_n=mc)
+    _, sc_hist, _ = nt.compute_stl_dense(prev_in, stls, hl.repeat(mc, 1), prev_in["dense_valids"].reshape(-1), args)
+    sc_hist = sc_hist.reshape(mc, n)
+    sc_max, sc_idx = torch.max(sc_hist, dim=0)
+    c_max = ctrls_mul.reshape(mc, n, args.nt, 2)[sc_idx, range(n)]
+    rect_controls = net.rect_forward(feature, hl, batch_cuda["stlp_dense"][:, 0], c_max.detach(), sc_max.detach(), extras=clist)
+    nn_trajs = nt.generate_trajs(dense_states_flat, c_max, args.dt)
+    rect_trajs = nt.generate_trajs(dense_states_flat, rect_controls, args.dt)
+    extras = (None, est_a, hl, dense_scores, dense_valids, 0, noise, c_max, tsteps, rect_controls)
+    rd, _ = nt.compute_policy_loss(batch_cuda, None, stls, nn_trajs, rect_trajs, dense_trajs, args, diffusion_extras=extras,
+                                   opt_controls=dense_controls)
+    before = {k: v.detach().clone() for k, v in net.rect_net.state_dict().items()}
+    optimizer.zero_grad()
+    rd["loss"].backward()
+    grads = {k: p.grad.detach().clone() for k, p in net.rect_net.named_parameters()}
+    feat_grad_norm = float(sum((p.grad ** 2).sum() for nme, p in net.named_parameters() if "encoder" in nme and p.grad is not None))
+    optimizer.step()
+    after = {k: v.detach().clone() for k, v in net.rect_net.state_dict().items()}
+    out = {"x_T": np_(draws[0]), "z": np_(torch.stack(draws[1:] + [torch.zeros_like(draws[0])], dim=0)),
+           "sel_controls": np_(c_max), "sel_scores": np_(sc_max), "rect_controls": np_(rect_controls),
+           "scores": np_(rd["scores"]), "loss": np.float32(rd["loss"].item()), "loss_stl": np.float32(rd["loss_stl"].item()),
+           "acc": np.float32(rd["acc"].item()), "feature_scene": np_(feature.reshape(bs, S * 3, -1)[:, 0]),
+           "encoder_grad_sqnorm": np.float64(feat_grad_norm)}
+    for k in grads:
+        out["grad_rect_net." + k] = np_(grads[k])
+        out["after_rect_net." + k] = np_(after[k])
+        assert torch.equal(before[k], torch.from_numpy(sd["rect_net." + k]))
+    for k in ["ego_traj", "neighbors", "neighbors_traj", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
+              "curr_id", "left_id", "right_id", "stlp_modes"]:
+        out["in_" + k] = np_(batch[k])
+    out["meta"] = np.array([bs, S, K, steps, seed, mc], dtype=np.int64)
+    out["meta_f"] = np.array([args.lr, args.stl_nn_thres], dtype=np.float64)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    gn = float(sum((g ** 2).sum() for g in grads.values())) ** 0.5
+    print("%-28s N=%d loss=%.5f acc=%.3f |grad|=%.3e viol=%d/%d -> %s (%.1f KB)" % (
+        name, n, rd["loss"].item(), rd["acc"].item(), gn, int((sc_max < 0).sum()), n, os.path.basename(path),
+        os.path.getsize(path) / 1024))
+
+
+def main_train():
+    ref = ref_harness.load_reference()
+    sd = dict(np.load(WEIGHTS_FILE))
+    train_case(ref, sd, "train_e8_step", bs=3, S=8, K=3, steps=10, seed=31)
+    train_case(ref, sd, "train_e8_step_b", bs=4, S=16, K=5, steps=8, seed=32)
+
+
+if __name__ == "__main__" and "--train" in sys.argv:
+    main_train()

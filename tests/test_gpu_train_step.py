@@ -1,0 +1,78 @@
+"""GPU test (-m gpu) of the RefineNet training step: loss, the gradients of the six rect_net
+tensors and the weights after one Adam step, against the reference's own autograd/optimizer (golden) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_weights, load_golden, scene_from_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(d, dev):
+    from pstl_diffusion_policy_amd.engine import PackedWeights, RectTrainer, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import default_hparams
+    bs, S, K, steps, seed, mc = [int(v) for v in d["meta"]]
+    hp = default_hparams()
+    sd = {k: torch.from_numpy(v).to(dev) for k, v in golden_weights().items()}
+    sm = Sampler(PackedWeights(sd, dev), hp)
+    sb = SceneBatch({k: torch.from_numpy(v) for k, v in scene_from_golden(d).items()}, S, hp, dev)
+    return sm, sb, sd, RectTrainer(sm)
+
+
+@pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b"])
+def test_rect_train_step_matches_reference(name):
+    dev = torch.device("cuda:0")
+    d = load_golden(name)
+    lr = float(d["meta_f"][0])
+    sm, sb, sd, tr = _setup(d, dev)
+    feature, _, base_r = sm.encode(sb)
+    init = torch.from_numpy(d["sel_controls"]).reshape(sb.N, 40).to(dev)
+    prev = torch.from_numpy(d["sel_scores"]).to(dev)
+    params = {k: sd[k].clone().requires_grad_() for k in tr.NAMES}
+    opt = torch.optim.Adam([params[k] for k in tr.NAMES], lr=lr)
+    loss, rect, scores, g = tr.loss_and_grads(sb, feature, base_r, params["rect_net.2.weight"], params["rect_net.4.weight"],
+                                              init, prev)
+    np.testing.assert_allclose(rect.reshape(sb.N, 20, 2).cpu().numpy(), d["rect_controls"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(scores.cpu().numpy(), d["scores"], rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(float(loss), float(d["loss"]), rtol=2e-4)
+    for k in tr.NAMES:
+        ref = d["grad_" + k]
+        np.testing.assert_allclose(g[k].cpu().numpy(), ref, rtol=5e-3, atol=5e-5 * np.abs(ref).max(), err_msg=k)
+        params[k].grad = g[k]
+    opt.step()
+    for k in tr.NAMES:
+        got, want, gref = params[k].detach().cpu().numpy(), d["after_" + k], d["grad_" + k]
+        # Adam's first step moves every weight by lr * g/(|g| + 1e-8): where the gradient is at rounding-noise level its
+        # sign -- hence the direction of the step -- is not determined, so those entries may differ by up to 2*lr
+        solid = np.abs(gref) > 1e-4 * np.abs(gref).max()
+        np.testing.assert_allclose(got[solid], want[solid], rtol=0, atol=5e-5, err_msg=k)
+        assert np.abs(got - want).max() <= 2 * lr + 1e-6, k
+        assert solid.mean() > 0.5, k
+
+
+def test_rect_train_step_against_oracle_on_fresh_scenes():
+    from oracle import pstl_oracle as orc
+    from pstl_diffusion_policy_amd.engine import PackedWeights, RectTrainer, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    dev = torch.device("cuda:0")
+    hp = default_hparams()
+    bs, S, K = 5, 64, 4
+    scene = make_scene_batch(bs, K=K, S=S, seed=77, invalid_lane_frac=0.3, stlp_mode="wide")
+    sdn = golden_weights()
+    g = torch.Generator().manual_seed(2)
+    N = bs * S * 3
+    init = (torch.randn(N, 20, 2, generator=g) * torch.tensor([0.1, 1.0])).clamp(-0.5, 0.5)
+    prev = torch.randn(N, generator=g)
+    ref = orc.rect_train_step(sdn, {k: v.numpy() for k, v in scene.items()}, S, hp, init, prev, 3e-4)
+    sd = {k: torch.from_numpy(v).to(dev) for k, v in sdn.items()}
+    sm = Sampler(PackedWeights(sd, dev), hp)
+    sb = SceneBatch(scene, S, hp, dev)
+    tr = RectTrainer(sm)
+    feature, _, base_r = sm.encode(sb)
+    loss, rect, scores, gr = tr.loss_and_grads(sb, feature, base_r, sd["rect_net.2.weight"], sd["rect_net.4.weight"],
+                                               init.reshape(N, 40).to(dev), prev.to(dev))
+    np.testing.assert_allclose(float(loss), float(ref["loss"]), rtol=2e-4)
+    for k in tr.NAMES:
+        r = ref["grads"][k].numpy()
+        np.testing.assert_allclose(gr[k].cpu().numpy(), r, rtol=5e-3, atol=5e-5 * np.abs(r).max(), err_msg=k)

@@ -1,0 +1,23 @@
+"""Pins the oracle's RefineNet training step (N1, config 5) against the reference's own gradients and Adam update."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_weights, load_golden, scene_from_golden
+from oracle import pstl_oracle as orc
+from pstl_diffusion_policy_amd.synthetic import default_hparams
+
+
+@pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b"])
+def test_rect_train_step_matches_reference(name):
+    d = load_golden(name)
+    bs, S, K, steps, seed, mc = [int(v) for v in d["meta"]]
+    lr = float(d["meta_f"][0])
+    sd = {k: v for k, v in golden_weights().items()}
+    out = orc.rect_train_step(sd, scene_from_golden(d), S, default_hparams(), d["sel_controls"], d["sel_scores"], lr)
+    np.testing.assert_allclose(out["rect_controls"].numpy(), d["rect_controls"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(float(out["loss"]), float(d["loss"]), rtol=1e-5)
+    for k, g in out["grads"].items():
+        ref = d["grad_" + k]
+        np.testing.assert_allclose(g.numpy(), ref, rtol=2e-3, atol=2e-5 * np.abs(ref).max(), err_msg=k)
+        np.testing.assert_allclose(out["after"][k].numpy(), d["after_" + k], rtol=0, atol=2e-5, err_msg=k)
