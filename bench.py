@@ -28,7 +28,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="e7_guid", choices=["e5", "e7", "e7_guid"])
+    p.add_argument("--workload", default="e7_guid", choices=["e5", "e7", "e7_guid", "e8_train"])
     p.add_argument("--scenes", type=int, default=4096, help="scenes per GPU (weak scaling)")
     p.add_argument("--sampling_size", type=int, default=64)
     p.add_argument("--neighbors", type=int, default=2)
@@ -91,12 +91,18 @@ def main():
     hp = default_hparams()
     rect_head = a.workload != "e5"
     guidance = dict(enabled=True, before=10, niters=1, lr=0.01) if a.workload == "e7_guid" else None
+    train = a.workload == "e8_train"     # config 5: one optimisation step of RefineNet under the STL loss
     sd = init_state_dict(1007)     # random init as in the reference under seed 1007 (no checkpoints offline)
     S, steps, bs = a.sampling_size, a.diffusion_steps, a.scenes
     # every rank owns its own contiguous block of scenes (seeded by the global scene offset); no data-path collective
     scene = make_scene_batch(bs, K=a.neighbors, S=S, seed=1000 + rank, invalid_lane_frac=0.2, stlp_mode="wide")
     scene = {k: v.to(dev) for k, v in scene.items() if k not in ("params", "pre_stlp", "tj_scores_prior")}
     sampler = Sampler(PackedWeights(sd, dev), hp, chain_waves=a.chain_waves)
+    if train:
+        from pstl_diffusion_policy_amd.engine import RectTrainer
+        tparams = {k: sd[k].to(dev).clone().requires_grad_() for k in RectTrainer.NAMES}
+        topt = torch.optim.Adam([tparams[k] for k in RectTrainer.NAMES], lr=3e-4)
+        sd_live = {k: (tparams[k] if k in tparams else v) for k, v in sd.items()}
     coeffs = diffusion_coeffs(steps, dev)
     N = bs * S * 3
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -116,6 +122,13 @@ def main():
             x_T = z = None
             call[0] += 1
             seed = 987654321 + call[0]
+        if train:
+            sm_t = Sampler(PackedWeights(sd_live, dev), hp, chain_waves=a.chain_waves)   # weights changed: re-pack
+            sm_t.trace = sampler.trace
+            loss, scores = RectTrainer(sm_t).train_step(sb, tparams, topt, steps, x_T=x_T, noise=z, seed=seed,
+                                                        multi_cands=a.multi_cands, coeffs=coeffs)
+            counts, _ = sm_t.metrics(sb, scores)
+            return gather_counts(counts)
         out = sampler.sampling_region(sb, steps, x_T, z, rect_head=rect_head,
                                       multi_cands=a.multi_cands if rect_head else None, guidance=guidance, coeffs=coeffs,
                                       want_scores3=False, seed=seed)

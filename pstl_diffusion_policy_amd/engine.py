@@ -389,3 +389,33 @@ class RectTrainer:
         # loss = mean(relu(thres - score) * valid) / clip(mean(valid), 1e-2): grad_scale is exactly (1/clip)/N
         loss = parts.sum() * sb.grad_scale
         return loss, rect, scores, g
+
+    def train_step(self, sb, params, optimizer, steps, x_T=None, noise=None, seed=None, multi_cands=5, coeffs=None,
+                   group=None):
+        """One optimisation step of config 5 on one batch shard: sampling under no-grad (rollout, candidate scoring and
+        selection), RefineNet forward/backward under the STL loss, gradient all-reduce over the ranks (the loss is a
+        mean over the GLOBAL batch, so per-rank gradients simply add), optimizer.step() on the caller's parameters.
+        `params`: dict name -> live torch Parameter/Tensor for RectTrainer.NAMES (the weights used by the kernels are
+        re-packed from them by the caller after the step)."""
+        import torch.distributed as dist
+        sm = self.sm
+        feature, base_p, base_r = sm.encode(sb, need_rect=True)
+        x = sm.fill_normal(sb, steps, steps, seed) if seed is not None else x_T.clone()
+        emit = sm.rollout(sb, base_p, x, noise, steps, n_emit=max(multi_cands, 1), clip=True, coeffs=coeffs, seed=seed)
+        r = sm.score(sb, emit[-multi_cands:].contiguous(), select=True)
+        loss, rect, scores, g = self.loss_and_grads(sb, feature, base_r, params["rect_net.2.weight"],
+                                                    params["rect_net.4.weight"], r["sel_controls"], r["sel_scores"])
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            flat = torch.cat([g[k].reshape(-1) for k in self.NAMES] + [loss.reshape(1)])
+            dist.all_reduce(flat, group=group)          # 145 704 gradients + the loss: one 583 KB all-reduce
+            o = 0
+            for k in self.NAMES:
+                n = g[k].numel()
+                g[k] = flat[o:o + n].reshape(g[k].shape)
+                o += n
+            loss = flat[o]
+        optimizer.zero_grad(set_to_none=True)
+        for k in self.NAMES:
+            params[k].grad = g[k]
+        optimizer.step()
+        return loss, scores

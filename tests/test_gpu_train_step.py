@@ -76,3 +76,30 @@ def test_rect_train_step_against_oracle_on_fresh_scenes():
     for k in tr.NAMES:
         r = ref["grads"][k].numpy()
         np.testing.assert_allclose(gr[k].cpu().numpy(), r, rtol=5e-3, atol=5e-5 * np.abs(r).max(), err_msg=k)
+
+
+def test_train_step_reduces_the_loss_and_repacks_weights():
+    """A few optimisation steps on one synthetic batch with frozen noise: the STL loss must go down, and the kernels must
+    see the updated weights after re-packing (Net.packed() notices the in-place optimiser update)."""
+    from pstl_diffusion_policy_amd import nusc_train as nt
+    from pstl_diffusion_policy_amd.engine import RectTrainer, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    dev = torch.device("cuda:0")
+    args = nt.generate_parser(["--diffusion", "--stl_weight", "1.0", "--load_stlp", "--load_tj", "--rect_head", "--flex",
+                               "--multi_cands", "5", "--diffusion_steps", "12", "--n_randoms", "64", "--sampling_size",
+                               "64", "--n_neighbors", "3", "--lr", "3e-4"])
+    net = nt.Net(args).cuda()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in golden_weights().items() if not k.startswith("merge_net")})
+    opt = torch.optim.Adam(net.rect_net.parameters(), lr=args.lr)
+    hp = net.hparams()
+    scene = make_scene_batch(6, K=3, S=64, seed=5, invalid_lane_frac=0.2, stlp_mode="wide")
+    sb = SceneBatch(scene, 64, hp, dev)
+    params = {"rect_net." + k: p for k, p in net.rect_net.named_parameters()}
+    losses = []
+    for it in range(6):
+        sm = Sampler(net.packed(), hp)
+        tr = RectTrainer(sm)
+        loss, _ = tr.train_step(sb, params, opt, args.diffusion_steps, seed=11, multi_cands=5)
+        losses.append(float(loss))
+    assert losses[-1] < losses[0], losses
+    assert all(np.isfinite(losses))
