@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
   float* wm = MULTI ? a.work + row * (2 * kT) : nullptr;
   const float* zr = a.z ? a.z + row * (2 * kT) : nullptr;
   float* er = a.emit_out ? a.emit_out + row * (2 * kT) : nullptr;
-  auto update = [=](int e, float g, float nscale) {
+  auto update = [=](int e, float g, float nscale, float zdrawn) {
     // torch.optim.Adam, single-tensor path, betas (0.9, 0.999), eps 1e-8 (see oracle guidance_update)
     float m = 0.0f, v = 0.0f;
     if (MULTI && a.iter > 0) {
@@ -236,12 +236,7 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
       }
     }
     if (last) {
-      float zv = zr ? zr[e] : 0.0f;
-      if (a.rng && a.step > 1) {
-        float z4[4];
-        normal4(a.seed, a.row_offset + row, e >> 2, a.step, z4);
-        zv = z4[e & 3];
-      }
+      const float zv = a.rng ? zdrawn : (zr ? zr[e] : 0.0f);
       const float x = p + a.sqrt_beta * zv;
       mu[e] = x;
       if (er) {
@@ -259,8 +254,12 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
       a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
       [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
       [=](int t, float gw, float ga) {
-        update(2 * t, gw, a.wscale);
-        update(2 * t + 1, ga, a.ascale);
+        // elements 2t, 2t+1 share one noise quad: one Philox draw per time step
+        float z4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (a.rng && a.step > 1 && last) normal4(a.seed, a.row_offset + row, t >> 1, a.step, z4);
+        const int o = (t & 1) * 2;
+        update(2 * t, gw, a.wscale, o ? z4[2] : z4[0]);
+        update(2 * t + 1, ga, a.ascale, o ? z4[3] : z4[1]);
       });
 }
 
