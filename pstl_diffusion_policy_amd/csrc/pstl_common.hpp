@@ -9,7 +9,7 @@ namespace pstl {
 
 inline int check_cfg(const pstl_cfg* c) {
   if (!c) return PSTL_ERR_ARG;
-  if (c->bs <= 0 || c->rows_per_scene <= 0 || c->K < 0 || c->steps < 2) return PSTL_ERR_ARG;
+  if (c->bs <= 0 || c->rows_per_scene <= 0 || c->K < 1 || c->steps < 2) return PSTL_ERR_ARG;  // the reference needs K >= 1 too
   return PSTL_OK;
 }
 

@@ -77,7 +77,7 @@ def generate_trajs(s, us, dt):
     R = u.shape[0]
     out = torch.empty(R, ffi.T + 1, 4, dtype=torch.float32, device=dev)
     hp = dict(smoothing_factor=1.0, stl_nn_thres=0.0, mul_w_max=1.0, mul_a_max=1.0, dt=float(dt), ego_L=1.0, ego_W=1.0)
-    cfg = ffi.make_cfg(R, 1, 1, 0, 2, hp)
+    cfg = ffi.make_cfg(R, 1, 1, 1, 2, hp)
     ffi.check(ffi.lib().pstl_generate_trajs(ctypes.byref(cfg), ffi.ptr(s0), ffi.ptr(u), ffi.ptr(out), ffi.stream()),
               "generate_trajs")
     return out.reshape(lead + (ffi.T + 1, 4))
