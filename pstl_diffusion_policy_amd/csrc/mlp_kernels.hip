@@ -29,7 +29,7 @@ constexpr int kFeat = PSTL_FEAT;   // 224
 constexpr int kCtrl = PSTL_CTRL;   // 40
 constexpr int kKx = 48;            // per-row input columns of layer 1 (40 + 1 + 6, padded to 48)
 constexpr int kTileRows = 16;
-constexpr int kG = 12;             // tiles per workgroup
+constexpr int kG = 12;             // tiles per workgroup (upper bound; small batches use fewer, see tiles_per_group)
 constexpr int kMaxLaunchSteps = 128;  // reverse steps per launch (longer segments are split by pstl_rollout)
 
 // ---- packed weight buffer (float offsets) -----------------------------------------------------------------------
@@ -334,6 +334,7 @@ struct ChainArgs {
   const float* alpha;
   const float* alpha_hat;
   const float* noise;    // (steps-1,N,40) or null
+  int tiles_per_group;   // 16-row tiles owned by one workgroup (4..kG)
   int rng;               // draw the noise in the kernel (seed, row_offset)
   unsigned long long seed;
   long row_offset;
@@ -396,9 +397,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   float* crow = coef + 4 * kMaxLaunchSteps; // [3][2][256] UT only: base[scene] row and tbias[step] row of a tile-step
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
-  const long tile0 = (long)blockIdx.x * kG;
+  const long tile0 = (long)blockIdx.x * a.tiles_per_group;
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
-  int G = (int)((n_tiles - tile0) < kG ? (n_tiles - tile0) : kG);
+  int G = (int)((n_tiles - tile0) < a.tiles_per_group ? (n_tiles - tile0) : a.tiles_per_group);
   // Layer 1 runs two tile-steps ahead and the epilogue one behind, so >= 4 tiles must be in flight (see the hazard
   // notes below); short tail blocks process phantom tiles whose rows are clamped on load and masked on store.
   if (G < 4) G = 4;
@@ -808,6 +809,17 @@ __global__ void k_fill_normal(long N, unsigned long long seed, long row_offset, 
   *reinterpret_cast<f32x4*>(out + row * kCtrl + 4 * quad) = f32x4{z[0], z[1], z[2], z[3]};
 }
 
+// Tiles per workgroup: 12 (192 rows) when there is enough work for every CU; small batches (the closed-loop caller
+// runs 192 rows per simulation step, reference nusc_sim.py) are spread over more workgroups, down to the 4 tiles the
+// software pipeline needs, which cuts the latency of one reverse step from 12 to 4 tile-iterations.
+inline int tiles_per_group(long N) {
+  const long n_tiles = (N + kTileRows - 1) / kTileRows;
+  long g = n_tiles / 256;
+  if (g < 4) g = 4;
+  if (g > kG) g = kG;
+  return (int)g;
+}
+
 template <int NW>
 size_t chain_lds_bytes() {
   return (size_t)(kG * 768 + 3 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps + 3 * 512) * sizeof(float);
@@ -816,7 +828,7 @@ size_t chain_lds_bytes() {
 template <int NW, bool REFINE, int ABL = 0, bool UT = false>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
-  const dim3 grid((unsigned)((n_tiles + kG - 1) / kG));
+  const dim3 grid((unsigned)((n_tiles + a.tiles_per_group - 1) / a.tiles_per_group));
   const size_t lds = chain_lds_bytes<NW>();
   auto fn = k_chain<NW, REFINE, ABL, UT>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -993,6 +1005,7 @@ extern "C" int pstl_rollout(const pstl_cfg* cfg, const float* packed, const floa
   if (n_emit < 0 || n_emit > cfg->steps || (n_emit > 0 && !emit_out)) return PSTL_ERR_ARG;
   ChainArgs a = {};
   a.N = n_rows(cfg);
+  a.tiles_per_group = tiles_per_group(a.N);
   a.rows_per_scene = cfg->rows_per_scene;
   a.steps = cfg->steps;
   a.step_hi = step_hi;
@@ -1073,6 +1086,7 @@ static int refine_impl(const pstl_cfg* cfg, const float* packed, const float* ba
   }
   ChainArgs a = {};
   a.N = n_rows(cfg);
+  a.tiles_per_group = tiles_per_group(a.N);
   a.rows_per_scene = cfg->rows_per_scene;
   a.steps = cfg->steps;
   a.clip = (cfg->flags & PSTL_FLAG_CLIP_RECT) ? 1 : 0;

@@ -1,0 +1,112 @@
+"""Closed-loop (receding-horizon) caller of the sampling path on a synthetic world.
+
+Reference: nusc_sim.py:388-755.  Per simulation step the reference builds a ONE-scene batch (192 rows = sampling_size 64
+x 3 modes), overwrites the STL parameters with fixed values (:467-472), runs `diffusion_rollout(..., maximize=True)`
+with guidance (:481), candidate selection + RefineNet (:518-536), picks the best-scoring lane-keeping sample
+(`scores_all[:, 1:3] = -10000; argmax`, :676-681), applies its first control with the unicycle model (:118) and asks the
+nuScenes devkit for the next observation.  The devkit world is out of scope; here the world is a seeded synthetic
+three-lane road with constant-velocity neighbours (synthetic.py), which is enough to exercise -- and time -- the
+small-batch, latency-bound use of the same kernels (the chain kernel then runs 4 tiles per workgroup, see
+tiles_per_group in csrc/mlp_kernels.hip).
+"""
+import math
+import time
+
+import torch
+
+from . import ffi
+from .engine import PackedWeights, Sampler, SceneBatch
+from .synthetic import default_hparams, make_scene_batch
+
+FIXED_STLP = (1.0, 9.0, -3.0, 2.0, 0.1, 0.2)   # vmin, vmax, dmin, dmax, dsafe, thmax (reference nusc_sim.py:467-472)
+
+
+class SyntheticWorld:
+    """One ego vehicle on a three-lane road with K constant-velocity neighbours; unicycle dynamics (nusc_train.py:29-37)."""
+
+    def __init__(self, K=8, seed=0, dt=0.5, nt=20):
+        self.K, self.dt, self.nt = K, dt, nt
+        base = make_scene_batch(1, K=K, nt=nt, S=1, seed=seed, dt=dt, random_pose=False, curved=False, stlp_mode="fixed")
+        self.lanes = {k: base["%slane_wpts" % k].clone() for k in ("curr", "left", "right")}
+        self.state = base["ego_traj"][0, 0, :4].clone()                  # x, y, th, v
+        self.nei0 = base["neighbors"][0].clone()                          # (K,7) valid,x,y,th,v,L,W
+        self.t = 0
+
+    def observation(self):
+        """The one-scene batch the sampling path consumes (schema of SURVEY 3.0)."""
+        tt = torch.arange(self.nt).float() * self.dt
+        x, y, th, v = self.state.tolist()
+        ego = torch.stack([x + v * tt * math.cos(th), y + v * tt * math.sin(th), torch.full_like(tt, th),
+                           torch.full_like(tt, v), torch.full_like(tt, 4.084), torch.full_like(tt, 1.73)], dim=-1)[None]
+        n = self.nei0
+        adv = (self.t * self.dt + tt)[None, :]                            # neighbours keep their velocity
+        nx = n[:, 1:2] + n[:, 4:5] * adv * torch.cos(n[:, 3:4])
+        ny = n[:, 2:3] + n[:, 4:5] * adv * torch.sin(n[:, 3:4])
+        traj = torch.stack([n[:, 0:1].expand(-1, self.nt), nx, ny, n[:, 3:4].expand(-1, self.nt),
+                            n[:, 4:5].expand(-1, self.nt), n[:, 5:6].expand(-1, self.nt), n[:, 6:7].expand(-1, self.nt)], dim=-1)
+        traj = traj * n[:, 0:1, None]
+        # lanes re-anchored around the ego's longitudinal position, as the dataset does per sample
+        shift = torch.tensor([x, 0.0, 0.0])
+        obs = {"ego_traj": ego, "neighbors_traj": traj[None], "neighbors": traj[None, :, 0, :].contiguous(),
+               "curr_id": torch.ones(1, 1), "left_id": torch.ones(1, 1), "right_id": torch.ones(1, 1),
+               "stlp_modes": torch.tensor(FIXED_STLP).reshape(1, 1, 6).repeat(1, 3, 1)}
+        for k in ("curr", "left", "right"):
+            obs["%slane_wpts" % k] = self.lanes[k] + shift
+        return obs
+
+    def step(self, control):
+        w, a = float(control[0]), float(control[1])
+        x, y, th, v = self.state.tolist()
+        self.state = torch.tensor([x + v * math.cos(th) * self.dt, y + v * math.sin(th) * self.dt, th + w * self.dt,
+                                   v + a * self.dt])
+        self.t += 1
+
+    def min_clearance(self):
+        """Centre distance to the closest valid neighbour now (coarse collision indicator for the report)."""
+        n = self.nei0
+        adv = self.t * self.dt
+        nx = n[:, 1] + n[:, 4] * adv * torch.cos(n[:, 3])
+        ny = n[:, 2] + n[:, 4] * adv * torch.sin(n[:, 3])
+        d = torch.sqrt((nx - self.state[0]) ** 2 + (ny - self.state[1]) ** 2)
+        d = torch.where(n[:, 0] > 0.5, d, torch.full_like(d, 1e9))
+        return float(d.min())
+
+
+def closed_loop(state_dict, n_sim_steps=20, K=8, S=64, diffusion_steps=100, multi_cands=5, guidance=True, guidance_before=10,
+                guidance_lr=0.04, seed=0, device="cuda:0", verbose=True):
+    """Runs the receding-horizon loop; returns per-step records (latency in seconds with device sync, score, state)."""
+    dev = torch.device(device)
+    hp = default_hparams()
+    sm = Sampler(PackedWeights(state_dict, dev), hp)
+    world = SyntheticWorld(K=K, seed=seed, dt=hp["dt"], nt=hp["nt"])
+    g = dict(enabled=True, before=guidance_before, niters=1, lr=guidance_lr, maximize=True) if guidance else None
+    records = []
+    for it in range(n_sim_steps):
+        obs = world.observation()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sb = SceneBatch(obs, S, hp, dev)
+        out = sm.sampling_region(sb, diffusion_steps, None, None, rect_head=True, multi_cands=multi_cands, guidance=g,
+                                 seed=seed * 100003 + it, want_scores3=False)
+        scores = out["final_scores"].reshape(S, 3).clone()
+        scores[:, 1:3] = -10000.0                                            # lane-keeping samples only (:676-677)
+        best = int(torch.argmax(scores))                                      # flat index into (S,3): row = best
+        ctrl = out["final_controls"].reshape(S * 3, ffi.T, 2)[best, 0].cpu()  # first control of the chosen sample
+        torch.cuda.synchronize()
+        lat = time.perf_counter() - t0
+        world.step(ctrl)
+        rec = dict(step=it, latency_s=lat, best_score=float(scores.flatten()[best]), x=float(world.state[0]),
+                   y=float(world.state[1]), v=float(world.state[3]), clearance=world.min_clearance())
+        records.append(rec)
+        if verbose:
+            print("sim %02d latency %.2f ms score %.3f x %.1f y %.2f v %.2f clearance %.1f" % (
+                it, lat * 1e3, rec["best_score"], rec["x"], rec["y"], rec["v"], rec["clearance"]))
+    return records
+
+
+if __name__ == "__main__":
+    from .nusc_model import init_state_dict
+    recs = closed_loop(init_state_dict(1007))
+    lats = sorted(r["latency_s"] for r in recs[2:])
+    print("median latency per simulation step: %.2f ms (192 rows, 100 diffusion steps, guidance on the last 10)"
+          % (lats[len(lats) // 2] * 1e3))

@@ -30,12 +30,13 @@ def scene_from_golden(d):
 
 def golden_meta(d):
     names = ["bs", "S", "K", "steps", "seed", "rect_head", "guidance", "multi_cands", "diffusion_clip",
-             "force_full", "guidance_before", "guidance_niters", "n_rolls", "zero_net_out"]
+             "force_full", "guidance_before", "guidance_niters", "n_rolls", "zero_net_out", "maximize"]
     m = {k: int(v) for k, v in zip(names, d["meta"])}
+    m.setdefault("maximize", 0)
     m["guidance_lr"], m["stl_nn_thres"], m["tau"] = [float(v) for v in d["meta_f"]]
     return m
 
 
 SAMPLING_CASES = ["e5_steps10", "e5_steps100", "e7_steps12", "e7_steps50_k8", "e7_damped", "e7_wide", "e7_guid",
-                  "e7_guid_n2_rolls", "e5_guid_all"]
+                  "e7_guid_n2_rolls", "e5_guid_all", "sim_maximize", "sim_maximize_b"]
 STL_CASES = ["stl_mixed", "stl_mixed_k8", "stl_wild"]

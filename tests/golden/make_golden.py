@@ -46,7 +46,7 @@ def load_net(ref, args, sd):
 
 
 def sampling_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=0.0, stlp_mode="loose",
-                  zero_net_out=False):
+                  zero_net_out=False, maximize=False):
     nt = ref.nusc_train
     argv = list(argv) + ["--diffusion_steps", str(steps), "--sampling_size", str(S), "--n_randoms", str(S),
                          "--n_neighbors", str(K), "--test", "--run_sampling_test"]
@@ -79,7 +79,7 @@ def sampling_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=
     with ref_harness.record_randn_like(draws):
         controls, feature, clist = nt.diffusion_rollout(noise, net, new_batch, hl, None, args, coeffs,
                                                         fastforward=False, n_randoms=S, return_feature=True,
-                                                        guidance_extras=gextras)
+                                                        guidance_extras=gextras, maximize=maximize)
     E = steps - 1
     assert len(draws) == 1 + (E - 1), len(draws)
     out["x_T"] = np_(draws[0])
@@ -142,7 +142,8 @@ def sampling_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=
     out["meta"] = np.array([bs, S, K, steps, seed, int(args.rect_head), int(args.guidance),
                             -1 if args.multi_cands is None else args.multi_cands,
                             int(args.diffusion_clip), int(force_full), args.guidance_before, args.guidance_niters,
-                            -1 if args.n_rolls is None else args.n_rolls, int(zero_net_out)], dtype=np.int64)
+                            -1 if args.n_rolls is None else args.n_rolls, int(zero_net_out), int(maximize)],
+                           dtype=np.int64)
     out["meta_f"] = np.array([args.guidance_lr, args.stl_nn_thres, args.smoothing_factor], dtype=np.float64)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
@@ -224,7 +225,7 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and "--train" not in sys.argv:
+if __name__ == "__main__" and "--train" not in sys.argv and "--closed-loop" not in sys.argv:
     main()
 
 
@@ -312,6 +313,18 @@ def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4):
         os.path.getsize(path) / 1024))
 
 
+def main_closed_loop():
+    """The closed-loop caller's use of the path (nusc_sim.py:467-481): one scene, fixed STL parameters,
+    guidance with maximize=True (loss relu(100 - score))."""
+    ref = ref_harness.load_reference()
+    sd = dict(np.load(WEIGHTS_FILE))
+    e7 = ["--diffusion", "--load_stlp", "--rect_head", "--flex", "--diverse_loss", "--multi_cands", "5"]
+    gd = ["--guidance", "--guidance_before", "4", "--guidance_niters", "1", "--guidance_lr", "0.04"]
+    sampling_case(ref, sd, "sim_maximize", e7 + gd, bs=1, S=8, K=4, steps=12, seed=41, stlp_mode="fixed", maximize=True)
+    sampling_case(ref, sd, "sim_maximize_b", e7 + gd, bs=2, S=16, K=3, steps=10, seed=42, stlp_mode="fixed",
+                  invalid_lane_frac=0.5, maximize=True)
+
+
 def main_train():
     ref = ref_harness.load_reference()
     sd = dict(np.load(WEIGHTS_FILE))
@@ -321,3 +334,5 @@ def main_train():
 
 if __name__ == "__main__" and "--train" in sys.argv:
     main_train()
+if __name__ == "__main__" and "--closed-loop" in sys.argv:
+    main_closed_loop()

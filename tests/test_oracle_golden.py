@@ -19,7 +19,8 @@ def _weights_for(meta):
 def _guidance_cfg(meta):
     if not meta["guidance"]:
         return None
-    return dict(enabled=True, before=meta["guidance_before"], niters=meta["guidance_niters"], lr=meta["guidance_lr"])
+    return dict(enabled=True, before=meta["guidance_before"], niters=meta["guidance_niters"], lr=meta["guidance_lr"],
+                maximize=bool(meta["maximize"]))
 
 
 def test_schedule_matches_reference():
