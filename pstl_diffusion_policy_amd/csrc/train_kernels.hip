@@ -4,8 +4,10 @@
 //   forward (pstl_refine_train_forward, mlp_kernels.hip) keeps h1 = relu(L1), h2 = relu(L2), pre = L3 output.
 //   d loss / d rect_controls comes from pstl_stl_backward (the STL adjoint already used by guidance).
 //   here: interval/tanh head backward (fused elementwise kernel), ReLU masks + column sums (fused, deterministic
-//   two-stage reduction), per-scene reduction for the 224 scene-constant input columns, and five PLAIN fp32 GEMMs
-//   (dH2 = dO W3, dW3 = dO^T h2, dH1 = dH2 W2, dW2 = dH2^T h1, dW1 = dH1^T [feature|hl|stlp|init]) which go to rocBLAS.
+//   two-stage reduction), per-scene reduction for the 224 scene-constant input columns, the three weight-gradient
+//   contractions over the rows (dW3 = dO^T h2, dW2 = dH2^T h1, dW1x = dH1^T [hl|stlp|init]) as a hand-written split-K
+//   fp32-MFMA kernel (k_wgrad: rocBLAS ran these K = 786 432, tiny-M-by-N shapes at 22 TFLOP/s, 4.7 ms each), and
+//   three PLAIN fp32 GEMMs left to rocBLAS (dH2 = dO W3, dH1 = dH2 W2, dW1f = S^T feature).
 #include <rocblas/rocblas.h>
 
 #include "pstl_common.hpp"
@@ -108,6 +110,146 @@ int gemm_rm(rocblas_handle h, bool ta, bool tb, int m, int n, long k, const floa
 
 constexpr int kRedBlocks = 512;
 
+// ---- weight gradient: D[f][c] = sum over rows of G[row][f] * H[row][c]  (split-K over workgroups) -------------------
+// v_mfma_f32_16x16x4_f32 with the ROW index as the contraction: A[i = f][k = row], B[k = row][j = c], 16 rows (4 k-steps)
+// per staged chunk.  FT x CT output tiles of 16x16 are spread over 8 waves as WF x WC; every wave keeps its
+// (FT/WF) x (CT/WC) accumulator tiles in registers for its whole row range, then writes one partial slab;
+// k_slab_reduce adds the slabs in a fixed order (deterministic).  Chunks are staged global -> registers -> LDS with the
+// next chunk's loads in flight during the MFMAs; LDS rows are padded so that the 4 rows a ds_read_b32 touches fall
+// into different bank halves.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kWgRows = 16;
+
+template <int FT, int CT, int WF, int WC>
+__global__ __launch_bounds__(512, 2) void k_wgrad(long N, const float* G, int ldg, int fvalid, const float* H, int ldh,
+                                                  int cvalid, float* slabs) {
+  static_assert(WF * WC == 8 && FT % WF == 0 && CT % WC == 0, "tile split");
+  constexpr int F = 16 * FT, C = 16 * CT;
+  constexpr int SG = (F % 32 == 16) ? F : F + 16, SH = (C % 32 == 16) ? C : C + 16;   // padded LDS row strides
+  constexpr int MF = FT / WF, MC = CT / WC;                                           // tiles per wave
+  constexpr int VG = (kWgRows * F / 4 + 511) / 512, VH = (kWgRows * C / 4 + 511) / 512;  // float4 loads per thread
+  __shared__ __attribute__((aligned(16))) float lg[2][kWgRows * SG];
+  __shared__ __attribute__((aligned(16))) float lh[2][kWgRows * SH];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wf = w / WC, wc = w % WC;
+  const int li = lane & 15, kk = lane >> 4;
+  const long n_chunks = (N + kWgRows - 1) / kWgRows;
+  const long per = (n_chunks + gridDim.x - 1) / gridDim.x;
+  const long c0 = blockIdx.x * per, c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
+
+  f32x4 acc[MF][MC];
+#pragma unroll
+  for (int a = 0; a < MF; ++a)
+#pragma unroll
+    for (int b = 0; b < MC; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  f32x4 rg[VG], rh[VH];
+  auto load_chunk = [&](long ch) {
+#pragma unroll
+    for (int v = 0; v < VG; ++v) {
+      const int e = tid + v * 512;                 // float4 index inside the chunk: (row, col4)
+      const int r = e / (F / 4), c4 = e % (F / 4);
+      const long row = ch * kWgRows + r;
+      f32x4 val = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (e < kWgRows * F / 4 && row < N) {
+        const float* src = G + row * ldg + 4 * c4;
+        if (4 * c4 + 3 < fvalid && (ldg % 4 == 0)) {
+          val = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) val[q] = (4 * c4 + q < fvalid) ? src[q] : 0.0f;
+        }
+      }
+      rg[v] = val;
+    }
+#pragma unroll
+    for (int v = 0; v < VH; ++v) {
+      const int e = tid + v * 512;
+      const int r = e / (C / 4), c4 = e % (C / 4);
+      const long row = ch * kWgRows + r;
+      f32x4 val = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (e < kWgRows * C / 4 && row < N) {
+        const float* src = H + row * ldh + 4 * c4;
+        if (4 * c4 + 3 < cvalid && (ldh % 4 == 0)) {
+          val = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) val[q] = (4 * c4 + q < cvalid) ? src[q] : 0.0f;
+        }
+      }
+      rh[v] = val;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < VG; ++v) {
+      const int e = tid + v * 512;
+      if (e < kWgRows * F / 4) *reinterpret_cast<f32x4*>(&lg[buf][(e / (F / 4)) * SG + 4 * (e % (F / 4))]) = rg[v];
+    }
+#pragma unroll
+    for (int v = 0; v < VH; ++v) {
+      const int e = tid + v * 512;
+      if (e < kWgRows * C / 4) *reinterpret_cast<f32x4*>(&lh[buf][(e / (C / 4)) * SH + 4 * (e % (C / 4))]) = rh[v];
+    }
+  };
+
+  if (c0 < c1) {
+    load_chunk(c0);
+    store_chunk(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (long ch = c0; ch < c1; ++ch) {
+    if (ch + 1 < c1) load_chunk(ch + 1);          // in flight during the MFMAs below
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      float av[MF], bv[MC];
+#pragma unroll
+      for (int a = 0; a < MF; ++a) av[a] = lg[buf][(4 * s4 + kk) * SG + 16 * (wf * MF + a) + li];
+#pragma unroll
+      for (int b = 0; b < MC; ++b) bv[b] = lh[buf][(4 * s4 + kk) * SH + 16 * (wc * MC + b) + li];
+#pragma unroll
+      for (int a = 0; a < MF; ++a)
+#pragma unroll
+        for (int b = 0; b < MC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    if (ch + 1 < c1) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // partial slab of this workgroup: [F][C] row-major; accumulator tile: row f = 16 ft + 4 (lane>>4) + r, col = 16 ct + (lane&15)
+  float* out = slabs + (long)blockIdx.x * F * C;
+#pragma unroll
+  for (int a = 0; a < MF; ++a)
+#pragma unroll
+    for (int b = 0; b < MC; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(16 * (wf * MF + a) + 4 * kk + r) * C + 16 * (wc * MC + b) + li] = acc[a][b][r];
+}
+
+// D[f][c] (row-major, leading dimension ldd) = sum over slabs, for f < fvalid, c < cvalid
+__global__ void k_slab_reduce(int nslabs, int F, int C, int fvalid, int cvalid, const float* slabs, float* D, int ldd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * C) return;
+  const int f = i / C, c = i % C;
+  if (f >= fvalid || c >= cvalid) return;
+  float acc = 0.0f;
+  for (int s = 0; s < nslabs; ++s) acc += slabs[(long)s * F * C + i];
+  D[(long)f * ldd + c] = acc;
+}
+
+template <int FT, int CT, int WF, int WC>
+int wgrad(long N, const float* G, int ldg, int fvalid, const float* H, int ldh, int cvalid, float* slabs, float* D, int ldd,
+          hipStream_t st) {
+  const long n_chunks = (N + kWgRows - 1) / kWgRows;
+  const int nb = (int)(n_chunks < kRedBlocks ? n_chunks : kRedBlocks);
+  hipLaunchKernelGGL((k_wgrad<FT, CT, WF, WC>), dim3(nb), dim3(512), 0, st, N, G, ldg, fvalid, H, ldh, cvalid, slabs);
+  hipLaunchKernelGGL(k_slab_reduce, dim3((16 * FT * 16 * CT + 255) / 256), dim3(256), 0, st, nb, 16 * FT, 16 * CT, fvalid,
+                     cvalid, slabs, D, ldd);
+  return launch_status();
+}
+
 }  // namespace
 }  // namespace pstl
 
@@ -135,7 +277,8 @@ extern "C" int pstl_train_destroy(void* ctx) {
 extern "C" size_t pstl_train_work_floats(const pstl_cfg* cfg) {
   if (check_cfg(cfg)) return 0;
   const long N = n_rows(cfg);
-  return (size_t)(N * (kCtrl + kX47 + 2L * kHid) + (long)cfg->bs * kHid + (long)kRedBlocks * kHid + 64);
+  return (size_t)(N * (kCtrl + kX47 + 2L * kHid) + (long)cfg->bs * kHid + (long)kRedBlocks * kHid +
+                  (long)kRedBlocks * kHid * kHid + 64);
 }
 
 extern "C" int pstl_loss_grad(const pstl_cfg* cfg, const float* scores, const float* valid, float grad_scale, float* dscore,
@@ -169,6 +312,7 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
   float* dH1 = dH2 + N * kHid;            // (N,256)
   float* S = dH1 + N * kHid;              // (bs,256)
   float* part = S + (long)cfg->bs * kHid; // (kRedBlocks,256)
+  float* slabs = part + (long)kRedBlocks * kHid;  // (kRedBlocks,256,256) split-K partials of k_wgrad
   const int nb = (int)(N < kRedBlocks ? N : kRedBlocks);
 
   hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)((N * kCtrl + 255) / 256)), dim3(256), 0, st, N, cfg->w_max, cfg->a_max,
@@ -176,18 +320,18 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
   // layer 3
   hipLaunchKernelGGL(k_mask_colsum, dim3(nb), dim3(64), 0, st, N, kCtrl, dO, (const float*)nullptr, part);
   hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(64), 0, st, nb, kCtrl, part, db3);
-  if (int e = gemm_rm(c->h, true, false, kCtrl, kHid, N, dO, kCtrl, h2, kHid, dw3, kHid)) return e;   // dW3 = dO^T h2
+  if (int e = wgrad<3, 16, 1, 8>(N, dO, kCtrl, kCtrl, h2, kHid, kHid, slabs, dw3, kHid, st)) return e;  // dW3 = dO^T h2
   if (int e = gemm_rm(c->h, false, false, (int)N, kHid, kCtrl, dO, kCtrl, w3, kHid, dH2, kHid)) return e;  // dH2 = dO W3
   // layer 2
   hipLaunchKernelGGL(k_mask_colsum, dim3(nb), dim3(256), 0, st, N, kHid, dH2, h2, part);
   hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(256), 0, st, nb, kHid, part, db2);
-  if (int e = gemm_rm(c->h, true, false, kHid, kHid, N, dH2, kHid, h1, kHid, dw2, kHid)) return e;    // dW2 = dH2^T h1
+  if (int e = wgrad<16, 16, 4, 2>(N, dH2, kHid, kHid, h1, kHid, kHid, slabs, dw2, kHid, st)) return e;  // dW2 = dH2^T h1
   if (int e = gemm_rm(c->h, false, false, (int)N, kHid, kHid, dH2, kHid, w2, kHid, dH1, kHid)) return e;  // dH1 = dH2 W2
   // layer 1
   hipLaunchKernelGGL(k_mask_colsum, dim3(nb), dim3(256), 0, st, N, kHid, dH1, h1, part);
   hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(256), 0, st, nb, kHid, part, db1);
   hipLaunchKernelGGL(k_scene_sum, dim3(cfg->bs), dim3(256), 0, st, cfg->rows_per_scene, dH1, S);
   if (int e = gemm_rm(c->h, true, false, kHid, kFeat, cfg->bs, S, kHid, feature, kFeat, dw1, kIn)) return e;
-  if (int e = gemm_rm(c->h, true, false, kHid, kX47, N, dH1, kHid, x47, kX47, dw1 + kFeat, kIn)) return e;
+  if (int e = wgrad<16, 3, 8, 1>(N, dH1, kHid, kHid, x47, kX47, kX47, slabs, dw1 + kFeat, kIn, st)) return e;
   return launch_status();
 }
