@@ -4,7 +4,8 @@
 A "step" is one pass of the timed region of the reference's sampling harness (nusc_train.py:957-1105) over one
 synthetic batch already resident in HBM: row constants, scene preparation, scene encoder, noise generation,
 `diffusion_steps-1` denoiser evaluations (+ STL guidance on the last `guidance_before` steps), candidate scoring +
-selection, RefineNet, final STL scoring and the satisfaction counts (+ one RCCL all-gather of 8 counters when N > 1).
+selection, RefineNet, final STL scoring, the satisfaction counts and the diversity metrics (std, hull volume, entropies,
+occupancy area, ADE/FDE) (+ one RCCL all-gather of 20 eight-byte words -- counters and diversity totals -- when N > 1).
 Unit: sampled trajectories per second = rows (scenes x sampling_size x 3 modes) / wall time, whole job.
 """
 import argparse
@@ -84,7 +85,7 @@ def main():
     dev = torch.device("cuda", local)
 
     from pstl_diffusion_policy_amd.engine import (PackedWeights, SceneBatch, Sampler, acc_from_counts,
-                                                  diffusion_coeffs)
+                                                  diffusion_coeffs, diversity_from_totals)
     from pstl_diffusion_policy_amd.nusc_model import init_state_dict
     from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
 
@@ -106,7 +107,7 @@ def main():
     coeffs = diffusion_coeffs(steps, dev)
     N = bs * S * 3
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    from pstl_diffusion_policy_amd.shard import gather_counts, global_valid_stats
+    from pstl_diffusion_policy_amd.shard import gather_final, global_valid_stats
     call = [0]
 
     def one_step():
@@ -128,22 +129,23 @@ def main():
             loss, scores = RectTrainer(sm_t).train_step(sb, tparams, topt, steps, x_T=x_T, noise=z, seed=seed,
                                                         multi_cands=a.multi_cands, coeffs=coeffs)
             counts, _ = sm_t.metrics(sb, scores)
-            return gather_counts(counts)
+            return gather_final(counts, torch.zeros(12, dtype=torch.float64, device=dev))
         out = sampler.sampling_region(sb, steps, x_T, z, rect_head=rect_head,
                                       multi_cands=a.multi_cands if rect_head else None, guidance=guidance, coeffs=coeffs,
-                                      want_scores3=False, seed=seed)
-        # the only exchange after the rollout: 8 counters per rank (RCCL all-gather over xGMI when N > 1)
-        return gather_counts(out["counts"])
+                                      want_scores3=False, seed=seed, diversity=True)
+        # the only exchange after the rollout: the final diversity / STL-satisfaction reduction -- 8 counters + 12
+        # diversity totals per rank in one RCCL all-gather over xGMI (when N > 1)
+        return gather_final(out["counts"], out["div_totals"])
 
     for _ in range(a.warmup):
-        counts = one_step()
+        counts, div_totals = one_step()
     sampler.trace = []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        counts = one_step()
+        counts, div_totals = one_step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -185,6 +187,7 @@ def main():
                        "chain_waves": a.chain_waves or 8,
                        "noise": "in-kernel Philox4x32-10" if a.noise == "kernel" else "torch.randn tensors"},
             "stl_sat_rate": acc, "scene_sat_rate": sacc,
+            "diversity": None if train else diversity_from_totals(div_totals),
             "roofline": {"bound": "mfma", "kernel": "k_chain (denoiser MLP chain, %d reverse steps per launch)" % nst,
                          "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,

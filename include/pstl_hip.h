@@ -210,6 +210,22 @@ int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float* w2, const 
 int pstl_reduce_metrics(const pstl_cfg* cfg, const float* scores, const float* valid /* (N,) */, uint64_t* counts,
                         uint8_t* sat_mask, void* stream);
 
+/* ---- post-sampling diversity metrics (the numbers run_sampling_test prints after its timer) -------- */
+/* measure_diversity (nusc_api.py:817-875), measure_extra_diversity (nusc_api.py:894-936, compute_entropy
+ * utils.py:388-417, compute_area nusc_api.py:878-891) and compute_ade_fde (nusc_train.py:877-887) for the final
+ * controls (N,40) (physical units; the trajectories are rolled out in the kernel), their scores (N,) and valid (N,).
+ * gt_traj (bs,T,gt_stride): ground-truth ego states, components 0..3 = x,y,th,v (the dataset's ego_traj has stride 6).
+ * alphas: DEVICE array of 11 floats = torch.linspace(0,1,11) (the entropy bin fractions, utils.py:406).
+ * per_mode (bs,3,8) float64: std, vol, ent_s, sum_t ent_w, sum_t ent_a, area, #satisfied samples, lane valid (0/1);
+ * per_scene (bs,2) float32: min-over-rows ADE and FDE (squared-error form, as the reference defines them);
+ * totals (12) float64 or null: [0] sum std*valid [1] sum vol*valid [2] #valid (scene,mode) [3] sum ent_s [4] sum ent_w
+ * [5] sum ent_a [6] sum area [7] #(scene,mode) [8] sum ADE [9] sum FDE [10] #scenes [11] 0 -- the reference's printed
+ * values are the ratios (std = [0]/[2], vol = [1]/[2], ent_s = [3]/[7], ent_w = [4]/([7]*T), area = [6]/[7],
+ * ade = [8]/[10]); sums of shards add, so a sharded run all-gathers these 12 numbers.  Requires S <= 64. */
+int pstl_diversity(const pstl_cfg* cfg, const float* s0, const float* gt_traj, int gt_stride, const float* controls,
+                   const float* scores, const float* valid, const float* alphas, double* per_mode, float* per_scene,
+                   double* totals, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,7 @@ class SceneBatch:
         self.hp, self.S, self.device = hp, int(S), dev
         ego = f("ego_traj")
         self.bs = ego.shape[0]
+        self.ego_traj = ego                       # (bs,nt,6): the ground-truth future, only read by the ADE/FDE metric
         self.ego0 = ego[:, 0, :].contiguous()
         self.s0 = ego[:, 0, :4].contiguous()
         self.neighbors = f("neighbors")
@@ -278,9 +279,28 @@ class Sampler:
                   "reduce_metrics")
         return counts, mask
 
+    # ---- N2: post-sampling diversity metrics ----
+    def diversity(self, sb, controls, scores):
+        """std / hull volume / entropies / occupancy area / ADE / FDE of the final controls (N,40) (physical units):
+        what the reference computes on the CPU after its timer (nusc_train.py:1107-1140).  Returns device tensors
+        per_mode (bs,3,8) f64, per_scene (bs,2) f32, totals (12) f64 (see include/pstl_hip.h); no host sync."""
+        dev = sb.device
+        if getattr(self, "_alphas", None) is None or self._alphas.device != dev:
+            self._alphas = torch.linspace(0.0, 1.0, 11).to(dev)       # utils.py:406, computed on the host as there
+        per_mode = torch.empty(sb.bs, 3, 8, dtype=torch.float64, device=dev)
+        per_scene = torch.empty(sb.bs, 2, dtype=torch.float32, device=dev)
+        totals = torch.empty(12, dtype=torch.float64, device=dev)
+        cfg = sb.cfg(2)
+        ffi.check(self.L.pstl_diversity(ctypes.byref(cfg), ffi.ptr(sb.s0), ffi.ptr(sb.ego_traj),
+                                        int(sb.ego_traj.shape[-1]), ffi.ptr(controls), ffi.ptr(scores), ffi.ptr(sb.valid),
+                                        ffi.ptr(self._alphas), ffi.ptr(per_mode, torch.float64), ffi.ptr(per_scene),
+                                        ffi.ptr(totals, torch.float64), ffi.stream()), "diversity")
+        return per_mode, per_scene, totals
+
     # ---- A12: the timed region ----
     def sampling_region(self, sb, steps, x_T, noise, rect_head=False, multi_cands=None, refinenet=True, guidance=None,
-                        n_rolls=None, diverse=True, full_list=False, coeffs=None, want_scores3=True, seed=None):
+                        n_rolls=None, diverse=True, full_list=False, coeffs=None, want_scores3=True, seed=None,
+                        diversity=False):
         """x_T (N,40) and noise (steps-1,N,40) supplied by the caller (parity), or seed != None: x_T and all noise are
         drawn by the kernels (x_T / noise arguments ignored)."""
         out = {}
@@ -316,9 +336,24 @@ class Sampler:
         fin = self.score(sb, controls.reshape(1, sb.N, ffi.CTRL), all3=want_scores3)
         counts, _ = self.metrics(sb, fin["scores"][0])
         out.update(final_controls=controls, final_scores=fin["scores"][0], counts=counts)
+        if diversity:   # std / hull volume / entropies / area / ADE / FDE (the reference: on the CPU, after its timer)
+            pm, ps, tot = self.diversity(sb, controls, fin["scores"][0])
+            out.update(div_per_mode=pm, div_per_scene=ps, div_totals=tot)
         if want_scores3:   # the three formulas before mode selection (what compute_stl_dense returns as scores_list)
             out["final_scores3"] = fin["scores3"][:, 0]
         return out
+
+
+def diversity_from_totals(totals, nt=ffi.T):
+    """The reference's printed diversity numbers from the 12 additive totals of pstl_diversity (sums over shards add)."""
+    t = [float(v) for v in (totals.tolist() if hasattr(totals, "tolist") else totals)]
+    nan = float("nan")
+    nv, nm, ns = t[2], t[7], t[10]
+    out = dict(std=t[0] / nv if nv else nan, vol=t[1] / nv if nv else nan, ent_s=t[3] / nm if nm else nan,
+               ent_w=t[4] / (nm * nt) if nm else nan, ent_a=t[5] / (nm * nt) if nm else nan,
+               area=t[6] / nm if nm else nan, ade=t[8] / ns if ns else nan, fde=t[9] / ns if ns else nan)
+    out["ent_wa"] = out["ent_w"] + out["ent_a"]
+    return out
 
 
 def acc_from_counts(counts):

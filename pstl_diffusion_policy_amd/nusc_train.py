@@ -12,8 +12,9 @@ Differences that are deliberate:
     per row; the reference's dense keys (`neighbors_dense`, ...) are only materialised with `dense=True`.
     `compute_stl_dense` also accepts a purely dense `stl_input` (rows_per_scene = 1) as the reference passes it.
   * data comes from the seeded synthetic scene generator (synthetic.py): the nuScenes cache / devkit are out of scope.
-  * metrics that the reference computes on the CPU after its timer stops (diversity std / hull volume / entropy,
-    ADE/FDE) are outside this path and printed as nan.
+  * the metrics the reference computes on the CPU after its timer stops (diversity std / hull volume / entropies /
+    occupancy area, ADE/FDE; nusc_train.py:1107-1140) come from one HIP kernel (pstl_diversity); the traj-opt "TJ"
+    columns need the dataset's stored traj-opt solutions and are printed as nan.
 """
 import argparse
 import ctypes
@@ -23,7 +24,7 @@ import numpy as np
 import torch
 
 from . import ffi
-from .engine import Sampler, SceneBatch, acc_from_counts, diffusion_coeffs
+from .engine import Sampler, SceneBatch, acc_from_counts, diffusion_coeffs, diversity_from_totals
 from .nusc_model import Net
 from .synthetic import make_scene_batch
 
@@ -386,11 +387,15 @@ def run_sampling_test(stls_cac, data_loader, net, coeffs, args, result_queue=Non
         md.update("acc", acc.item())
         md.update("scene_acc", scene_acc.item())
         md.update("time", tttt2 - tttt1)
+        # after the timer, as in the reference (nusc_train.py:1107-1130): diversity + ADE/FDE of the final samples
+        _, _, div_totals = sm.diversity(sb, nn_controls.reshape(N, -1).contiguous(), scores.contiguous())
+        for k, v in diversity_from_totals(div_totals).items():
+            md.update(k, v)
         nan = float("nan")
         print("###[%02d] TJ acc:%.3f scene_acc:%.3f ade:%.3f fde:%.3f std:%.3f vol:%.3f area:%.3f s:%.3f u:%.3f| "
               "NN acc:%.3f scene_acc:%.3f ade:%.3f fde:%.3f std:%.3f vol:%.3f area:%.3f s:%.3f u:%.3f ||| T:%.3f" % (
-                  bi, nan, nan, nan, nan, nan, nan, nan, nan, nan, md("acc"), md("scene_acc"), nan, nan, nan, nan, nan,
-                  nan, nan, md("time")))
+                  bi, nan, nan, nan, nan, nan, nan, nan, nan, nan, md("acc"), md("scene_acc"), md("ade"), md("fde"),
+                  md("std"), md("vol"), md("area"), md("ent_s"), md("ent_wa"), md("time")))
     if myt:
         myt.print_profile()
     return md

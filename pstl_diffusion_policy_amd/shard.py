@@ -4,7 +4,8 @@ Rows interact only inside a scene (merge_net max-pool, scene_acc; SURVEY.md sect
 path on a contiguous block of scenes with no data-path collective.  Two tiny exchanges remain:
   * before the rollout: the global sum of valid rows and the global row count (the guidance loss is a mean over the
     WHOLE batch, reference nusc_train.py:23-27,619, so its scale must not depend on how the batch was split);
-  * after the final scoring: the 8 integer satisfaction counters of each rank (all-gather, then summed).
+  * after the final scoring: the 8 integer satisfaction counters and the 12 additive diversity totals
+    (pstl_diversity) of each rank -- ONE all-gather of 20 eight-byte words, then summed in rank order.
 """
 import torch
 import torch.distributed as dist
@@ -37,3 +38,21 @@ def gather_counts(counts, group=None):
     parts = [torch.empty_like(counts) for _ in range(dist.get_world_size(group))]
     dist.all_gather(parts, counts, group=group)
     return torch.stack(parts).sum(dim=0)
+
+
+def gather_final(counts, totals, group=None):
+    """The final reduction of a sharded run: per-rank satisfaction counters (8 x int64) and diversity totals
+    (12 x float64) travel in ONE all-gather (the doubles ride along bit-cast to int64); returns their sums over the
+    ranks (floats added in rank order, so every rank gets bit-identical numbers)."""
+    if not _active(group):
+        return counts, totals
+    packed = torch.cat([counts, totals.view(torch.int64)])
+    parts = [torch.empty_like(packed) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, packed, group=group)
+    allp = torch.stack(parts)
+    n = counts.numel()
+    tot = allp[:, n:].contiguous().view(torch.float64)
+    acc = tot[0].clone()
+    for r in range(1, tot.shape[0]):
+        acc += tot[r]
+    return allp[:, :n].sum(dim=0), acc

@@ -225,7 +225,7 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and "--train" not in sys.argv and "--closed-loop" not in sys.argv:
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--closed-loop", "--diversity", "--stl-lib", "--trajopt")):
     main()
 
 
@@ -336,3 +336,64 @@ if __name__ == "__main__" and "--train" in sys.argv:
     main_train()
 if __name__ == "__main__" and "--closed-loop" in sys.argv:
     main_closed_loop()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# post-sampling metrics (reference nusc_train.py:1107-1140): measure_diversity, measure_extra_diversity, ADE/FDE
+# ---------------------------------------------------------------------------------------------------------------
+def diversity_case(ref, name, bs, S, seed, ctrl_scale, sat_frac, invalid_lane_frac=0.3, clip_frac=0.0, special=True):
+    nt_ = ref.nusc_train
+    args = ref_harness.parse_reference_args(["--diffusion", "--load_stlp", "--rect_head", "--test", "--run_sampling_test"])
+    batch = make_scene_batch(bs, K=2, S=S, seed=seed, invalid_lane_frac=invalid_lane_frac, stlp_mode="wide")
+    g = torch.Generator().manual_seed(seed + 5)
+    N = bs * S * 3
+    ctrl = torch.randn(N, args.nt, 2, generator=g) * ctrl_scale
+    ctrl = ctrl + torch.randn(N, 1, 2, generator=g) * ctrl_scale          # a per-trajectory bias spreads the end points
+    ctrl = ctrl * torch.tensor([args.mul_w_max, args.mul_a_max])
+    ctrl = torch.maximum(torch.minimum(ctrl, torch.tensor([args.mul_w_max, args.mul_a_max])),
+                         -torch.tensor([args.mul_w_max, args.mul_a_max]))
+    if clip_frac > 0:   # entries sitting exactly on +-max, as --diffusion_clip produces (the bins' outer edges)
+        hit = torch.rand(N, args.nt, 2, generator=g) < clip_frac
+        sign = torch.where(torch.rand(N, args.nt, 2, generator=g) < 0.5, -1.0, 1.0)
+        ctrl = torch.where(hit, sign * torch.tensor([args.mul_w_max, args.mul_a_max]), ctrl)
+    scores = torch.randn(N, generator=g) * 0.3 + (sat_frac - 0.5)
+    sc = scores.reshape(bs, S, 3)
+    if special and bs >= 3:
+        sc[0, :, 0] = -sc[0, :, 0].abs() - 0.01        # nobody satisfies
+        sc[1, :, 1] = -sc[1, :, 1].abs() - 0.01
+        sc[1, 0, 1] = 0.2                              # exactly one satisfied sample
+        sc[2, :, 2] = -sc[2, :, 2].abs() - 0.01
+        sc[2, :2, 2] = 0.3                             # exactly two
+        sc[2, :, 0] = sc[2, :, 0].abs() + 0.01         # everybody
+    scores = sc.reshape(N)
+    valids = torch.cat([batch["curr_id"], batch["left_id"], batch["right_id"]], dim=-1)      # (bs,3)
+    valids_dense = valids[:, None, :].repeat(1, S, 1).reshape(bs * S, 3)
+    states = batch["ego_traj"][:, 0, :4]
+    states_flat = states.unsqueeze(1).unsqueeze(1).repeat(1, S, 3, 1).reshape(N, 4)
+    trajs = nt_.generate_trajs(states_flat, ctrl, args.dt).reshape(N, args.nt + 1, 4)
+    ma_std, ma_vol, std_list, vol_list = ref.nusc_api.measure_diversity(
+        trajs[:, :-1, :2].reshape(bs, S, 3, args.nt * 2), scores.reshape(bs, S, 3), valids_dense.reshape(bs, S, 3), args.nt)
+    ade, fde = nt_.compute_ade_fde(batch["ego_traj"][..., :4], trajs[..., :-1, :4], valids_dense)
+    ex = ref.nusc_api.measure_extra_diversity(
+        trajs[:, :-1].reshape(bs, S, 3, args.nt * 4), scores.reshape(bs, S, 3), valids_dense.reshape(bs, S, 3), args.nt,
+        ctrl.reshape(bs, S, 3, args.nt * 2), -args.mul_w_max, args.mul_w_max, -args.mul_a_max, args.mul_a_max)
+    out = dict(S=np.int32(S), in_ego_traj=np_(batch["ego_traj"]), in_controls=np_(ctrl), in_scores=np_(scores),
+               in_valids=np_(valids), std=np.float64(ma_std), vol=np.float64(ma_vol), ade=np.float32(ade.item()),
+               fde=np.float32(fde.item()), std_overall=np.asarray(std_list[0]), std0=np.asarray(std_list[1]),
+               std1=np.asarray(std_list[2]), std2=np.asarray(std_list[3]), vol0=np.asarray(vol_list[1]),
+               vol1=np.asarray(vol_list[2]), vol2=np.asarray(vol_list[3]))
+    for k, v in ex.items():
+        out[k] = np.float32(v.item())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: float(v) for k, v in out.items() if np.ndim(v) == 0})
+
+
+def main_diversity():
+    ref = ref_harness.load_reference()
+    diversity_case(ref, "div_mixed", bs=6, S=16, seed=51, ctrl_scale=0.3, sat_frac=0.6)
+    diversity_case(ref, "div_s64_clip", bs=4, S=64, seed=52, ctrl_scale=0.8, sat_frac=0.5, clip_frac=0.05)
+    diversity_case(ref, "div_sparse", bs=5, S=8, seed=53, ctrl_scale=0.1, sat_frac=0.2, invalid_lane_frac=0.5)
+
+
+if __name__ == "__main__" and "--diversity" in sys.argv:
+    main_diversity()

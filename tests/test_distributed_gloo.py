@@ -21,13 +21,32 @@ def _counts_from_scores(scores, valid, bs, S):
     return torch.tensor([sat, int(valid.sum()), bs * S * 3, ssat, int(v0.sum()), bs * 3, 0, 0], dtype=torch.int64)
 
 
+def _div_totals(o, lane_valid, nt=20):
+    """The 12 additive totals of pstl_diversity (include/pstl_hip.h) from the oracle's per-(scene,mode) arrays."""
+    v = lane_valid.numpy().astype(np.float64)
+    o = {k: np.asarray(x, dtype=np.float64) for k, x in o.items() if np.ndim(x) > 0}
+    t = [float((o["std_sm"] * v).sum()), float((o["vol_sm"] * v).sum()), float(v.sum()), float(o["ent_s_sm"].sum()),
+         float(o["ent_w_sm"].sum()), float(o["ent_a_sm"].sum()), float(o["area_sm"].sum()), float(v.size),
+         float(o["ade_s"].sum()), float(o["fde_s"].sum()), float(v.shape[0]), 0.0]
+    return torch.tensor(t, dtype=torch.float64)
+
+
+def _oracle_div(scene, u, score, valid_rows, S, hp):
+    from oracle import diversity_oracle as dorc
+    from oracle import pstl_oracle as orc
+    ego = torch.as_tensor(scene["ego_traj"])
+    lane_valid = torch.cat([torch.as_tensor(scene[k]) for k in ("curr_id", "left_id", "right_id")], dim=-1)
+    o = dorc.all_metrics(ego[:, 0, :4], ego, u, score, valid_rows, S, hp, orc.unicycle_rollout)
+    return o, _div_totals(o, lane_valid)
+
+
 def _worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import pstl_oracle as orc
-    from pstl_diffusion_policy_amd.shard import gather_counts, global_valid_stats, shard_range
+    from pstl_diffusion_policy_amd.shard import gather_counts, gather_final, global_valid_stats, shard_range
     from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
     hp = default_hparams()
     bs, S, K = 7, 4, 3
@@ -40,9 +59,13 @@ def _worker(rank, world, port, out_path):
     u = u_all[lo * S * 3:hi * S * 3]
     vsum, vrows = global_valid_stats(float(rows.valid.sum()), rows.N, torch.device("cpu"))
     _, score, _ = rows.score(u)
-    counts = gather_counts(_counts_from_scores(score, rows.valid, hi - lo, S))
+    local_counts = _counts_from_scores(score, rows.valid, hi - lo, S)
+    counts = gather_counts(local_counts)
+    _, tot = _oracle_div(sub, u, score, rows.valid, S, hp)
+    counts2, totals = gather_final(local_counts, tot)
+    assert torch.equal(counts, counts2)
     if rank == 0:
-        torch.save({"vsum": vsum, "vrows": vrows, "counts": counts}, out_path)
+        torch.save({"vsum": vsum, "vrows": vrows, "counts": counts, "totals": totals}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,3 +94,10 @@ def test_two_shards_reproduce_the_single_process_numbers(tmp_path):
     acc, sacc = orc.stl_metrics(score, rows.valid, S)
     a, s = acc_from_counts(got["counts"])
     assert a == float(acc) and s == float(sacc)
+    # the diversity half of the final reduction: per-shard totals add up to the single-process numbers
+    from pstl_diffusion_policy_amd.engine import diversity_from_totals
+    o, want_tot = _oracle_div(scene, u, score, rows.valid, S, hp)
+    np.testing.assert_allclose(got["totals"].numpy(), want_tot.numpy(), rtol=1e-12)
+    d = diversity_from_totals(got["totals"])
+    for k in ("std", "vol", "ade", "fde", "ent_s", "ent_w", "ent_a", "area"):
+        assert d[k] == pytest.approx(o[k], rel=1e-5), k
