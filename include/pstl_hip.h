@@ -226,6 +226,33 @@ int pstl_diversity(const pstl_cfg* cfg, const float* s0, const float* gt_traj, i
                    const float* scores, const float* valid, const float* alphas, double* per_mode, float* per_scene,
                    double* totals, void* stream);
 
+/* ---- generic STL formulas (the operator library stl_d_lib.py; SURVEY 8b "formulas are callable") ------------------ */
+/* A formula tree is flattened by the host into postfix order (children before parents; the last node is the root).
+ * Node types: SIGNAL a = index of an input signal (an AP's expression, stl_d_lib.py:70-84);  NOT a (:125);
+ * AND a,b / OR a,b = soft min / soft max of two nodes (:87,:113);  LISTAND = soft min over lists[list_off .. +n_list)
+ * (:97);  ALWAYS / EVENTUALLY a with window [t+ts, t+te) clipped to [0,T) (:144-169; Once :171 is EVENTUALLY with
+ * ts < 0).  PSTL_STL_FLAG_SOFT: the node ignores `hard` (the cumulative operators of UntimedUntil, :183-193). */
+enum {
+  PSTL_STL_SIGNAL = 0, PSTL_STL_NOT = 1, PSTL_STL_AND = 2, PSTL_STL_OR = 3, PSTL_STL_LISTAND = 4, PSTL_STL_ALWAYS = 5,
+  PSTL_STL_EVENTUALLY = 6
+};
+#define PSTL_STL_FLAG_SOFT 1
+#define PSTL_STL_MAX_T 1024
+typedef struct pstl_stl_node {
+  int32_t op, a, b, ts, te, n_list, list_off, flags;
+} pstl_stl_node;
+
+/* Robustness of the whole tree for n rows: signals (n_sig,n,T) -> out (n,T) (the value of the root at every t, as
+ * formula(x, tau) returns it in the reference).  nodes / lists are DEVICE arrays.  vals (n_nodes,T,n): workspace that
+ * keeps every node's value for the adjoint.  hard != 0: max/min instead of logsumexp (d["hard"], stl_d_lib.py:10-11). */
+int pstl_stl_program_forward(const pstl_stl_node* nodes, int n_nodes, const int32_t* lists, int64_t n, int T,
+                             const float* signals, float tau, int hard, float* vals, float* out, void* stream);
+/* dsignals (n_sig,n,T) += d(sum(out * dout)) / d signals; dsignals must be zeroed by the caller; adj (n_nodes,T,n)
+ * scratch; vals from the forward call. */
+int pstl_stl_program_backward(const pstl_stl_node* nodes, int n_nodes, const int32_t* lists, int64_t n, int T,
+                              const float* vals, float tau, int hard, const float* dout, float* adj, float* dsignals,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

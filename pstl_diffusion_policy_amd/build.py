@@ -10,7 +10,7 @@ ARCH = "gfx950"
 
 # (source, extra flags).  stl_kernels must not contract mul+add into fma: see csrc/stl_core.hpp.
 UNITS = [("stl_kernels.hip", ["-ffp-contract=off"]), ("mlp_kernels.hip", []), ("train_kernels.hip", []),
-         ("diversity_kernels.hip", ["-ffp-contract=off"])]
+         ("diversity_kernels.hip", ["-ffp-contract=off"]), ("stl_program.hip", ["-ffp-contract=off"])]
 # rocBLAS only serves the plain fp32 GEMMs of the RefineNet backward pass (train_kernels.hip)
 LINK_LIBS = ["-lrocblas"]
 

@@ -26,6 +26,7 @@ import torch
 from . import ffi
 from .engine import Sampler, SceneBatch, acc_from_counts, diffusion_coeffs, diversity_from_totals
 from .nusc_model import Net
+from .stl_d_lib import AP, Always, And, Eventually, ListAnd
 from .synthetic import make_scene_batch
 
 
@@ -84,25 +85,49 @@ def generate_trajs(s, us, dt):
     return out.reshape(lead + (ffi.T + 1, 4))
 
 
-class StlFormula:
-    """Descriptor of one of the three fixed formulas of the path (reference build_stl_cache, nusc_train.py:95-140).
-    The robustness itself is evaluated by the fused HIP kernel in compute_stl_dense, not by composing Python objects."""
-    def __init__(self, name, text):
-        self.name, self.text = name, text
-
-    def __str__(self):
-        return self.text
+# indices into stlp (reference nusc_train.py:52-57) and the state vector
+I_VMIN, I_VMAX, I_DMIN, I_DMAX, I_DSAFE, I_THMAX = range(6)
+I_V = 3
 
 
 def build_stl_cache(args):
-    if getattr(args, "norm_stl", False):
-        raise NotImplementedError("--norm_stl is not on the hot path")
+    """The three lane-mode formulas [keep lane, change left, change right] of the path (reference nusc_train.py:95-140)
+    as callable stl_d_lib objects: `stls[m](x, tau)[:, 0]` is the robustness of rows under formula m, with x the signal
+    dict prep_stl_cache fills (ego_traj, stlp, x2{curr,left,right}_{d,th}, min_nei_d [, *_factor with --norm_stl]).
+    compute_stl_dense itself evaluates them through the fused kernel (pstl_stl_forward), which never materialises x."""
     nt = args.nt
-    keep = "G[0:%d](v>=vmin) & G(v<=vmax)" % nt
-    safe = "G(d_nei>=d_safe)"
-    return [StlFormula("stl_curr", "%s & G(dmin<=d_curr<=dmax) & G(th_curr<=thmax) & %s" % (keep, safe)),
-            StlFormula("stl_left", "%s & F[0:%d]G(dmin<=d_left<=dmax) & F[0:%d]G(th_left<=thmax) & %s" % (keep, nt // 2, nt // 2, safe)),
-            StlFormula("stl_right", "%s & F[0:%d]G(dmin<=d_right<=dmax) & F[0:%d]G(th_right<=thmax) & %s" % (keep, nt // 2, nt // 2, safe))]
+    norm = bool(getattr(args, "norm_stl", False))
+
+    def over(expr, factor):      # --norm_stl divides every metric predicate by its factor (nusc_train.py:97-113)
+        return (lambda x: expr(x) / x[factor]) if norm else expr
+
+    def at_least(sig, idx, factor):
+        return AP(over(lambda x: sig(x) - x["stlp"][..., idx], factor))
+
+    def at_most(sig, idx, factor):
+        return AP(over(lambda x: -sig(x) + x["stlp"][..., idx], factor))
+
+    def heading_ok(key):
+        return AP(lambda x: (x["stlp"][..., I_THMAX] - x[key]) / x["stlp"][..., I_THMAX])
+
+    speed = lambda x: x["ego_traj"][..., I_V]
+    field = lambda key: (lambda x: x[key])
+    keep_speed = [Always(0, nt, at_least(speed, I_VMIN, "v_factor")), Always(0, nt, at_most(speed, I_VMAX, "v_factor"))]
+    keep_lane = [Always(0, nt, at_least(field("x2curr_d"), I_DMIN, "d_factor")),
+                 Always(0, nt, at_most(field("x2curr_d"), I_DMAX, "d_factor")), Always(0, nt, heading_ok("x2curr_th"))]
+    safe = [Always(0, nt, at_least(field("min_nei_d"), I_DSAFE, "safe_factor"))]
+
+    def reach(side):
+        band = And(at_least(field("x2%s_d" % side), I_DMIN, "d_factor"), at_most(field("x2%s_d" % side), I_DMAX, "d_factor"))
+        return [Eventually(0, nt // 2, Always(0, nt, band)), Eventually(0, nt // 2, Always(0, nt, heading_ok("x2%s_th" % side)))]
+
+    return [ListAnd(keep_speed + keep_lane + safe), ListAnd(keep_speed + reach("left") + safe),
+            ListAnd(keep_speed + reach("right") + safe)]
+
+
+def get_stl_scores(scores_list, stl_i):
+    """Mode select (reference nusc_train.py:150-151)."""
+    return sum(scores_list[m] * (stl_i == m).float() for m in range(4))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -397,3 +397,42 @@ def main_diversity():
 
 if __name__ == "__main__" and "--diversity" in sys.argv:
     main_diversity()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# generic STL formulas: the reference's stl_d_lib evaluated on random signals (values + autograd gradients)
+# ---------------------------------------------------------------------------------------------------------------
+def main_stl_lib():
+    ref = ref_harness.load_reference()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import stl_specs
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    for T, n in ((20, 9), (13, 5)):
+        sig = (torch.randn(4, n, T, generator=g) * 0.7).float()
+        sig[1] = sig[1] * 3.0 + 0.5
+        out["signals_T%d" % T] = np_(sig)
+        W = torch.randn(n, T, generator=g)
+        out["W_T%d" % T] = np_(W)
+        for name, spec in stl_specs.SPECS.items():
+            for tau in (100.0, 4.0):
+                for hard in (False, True):
+                    f = stl_specs.build(spec, ref.stl_d_lib)
+                    x = sig.clone().requires_grad_()
+                    d = {"hard": True} if hard else None
+                    y = f(x, tau, d)
+                    assert y.shape == (n, T), (name, y.shape)
+                    fin = torch.isfinite(y)
+                    (torch.where(fin, y, torch.zeros_like(y)) * W).sum().backward()
+                    key = "%s|T%d|tau%g|%s" % (name, T, tau, "hard" if hard else "soft")
+                    out[key + "|y"] = np_(y)
+                    out[key + "|g"] = np_(torch.nan_to_num(x.grad, nan=0.0))
+    f = stl_specs.build(stl_specs.SPECS["listand_path"], ref.stl_d_lib)
+    s, v = f(torch.from_numpy(out["signals_T20"]), 100.0, None, full=True)
+    out["listand_full_s"], out["listand_full_v"] = np_(s), np_(v)
+    np.savez_compressed(os.path.join(HERE, "stl_lib.npz"), **out)
+    print("stl_lib.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__" and "--stl-lib" in sys.argv:
+    main_stl_lib()

@@ -1,0 +1,95 @@
+"""GPU parity of the generic STL formula evaluator (pstl_diffusion_policy_amd.stl_d_lib -> pstl_stl_program_*):
+values and gradients against (1) golden vectors from the reference's own stl_d_lib and (2) the CPU oracle on fresh
+inputs.  Tolerances: robustness 2e-6 abs + 2e-6 rel (float32 logsumexp), gradients 2e-5 abs + 1e-4 rel."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import stl_specs
+
+pytestmark = pytest.mark.gpu
+G = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "stl_lib.npz")))
+KEYS = sorted(k[:-2] for k in G if k.endswith("|y"))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    from pstl_diffusion_policy_amd import ffi
+    ffi.lib()
+    return torch.device("cuda:0")
+
+
+def _run(spec, x, W, tau, hard):
+    from pstl_diffusion_policy_amd import stl_d_lib
+    f = stl_specs.build(spec, stl_d_lib)
+    x = x.clone().requires_grad_()
+    y = f(x, tau, {"hard": True} if hard else None)
+    (torch.where(torch.isfinite(y), y, torch.zeros_like(y)) * W).sum().backward()
+    return y.detach().cpu().numpy(), torch.nan_to_num(x.grad, nan=0.0).cpu().numpy()
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_formula_matches_reference_golden(dev, key):
+    name, T, tau, mode = key.split("|")
+    y, g = _run(stl_specs.SPECS[name], torch.from_numpy(G["signals_" + T]).to(dev), torch.from_numpy(G["W_" + T]).to(dev),
+                float(tau[3:]), mode == "hard")
+    want = G[key + "|y"]
+    fin = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(y), fin)
+    np.testing.assert_allclose(y[fin], want[fin], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(g, G[key + "|g"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", sorted(stl_specs.SPECS))
+def test_formula_matches_oracle_fresh_inputs(dev, name):
+    from oracle import stl_lib_oracle as so
+    g = torch.Generator().manual_seed(abs(hash(name)) % 1000)
+    n, T = 300, 17
+    x = torch.randn(4, n, T, generator=g) * 1.5
+    W = torch.randn(n, T, generator=g)
+    for tau, hard in ((100.0, False), (10.0, False), (100.0, True)):
+        xo = x.clone().requires_grad_()
+        yo = so.evaluate(stl_specs.SPECS[name], xo, tau, hard)
+        (torch.where(torch.isfinite(yo), yo, torch.zeros_like(yo)) * W).sum().backward()
+        y, gr = _run(stl_specs.SPECS[name], x.to(dev), W.to(dev), tau, hard)
+        fin = np.isfinite(yo.detach().numpy())
+        np.testing.assert_array_equal(np.isfinite(y), fin)
+        np.testing.assert_allclose(y[fin], yo.detach().numpy()[fin], rtol=2e-6, atol=2e-6)
+        # tau*x reaches a few hundred here, where float32 spacing is ~3e-5: every softmax weight exp(tau*(x - max)) carries
+        # that much relative noise per nesting level in ANY float32 implementation, hence the wider gate than on the goldens
+        np.testing.assert_allclose(gr, torch.nan_to_num(xo.grad, nan=0.0).numpy(), rtol=1e-3, atol=5e-5)
+
+
+def test_listand_full_returns_children(dev):
+    from pstl_diffusion_policy_amd import stl_d_lib
+    f = stl_specs.build(stl_specs.SPECS["listand_path"], stl_d_lib)
+    s, v = f(torch.from_numpy(G["signals_T20"]).to(dev), 100.0, None, full=True)
+    np.testing.assert_allclose(s.cpu().numpy(), G["listand_full_s"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(v.cpu().numpy(), G["listand_full_v"], rtol=2e-6, atol=2e-6)
+
+
+def test_cpu_tensors_are_rejected(dev):
+    from pstl_diffusion_policy_amd import stl_d_lib
+    f = stl_specs.build(stl_specs.SPECS["alw_ap"], stl_d_lib)
+    with pytest.raises(RuntimeError):
+        f(torch.zeros(4, 3, 20), 100.0)
+
+
+@pytest.mark.parametrize("name", ["stl_mixed", "stl_mixed_k8", "stl_wild"])
+def test_build_stl_cache_formulas_match_fused_kernel_and_reference(dev, name):
+    """The three formulas build_stl_cache returns are real, callable stl_d_lib objects (as in the reference): fed with
+    the reference's own signal dict (golden sig_*), they reproduce the reference's scores and the fused kernel's."""
+    from conftest import load_golden
+    from pstl_diffusion_policy_amd import nusc_train as nt
+    d = load_golden(name)
+    args = nt.generate_parser(["--diffusion", "--load_stlp"])
+    stls = nt.build_stl_cache(args)
+    x = {"ego_traj": torch.from_numpy(d["trajs"][:, :-1]).to(dev), "stlp": torch.from_numpy(d["in_stlp_dense"]).to(dev)}
+    for k in ("x2curr_d", "x2curr_th", "x2left_d", "x2left_th", "x2right_d", "x2right_th", "min_nei_d"):
+        x[k] = torch.from_numpy(d["sig_" + k]).to(dev)
+    for m in range(3):
+        s = stls[m](x, args.smoothing_factor)[:, 0].cpu().numpy()
+        np.testing.assert_allclose(s, d["scores3"][m], rtol=1e-5, atol=2e-5)
