@@ -253,6 +253,21 @@ int pstl_stl_program_backward(const pstl_stl_node* nodes, int n_nodes, const int
                               const float* vals, float tau, int hard, const float* dout, float* adj, float* dsignals,
                               void* stream);
 
+/* ---- trajectory optimisation (the data-augmentation loop, nusc_train.py:1302-1325) ------------------- */
+/* Runs `iters` iterations of  torch.optim.Adam([params], lr)  on
+ *   loss = mean(relu(thres - score) * valid) / clip(mean(valid), 1e-3) + reg_loss * (mean(relu(w^2 - w_max^2)) +
+ *          mean(relu(a^2 - a_max^2)))                                  (compute_trajopt_loss_lite, nusc_train.py:287-300)
+ * for all N rows in ONE launch; params (N,40) are controls in physical units (the dataset's `params`, (bs,M,3,nt,2)).
+ * grad_scale = (1/clip(mean(valid),1e-3))/N_global; reg_scale = reg_loss/(N_global*nt);
+ * adam_neg_step / adam_bc2_sqrt: DEVICE arrays [iters] = float(-lr/(1-0.9^k)), float(sqrt(1-0.999^k)), k = first
+ * iteration number (1-based) ... ; work (2,N,40) holds Adam's m and v: written always, read when resume != 0 (a run can be
+ * split over several calls).  scores (N,) or null: robustness of the iterate the last update started from (what the
+ * reference saves as scores_*.npy).  thres = --stl_trajopt_thres. */
+int pstl_trajopt(const pstl_cfg* cfg, const float* s0, const float* nei_prep, const float* lane_prep, const float* stlp,
+                 const float* hl, const float* valid, float thres, float grad_scale, float reg_scale, int iters,
+                 const float* adam_neg_step, const float* adam_bc2_sqrt, int resume, float* params_inout, float* work,
+                 float* scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -268,8 +268,11 @@ class Rows:
         self.s0 = rows_from_scenes(_t(scene["ego_traj"])[:, 0, :4], m)
         self.nei = rows_from_scenes(_t(scene["neighbors_traj"])[..., :7], m)
         self.lanes = [rows_from_scenes(_t(scene["%slane_wpts" % k]), m) for k in ("curr", "left", "right")]
-        stlp_modes = _t(scene["stlp_modes"])                                          # (bs,3,6)
-        self.stlp = stlp_modes[:, None].repeat(1, S, 1, 1).reshape(self.N, 6)        # nusc_train.py:745
+        if "stlp_rows" in scene:      # per-row parameters (the traj-opt loop draws them per sample, get_dense_stlp)
+            self.stlp = _t(scene["stlp_rows"]).reshape(self.N, 6)
+        else:
+            stlp_modes = _t(scene["stlp_modes"])                                      # (bs,3,6)
+            self.stlp = stlp_modes[:, None].repeat(1, S, 1, 1).reshape(self.N, 6)    # nusc_train.py:745
         self.hl = torch.tensor([0.0, 1.0, 2.0]).repeat(self.bs * S).reshape(self.N, 1)  # nusc_train.py:753
         ids = torch.cat([_t(scene["curr_id"]), _t(scene["left_id"]), _t(scene["right_id"])], dim=-1)
         self.valid = rows_from_scenes(ids, S).reshape(self.N)                        # nusc_train.py:751-752
@@ -450,3 +453,33 @@ def rect_train_step(sd, scene, S, hp, init_controls, prev_scores, lr, diverse=Fa
     opt.step()
     return dict(loss=loss.detach(), rect_controls=rect.detach(), scores=score.detach(),
                 grads={k: g for k, g in zip(names, grads)}, after={k: params[k].detach() for k in names})
+
+
+# ------------------------------------------------------------------------------------------------
+# N4  trajectory optimisation (reference nusc_train.py:1302-1325, compute_trajopt_loss_lite :287-300)
+# ------------------------------------------------------------------------------------------------
+def trajopt(rows, params, iters, lr, thres, reg_loss, checkpoints=()):
+    """params (N,T,2) controls in physical units.  `iters` Adam iterations on
+    mean(relu(thres - score)*valid)/clip(mean(valid),1e-3) + reg_loss*(mean(relu(w^2-wmax^2)) + mean(relu(a^2-amax^2))).
+    Returns dict(params, scores_last (scores of the iterate the last step started from), losses [(total, stl, reg, acc)],
+    grad0, checkpoints {k: params after k iterations})."""
+    hp = rows.hp
+    p = params.detach().clone().requires_grad_()
+    opt = torch.optim.Adam([p], lr=lr)
+    losses, ck, grad0, scores = [], {}, None, None
+    for ii in range(iters):
+        _, scores, _ = rows.score(p)
+        dense = torch.mean(torch.relu(thres - scores) * rows.valid) / torch.clip(torch.mean(rows.valid), 1e-3)
+        reg = (torch.mean(torch.relu(p[..., 0] ** 2 - hp["mul_w_max"] ** 2))
+               + torch.mean(torch.relu(p[..., 1] ** 2 - hp["mul_a_max"] ** 2))) * reg_loss
+        loss = dense + reg
+        acc = torch.mean((scores >= 0).float() * rows.valid) / torch.clip(torch.mean(rows.valid), 1e-3)
+        opt.zero_grad()
+        loss.backward()
+        if ii == 0:
+            grad0 = p.grad.detach().clone()
+        opt.step()
+        losses.append(tuple(float(v.detach()) for v in (loss, dense, reg, acc)))
+        if ii + 1 in checkpoints:
+            ck[ii + 1] = p.detach().clone()
+    return dict(params=p.detach(), scores_last=scores.detach(), losses=losses, grad0=grad0, checkpoints=ck)

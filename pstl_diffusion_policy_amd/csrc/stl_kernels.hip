@@ -263,6 +263,79 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
       });
 }
 
+// ---- trajectory optimisation (nusc_train.py:1302-1325 with compute_trajopt_loss_lite :287-316) --------
+// params (N,40): controls in physical units.  Every row is independent given the batch-wide constants, so ONE launch
+// runs all `iters` Adam iterations of a row back to back (forward sweep + adjoint + update), the scene tables staying
+// in LDS: the reference launches ~10^4 kernels per iteration, 2000 iterations per batch.
+//   loss = mean(relu(thres - score) * valid) / clip(mean(valid), 1e-3)
+//        + reg * (mean(relu(w^2 - w_max^2)) + mean(relu(a^2 - a_max^2)))
+struct TrajoptArgs {
+  long N;
+  int rows_per_scene;
+  int K;
+  StlEnv env;
+  float thres, grad_scale;   // (1/clip(mean(valid),1e-3))/N
+  float reg_scale;           // reg_loss / (N * nt): d reg / d relu-term
+  float w_max2, a_max2;
+  int iters;
+  const float* neg_step;     // [iters] device: -lr / (1 - 0.9^k)
+  const float* bc2_sqrt;     // [iters] device: sqrt(1 - 0.999^k)
+  const float* s0;
+  const float* nei_prep;
+  const float* lane_prep;
+  const float* stlp;
+  const float* hl;
+  const float* valid;
+  float* params;             // (N,40) in/out
+  float* work;               // (2,N,40): Adam m, v (read when resume != 0, always written)
+  float* scores;             // (N,) score of the iterate the LAST update started from (what the reference reports)
+  int resume;
+};
+
+template <bool STAGED>
+__global__ __launch_bounds__(kWave) void k_trajopt(TrajoptArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const long row = (long)blockIdx.x * kWave + threadIdx.x;
+  const f4* lanes;
+  const float* nei;
+  scene_tables<STAGED>(lds, kScratchGrad, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes,
+                       nei);
+  if (row >= a.N) return;
+  const Scratch st = {lds + threadIdx.x, kWave};
+  const long b = row / a.rows_per_scene;
+  const StlRow r = load_row(a.stlp, a.hl, row);
+  float* u = a.params + row * (2 * kT);
+  float* wm = a.work + row * (2 * kT);
+  const long plane = a.N * (2 * kT);
+  const float gs = a.grad_scale * a.valid[row];
+  const float thres = a.thres;
+  float score = 0.0f;
+  for (int it = 0; it < a.iters; ++it) {
+    const float neg_step = a.neg_step[it], bc2 = a.bc2_sqrt[it];
+    const bool fresh = (it == 0 && !a.resume);
+    auto update = [=](int e, float g, float lim2) {
+      const float p0 = u[e];
+      // d reg / d p: relu'(p^2 - lim^2) * 2p * reg_scale   (pow backward: grad * (2 * p))
+      if (p0 * p0 - lim2 > 0.0f) g = g + a.reg_scale * (2.0f * p0);
+      float m = fresh ? 0.0f : wm[e], v = fresh ? 0.0f : wm[plane + e];
+      m = m + 0.1f * (g - m);
+      v = v * 0.999f + (0.001f * g) * g;
+      const float denom = sqrtf(v) / bc2 + 1e-8f;
+      u[e] = p0 + (neg_step * m) / denom;
+      wm[e] = m;
+      wm[plane + e] = v;
+    };
+    score = stl_eval_grad(
+        a.env, r, lanes, nei, a.K, a.s0 + b * 4, u, st, 1.0f, 1.0f,
+        [=](float sc) { return (thres - sc > 0.0f) ? -gs : 0.0f; },
+        [=](int t, float gw, float ga) {
+          update(2 * t, gw, a.w_max2);
+          update(2 * t + 1, ga, a.a_max2);
+        });
+  }
+  if (a.scores) a.scores[row] = score;
+}
+
 // generate_trajs (nusc_train.py:39-49): T+1 states per row
 __global__ void k_generate_trajs(long R, int rows_per_scene, const float* s0, const float* controls, float dt,
                                  float* trajs) {
@@ -515,6 +588,46 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
     if (int e = launch_status()) return e;
   }
   return PSTL_OK;
+}
+
+extern "C" int pstl_trajopt(const pstl_cfg* cfg, const float* s0, const float* nei_prep, const float* lane_prep,
+                            const float* stlp, const float* hl, const float* valid, float thres, float grad_scale,
+                            float reg_scale, int iters, const float* adam_neg_step, const float* adam_bc2_sqrt, int resume,
+                            float* params_inout, float* work, float* scores, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!s0 || !lane_prep || !stlp || !hl || !valid || !params_inout || !work || !adam_neg_step || !adam_bc2_sqrt ||
+      iters < 1)
+    return PSTL_ERR_ARG;
+  if (cfg->K > 0 && !nei_prep) return PSTL_ERR_ARG;
+  TrajoptArgs a;
+  a.N = n_rows(cfg);
+  a.rows_per_scene = cfg->rows_per_scene;
+  a.K = cfg->K;
+  a.env = make_env(cfg->tau, cfg->dt, cfg->ego_L, cfg->ego_W);
+  a.thres = thres;
+  a.grad_scale = grad_scale;
+  a.reg_scale = reg_scale;
+  a.w_max2 = cfg->w_max * cfg->w_max;
+  a.a_max2 = cfg->a_max * cfg->a_max;
+  a.iters = iters;
+  a.neg_step = adam_neg_step;
+  a.bc2_sqrt = adam_bc2_sqrt;
+  a.s0 = s0;
+  a.nei_prep = nei_prep;
+  a.lane_prep = lane_prep;
+  a.stlp = stlp;
+  a.hl = hl;
+  a.valid = valid;
+  a.params = params_inout;
+  a.work = work;
+  a.scores = scores;
+  a.resume = resume;
+  const bool staged = scene_staged(cfg);
+  const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged);
+  void (*fn)(TrajoptArgs) = staged ? k_trajopt<true> : k_trajopt<false>;
+  if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
+  hipLaunchKernelGGL(fn, dim3((unsigned)((a.N + kWave - 1) / kWave)), dim3(kWave), lds, as_stream(stream), a);
+  return launch_status();
 }
 
 extern "C" int pstl_reduce_metrics(const pstl_cfg* cfg, const float* scores, const float* valid, uint64_t* counts,

@@ -279,6 +279,36 @@ class Sampler:
                   "reduce_metrics")
         return counts, mask
 
+    # ---- N4: trajectory optimisation (the data-augmentation loop) ----
+    def trajopt(self, sb, params, iters, lr, thres=0.01, reg_loss=10.0, work=None, first_iter=0,
+                global_valid_sum=None, global_rows=None):
+        """`iters` Adam iterations on params (N,40) (controls in physical units, updated IN PLACE) under the traj-opt
+        loss (reference nusc_train.py:1302-1325, compute_trajopt_loss_lite :287-300) -- one launch for all of them.
+        A run may be split over several calls: pass the returned `work` (Adam m, v) back with first_iter = iterations
+        already done.  Returns (scores of the iterate the last step started from (N,), work)."""
+        dev = sb.device
+        N = sb.N
+        f32 = np.float32
+        vsum = float(sb.valid.sum().item()) if global_valid_sum is None else float(global_valid_sum)
+        rows = N if global_rows is None else int(global_rows)
+        c = f32(max(f32(f32(vsum) / f32(rows)), f32(1e-3)))                  # clip(mean(valid), 1e-3)
+        grad_scale = float(f32(f32(1.0) / c) / f32(rows))
+        reg_scale = float(f32(reg_loss) / f32(rows * ffi.T))
+        ks = range(first_iter + 1, first_iter + iters + 1)
+        neg_step = torch.tensor([-lr / (1 - 0.9 ** k) for k in ks], dtype=torch.float32, device=dev)
+        bc2 = torch.tensor([math.sqrt(1 - 0.999 ** k) for k in ks], dtype=torch.float32, device=dev)
+        resume = 1 if work is not None else 0
+        if work is None:
+            work = torch.empty(2, N, ffi.CTRL, dtype=torch.float32, device=dev)
+        scores = torch.empty(N, dtype=torch.float32, device=dev)
+        cfg = sb.cfg(2)
+        ffi.check(self.L.pstl_trajopt(ctypes.byref(cfg), ffi.ptr(sb.s0), ffi.ptr(sb.nei_prep), ffi.ptr(sb.lane_prep),
+                                      ffi.ptr(sb.stlp), ffi.ptr(sb.hl), ffi.ptr(sb.valid), ctypes.c_float(thres),
+                                      ctypes.c_float(grad_scale), ctypes.c_float(reg_scale), int(iters), ffi.ptr(neg_step),
+                                      ffi.ptr(bc2), resume, ffi.ptr(params), ffi.ptr(work), ffi.ptr(scores), ffi.stream()),
+                  "trajopt")
+        return scores, work
+
     # ---- N2: post-sampling diversity metrics ----
     def diversity(self, sb, controls, scores):
         """std / hull volume / entropies / occupancy area / ADE / FDE of the final controls (N,40) (physical units):

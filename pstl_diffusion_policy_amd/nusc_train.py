@@ -426,6 +426,76 @@ def run_sampling_test(stls_cac, data_loader, net, coeffs, args, result_queue=Non
     return md
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# trajectory optimisation = the data-augmentation pass (reference --trajopt_only, nusc_train.py:1302-1349)
+# ---------------------------------------------------------------------------------------------------------------
+def save_trajopt_params(params, iter_i, traj_i, ti, args, save_stlp=None):
+    """On-disk format of the traj-opt solutions (reference nusc_train.py:775-797; read back by nusc_dataset.py:203-225):
+    one .npy per scene -- params_%05d_%04d{_init,}.npy (n_randoms,3,nt,2), scores_%05d_%04d.npy (n_randoms,3),
+    params_%05d_%04d_stlp.npy (n_randoms,3,1,6)."""
+    import os
+    if args.test or not args.model_dir:
+        return
+    os.makedirs(args.model_dir, exist_ok=True)
+    params_np = params.detach().cpu().numpy()
+    bs = params_np.shape[0]
+    stlp_np = None
+    if save_stlp is not None:
+        stlp_np = save_stlp.detach().cpu().numpy().reshape(bs, args.n_randoms, 3, 1, save_stlp.shape[-1])
+    for i in range(bs):
+        key = (int(traj_i[i]), int(ti[i]))
+        if iter_i == "scores":
+            name = "scores_%05d_%04d.npy" % key
+        elif iter_i == "init":
+            name = "params_%05d_%04d_init.npy" % key
+        elif iter_i == "final":
+            name = "params_%05d_%04d.npy" % key
+        else:
+            name = "params_%05d_%04d_iter%05d.npy" % (key + (int(iter_i),))
+        np.save(os.path.join(args.model_dir, name), params_np[i])
+        if stlp_np is not None:
+            np.save(os.path.join(args.model_dir, "params_%05d_%04d_stlp.npy" % key), stlp_np[i])
+
+
+def run_trajopt(data_loader, args):
+    """For every batch: args.traj_opt_iters Adam iterations on the dataset's `params` under the STL loss, all inside one
+    kernel launch (engine.Sampler.trajopt), then the reference's three files per scene."""
+    from . import ffi as _ffi
+    md = MeterDict()
+    sm = Sampler.__new__(Sampler)
+    sm.L = _ffi.lib()
+    for bi, batch in enumerate(data_loader):
+        batch_cuda = dict_to_cuda(batch)
+        bs = batch_cuda["ego_traj"].shape[0]
+        S = args.n_randoms
+        N = bs * S * 3
+        new_batch = {k: batch_cuda[k] for k in ("ego_traj", "neighbors", "currlane_wpts", "leftlane_wpts",
+                                                "rightlane_wpts", "curr_id", "left_id", "right_id", "gt_high_level",
+                                                "pre_stlp")}
+        new_batch["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
+        load_stlp, args.load_stlp = args.load_stlp, True        # synthetic scenes carry their per-row parameters
+        new_batch = augment_batch_data(new_batch, batch_cuda["stlp_modes"][:, 0], args)
+        args.load_stlp = load_stlp
+        sb = new_batch["_pstl"]
+        traj_i = batch_cuda.get("traj_i", torch.full((bs,), bi))
+        ti = batch_cuda.get("ti", torch.arange(bs))
+        params = batch_cuda["params"].reshape(N, -1).float().contiguous().clone()
+        save_trajopt_params(params.reshape(bs, S, 3, args.nt, 2), "init", traj_i, ti, args, save_stlp=new_batch["stlp_dense"])
+        torch.cuda.synchronize()
+        t0 = time.time()
+        scores, _ = sm.trajopt(sb, params, args.traj_opt_iters, args.trajopt_lr, args.stl_trajopt_thres, args.reg_loss)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        acc = mask_mean((scores >= 0).float(), sb.valid)
+        md.update("avg_acc", acc.item())
+        md.update("time", dt)
+        save_trajopt_params(params.reshape(bs, S, 3, args.nt, 2), "final", traj_i, ti, args)
+        save_trajopt_params(scores.reshape(bs, S, 3), "scores", traj_i, ti, args)
+        print("trajopt batch %d: %d rows x %d iters in %.3f s (%.3e row-iterations/s), acc %.3f" % (
+            bi, N, args.traj_opt_iters, dt, N * args.traj_opt_iters / dt, md["avg_acc"]))
+    return md
+
+
 def generate_parser(argv=None):
     """The reference's flags and post-parse overrides (nusc_train.py:1635-1814)."""
     parser = argparse.ArgumentParser("")
@@ -505,6 +575,18 @@ def generate_parser(argv=None):
     add("--suffix", type=str, default=None)
     add("--no_refinenet", action="store_true", default=False)
     add("--time_profile", action="store_true", default=False)
+    add("--stl_trajopt_thres", type=float, default=0.01)
+    add("--trajopt_only", action="store_true", default=False)
+    add("--traj_opt_iters", type=int, default=2000)
+    add("--trajopt_lr", type=float, default=0.005)
+    add("--opt_epochs", type=int, default=0)
+    add("--reg_loss", type=float, default=10.0)
+    add("--model_dir", type=str, default=None, help="where params_*.npy / scores_*.npy go (reference: exps/<run>/models)")
+    add("--offline", action="store_true", default=False)
+    add("--cache_path", type=str, default=None,
+        help="experiment directory holding cache.npz, *_split.txt and models/ (nusc_dataset.write_synthetic_experiment); "
+             "without it batches come straight from the synthetic scene generator")
+    add("--test_t1", action="store_true", default=False)
     args = parser.parse_args(argv)
     args.cos = True
     args.measure_diversity = True
@@ -524,13 +606,25 @@ def generate_parser(argv=None):
 
 def main(argv=None):
     args = generate_parser(argv)
+    def loader_for(split, n_batches=None):
+        if args.cache_path:      # from files, as the reference does (cache.npz + split file + models/*.npy)
+            from . import nusc_dataset
+            return nusc_dataset.get_dataloader(args, args.cache_path, split=split)
+        return SyntheticLoader(args, n_batches=n_batches)
+
+    if args.trajopt_only:
+        torch.manual_seed(args.seed)
+        if args.cache_path and not args.model_dir:
+            import os
+            args.model_dir = os.path.join(args.cache_path, "models")
+        return run_trajopt(loader_for("train", n_batches=min(args.n_trials, 2)), args)
     if not args.run_sampling_test:
-        raise SystemExit("only --run_sampling_test (the sampling + STL hot path) is implemented on MI355X")
+        raise SystemExit("only --run_sampling_test (the sampling + STL hot path) and --trajopt_only are implemented on MI355X")
     if args.sampling_size != args.n_randoms:
         raise SystemExit("--sampling_size must equal --n_randoms (merge_net pooling, reference nusc_model.py:187-196)")
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
-    loader = SyntheticLoader(args)
+    loader = loader_for("val")
     stls_cac = build_stl_cache(args)
     net = Net(args).cuda()
     if args.net_pretrained_path is not None:

@@ -225,7 +225,7 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--closed-loop", "--diversity", "--stl-lib", "--trajopt")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats")):
     main()
 
 
@@ -436,3 +436,81 @@ def main_stl_lib():
 
 if __name__ == "__main__" and "--stl-lib" in sys.argv:
     main_stl_lib()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# trajectory optimisation (data augmentation loop, reference nusc_train.py:1302-1325 + compute_trajopt_loss_lite)
+# ---------------------------------------------------------------------------------------------------------------
+def trajopt_case(ref, name, bs, S, K, seed, iters, lr, ctrl_boost=1.0, invalid_lane_frac=0.25, stlp_mode="wide"):
+    nt = ref.nusc_train
+    argv = ["--trajopt_only", "--traj_opt_iters", str(iters), "--trajopt_lr", str(lr), "--n_randoms", str(S),
+            "--n_neighbors", str(K), "--opt_epochs", "1"]
+    args = ref_harness.parse_reference_args(argv)
+    args.measure_diversity = False
+    stls = nt.build_stl_cache(args)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    batch = make_scene_batch(bs, K=K, S=S, seed=seed, invalid_lane_frac=invalid_lane_frac, stlp_mode=stlp_mode)
+    batch_cuda = dict(batch)
+    batch_cuda["params"] = batch_cuda["params"] * ctrl_boost      # boost > 1 puts some controls beyond +-max (reg term)
+    states = batch_cuda["ego_traj"][..., 0, :4]
+    batch_cuda["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
+    gt_stlp = batch_cuda["stlp_modes"][:, 0]
+    batch_cuda = nt.augment_batch_data(batch_cuda, gt_stlp, args)
+    dense_states = states.unsqueeze(1).unsqueeze(1).repeat(1, S, 3, 1)
+    out = {"params_init": np_(batch_cuda["params"])}
+    dense_controls = batch_cuda["params"] = batch_cuda["params"].clone().requires_grad_()
+    opt = torch.optim.Adam([batch_cuda["params"]], lr=args.trajopt_lr)
+    losses = []
+    for ii in range(iters):
+        dense_trajs = nt.generate_trajs(dense_states, dense_controls, args.dt)
+        cache = nt.pre_prepare_stl_cache(batch_cuda)
+        res = nt.compute_trajopt_loss_lite(dense_controls, dense_trajs, stls, cache, ii, iters)
+        trajopt_loss, dense_loss, reg_loss, avg_acc, _, dense_scores = res[:6]
+        opt.zero_grad()
+        trajopt_loss.backward()
+        if ii == 0:
+            out["grad_iter0"] = np_(batch_cuda["params"].grad).copy()
+        opt.step()
+        losses.append([trajopt_loss.item(), dense_loss.item(), reg_loss.item(), avg_acc.item()])
+        if ii in (0, 2, iters - 1):
+            out["params_after%d" % (ii + 1)] = np_(batch_cuda["params"]).copy()   # .numpy() aliases the live tensor
+    out["scores_last"] = np_(dense_scores)                    # (bs*S, 3): scores of the iterate the last step started from
+    out["losses"] = np.asarray(losses, dtype=np.float64)
+    for k in ["ego_traj", "neighbors", "neighbors_traj", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
+              "curr_id", "left_id", "right_id", "stlp_modes"]:
+        out["in_" + k] = np_(batch[k])
+    out["in_stlp_dense"] = np_(batch_cuda["stlp_dense"])     # per-row STL parameters drawn by get_dense_stlp (random)
+    out["meta"] = np.array([bs, S, K, seed, iters], dtype=np.int64)
+    out["meta_f"] = np.array([lr, args.stl_trajopt_thres, args.reg_loss], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "losses first/last", losses[0], losses[-1])
+
+
+def main_trajopt():
+    ref = ref_harness.load_reference()
+    trajopt_case(ref, "trajopt_a", bs=3, S=8, K=3, seed=61, iters=12, lr=0.005)
+    trajopt_case(ref, "trajopt_b", bs=2, S=16, K=5, seed=62, iters=8, lr=0.05, ctrl_boost=7.0, invalid_lane_frac=0.5)
+
+
+if __name__ == "__main__" and "--trajopt" in sys.argv:
+    main_trajopt()
+
+
+def main_formats():
+    """A cache.npz written by the reference's own save_cache_data (nusc_train.py:190-201) + np.savez (:208)."""
+    ref = ref_harness.load_reference()
+    batch = make_scene_batch(3, K=2, S=4, seed=9)
+    keys = ("ego_traj", "neighbors", "neighbors_traj", "currlane_wpts", "leftlane_wpts", "rightlane_wpts", "curr_id",
+            "left_id", "right_id", "gt_high_level", "stlp_modes")
+    b = {k: batch[k] for k in keys}
+    b.update(traj_i=torch.tensor([0, 0, 1]), ti=torch.tensor([1, 2, 1]), len_full=torch.tensor([30, 30, 30]),
+             params=batch["params"])
+    saved = ref.nusc_train.save_cache_data(b, {})
+    meta_list = [(0, ["t%d" % i for i in range(30)]), (1, ["u%d" % i for i in range(30)])]
+    np.savez(os.path.join(HERE, "ref_cache.npz"), data=saved, meta_list=np.asarray(meta_list, dtype=object))
+    print("ref_cache.npz", os.path.getsize(os.path.join(HERE, "ref_cache.npz")))
+
+
+if __name__ == "__main__" and "--formats" in sys.argv:
+    main_formats()

@@ -1,0 +1,36 @@
+"""Config 1 end to end FROM FILES on the GPU: an experiment directory in the reference's formats (cache.npz, split file,
+models/params_*.npy, model_last.ckpt) -> nusc_train.main(--run_sampling_test) and main(--trajopt_only), which writes the
+traj-opt solution files the dataset then reads back."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sampling_test_and_trajopt_from_files(tmp_path, capsys):
+    assert torch.cuda.is_available()
+    from pstl_diffusion_policy_amd import nusc_dataset as nd
+    from pstl_diffusion_policy_amd import nusc_train as nt
+    from pstl_diffusion_policy_amd.nusc_model import init_state_dict
+    root = str(tmp_path / "e1")
+    base = ["--diffusion", "--load_stlp", "--n_randoms", "8", "--sampling_size", "8", "--n_neighbors", "3", "--batch_size", "4",
+            "--diffusion_steps", "10", "--cache_path", root]
+    args = nt.generate_parser(base)
+    nd.write_synthetic_experiment(root, 12, args, seed=5)
+    nd.save_checkpoint(init_state_dict(1007), os.path.join(root, "models"))
+    md = nt.main(base + ["--rect_head", "--multi_cands", "3", "--run_sampling_test", "--test", "-P", nd.smart_path(root)])
+    out = capsys.readouterr().out
+    assert "NN acc:" in out and "nan" not in out.split("| NN")[1]
+    assert 0.0 <= md("acc") <= 1.0 and np.isfinite(md("std")) and np.isfinite(md("ade"))
+    # the data-augmentation pass over the train split rewrites params_*.npy / scores_*.npy
+    before = np.load(nd.trajopt_paths(os.path.join(root, "models"), 0, 1)["params"])
+    nt.main(base + ["--trajopt_only", "--traj_opt_iters", "25", "--trajopt_lr", "0.01"])
+    after = np.load(nd.trajopt_paths(os.path.join(root, "models"), 0, 1)["params"])
+    assert after.shape == before.shape == (8, 3, 20, 2) and np.abs(after - before).max() > 1e-3
+    sc = np.load(nd.trajopt_paths(os.path.join(root, "models"), 0, 1)["tj_scores_prior"])
+    assert sc.shape == (8, 3) and np.isfinite(sc).all()
+    ds = nd.get_dataloader(nt.generate_parser(base), root, split="train").dataset
+    assert torch.equal(ds[0]["params"], torch.from_numpy(after))
