@@ -195,12 +195,26 @@ int pstl_train_destroy(void* ctx);
 size_t pstl_train_work_floats(const pstl_cfg* cfg);
 /* d loss / d rect_net parameters given dcontrols = d loss / d out_controls (from pstl_stl_backward).  w2, w3: the
  * reference-layout weights rect_net.2.weight (256,256), rect_net.4.weight (40,256).  Gradients in the reference layout:
- * dw1 (256,271), db1 (256), dw2 (256,256), db2 (256), dw3 (40,256), db3 (40).  Gradients w.r.t. the scene feature
- * (needed only with --joint) are not produced.  work: pstl_train_work_floats(cfg) floats. */
+ * dw1 (256,271), db1 (256), dw2 (256,256), db2 (256), dw3 (40,256), db3 (40).  Gradients w.r.t. the scene feature and
+ * merge_net (both needed only with --joint: the reference's optimiser holds rect_net.parameters() otherwise,
+ * nusc_train.py:1230-1233) are not produced.  work: pstl_train_work_floats(cfg) floats. */
 int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float* w2, const float* w3, const float* feature,
-                         const float* stlp, const float* hl, const float* init_controls, const float* prev_scores,
-                         const float* h1, const float* h2, const float* pre, const float* dcontrols, float* work,
-                         float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, void* stream);
+                         const float* stlp, const float* hl, const float* init_controls,
+                         const float* pooled /* (bs,3,n_shards,40) from the forward call; null with PSTL_FLAG_NO_MERGE */,
+                         const float* prev_scores, const float* h1, const float* h2, const float* pre,
+                         const float* dcontrols, float* work, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
+                         float* db3, void* stream);
+/* e7 training objective (--diverse_loss, reference nusc_train.py:442-467).  For every (scene, mode, shard) group of
+ * S/n_shards samples the DPP diversity tr(I - (L+I)^-1), L = diag(q) exp(-diversity_scale |x_i - x_j|) diag(q),
+ * x = rect_controls/(w_max,a_max), q = exp(score)[score>0] (detach != 0: q = [score>0], no gradient into the scores).
+ * group_div (bs*3*n_shards): the diversities (loss_diversity = -mean(group_div) * diversity_weight);
+ * dcontrols (N,40), dscore (N): WRITTEN with d(loss_diversity)/d rect_controls and /d scores.
+ * Optional regulariser loss_reg = mask_mean(square(rect - init), [score >= 0]) (:466): reg_out[0] = loss_reg (reg_out,
+ * 2 floats, and reg_work, 512 doubles, may be null when rect_reg_weight == 0); dcontrols += rect_reg_weight * d loss_reg.
+ * Requires rows_per_scene == 3*S and S/n_shards <= 64. */
+int pstl_diversity_loss(const pstl_cfg* cfg, const float* rect_controls, const float* init_controls, const float* scores,
+                        float diversity_scale, float diversity_weight, int detach, float rect_reg_weight, float* group_div,
+                        float* reg_out, double* reg_work, float* dcontrols, float* dscore, void* stream);
 
 /* ---- metrics --------------------------------------------------------------------------------------------------- */
 /* counts[0] = #rows with score>0 and valid, counts[1] = #valid rows, counts[2] = #rows,

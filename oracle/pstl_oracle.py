@@ -435,16 +435,47 @@ def sampling_region(sd, scene, S, steps, hp, x_T, z, rect_head=False, multi_cand
 # N1  training step of RefineNet under the STL loss (reference nusc_train.py:1400-1427, compute_policy_loss
 #     :370-478 with rect_head and no diverse_loss, optimizer :1233,1522-1525)
 # ------------------------------------------------------------------------------------------------
-def rect_train_step(sd, scene, S, hp, init_controls, prev_scores, lr, diverse=False, n_shards=4):
-    """loss = mask_mean(relu(thres - score(rect_controls)), valid) (+ zero-weight regularisers); returns the loss, the
-    gradients of the six rect_net tensors and the tensors after one Adam step (fresh optimiser state)."""
+def dpp_diversity(rect, scores, bs, S, n_shards, hp, scale=1.0, detach=False):
+    """DPP diversity term of e7 training (reference nusc_train.py:442-464): per (scene, mode, shard) group of S/n_shards
+    samples, L = diag(q) exp(-scale*dist) diag(q) with q = exp(score)*[score>0] (or just [score>0] with
+    --diverse_detach), diversity = tr(I - (L+I)^-1); returns mean(-diversity) and the per-group diversities."""
+    n = S // n_shards
+    G = bs * 3 * n_shards
+    x = rect.reshape(bs, S, 3, -1).permute(0, 2, 1, 3).reshape(G, n, -1, 2)
+    x = (x / torch.tensor([hp["mul_w_max"], hp["mul_a_max"]])).reshape(G, n, -1)
+    quality = scores.reshape(bs, S, 3).permute(0, 2, 1).reshape(G, n)
+    dist = torch.norm(x[:, :, None] - x[:, None, :], dim=-1)
+    sim = torch.exp(-scale * dist)
+    pos = (quality > 0).float()
+    q = pos.detach() if detach else torch.exp(quality) * pos
+    nL = torch.bmm(torch.bmm(torch.diag_embed(q), sim), torch.diag_embed(q))
+    eye = torch.eye(n)[None]
+    div = torch.einsum("bii->b", eye - torch.inverse(nL + eye))
+    return torch.mean(-div), div
+
+
+def rect_train_step(sd, scene, S, hp, init_controls, prev_scores, lr, diverse=False, n_shards=4, e7=None):
+    """e7 is None: loss = mask_mean(relu(thres - score(rect_controls)), valid) (config 5; zero-weight regularisers).
+    e7 = dict(stl_weight, diversity_weight, diversity_scale, rect_reg_loss, detach): the --diverse_loss objective
+    loss_stl*stl_weight + loss_reg*rect_reg_loss + loss_diversity*diversity_weight (reference nusc_train.py:442-467),
+    with the merge_net architecture.  Returns the loss, the gradients of the six rect_net tensors (the only parameters
+    in the reference's optimiser without --joint, :1230-1233) and the tensors after one Adam step."""
     rows = Rows(scene, S, hp)
     params = {k: _t(v).clone().requires_grad_() for k, v in sd.items() if k.startswith("rect_net.")}
     sd_live = {k: (params[k] if k in params else _t(v)) for k, v in sd.items()}
     feature = encode_feat(sd_live, scene).detach()
-    rect = rect_forward(sd_live, feature, rows, _t(init_controls), _t(prev_scores), n_shards, diverse)
+    init = _t(init_controls)
+    rect = rect_forward(sd_live, feature, rows, init, _t(prev_scores), n_shards, diverse or e7 is not None)
     _, score, _ = rows.score(rect)
-    loss = mask_mean(torch.relu(hp["stl_nn_thres"] - score), rows.valid)
+    loss_stl = mask_mean(torch.relu(hp["stl_nn_thres"] - score), rows.valid)
+    extra = {}
+    if e7 is None:
+        loss = loss_stl
+    else:
+        ldiv, div = dpp_diversity(rect, score, rows.bs, S, n_shards, hp, e7.get("diversity_scale", 1.0), e7.get("detach", False))
+        lreg = mask_mean(torch.square(rect - init.reshape(rect.shape).detach()), (score[:, None, None] >= 0).float())
+        loss = loss_stl * e7["stl_weight"] + lreg * e7.get("rect_reg_loss", 0.0) + ldiv * e7["diversity_weight"]
+        extra = dict(loss_diversity=(ldiv * e7["diversity_weight"]).detach(), loss_reg=lreg.detach(), diversity=div.detach())
     names = sorted(params)
     grads = torch.autograd.grad(loss, [params[k] for k in names])
     opt = torch.optim.Adam([params[k] for k in names], lr=lr)
@@ -452,7 +483,7 @@ def rect_train_step(sd, scene, S, hp, init_controls, prev_scores, lr, diverse=Fa
         params[k].grad = g
     opt.step()
     return dict(loss=loss.detach(), rect_controls=rect.detach(), scores=score.detach(),
-                grads={k: g for k, g in zip(names, grads)}, after={k: params[k].detach() for k in names})
+                grads={k: g for k, g in zip(names, grads)}, after={k: params[k].detach() for k in names}, **extra)
 
 
 # ------------------------------------------------------------------------------------------------

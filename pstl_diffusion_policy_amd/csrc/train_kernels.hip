@@ -25,8 +25,10 @@ struct TrainCtx {
 
 // dO = dcontrols * [prev_score < 0] * d interval / d raw * (1 - raw^2), raw = tanh(pre)   (nusc_model.py:212-229)
 // x47 = [hl | stlp | init]
+// With the merge_net architecture (pooled != null) the last 40 input columns are init + pooled[scene, mode, shard].
 __global__ void k_head_bwd(long N, float w_max, float a_max, const float* dctrl, const float* pre, const float* init,
-                           const float* prev_scores, const float* hl, const float* stlp, float* dO, float* x47) {
+                           const float* prev_scores, const float* hl, const float* stlp, const float* pooled, int S,
+                           int n_shards, float* dO, float* x47) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * kCtrl) return;
   const long row = i / kCtrl;
@@ -37,7 +39,14 @@ __global__ void k_head_bwd(long N, float w_max, float a_max, const float* dctrl,
   const float slope = raw >= 0.0f ? (sc - in0) : (in0 - (-sc));
   const float viol = prev_scores[row] < 0.0f ? 1.0f : 0.0f;
   dO[i] = dctrl[i] * viol * slope * (1.0f - raw * raw);
-  x47[row * kX47 + 7 + f] = in0;
+  float fused = in0;
+  if (pooled) {   // row = (b*S + s)*3 + mode ; shard = s / (S/n_shards)
+    const long bs_ = row / 3;
+    const int mode = (int)(row % 3), s_ = (int)(bs_ % S);
+    const long b = bs_ / S;
+    fused = in0 + pooled[((b * 3 + mode) * n_shards + s_ / (S / n_shards)) * kCtrl + f];
+  }
+  x47[row * kX47 + 7 + f] = fused;
   if (f == 0) x47[row * kX47] = hl[row];
   if (f < 6) x47[row * kX47 + 1 + f] = stlp[row * 6 + f];
 }
@@ -95,6 +104,171 @@ __global__ void k_loss_grad(long N, const float* scores, const float* valid, flo
     __syncthreads();
   }
   if (threadIdx.x == 0) loss_parts[blockIdx.x] = red[0];
+}
+
+// ---- DPP diversity loss of e7 training (reference nusc_train.py:442-464) ----------------------------------------------
+// One wavefront per (scene, mode, shard) group of n = S/n_shards samples.  x_i = rect_controls_i / (w_max, a_max);
+// L = diag(q) exp(-scale * |x_i - x_j|) diag(q), q_i = exp(score_i) [score_i > 0] (or [score_i > 0] with
+// --diverse_detach); M = (L + I)^-1; diversity = tr(I - M); loss = weight * mean_g(-diversity).
+// L + I is symmetric positive definite with eigenvalues >= 1, so the in-place Gauss-Jordan inversion below needs no
+// pivoting; it runs in float64 (full-rate on MI355X), lane j owning column j.  Backward, with c = weight / #groups:
+//   d loss / d L = -c (M M)^T ;  d/d sim_ij = (.)_ij q_i q_j ;  d/d q_i = sum_j ((.)_ij + (.)_ji) sim_ij q_j ;
+//   d/d dist_ij = -scale sim_ij d/d sim_ij ;  d/d x_i = sum_j (d/d dist_ij + d/d dist_ji) (x_i - x_j)/dist_ij  (0 at dist 0,
+//   as torch.norm's backward defines it) ;  d/d score_i = d/d q_i * q_i   (0 with --diverse_detach).
+struct DppArgs {
+  int bs, S, n_shards;
+  float w_max, a_max, scale, c;
+  int detach;
+  const float* rect;     // (N,40)
+  const float* scores;   // (N,)
+  float* group_div;      // (bs*3*n_shards,)
+  float* dcontrols;      // (N,40) written
+  float* dscore;         // (N,) written
+};
+
+__global__ __launch_bounds__(64) void k_dpp(DppArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n = a.S / a.n_shards;
+  const int ld = n + 1;                                   // padded leading dimension (doubles)
+  double* A = reinterpret_cast<double*>(smem);            // n x ld : L + I, then M
+  double* Q = A + n * ld;                                 // n x ld : M M
+  float* X = reinterpret_cast<float*>(Q + n * ld);        // n x 40 normalised controls
+  float* SIM = X + n * kCtrl;                             // n x ld
+  float* DST = SIM + n * ld;                              // n x ld
+  float* qv = DST + n * ld;                               // n
+  const int lane = threadIdx.x;
+  const int g = blockIdx.x;
+  const int shard = g % a.n_shards, bm = g / a.n_shards, mode = bm % 3, b = bm / 3;
+  const bool own = lane < n;
+  const long row = ((long)b * a.S + shard * n + (own ? lane : 0)) * 3 + mode;
+  float score = 0.0f, q = 0.0f;
+  if (own) {
+    score = a.scores[row];
+    const float pos = score > 0.0f ? 1.0f : 0.0f;
+    q = a.detach ? pos : expf(score) * pos;
+    qv[lane] = q;
+    const float* src = a.rect + row * kCtrl;
+#pragma unroll 8
+    for (int f = 0; f < kCtrl; ++f) X[lane * kCtrl + f] = src[f] / ((f & 1) ? a.a_max : a.w_max);
+  }
+  __syncthreads();
+  if (own) {   // column j = lane
+    for (int i = 0; i < n; ++i) {
+      float acc = 0.0f;
+      for (int f = 0; f < kCtrl; ++f) {
+        const float d = X[i * kCtrl + f] - X[lane * kCtrl + f];
+        acc += d * d;
+      }
+      const float dist = sqrtf(acc);
+      const float sim = expf(-a.scale * dist);
+      DST[i * ld + lane] = dist;
+      SIM[i * ld + lane] = sim;
+      A[i * ld + lane] = (double)((qv[i] * sim) * q) + (i == lane ? 1.0 : 0.0);
+    }
+  }
+  __syncthreads();
+  // in-place Gauss-Jordan inversion: after step k, column/row k of A hold those of the partial inverse
+  for (int k = 0; k < n; ++k) {
+    const double p = A[k * ld + k];
+    __syncthreads();
+    if (own) A[k * ld + lane] = (lane == k ? 1.0 : A[k * ld + lane]) / p;
+    __syncthreads();
+    if (own) {
+      const double rk = A[k * ld + lane];
+      for (int i = 0; i < n; ++i) {
+        if (i == k) continue;
+        const double f = A[i * ld + k];                 // column k is only rewritten by lane k, after it has read f
+        const double cur = (lane == k) ? 0.0 : A[i * ld + lane];
+        A[i * ld + lane] = cur - f * rk;
+      }
+    }
+    __syncthreads();
+  }
+  if (own) {   // Q = M M (column j = lane), trace
+    for (int i = 0; i < n; ++i) {
+      double acc = 0.0;
+      for (int k = 0; k < n; ++k) acc += A[i * ld + k] * A[k * ld + lane];
+      Q[i * ld + lane] = acc;
+    }
+  }
+  double tr = own ? 1.0 - A[lane * ld + lane] : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
+  if (lane == 0) a.group_div[g] = (float)tr;
+  __syncthreads();
+  if (own) {   // row i = lane
+    const int i = lane;
+    double dq = 0.0;
+    float dx[kCtrl];
+#pragma unroll
+    for (int f = 0; f < kCtrl; ++f) dx[f] = 0.0f;
+    for (int j = 0; j < n; ++j) {
+      const double gij = -(double)a.c * Q[j * ld + i], gji = -(double)a.c * Q[i * ld + j];   // (M M)^T_ij = Q_ji
+      const float sim = SIM[i * ld + j], dist = DST[i * ld + j];
+      dq += (gij + gji) * (double)sim * (double)qv[j];
+      if (dist != 0.0f) {
+        const double dd = (gij + gji) * (double)q * (double)qv[j] * (-(double)a.scale * (double)sim);   // both orientations
+        const float coef = (float)(dd / (double)dist);
+#pragma unroll
+        for (int f = 0; f < kCtrl; ++f) dx[f] += coef * (X[i * kCtrl + f] - X[j * kCtrl + f]);
+      }
+    }
+    float* out = a.dcontrols + row * kCtrl;
+#pragma unroll
+    for (int f = 0; f < kCtrl; ++f) out[f] = dx[f] / ((f & 1) ? a.a_max : a.w_max);
+    a.dscore[row] = a.detach ? 0.0f : (float)(dq * (double)q);
+  }
+}
+
+// loss_reg = mask_mean(square(rect - init), [score >= 0]) (reference nusc_train.py:466): partial sums per block of
+// (sum of squares over masked rows, number of masked rows); the gradient kernel needs the masked-row count first.
+__global__ void k_reg_partials(long N, const float* rect, const float* init, const float* scores, double* parts) {
+  __shared__ double r0[256], r1[256];
+  double sq = 0.0, cnt = 0.0;
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (long)gridDim.x * blockDim.x) {
+    if (scores[r] >= 0.0f) {
+      cnt += 1.0;
+      for (int f = 0; f < kCtrl; ++f) {
+        const float d = rect[r * kCtrl + f] - init[r * kCtrl + f];
+        sq += (double)(d * d);
+      }
+    }
+  }
+  r0[threadIdx.x] = sq;
+  r1[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      r0[threadIdx.x] += r0[threadIdx.x + o];
+      r1[threadIdx.x] += r1[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    parts[2 * blockIdx.x] = r0[0];
+    parts[2 * blockIdx.x + 1] = r1[0];
+  }
+}
+__global__ void k_reg_final(int nblocks, long N, double* parts, float* reg_out /* [0] loss_reg, [1] 1/clip(mean m) */) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double sq = 0.0, cnt = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    sq += parts[2 * b];
+    cnt += parts[2 * b + 1];
+  }
+  const float mean_m = (float)(cnt / (double)N);
+  const float den = fmaxf(mean_m, 1e-2f);
+  reg_out[0] = (float)(sq / ((double)N * kCtrl)) / den;
+  reg_out[1] = 1.0f / den;
+}
+// dcontrols += weight * 2 (rect - init) [score >= 0] / (N*40) / clip(mean m)
+__global__ void k_reg_grad(long N, float weight, const float* rect, const float* init, const float* scores,
+                           const float* reg_out, float* dcontrols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * kCtrl) return;
+  const long r = i / kCtrl;
+  if (scores[r] >= 0.0f)
+    dcontrols[i] += (weight * reg_out[1] / (float)(N * kCtrl)) * (2.0f * (rect[i] - init[i]));
 }
 
 // row-major C(m x n) = op(A) op(B) through column-major rocBLAS
@@ -293,15 +467,18 @@ extern "C" int pstl_loss_grad(const pstl_cfg* cfg, const float* scores, const fl
 
 extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float* w2 /* (256,256) */,
                                     const float* w3 /* (40,256) */, const float* feature /* (bs,224) */, const float* stlp,
-                                    const float* hl, const float* init_controls, const float* prev_scores,
-                                    const float* h1, const float* h2, const float* pre, const float* dcontrols,
-                                    float* work, float* dw1 /* (256,271) */, float* db1, float* dw2, float* db2,
-                                    float* dw3 /* (40,256) */, float* db3, void* stream) {
+                                    const float* hl, const float* init_controls, const float* pooled,
+                                    const float* prev_scores, const float* h1, const float* h2, const float* pre,
+                                    const float* dcontrols, float* work, float* dw1 /* (256,271) */, float* db1,
+                                    float* dw2, float* db2, float* dw3 /* (40,256) */, float* db3, void* stream) {
   if (int e = check_cfg(cfg)) return e;
   if (!ctx || !w2 || !w3 || !feature || !stlp || !hl || !init_controls || !prev_scores || !h1 || !h2 || !pre ||
       !dcontrols || !work || !dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3)
     return PSTL_ERR_ARG;
   if (cfg->flags & PSTL_FLAG_CLIP_RECT) return PSTL_ERR_SHAPE;  // the reference trains without --clip_rect
+  const bool merge = !(cfg->flags & PSTL_FLAG_NO_MERGE);
+  if (merge && (!pooled || cfg->rows_per_scene != 3 * cfg->S || cfg->n_shards < 1 || cfg->S % cfg->n_shards != 0))
+    return PSTL_ERR_ARG;
   TrainCtx* c = static_cast<TrainCtx*>(ctx);
   hipStream_t st = as_stream(stream);
   if (rocblas_set_stream(c->h, st) != rocblas_status_success) return PSTL_ERR_LAUNCH;
@@ -316,7 +493,8 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
   const int nb = (int)(N < kRedBlocks ? N : kRedBlocks);
 
   hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)((N * kCtrl + 255) / 256)), dim3(256), 0, st, N, cfg->w_max, cfg->a_max,
-                     dcontrols, pre, init_controls, prev_scores, hl, stlp, dO, x47);
+                     dcontrols, pre, init_controls, prev_scores, hl, stlp, merge ? pooled : (const float*)nullptr, cfg->S,
+                     cfg->n_shards, dO, x47);
   // layer 3
   hipLaunchKernelGGL(k_mask_colsum, dim3(nb), dim3(64), 0, st, N, kCtrl, dO, (const float*)nullptr, part);
   hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(64), 0, st, nb, kCtrl, part, db3);
@@ -333,5 +511,51 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
   hipLaunchKernelGGL(k_scene_sum, dim3(cfg->bs), dim3(256), 0, st, cfg->rows_per_scene, dH1, S);
   if (int e = gemm_rm(c->h, true, false, kHid, kFeat, cfg->bs, S, kHid, feature, kFeat, dw1, kIn)) return e;
   if (int e = wgrad<16, 3, 8, 1>(N, dH1, kHid, kHid, x47, kX47, kX47, slabs, dw1 + kFeat, kIn, st)) return e;
+  return launch_status();
+}
+
+
+extern "C" int pstl_diversity_loss(const pstl_cfg* cfg, const float* rect_controls, const float* init_controls,
+                                   const float* scores, float diversity_scale, float diversity_weight, int detach,
+                                   float rect_reg_weight, float* group_div, float* reg_out, double* reg_work,
+                                   float* dcontrols, float* dscore, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!rect_controls || !scores || !group_div || !dcontrols || !dscore) return PSTL_ERR_ARG;
+  if (cfg->rows_per_scene != 3 * cfg->S || cfg->n_shards < 1 || cfg->S % cfg->n_shards != 0) return PSTL_ERR_SHAPE;
+  const int n = cfg->S / cfg->n_shards;
+  if (n > 64) return PSTL_ERR_SHAPE;
+  hipStream_t st = as_stream(stream);
+  const long N = n_rows(cfg);
+  const int groups = cfg->bs * 3 * cfg->n_shards;
+  DppArgs a;
+  a.bs = cfg->bs;
+  a.S = cfg->S;
+  a.n_shards = cfg->n_shards;
+  a.w_max = cfg->w_max;
+  a.a_max = cfg->a_max;
+  a.scale = diversity_scale;
+  a.c = diversity_weight / (float)groups;
+  a.detach = detach;
+  a.rect = rect_controls;
+  a.scores = scores;
+  a.group_div = group_div;
+  a.dcontrols = dcontrols;
+  a.dscore = dscore;
+  const int ld = n + 1;
+  const size_t lds = (size_t)2 * n * ld * sizeof(double) + ((size_t)n * kCtrl + 2 * (size_t)n * ld + n) * sizeof(float);
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_dpp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+          hipSuccess)
+    return PSTL_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_dpp, dim3((unsigned)groups), dim3(64), lds, st, a);
+  if (rect_reg_weight != 0.0f || reg_out) {
+    if (!init_controls || !reg_out || !reg_work) return PSTL_ERR_ARG;
+    const int nb = 256;
+    hipLaunchKernelGGL(k_reg_partials, dim3(nb), dim3(256), 0, st, N, rect_controls, init_controls, scores, reg_work);
+    hipLaunchKernelGGL(k_reg_final, dim3(1), dim3(1), 0, st, nb, N, reg_work, reg_out);
+    if (rect_reg_weight != 0.0f)
+      hipLaunchKernelGGL(k_reg_grad, dim3((unsigned)((N * kCtrl + 255) / 256)), dim3(256), 0, st, N, rect_reg_weight,
+                         rect_controls, init_controls, scores, reg_out, dcontrols);
+  }
   return launch_status();
 }

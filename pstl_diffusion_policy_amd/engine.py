@@ -417,46 +417,74 @@ class RectTrainer:
         except Exception:
             pass
 
-    def loss_and_grads(self, sb, feature, base_rect, w2, w3, init_controls, prev_scores):
+    def loss_and_grads(self, sb, feature, base_rect, w2, w3, init_controls, prev_scores, e7=None):
         """init_controls (N,40) physical units, prev_scores (N,) (both detached in the reference).  w2, w3: the live
-        rect_net.2.weight / rect_net.4.weight tensors.  Returns (loss tensor, rect_controls, scores, {name: grad})."""
+        rect_net.2.weight / rect_net.4.weight tensors.  Returns (loss tensor, rect_controls, scores, {name: grad}).
+        e7 = None: config 5, loss = mask_mean(relu(thres - score), valid), plain rect_net input.
+        e7 = dict(stl_weight, diversity_weight[, diversity_scale, rect_reg_loss, detach]): the --diverse_loss objective
+        loss_stl*stl_weight + loss_reg*rect_reg_loss + loss_diversity (reference nusc_train.py:442-467) with the
+        merge_net architecture; self.last holds the individual terms."""
         dev = sb.device
         N = sb.N
-        cfg = sb.cfg(2, ffi.PSTL_FLAG_NO_MERGE, self.sm.chain_waves)
+        merge = e7 is not None
+        cfg = sb.cfg(2, 0 if merge else ffi.PSTL_FLAG_NO_MERGE, self.sm.chain_waves)
         h1 = torch.empty(N, ffi.HID, dtype=torch.float32, device=dev)
         h2 = torch.empty(N, ffi.HID, dtype=torch.float32, device=dev)
         pre = torch.empty(N, ffi.CTRL, dtype=torch.float32, device=dev)
         rect = torch.empty(N, ffi.CTRL, dtype=torch.float32, device=dev)
+        pooled = torch.empty(sb.bs, 3, cfg.n_shards, ffi.CTRL, dtype=torch.float32, device=dev) if merge else None
         ffi.check(self.L.pstl_refine_train_forward(ctypes.byref(cfg), ffi.ptr(self.sm.w.packed), ffi.ptr(base_rect),
                                                    ffi.ptr(sb.stlp), ffi.ptr(sb.hl), ffi.ptr(init_controls),
-                                                   ffi.ptr(prev_scores), ffi.ptr(None), ffi.ptr(rect), ffi.ptr(h1),
+                                                   ffi.ptr(prev_scores), ffi.ptr(pooled), ffi.ptr(rect), ffi.ptr(h1),
                                                    ffi.ptr(h2), ffi.ptr(pre), ffi.stream()), "refine_train_forward")
         scores = self.sm.score(sb, rect.reshape(1, N, ffi.CTRL))["scores"][0]
         dscore = torch.empty(N, dtype=torch.float32, device=dev)
         parts = torch.empty(256, dtype=torch.float32, device=dev)
+        stl_w = float(e7["stl_weight"]) if merge else 1.0
         ffi.check(self.L.pstl_loss_grad(ctypes.byref(cfg), ffi.ptr(scores), ffi.ptr(sb.valid),
-                                        ctypes.c_float(sb.grad_scale), ffi.ptr(dscore), ffi.ptr(parts), ffi.stream()),
+                                        ctypes.c_float(sb.grad_scale * stl_w), ffi.ptr(dscore), ffi.ptr(parts), ffi.stream()),
                   "loss_grad")
+        # loss = mean(relu(thres - score) * valid) / clip(mean(valid), 1e-2): grad_scale is exactly (1/clip)/N
+        loss = parts.sum() * (sb.grad_scale * stl_w)
+        dctrl_extra = None
+        if merge:
+            groups = sb.bs * 3 * cfg.n_shards
+            group_div = torch.empty(groups, dtype=torch.float32, device=dev)
+            reg_out = torch.empty(2, dtype=torch.float32, device=dev)
+            reg_work = torch.empty(512, dtype=torch.float64, device=dev)
+            dctrl_extra = torch.empty(N, ffi.CTRL, dtype=torch.float32, device=dev)
+            dscore_div = torch.empty(N, dtype=torch.float32, device=dev)
+            div_w, reg_w = float(e7["diversity_weight"]), float(e7.get("rect_reg_loss", 0.0))
+            ffi.check(self.L.pstl_diversity_loss(ctypes.byref(cfg), ffi.ptr(rect), ffi.ptr(init_controls), ffi.ptr(scores),
+                                                 ctypes.c_float(float(e7.get("diversity_scale", 1.0))), ctypes.c_float(div_w),
+                                                 int(bool(e7.get("detach", False))), ctypes.c_float(reg_w),
+                                                 ffi.ptr(group_div), ffi.ptr(reg_out), ffi.ptr(reg_work, torch.float64),
+                                                 ffi.ptr(dctrl_extra), ffi.ptr(dscore_div), ffi.stream()), "diversity_loss")
+            dscore = dscore + dscore_div
+            loss_div = -group_div.mean() * div_w
+            self.last = dict(loss_stl=loss, loss_diversity=loss_div, loss_reg=reg_out[0], group_div=group_div)
+            loss = loss + loss_div + reg_out[0] * reg_w
         _, dctrl = self.sm.score_grad(sb, rect, dscore=dscore)
+        if dctrl_extra is not None:
+            dctrl = dctrl + dctrl_extra
         work = torch.empty(self.L.pstl_train_work_floats(ctypes.byref(cfg)), dtype=torch.float32, device=dev)
         shapes = {"rect_net.0.weight": (ffi.HID, ffi.FEAT + 47), "rect_net.0.bias": (ffi.HID,),
                   "rect_net.2.weight": (ffi.HID, ffi.HID), "rect_net.2.bias": (ffi.HID,),
                   "rect_net.4.weight": (ffi.CTRL, ffi.HID), "rect_net.4.bias": (ffi.CTRL,)}
         g = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in self.NAMES}
-        ffi.check(self.L.pstl_refine_backward(ctypes.byref(cfg), self.ctx, ffi.ptr(ffi.f32(w2.detach(), dev)),
-                                              ffi.ptr(ffi.f32(w3.detach(), dev)), ffi.ptr(feature), ffi.ptr(sb.stlp),
-                                              ffi.ptr(sb.hl), ffi.ptr(init_controls), ffi.ptr(prev_scores), ffi.ptr(h1),
-                                              ffi.ptr(h2), ffi.ptr(pre), ffi.ptr(dctrl), ffi.ptr(work),
+        w2c, w3c = ffi.f32(w2.detach(), dev), ffi.f32(w3.detach(), dev)   # named: a converted copy must outlive the launch
+        ffi.check(self.L.pstl_refine_backward(ctypes.byref(cfg), self.ctx, ffi.ptr(w2c),
+                                              ffi.ptr(w3c), ffi.ptr(feature), ffi.ptr(sb.stlp),
+                                              ffi.ptr(sb.hl), ffi.ptr(init_controls), ffi.ptr(pooled), ffi.ptr(prev_scores),
+                                              ffi.ptr(h1), ffi.ptr(h2), ffi.ptr(pre), ffi.ptr(dctrl), ffi.ptr(work),
                                               ffi.ptr(g["rect_net.0.weight"]), ffi.ptr(g["rect_net.0.bias"]),
                                               ffi.ptr(g["rect_net.2.weight"]), ffi.ptr(g["rect_net.2.bias"]),
                                               ffi.ptr(g["rect_net.4.weight"]), ffi.ptr(g["rect_net.4.bias"]),
                                               ffi.stream()), "refine_backward")
-        # loss = mean(relu(thres - score) * valid) / clip(mean(valid), 1e-2): grad_scale is exactly (1/clip)/N
-        loss = parts.sum() * sb.grad_scale
         return loss, rect, scores, g
 
     def train_step(self, sb, params, optimizer, steps, x_T=None, noise=None, seed=None, multi_cands=5, coeffs=None,
-                   group=None):
+                   group=None, e7=None):
         """One optimisation step of config 5 on one batch shard: sampling under no-grad (rollout, candidate scoring and
         selection), RefineNet forward/backward under the STL loss, gradient all-reduce over the ranks (the loss is a
         mean over the GLOBAL batch, so per-rank gradients simply add), optimizer.step() on the caller's parameters.
@@ -468,8 +496,14 @@ class RectTrainer:
         x = sm.fill_normal(sb, steps, steps, seed) if seed is not None else x_T.clone()
         emit = sm.rollout(sb, base_p, x, noise, steps, n_emit=max(multi_cands, 1), clip=True, coeffs=coeffs, seed=seed)
         r = sm.score(sb, emit[-multi_cands:].contiguous(), select=True)
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if e7 is not None and world > 1:
+            # loss_diversity is a mean over the groups of the GLOBAL batch: with equal shards every rank contributes 1/world
+            # (loss_reg's mask_mean is normalised per shard; its weight --rect_reg_loss is 0 in every README command)
+            e7 = dict(e7, diversity_weight=float(e7["diversity_weight"]) / world,
+                      rect_reg_loss=float(e7.get("rect_reg_loss", 0.0)) / world)
         loss, rect, scores, g = self.loss_and_grads(sb, feature, base_r, params["rect_net.2.weight"],
-                                                    params["rect_net.4.weight"], r["sel_controls"], r["sel_scores"])
+                                                    params["rect_net.4.weight"], r["sel_controls"], r["sel_scores"], e7=e7)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             flat = torch.cat([g[k].reshape(-1) for k in self.NAMES] + [loss.reshape(1)])
             dist.all_reduce(flat, group=group)          # 145 704 gradients + the loss: one 583 KB all-reduce

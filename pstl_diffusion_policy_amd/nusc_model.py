@@ -166,9 +166,11 @@ class Net(nn.Module):
         init = ffi.f32(init_controls.reshape(N, -1), dev)
         pooled = torch.empty(N // rps, 3, cfg.n_shards, ffi.CTRL, dtype=torch.float32, device=dev) if diverse else None
         out = torch.empty(N, ffi.CTRL, dtype=torch.float32, device=dev)
+        # converted copies get names: every argument is evaluated before the asynchronous launch, and an unnamed copy
+        # would be freed (and its block handed to the next copy) before the kernel reads it
+        stlp_c, hl_c, sc_c = ffi.f32(stlp_dense_feat, dev), ffi.f32(highlevel.reshape(N), dev), ffi.f32(scores.reshape(N), dev)
         ffi.check(ffi.lib().pstl_refine(ctypes.byref(cfg), ffi.ptr(pw.packed), ffi.ptr(info["base_rect"]),
-                                        ffi.ptr(ffi.f32(stlp_dense_feat, dev)), ffi.ptr(ffi.f32(highlevel.reshape(N), dev)),
-                                        ffi.ptr(init), ffi.ptr(ffi.f32(scores.reshape(N), dev)), ffi.ptr(pooled),
+                                        ffi.ptr(stlp_c), ffi.ptr(hl_c), ffi.ptr(init), ffi.ptr(sc_c), ffi.ptr(pooled),
                                         ffi.ptr(out), ffi.stream()), "refine")
         return out.reshape(N, a.nt, 2)
 

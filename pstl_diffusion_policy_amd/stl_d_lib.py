@@ -146,10 +146,11 @@ class _StlProgramFn(torch.autograd.Function):
         nodes, lists = ctx.prog.device_tables(dev)
         dsig = torch.zeros(n_sig, n, T, dtype=torch.float32, device=dev)
         adj = torch.empty_like(vals)
+        dout_c = ffi.f32(dout, dev)          # named: a contiguous copy must outlive the launch
         ffi.check(ffi.lib().pstl_stl_program_backward(ffi.ptr(nodes, torch.int32), int(nodes.shape[0]),
                                                       ffi.ptr(lists, torch.int32), ctypes.c_int64(n), int(T), ffi.ptr(vals),
                                                       ctypes.c_float(ctx.tau), ctx.hard,
-                                                      ffi.ptr(ffi.f32(dout, dev)), ffi.ptr(adj), ffi.ptr(dsig), ffi.stream()),
+                                                      ffi.ptr(dout_c), ffi.ptr(adj), ffi.ptr(dsig), ffi.stream()),
                   "stl_program_backward")
         return None, None, None, None, dsig
 

@@ -225,11 +225,11 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats")):
     main()
 
 
-def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4):
+def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None):
     """One training step of config 5 (e8_ours_ablation: --rect_head, STL loss through RefineNet; reference
     nusc_train.py:1365-1427 + compute_policy_loss :370-478 + optimizer :1522-1525), driven through the reference's own
     functions.  Stored: inputs, every noise draw, the loss, d loss / d rect_net parameters and the parameters after
@@ -239,10 +239,17 @@ def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4):
             "--diversity_weight", "0.0", "--n_shards", "4", "--interval", "--multi_cands", "5", "--diff_full",
             "--diffusion_steps", str(steps), "--n_randoms", str(S), "--sampling_size", str(S), "--n_neighbors", str(K),
             "--lr", str(lr)]
+    if e7 is not None:   # e7_ours training (README: --stl_weight 0.0 --diverse_loss): DPP diversity loss, merge_net arch
+        argv = ["--diffusion", "--stl_weight", str(e7["stl_weight"]), "--load_stlp", "--rect_head", "--flex",
+                "--diverse_loss", "--multi_cands", "5", "--diversity_weight", str(e7["diversity_weight"]),
+                "--diversity_scale", str(e7.get("diversity_scale", 1.0)), "--rect_reg_loss", str(e7.get("rect_reg_loss", 0.0)),
+                "--diffusion_steps", str(steps), "--n_randoms", str(S), "--sampling_size", str(S), "--n_neighbors", str(K),
+                "--lr", str(lr)] + (["--diverse_detach"] if e7.get("detach") else [])
     args = ref_harness.parse_reference_args(argv)
     args.measure_diversity = False        # CPU-side metric (scipy hull), not part of the loss
     net = ref.nusc_model.Net(args)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items() if not k.startswith("merge_net")}, strict=True)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()
+                         if e7 is not None or not k.startswith("merge_net")}, strict=True)
     optimizer = torch.optim.Adam(net.rect_net.parameters(), lr=args.lr)   # reference :1233 (no --joint)
     coeffs = nt.get_diffusion_coeffs(args)
     stls = nt.build_stl_cache(args)
@@ -296,6 +303,12 @@ def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4):
            "scores": np_(rd["scores"]), "loss": np.float32(rd["loss"].item()), "loss_stl": np.float32(rd["loss_stl"].item()),
            "acc": np.float32(rd["acc"].item()), "feature_scene": np_(feature.reshape(bs, S * 3, -1)[:, 0]),
            "encoder_grad_sqnorm": np.float64(feat_grad_norm)}
+    if e7 is not None:
+        out["loss_diversity"] = np.float32(rd["loss_diversity"].item())
+        out["loss_reg"] = np.float32(rd["loss_reg"].item())
+        out["meta_e7"] = np.array([e7["stl_weight"], e7["diversity_weight"], e7.get("diversity_scale", 1.0),
+                                   e7.get("rect_reg_loss", 0.0), 1.0 if e7.get("detach") else 0.0, args.n_shards],
+                                  dtype=np.float64)
     for k in grads:
         out["grad_rect_net." + k] = np_(grads[k])
         out["after_rect_net." + k] = np_(after[k])
@@ -330,8 +343,21 @@ def main_train():
     sd = dict(np.load(WEIGHTS_FILE))
     train_case(ref, sd, "train_e8_step", bs=3, S=8, K=3, steps=10, seed=31)
     train_case(ref, sd, "train_e8_step_b", bs=4, S=16, K=5, steps=8, seed=32)
+    main_train_e7(ref, sd)
 
 
+def main_train_e7(ref=None, sd=None):
+    ref = ref or ref_harness.load_reference()
+    sd = sd or dict(np.load(WEIGHTS_FILE))
+    train_case(ref, sd, "train_e7_step", bs=3, S=16, K=3, steps=10, seed=33, e7=dict(stl_weight=0.0, diversity_weight=1.0))
+    train_case(ref, sd, "train_e7_step_b", bs=2, S=64, K=4, steps=8, seed=34,
+               e7=dict(stl_weight=1.0, diversity_weight=0.5, diversity_scale=2.0, rect_reg_loss=0.3))
+    train_case(ref, sd, "train_e7_step_c", bs=3, S=8, K=3, steps=8, seed=35,
+               e7=dict(stl_weight=0.5, diversity_weight=1.0, detach=True))
+
+
+if __name__ == "__main__" and "--train-e7" in sys.argv:
+    main_train_e7()
 if __name__ == "__main__" and "--train" in sys.argv:
     main_train()
 if __name__ == "__main__" and "--closed-loop" in sys.argv:

@@ -103,3 +103,69 @@ def test_train_step_reduces_the_loss_and_repacks_weights():
         losses.append(float(loss))
     assert losses[-1] < losses[0], losses
     assert all(np.isfinite(losses))
+
+
+@pytest.mark.parametrize("name", ["train_e7_step", "train_e7_step_b", "train_e7_step_c"])
+def test_e7_diversity_train_step_matches_reference(name):
+    """e7 training objective (--diverse_loss): DPP diversity loss + merge_net architecture, gradients of rect_net."""
+    dev = torch.device("cuda:0")
+    d = load_golden(name)
+    lr = float(d["meta_f"][0])
+    stl_w, div_w, scale, reg_w, detach, n_shards = [float(v) for v in d["meta_e7"]]
+    e7 = dict(stl_weight=stl_w, diversity_weight=div_w, diversity_scale=scale, rect_reg_loss=reg_w, detach=bool(detach))
+    sm, sb, sd, tr = _setup(d, dev)
+    feature, _, base_r = sm.encode(sb)
+    init = torch.from_numpy(d["sel_controls"]).reshape(sb.N, 40).to(dev)
+    prev = torch.from_numpy(d["sel_scores"]).to(dev)
+    loss, rect, scores, g = tr.loss_and_grads(sb, feature, base_r, sd["rect_net.2.weight"], sd["rect_net.4.weight"], init,
+                                              prev, e7=e7)
+    np.testing.assert_allclose(rect.reshape(sb.N, 20, 2).cpu().numpy(), d["rect_controls"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(scores.cpu().numpy(), d["scores"], rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(float(tr.last["loss_diversity"]), float(d["loss_diversity"]), rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(float(tr.last["loss_reg"]), float(d["loss_reg"]), rtol=2e-4)
+    np.testing.assert_allclose(float(loss), float(d["loss"]), rtol=3e-4, atol=1e-5)
+    for k in tr.NAMES:
+        ref = d["grad_" + k]
+        np.testing.assert_allclose(g[k].cpu().numpy(), ref, rtol=5e-3, atol=3e-4 * np.abs(ref).max(), err_msg=k)
+
+
+@pytest.mark.parametrize("S,n_shards,detach", [(64, 4, False), (64, 1, False), (16, 4, True), (32, 2, False)])
+def test_dpp_kernel_matches_oracle(S, n_shards, detach):
+    """pstl_diversity_loss alone: group diversities, d/d rect_controls and d/d scores against torch autograd on the
+    oracle's restatement (float32 torch.inverse there, float64 Gauss-Jordan here)."""
+    import ctypes
+    from oracle import pstl_oracle as orc
+    from pstl_diffusion_policy_amd import ffi
+    from pstl_diffusion_policy_amd.synthetic import default_hparams
+    dev = torch.device("cuda:0")
+    hp = dict(default_hparams(), n_shards=n_shards)
+    bs = 3
+    N = bs * S * 3
+    g = torch.Generator().manual_seed(S + n_shards)
+    rect = (torch.randn(N, 20, 2, generator=g) * torch.tensor([0.1, 1.0])).requires_grad_()
+    scores = (torch.randn(N, generator=g) * 0.6).requires_grad_()
+    init = rect.detach() + torch.randn(N, 20, 2, generator=g) * 0.01
+    ldiv, div = orc.dpp_diversity(rect, scores, bs, S, n_shards, hp, scale=1.5, detach=detach)
+    lreg = orc.mask_mean(torch.square(rect - init), (scores[:, None, None] >= 0).float())
+    (ldiv * 0.7 + lreg * 0.2).backward()
+    cfg = ffi.make_cfg(bs, 3 * S, S, 2, 2, hp)
+    G = bs * 3 * n_shards
+    out = dict(div=torch.empty(G, device=dev), reg=torch.empty(2, device=dev),
+               work=torch.empty(512, dtype=torch.float64, device=dev), dc=torch.empty(N, 40, device=dev),
+               ds=torch.empty(N, device=dev))
+    # device copies must outlive the asynchronous launch: keep them in named variables
+    rect_d = rect.detach().reshape(N, 40).to(dev).contiguous()
+    init_d = init.reshape(N, 40).to(dev).contiguous()
+    scores_d = scores.detach().to(dev).contiguous()
+    ffi.check(ffi.lib().pstl_diversity_loss(ctypes.byref(cfg), ffi.ptr(rect_d), ffi.ptr(init_d), ffi.ptr(scores_d),
+                                            ctypes.c_float(1.5),
+                                            ctypes.c_float(0.7), int(detach), ctypes.c_float(0.2), ffi.ptr(out["div"]),
+                                            ffi.ptr(out["reg"]), ffi.ptr(out["work"], torch.float64), ffi.ptr(out["dc"]),
+                                            ffi.ptr(out["ds"]), ffi.stream()), "diversity_loss")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out["div"].cpu().numpy(), div.detach().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(float(out["reg"][0]), float(lreg), rtol=1e-5)
+    gd = rect.grad.reshape(N, 40).numpy()
+    np.testing.assert_allclose(out["dc"].cpu().numpy(), gd, rtol=2e-3, atol=2e-5 * np.abs(gd).max())
+    gs = scores.grad.numpy() if scores.grad is not None else np.zeros(N, dtype=np.float32)
+    np.testing.assert_allclose(out["ds"].cpu().numpy(), gs, rtol=2e-3, atol=2e-5 * max(np.abs(gs).max(), 1e-6))
