@@ -417,7 +417,7 @@ class RectTrainer:
         except Exception:
             pass
 
-    def loss_and_grads(self, sb, feature, base_rect, w2, w3, init_controls, prev_scores, e7=None):
+    def loss_and_grads(self, sb, feature, base_rect, w2, w3, init_controls, prev_scores, e7=None, stl_weight=1.0):
         """init_controls (N,40) physical units, prev_scores (N,) (both detached in the reference).  w2, w3: the live
         rect_net.2.weight / rect_net.4.weight tensors.  Returns (loss tensor, rect_controls, scores, {name: grad}).
         e7 = None: config 5, loss = mask_mean(relu(thres - score), valid), plain rect_net input.
@@ -440,7 +440,7 @@ class RectTrainer:
         scores = self.sm.score(sb, rect.reshape(1, N, ffi.CTRL))["scores"][0]
         dscore = torch.empty(N, dtype=torch.float32, device=dev)
         parts = torch.empty(256, dtype=torch.float32, device=dev)
-        stl_w = float(e7["stl_weight"]) if merge else 1.0
+        stl_w = float(e7["stl_weight"]) if merge else float(stl_weight)
         ffi.check(self.L.pstl_loss_grad(ctypes.byref(cfg), ffi.ptr(scores), ffi.ptr(sb.valid),
                                         ctypes.c_float(sb.grad_scale * stl_w), ffi.ptr(dscore), ffi.ptr(parts), ffi.stream()),
                   "loss_grad")
@@ -484,7 +484,7 @@ class RectTrainer:
         return loss, rect, scores, g
 
     def train_step(self, sb, params, optimizer, steps, x_T=None, noise=None, seed=None, multi_cands=5, coeffs=None,
-                   group=None, e7=None):
+                   group=None, e7=None, stl_weight=1.0):
         """One optimisation step of config 5 on one batch shard: sampling under no-grad (rollout, candidate scoring and
         selection), RefineNet forward/backward under the STL loss, gradient all-reduce over the ranks (the loss is a
         mean over the GLOBAL batch, so per-rank gradients simply add), optimizer.step() on the caller's parameters.
@@ -503,7 +503,8 @@ class RectTrainer:
             e7 = dict(e7, diversity_weight=float(e7["diversity_weight"]) / world,
                       rect_reg_loss=float(e7.get("rect_reg_loss", 0.0)) / world)
         loss, rect, scores, g = self.loss_and_grads(sb, feature, base_r, params["rect_net.2.weight"],
-                                                    params["rect_net.4.weight"], r["sel_controls"], r["sel_scores"], e7=e7)
+                                                    params["rect_net.4.weight"], r["sel_controls"], r["sel_scores"], e7=e7,
+                                                    stl_weight=stl_weight)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             flat = torch.cat([g[k].reshape(-1) for k in self.NAMES] + [loss.reshape(1)])
             dist.all_reduce(flat, group=group)          # 145 704 gradients + the loss: one 583 KB all-reduce

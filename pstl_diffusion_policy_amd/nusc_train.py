@@ -496,6 +496,53 @@ def run_trajopt(data_loader, args):
     return md
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# RefineNet training (reference main loop nusc_train.py:1237-1632 for --rect_head: configs e7_ours / e8_ours_ablation)
+# ---------------------------------------------------------------------------------------------------------------
+def run_training(data_loader, net, coeffs, args):
+    """Optimises rect_net (the only parameters in the reference's optimiser without --joint, nusc_train.py:1230-1233):
+    per batch, sampling under no-grad, candidate selection, RefineNet forward/backward under
+      --diverse_loss:  loss_stl*stl_weight + loss_reg*rect_reg_loss + loss_diversity      (e7_ours,  :442-467)
+      otherwise:       loss_stl*stl_weight                                                 (e8_ours_ablation, :468-478)
+    and torch.optim.Adam.step().  Writes <model_dir>/model_last.ckpt after every epoch (utils.py:81-85)."""
+    from .engine import RectTrainer
+    if not args.rect_head:
+        raise SystemExit("training of the denoiser itself (e5_ddpm) is outside this path; --rect_head trains RefineNet")
+    if args.joint:
+        raise SystemExit("--joint (gradients into the scene encoders / merge_net) is not implemented")
+    optimizer = torch.optim.Adam(net.rect_net.parameters(), lr=args.lr)
+    params = {"rect_net." + k: p for k, p in net.rect_net.named_parameters()}
+    e7 = None
+    if args.diverse_loss:
+        e7 = dict(stl_weight=args.stl_weight, diversity_weight=args.diversity_weight, diversity_scale=args.diversity_scale,
+                  rect_reg_loss=args.rect_reg_loss, detach=args.diverse_detach)
+    md = MeterDict()
+    step = 0
+    for epi in range(args.epochs):
+        for bi, batch in enumerate(data_loader):
+            batch_cuda = dict_to_cuda(batch)
+            new_batch = {k: batch_cuda[k] for k in ("ego_traj", "neighbors", "currlane_wpts", "leftlane_wpts",
+                                                    "rightlane_wpts", "curr_id", "left_id", "right_id", "gt_high_level",
+                                                    "pre_stlp")}
+            new_batch["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
+            new_batch = augment_batch_data(new_batch, batch_cuda["stlp_modes"][:, 0], args)
+            sb = new_batch["_pstl"]
+            tr = RectTrainer(Sampler(net.packed(), net.hparams()))     # packed() re-packs after the optimiser moved weights
+            step += 1
+            loss, scores = tr.train_step(sb, params, optimizer, args.diffusion_steps, seed=args.seed * 100003 + step,
+                                         multi_cands=args.multi_cands or 1, coeffs=coeffs, e7=e7, stl_weight=args.stl_weight)
+            counts, _ = tr.sm.metrics(sb, scores)
+            acc, _ = acc_from_counts(counts)
+            md.update("loss", float(loss))
+            md.update("acc", acc)
+            if bi % args.print_freq == 0:
+                print("epoch %03d batch %03d loss %.5f (avg %.5f) acc %.3f" % (epi, bi, md["loss"], md("loss"), md["acc"]))
+        if args.model_dir:
+            from . import nusc_dataset
+            nusc_dataset.save_checkpoint(net.state_dict(), args.model_dir)
+    return md
+
+
 def generate_parser(argv=None):
     """The reference's flags and post-parse overrides (nusc_train.py:1635-1814)."""
     parser = argparse.ArgumentParser("")
@@ -582,6 +629,12 @@ def generate_parser(argv=None):
     add("--opt_epochs", type=int, default=0)
     add("--reg_loss", type=float, default=10.0)
     add("--model_dir", type=str, default=None, help="where params_*.npy / scores_*.npy go (reference: exps/<run>/models)")
+    add("--rect_reg_loss", type=float, default=0.0)
+    add("--joint", action="store_true", default=False)
+    add("--diversity_weight", type=float, default=1.0)
+    add("--diversity_scale", type=float, default=1.0)
+    add("--diverse_detach", action="store_true", default=False)
+    add("--print_freq", type=int, default=10)
     add("--offline", action="store_true", default=False)
     add("--cache_path", type=str, default=None,
         help="experiment directory holding cache.npz, *_split.txt and models/ (nusc_dataset.write_synthetic_experiment); "
@@ -618,8 +671,6 @@ def main(argv=None):
             import os
             args.model_dir = os.path.join(args.cache_path, "models")
         return run_trajopt(loader_for("train", n_batches=min(args.n_trials, 2)), args)
-    if not args.run_sampling_test:
-        raise SystemExit("only --run_sampling_test (the sampling + STL hot path) and --trajopt_only are implemented on MI355X")
     if args.sampling_size != args.n_randoms:
         raise SystemExit("--sampling_size must equal --n_randoms (merge_net pooling, reference nusc_model.py:187-196)")
     torch.manual_seed(args.seed)
@@ -637,6 +688,13 @@ def main(argv=None):
         else:
             print("checkpoint %s not found: running with random-init weights (seed %d)" % (path, args.seed))
     coeffs = get_diffusion_coeffs(args)
+    if not args.run_sampling_test:
+        if args.test:
+            raise SystemExit("--test without --run_sampling_test: nothing to do on this path")
+        if args.cache_path and not args.model_dir:
+            import os
+            args.model_dir = os.path.join(args.cache_path, "models")
+        return run_training(loader_for("train", n_batches=min(args.n_trials, 4)), net, coeffs, args)
     return run_sampling_test(stls_cac, loader, net, coeffs, args, None, None)
 
 

@@ -34,3 +34,25 @@ def test_sampling_test_and_trajopt_from_files(tmp_path, capsys):
     assert sc.shape == (8, 3) and np.isfinite(sc).all()
     ds = nd.get_dataloader(nt.generate_parser(base), root, split="train").dataset
     assert torch.equal(ds[0]["params"], torch.from_numpy(after))
+
+
+def test_refinenet_training_from_files_updates_the_checkpoint(tmp_path, capsys):
+    """README training commands of the RefineNet configs (e7_ours: --diverse_loss --stl_weight 0; e8_ours_ablation:
+    --stl_weight 1 --diversity_weight 0) through the CLI mirror: only rect_net moves, model_last.ckpt is rewritten."""
+    from pstl_diffusion_policy_amd import nusc_dataset as nd
+    from pstl_diffusion_policy_amd import nusc_train as nt
+    from pstl_diffusion_policy_amd.nusc_model import init_state_dict
+    root = str(tmp_path / "e7")
+    base = ["--diffusion", "--load_stlp", "--n_randoms", "16", "--sampling_size", "16", "--n_neighbors", "3", "--batch_size", "4",
+            "--diffusion_steps", "10", "--cache_path", root, "--rect_head", "--flex", "--multi_cands", "3", "--epochs", "2",
+            "--lr", "1e-3", "--print_freq", "1"]
+    nd.write_synthetic_experiment(root, 12, nt.generate_parser(base), seed=6)
+    sd0 = init_state_dict(1007)
+    for extra in (["--diverse_loss", "--stl_weight", "0.0"], ["--stl_weight", "1.0", "--diversity_weight", "0.0"]):
+        nd.save_checkpoint(sd0, os.path.join(root, "models"))
+        md = nt.main(base + extra + ["-P", nd.smart_path(root)])
+        assert np.isfinite(md("loss"))
+        sd1 = torch.load(nd.smart_path(root), map_location="cpu")
+        moved = {k for k in sd1 if k in sd0 and not torch.equal(sd1[k], sd0[k].cpu())}
+        assert moved and all(k.startswith("rect_net.") for k in moved), moved
+    assert "epoch 001" in capsys.readouterr().out
