@@ -29,7 +29,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="e7_guid", choices=["e5", "e7", "e7_guid", "e8_train"])
+    p.add_argument("--workload", default="e7_guid", choices=["e5", "e7", "e7_guid", "e8_train", "e7_train", "trajopt"])
     p.add_argument("--scenes", type=int, default=4096, help="scenes per GPU (weak scaling)")
     p.add_argument("--sampling_size", type=int, default=64)
     p.add_argument("--neighbors", type=int, default=2)
@@ -40,6 +40,7 @@ def parse():
                    help="kernel: Philox noise drawn inside the HIP kernels; torch: torch.randn tensors (parity mode)")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_scenes", type=int, default=24)
+    p.add_argument("--trajopt_iters", type=int, default=50, help="Adam iterations per step of the trajopt workload")
     return p.parse_args()
 
 
@@ -92,12 +93,14 @@ def main():
     hp = default_hparams()
     rect_head = a.workload != "e5"
     guidance = dict(enabled=True, before=10, niters=1, lr=0.01) if a.workload == "e7_guid" else None
-    train = a.workload == "e8_train"     # config 5: one optimisation step of RefineNet under the STL loss
+    train = a.workload in ("e8_train", "e7_train")   # one optimisation step of RefineNet: config 5 / e7
+    e7 = dict(stl_weight=0.0, diversity_weight=1.0) if a.workload == "e7_train" else None
+    trajopt = a.workload == "trajopt"    # N4: the data-augmentation loop, trajopt_iters Adam iterations per step
     sd = init_state_dict(1007)     # random init as in the reference under seed 1007 (no checkpoints offline)
     S, steps, bs = a.sampling_size, a.diffusion_steps, a.scenes
     # every rank owns its own contiguous block of scenes (seeded by the global scene offset); no data-path collective
     scene = make_scene_batch(bs, K=a.neighbors, S=S, seed=1000 + rank, invalid_lane_frac=0.2, stlp_mode="wide")
-    scene = {k: v.to(dev) for k, v in scene.items() if k not in ("params", "pre_stlp", "tj_scores_prior")}
+    scene = {k: v.to(dev) for k, v in scene.items() if k not in ("pre_stlp", "tj_scores_prior")}
     sampler = Sampler(PackedWeights(sd, dev), hp, chain_waves=a.chain_waves)
     if train:
         from pstl_diffusion_policy_amd.engine import RectTrainer
@@ -123,11 +126,16 @@ def main():
             x_T = z = None
             call[0] += 1
             seed = 987654321 + call[0]
+        if trajopt:
+            params = scene["params"].reshape(N, 40).clone()
+            sc, _ = sampler.trajopt(sb, params, a.trajopt_iters, 0.005, 0.01, 10.0, global_valid_sum=vsum, global_rows=vrows)
+            counts, _ = sampler.metrics(sb, sc)
+            return gather_final(counts, torch.zeros(12, dtype=torch.float64, device=dev))
         if train:
             sm_t = Sampler(PackedWeights(sd_live, dev), hp, chain_waves=a.chain_waves)   # weights changed: re-pack
             sm_t.trace = sampler.trace
             loss, scores = RectTrainer(sm_t).train_step(sb, tparams, topt, steps, x_T=x_T, noise=z, seed=seed,
-                                                        multi_cands=a.multi_cands, coeffs=coeffs)
+                                                        multi_cands=a.multi_cands, coeffs=coeffs, e7=e7)
             counts, _ = sm_t.metrics(sb, scores)
             return gather_final(counts, torch.zeros(12, dtype=torch.float64, device=dev))
         out = sampler.sampling_region(sb, steps, x_T, z, rect_head=rect_head,
@@ -156,6 +164,20 @@ def main():
     dt = float(tmax.item())
 
     # dominant kernel (k_chain, the multi-step denoiser launch): HIP events on the launch stream
+    if trajopt:   # no denoiser in this workload: report row-iterations/s and stop
+        if rank == 0:
+            print(json.dumps({"metric": "traj-opt row-iterations/sec (STL forward + adjoint + Adam per row and iteration)",
+                              "value": world * N * a.trajopt_iters * a.steps / dt, "unit": "row-iterations/s",
+                              "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                              "data": "synthetic",
+                              "config": {"workload": "trajopt: %d scenes x %d x 3 = %d rows/GPU, K=%d, %d Adam iterations per "
+                                                     "step in one launch" % (bs, S, N, a.neighbors, a.trajopt_iters)},
+                              "stl_sat_rate": acc_from_counts(counts)[0]}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     ms = [e0.elapsed_time(e1) for (e0, e1, _, _) in sampler.trace]
     nst, nrows = sampler.trace[0][2], sampler.trace[0][3]
     k_ms = float(np.mean(ms))

@@ -150,6 +150,14 @@ int pstl_stl_forward(const pstl_cfg* cfg, const float* s0 /* (bs,4) */, const fl
                      float* scores, float* scores3, float* sel_controls, float* sel_scores, int32_t* sel_idx,
                      void* stream);
 
+/* prep_stl_cache (nusc_train.py:74-93): the seven signals the formulas read, signals (7,N,T) = x2curr_d, x2curr_th,
+ * x2left_d, x2left_th, x2right_d, x2right_th (compute_t2l_dist, nusc_api.py:685-739) and min_nei_d
+ * (compute_shortest_dist_refined, nusc_train.py:142-148), for given states (N,T,4) or for the rollout of controls (N,40)
+ * from s0 (bs,4) (states == null).  The fused scoring kernels never materialise these; this entry point serves callers of
+ * prep_stl_cache and the generic formula evaluator (--norm_stl). */
+int pstl_stl_signals(const pstl_cfg* cfg, const float* s0, const float* controls, const float* states,
+                     const float* nei_prep, const float* lane_prep, float* signals, void* stream);
+
 /* dcontrols[r] = dscore[r] * d score[r] / d controls[r]   (what autograd gives through compute_stl_dense +
  * generate_trajs).  dscore null = all ones. */
 int pstl_stl_backward(const pstl_cfg* cfg, const float* s0, const float* controls, const float* nei_prep,

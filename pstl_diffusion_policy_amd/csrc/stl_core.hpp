@@ -55,7 +55,9 @@ constexpr int kNeiPrep = 12;  // floats per prepared (neighbour, t)
 // the adjoint additionally keeps x_t, y_t (heading and speed are re-derived from the controls, see stl_eval_grad)
 constexpr int kScratchFwd = 2 * kFwin;       // selected formula only
 constexpr int kScratchFwd3 = 4 * kFwin;      // all three formulas (left and right lane)
-constexpr int kScratchGrad = 2 * kT + 2 * kFwin;
+constexpr int kCkStride = 4;                     // heading/speed checkpoints every 4 steps (adjoint replays <= 3 steps)
+constexpr int kCk = kT / kCkStride;               // 5 checkpoints
+constexpr int kScratchGrad = 2 * kT + 2 * kFwin + 2 * kCk;
 
 struct alignas(16) f4 {
   float x, y, z, w;
@@ -393,6 +395,10 @@ PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, cons
     if (XY >= 0) {
       st.at(XY + t) = x;
       st.at(XY + kT + t) = y;
+      if ((t & (kCkStride - 1)) == 0) {   // checkpoints of heading and speed for the adjoint's replay
+        st.at(XY + 2 * kT + 2 * kFwin + t / kCkStride) = th;
+        st.at(XY + 2 * kT + 2 * kFwin + kCk + t / kCkStride) = v;
+      }
     }
     gv1.add(-(v - r.vmin) * tau);
     gv2.add(-(-v + r.vmax) * tau);
@@ -460,10 +466,10 @@ PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, cons
 // Forward + adjoint of one row: returns the score and calls emit(t, gw, ga) once for every t in [0,T) with
 // (gw, ga) = dscore_fn(score) * d score / d (u[2t], u[2t+1])  (u = the 40 control values, scaled by wscale/ascale
 // inside the dynamics).  Only the formula of r.mode carries gradient (the others are multiplied by a 0 mask in the
-// reference).  Scratch: kScratchGrad floats per lane = x_t, y_t (2T) + the two suffix tables (2*10).  Heading and
-// speed at time t are re-derived from the controls by the very same chain of additions the forward sweep performed
-// (O(T^2) = 190 cheap steps per row), which keeps them bit-identical without storing them -- 40 % less LDS per
-// wavefront, i.e. more resident wavefronts.
+// reference).  Scratch: kScratchGrad floats per lane = x_t, y_t (2T) + the two suffix tables (2*10) + heading/speed
+// checkpoints every 4th step (2*5).  Heading and speed at time t are re-derived from the last checkpoint by the very
+// same additions the forward sweep performed (<= 3 steps, 30 in total per row instead of 190 from t = 0), which keeps
+// them bit-identical to the forward values at 30 % of the LDS a full (th_t, v_t) table would take.
 // ---------------------------------------------------------------------------------------------------------------
 template <class DScoreFn, class EmitFn>
 PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, const float* s0,
@@ -476,7 +482,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     return 1.0f;
   }
   const f4* lane = lanes + mode * kNseg;
-  const int XY = 0, LB = 2 * kT, LT = 2 * kT + kFwin;
+  const int XY = 0, LB = 2 * kT, LT = 2 * kT + kFwin, CKP = 2 * kT + 2 * kFwin;
   // ---- forward sweep ------------------------------------------------------------------------------------------
   FwdOut fo;
   const float score = stl_eval<false, 0>(env, r, lanes, nei, K, DynSrc(s0, u, wscale, ascale, env.dt), st, LB, nullptr, &fo);
@@ -520,9 +526,10 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   PSTL_NOUNROLL
   for (int t = kT - 1; t >= 1; --t) {
     const float x = st.at(XY + t), y = st.at(XY + kT + t);
-    float th = s0[2], v = s0[3];
+    const int ck = t / kCkStride;
+    float th = st.at(CKP + ck), v = st.at(CKP + kCk + ck);
     PSTL_NOUNROLL
-    for (int q = 0; q < t; ++q) {  // the forward sweep's own additions, replayed
+    for (int q = ck * kCkStride; q < t; ++q) {  // the forward sweep's own additions, replayed from the last checkpoint
       th = th + (u[2 * q] * wscale) * dt;
       v = v + (u[2 * q + 1] * ascale) * dt;
     }

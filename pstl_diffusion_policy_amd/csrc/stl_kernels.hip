@@ -336,6 +336,37 @@ __global__ __launch_bounds__(kWave) void k_trajopt(TrajoptArgs a) {
   if (a.scores) a.scores[row] = score;
 }
 
+// prep_stl_cache (nusc_train.py:74-93): the seven signals the formulas read, per row and time step --
+// signed lateral distance and heading error to the current / left / right lane (compute_t2l_dist, nusc_api.py:685-739)
+// and the clearance to the closest neighbour (compute_shortest_dist_refined, nusc_train.py:142-148).
+// out (7, N, T): x2curr_d, x2curr_th, x2left_d, x2left_th, x2right_d, x2right_th, min_nei_d.
+__global__ __launch_bounds__(kWave) void k_stl_signals(long N, int rows_per_scene, int K, StlEnv env, const float* s0,
+                                                       const float* controls, const float* states, const float* nei_prep,
+                                                       const float* lane_prep, float* out) {
+  const long row = (long)blockIdx.x * kWave + threadIdx.x;
+  if (row >= N) return;
+  const long b = row / rows_per_scene;
+  const f4* lanes = reinterpret_cast<const f4*>(lane_prep) + b * 3 * kNseg;
+  const float* nei = nei_prep + b * (long)K * kT * kNeiPrep;
+  DynSrc dyn(s0 ? s0 + b * 4 : lane_prep, controls ? controls + row * (2 * kT) : lane_prep, 1.0f, 1.0f, env.dt);
+  GivenSrc giv{states ? reinterpret_cast<const f4*>(states) + row * kT : nullptr};
+  const long plane = N * kT;
+  for (int t = 0; t < kT; ++t) {
+    float x, y, th, v, c, s;
+    if (states) giv.get(t, x, y, th, v, c, s); else dyn.get(t, x, y, th, v, c, s);
+    float* o = out + row * kT + t;
+    for (int m = 0; m < 3; ++m) {
+      LaneHit h;
+      lane_eval<false>(lanes + m * kNseg, x, y, th, h);
+      o[(2 * m) * plane] = h.d;
+      o[(2 * m + 1) * plane] = h.th;
+    }
+    ClearHit ch;
+    clearance_eval<false>(env, nei, K, t, x, y, c, s, ch);
+    o[6 * plane] = ch.dn;
+  }
+}
+
 // generate_trajs (nusc_train.py:39-49): T+1 states per row
 __global__ void k_generate_trajs(long R, int rows_per_scene, const float* s0, const float* controls, float dt,
                                  float* trajs) {
@@ -627,6 +658,17 @@ extern "C" int pstl_trajopt(const pstl_cfg* cfg, const float* s0, const float* n
   void (*fn)(TrajoptArgs) = staged ? k_trajopt<true> : k_trajopt<false>;
   if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
   hipLaunchKernelGGL(fn, dim3((unsigned)((a.N + kWave - 1) / kWave)), dim3(kWave), lds, as_stream(stream), a);
+  return launch_status();
+}
+
+extern "C" int pstl_stl_signals(const pstl_cfg* cfg, const float* s0, const float* controls, const float* states,
+                                const float* nei_prep, const float* lane_prep, float* signals, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!lane_prep || !signals || (!states && (!s0 || !controls)) || (cfg->K > 0 && !nei_prep)) return PSTL_ERR_ARG;
+  const long N = n_rows(cfg);
+  hipLaunchKernelGGL(k_stl_signals, dim3((unsigned)((N + kWave - 1) / kWave)), dim3(kWave), 0, as_stream(stream), N,
+                     cfg->rows_per_scene, cfg->K, make_env(cfg->tau, cfg->dt, cfg->ego_L, cfg->ego_W), s0, controls, states,
+                     nei_prep, lane_prep, signals);
   return launch_status();
 }
 

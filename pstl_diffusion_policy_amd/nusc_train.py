@@ -187,36 +187,77 @@ def pre_prepare_stl_cache(batch_cuda, dense_trajs=None, detach=False, repeat_n=N
     return stl_input
 
 
-def compute_stl_dense(stl_input, stls_cac, stl_idx, mask, args, debug=False, tj_scores=None, scene=False):
-    """Scores trajectories stl_input["ego_traj"] (R,T,4) (reference nusc_train.py:318-345).
-    Returns (scores_list [curr, left, right, ones], scores (R,), acc[, scene_acc])."""
-    traj = stl_input["ego_traj"]
-    dev = traj.device
-    R = traj.shape[0]
-    states = ffi.f32(traj[..., :4], dev).reshape(R, ffi.T, 4)
-    hp = _hp(args)
+def _scene_tables(stl_input, R, dev, hp):
+    """The prepared scene tables the STL kernels read, from either layout a caller may hand over: the scene-indexed side
+    channel `_pstl` (nothing replicated per row) or the reference's dense per-row tensors (rows_per_scene = 1).
+    Returns (cfg, s0, nei_prep, lane_prep, stlp, reps, n_per)."""
     sb = stl_input.get("_pstl")
     reps = stl_input.get("_pstl_reps", 1)
     if sb is not None and sb.N * reps == R:
-        n_per, s0 = sb.N, sb.s0
-        nei_prep, lane_prep, stlp = sb.nei_prep, sb.lane_prep, sb.stlp
-        hl = ffi.f32(stl_idx.reshape(reps, n_per)[0], dev)
-        cfg = sb.cfg(2)
-        states = states.reshape(reps, n_per, ffi.T, 4)
-    else:   # the reference's dense layout: every row carries its own scene tensors
-        nei = ffi.f32(stl_input["neighbors"][..., :7], dev)
-        lanes = [ffi.f32(stl_input["%slane_wpts" % k], dev) for k in ("curr", "left", "right")]
-        K = nei.shape[1]
-        cfg = ffi.make_cfg(R, 1, 1, K, 2, hp)
-        nei_prep = torch.empty(R, K, ffi.T, ffi.NEI_PREP, dtype=torch.float32, device=dev)
-        lane_prep = torch.empty(R, 3, ffi.NSEG, 4, dtype=torch.float32, device=dev)
-        ffi.check(ffi.lib().pstl_prepare_scene(ctypes.byref(cfg), ffi.ptr(nei), ffi.ptr(lanes[0]), ffi.ptr(lanes[1]),
-                                               ffi.ptr(lanes[2]), ffi.ptr(nei_prep), ffi.ptr(lane_prep), ffi.stream()),
-                  "prepare_scene")
-        stlp = ffi.f32(stl_input["stlp"].reshape(R, 6), dev)
-        hl = ffi.f32(stl_idx.reshape(R), dev)
-        reps, n_per, s0 = 1, R, None
-        states = states.reshape(1, R, ffi.T, 4)
+        return sb.cfg(2), sb.s0, sb.nei_prep, sb.lane_prep, sb.stlp, reps, sb.N
+    nei = ffi.f32(stl_input["neighbors"][..., :7], dev)
+    lanes = [ffi.f32(stl_input["%slane_wpts" % k], dev) for k in ("curr", "left", "right")]
+    K = nei.shape[1]
+    cfg = ffi.make_cfg(R, 1, 1, K, 2, hp)
+    nei_prep = torch.empty(R, K, ffi.T, ffi.NEI_PREP, dtype=torch.float32, device=dev)
+    lane_prep = torch.empty(R, 3, ffi.NSEG, 4, dtype=torch.float32, device=dev)
+    ffi.check(ffi.lib().pstl_prepare_scene(ctypes.byref(cfg), ffi.ptr(nei), ffi.ptr(lanes[0]), ffi.ptr(lanes[1]),
+                                           ffi.ptr(lanes[2]), ffi.ptr(nei_prep), ffi.ptr(lane_prep), ffi.stream()),
+              "prepare_scene")
+    return cfg, None, nei_prep, lane_prep, ffi.f32(stl_input["stlp"].reshape(R, 6), dev), 1, R
+
+
+SIGNAL_KEYS = ("x2curr_d", "x2curr_th", "x2left_d", "x2left_th", "x2right_d", "x2right_th", "min_nei_d")
+
+
+def prep_stl_cache(x, args):
+    """Adds the seven signals of the formulas to x IN PLACE, as the reference does (nusc_train.py:74-93): x2*_d / x2*_th
+    (signed lateral distance and heading error to the three lanes) and min_nei_d (clearance to the closest neighbour),
+    each (R,T) for x["ego_traj"] (R,T,>=4); with --norm_stl also the three normalisation factors (:88-91)."""
+    traj = x["ego_traj"]
+    dev = traj.device
+    R = traj.shape[0]
+    cfg, _, nei_prep, lane_prep, stlp, reps, n_per = _scene_tables(x, R, dev, _hp(args))
+    states = ffi.f32(traj[..., :4], dev).reshape(R, ffi.T, 4)
+    sig = torch.empty(7, reps, n_per, ffi.T, dtype=torch.float32, device=dev)
+    for r in range(reps):   # the scene tables repeat per candidate block (repeat_n of pre_prepare_stl_cache)
+        out_r = torch.empty(7, n_per, ffi.T, dtype=torch.float32, device=dev)
+        st_r = states.reshape(reps, n_per, ffi.T, 4)[r].contiguous()
+        ffi.check(ffi.lib().pstl_stl_signals(ctypes.byref(cfg), ffi.ptr(None), ffi.ptr(None), ffi.ptr(st_r), ffi.ptr(nei_prep),
+                                             ffi.ptr(lane_prep), ffi.ptr(out_r), ffi.stream()), "stl_signals")
+        sig[:, r] = out_r
+    for i, k in enumerate(SIGNAL_KEYS):
+        x[k] = sig[i].reshape(R, ffi.T)
+    if "stlp" not in x or x["stlp"].shape[0] != R:
+        x["stlp"] = stlp.reshape(n_per, 1, 6).repeat(reps, 1, 1)
+    if getattr(args, "norm_stl", False):
+        p = x["stlp"]
+        x["v_factor"] = torch.clip(p[..., I_VMAX] - p[..., I_VMIN], 0.3)
+        x["d_factor"] = torch.clip((p[..., I_DMAX] - p[..., I_DMIN]) * 5, 0.3)
+        x["safe_factor"] = torch.clip(p[..., I_DSAFE], 0.3)
+    return x
+
+
+def compute_stl_dense(stl_input, stls_cac, stl_idx, mask, args, debug=False, tj_scores=None, scene=False):
+    """Scores trajectories stl_input["ego_traj"] (R,T,4) (reference nusc_train.py:318-345).
+    Returns (scores_list [curr, left, right, ones], scores (R,), acc[, scene_acc]).
+    Default: the fused kernel (pstl_stl_forward) evaluates the three fixed formulas without materialising any signal.
+    --norm_stl: the signals are prepared (prep_stl_cache) and the formula objects of build_stl_cache are evaluated by the
+    generic program kernel, as the reference's code path reads (:319-323)."""
+    traj = stl_input["ego_traj"]
+    dev = traj.device
+    R = traj.shape[0]
+    hp = _hp(args)
+    if getattr(args, "norm_stl", False):
+        x = prep_stl_cache(stl_input, args)
+        scores_list = [stl(x, args.smoothing_factor)[:, 0] for stl in stls_cac]
+        scores_list.append(torch.ones_like(scores_list[0]))
+        scores = get_stl_scores(scores_list, stl_idx.reshape(R).to(dev))
+        return _stl_metrics_tail(stl_input, scores_list, scores, mask, args, debug, tj_scores, scene)
+    states = ffi.f32(traj[..., :4], dev).reshape(R, ffi.T, 4)
+    cfg, s0, nei_prep, lane_prep, stlp, reps, n_per = _scene_tables(stl_input, R, dev, hp)
+    hl = ffi.f32(stl_idx.reshape(reps, n_per)[0], dev)
+    states = states.reshape(reps, n_per, ffi.T, 4)
     scores = torch.empty(reps, n_per, dtype=torch.float32, device=dev)
     s3 = torch.empty(3, reps, n_per, dtype=torch.float32, device=dev)
     ffi.check(ffi.lib().pstl_stl_forward(ctypes.byref(cfg), ffi.ptr(s0), ffi.ptr(None), ffi.ptr(states), int(reps),
@@ -226,6 +267,10 @@ def compute_stl_dense(stl_input, stls_cac, stl_idx, mask, args, debug=False, tj_
     scores = scores.reshape(R)
     scores_list = [s3[0].reshape(R), s3[1].reshape(R), s3[2].reshape(R)]
     scores_list.append(torch.ones_like(scores))
+    return _stl_metrics_tail(stl_input, scores_list, scores, mask, args, debug, tj_scores, scene)
+
+
+def _stl_metrics_tail(stl_input, scores_list, scores, mask, args, debug, tj_scores, scene):
     mask_flat = mask.reshape(-1).to(scores.dtype)
     if getattr(args, "oracle_filter", False) and tj_scores is not None:
         cube = torch.max(tj_scores.reshape(-1, args.n_randoms, 3), dim=1, keepdim=True)[0]

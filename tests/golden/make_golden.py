@@ -152,11 +152,12 @@ def sampling_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=
         os.path.getsize(path) / 1024))
 
 
-def stl_case(ref, name, bs, S, K, seed, invalid_lane_frac, stlp_mode, ctrl_scale):
+def stl_case(ref, name, bs, S, K, seed, invalid_lane_frac, stlp_mode, ctrl_scale, norm_stl=False):
     """STL robustness + gradients w.r.t. the controls, on small random controls (mixed satisfied/violated rows)."""
     nt = ref.nusc_train
     args = ref_harness.parse_reference_args(
-        ["--diffusion", "--load_stlp", "--sampling_size", str(S), "--n_randoms", str(S), "--n_neighbors", str(K)])
+        ["--diffusion", "--load_stlp", "--sampling_size", str(S), "--n_randoms", str(S), "--n_neighbors", str(K)]
+        + (["--norm_stl"] if norm_stl else []))
     stls = nt.build_stl_cache(args)
     batch = make_scene_batch(bs, K=K, S=S, seed=seed, invalid_lane_frac=invalid_lane_frac, stlp_mode=stlp_mode)
     N = bs * S * 3
@@ -225,7 +226,7 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl")):
     main()
 
 
@@ -540,3 +541,12 @@ def main_formats():
 
 if __name__ == "__main__" and "--formats" in sys.argv:
     main_formats()
+
+
+def main_norm_stl():
+    ref = ref_harness.load_reference()
+    stl_case(ref, "stl_norm", bs=5, S=8, K=4, seed=24, invalid_lane_frac=0.3, stlp_mode="loose", ctrl_scale=0.03, norm_stl=True)
+
+
+if __name__ == "__main__" and "--norm-stl" in sys.argv:
+    main_norm_stl()

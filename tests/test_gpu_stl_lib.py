@@ -93,3 +93,48 @@ def test_build_stl_cache_formulas_match_fused_kernel_and_reference(dev, name):
     for m in range(3):
         s = stls[m](x, args.smoothing_factor)[:, 0].cpu().numpy()
         np.testing.assert_allclose(s, d["scores3"][m], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["stl_mixed", "stl_mixed_k8", "stl_wild", "stl_norm"])
+def test_prep_stl_cache_signals_match_reference(dev, name):
+    """prep_stl_cache (pstl_stl_signals): the seven (R,T) signals against the reference's compute_t2l_dist /
+    compute_shortest_dist_refined outputs, from the dense per-row layout AND the scene-indexed side channel."""
+    from conftest import load_golden, scene_from_golden
+    from pstl_diffusion_policy_amd import nusc_train as nt
+    from pstl_diffusion_policy_amd.engine import SceneBatch
+    d = load_golden(name)
+    bs, S, K, seed = [int(v) for v in d["meta"]]
+    args = nt.generate_parser(["--diffusion", "--load_stlp", "--n_randoms", str(S), "--sampling_size", str(S)])
+    traj = torch.from_numpy(d["trajs"][:, :-1]).to(dev)
+    m = 3 * S
+    dense = {"ego_traj": traj, "stlp": torch.from_numpy(d["in_stlp_dense"]).to(dev),
+             "neighbors": nt.dup(torch.from_numpy(d["in_neighbors_traj"]), m).to(dev)}
+    for k in ("curr", "left", "right"):
+        dense["%slane_wpts" % k] = nt.dup(torch.from_numpy(d["in_%slane_wpts" % k]), m).to(dev)
+    sb = SceneBatch({k: torch.from_numpy(v) for k, v in scene_from_golden(d).items()}, S, nt._hp(args), dev)
+    side = {"ego_traj": traj, "stlp": dense["stlp"], "_pstl": sb}
+    for x in (nt.prep_stl_cache(dense, args), nt.prep_stl_cache(side, args)):
+        for k in nt.SIGNAL_KEYS:
+            got, want = x[k].cpu().numpy(), d["sig_" + k]
+            tol = 2e-4 if k.endswith("_d") else 2e-6     # distances ~1e2 m computed from world coordinates ~1e3
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=tol, err_msg=k)
+
+
+def test_norm_stl_variant_matches_reference(dev):
+    """--norm_stl (nusc_train.py:88-91,97-113): signals by pstl_stl_signals, formulas by the generic program kernel."""
+    from conftest import load_golden, scene_from_golden
+    from pstl_diffusion_policy_amd import nusc_train as nt
+    from pstl_diffusion_policy_amd.engine import SceneBatch
+    d = load_golden("stl_norm")
+    bs, S, K, seed = [int(v) for v in d["meta"]]
+    args = nt.generate_parser(["--diffusion", "--load_stlp", "--norm_stl", "--n_randoms", str(S), "--sampling_size", str(S)])
+    stls = nt.build_stl_cache(args)
+    sb = SceneBatch({k: torch.from_numpy(v) for k, v in scene_from_golden(d).items()}, S, nt._hp(args), dev)
+    x = {"ego_traj": torch.from_numpy(d["trajs"][:, :-1]).to(dev), "stlp": torch.from_numpy(d["in_stlp_dense"]).to(dev),
+         "_pstl": sb}
+    hl = torch.from_numpy(d["in_highlevel_dense"]).to(dev)
+    valid = torch.from_numpy(d["in_valids_dense"]).to(dev)
+    scores_list, scores, acc, scene_acc = nt.compute_stl_dense(x, stls, hl, valid, args, scene=True)
+    np.testing.assert_allclose(torch.stack(scores_list[:3]).cpu().numpy(), d["scores3"], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(scores.cpu().numpy(), d["scores"], rtol=1e-4, atol=2e-4)
+    assert float(acc) == pytest.approx(float(d["acc"]), abs=1e-6) and float(scene_acc) == pytest.approx(float(d["scene_acc"]), abs=1e-6)
