@@ -1,0 +1,112 @@
+"""Edge cases of the hot path on the GPU, against the CPU oracle: ragged and minimal sizes (row counts that are not a
+multiple of the 16-row MFMA tile or the 64-lane wavefront), a single neighbour, every lane invalid, the shortest and the
+longest diffusion schedule (segments longer than one launch), and the error behaviour of the C ABI (status codes, never
+an exception or a crash)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_weights
+
+pytestmark = pytest.mark.gpu
+TRAJ_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    from pstl_diffusion_policy_amd import ffi
+    ffi.lib()
+    return torch.device("cuda:0")
+
+
+def _hp():
+    from pstl_diffusion_policy_amd.synthetic import default_hparams
+    return default_hparams()
+
+
+def _both(dev, scene, S, steps, seed, **kw):
+    from oracle import pstl_oracle as orc
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler, acc_from_counts
+    hp = dict(_hp(), n_shards=kw.pop("n_shards", 4))
+    sd = golden_weights()
+    bs = scene["ego_traj"].shape[0]
+    N = bs * S * 3
+    g = torch.Generator().manual_seed(seed)
+    x_T = torch.randn(N, 40, generator=g)
+    z = torch.randn(steps - 1, N, 40, generator=g)
+    ref = orc.sampling_region(sd, {k: v.numpy() for k, v in scene.items()}, S, steps, hp, x_T, z, n_shards=hp["n_shards"], **kw)
+    sm = Sampler(PackedWeights(sd, dev), hp)
+    out = sm.sampling_region(SceneBatch(scene, S, hp, dev), steps, x_T.to(dev), z.to(dev), **kw)
+    torch.cuda.synchronize()
+    err = (out["final_controls"].reshape(N, 20, 2).cpu() - ref["final_controls"]).abs().max().item()
+    assert err <= TRAJ_TOL, err
+    np.testing.assert_allclose(out["final_scores"].cpu().numpy(), ref["final_scores"].numpy(), rtol=1e-4, atol=2e-3)
+    acc, sacc = acc_from_counts(out["counts"])
+    assert abs(acc - float(ref["final_acc"])) <= 0.005 and abs(sacc - float(ref["final_scene_acc"])) <= 0.005
+    return out, ref
+
+
+@pytest.mark.parametrize("bs,S,K,n_shards", [(1, 1, 1, 1), (1, 2, 3, 2), (3, 5, 1, 5), (2, 7, 2, 1), (5, 12, 9, 4)])
+def test_ragged_and_minimal_sizes(dev, bs, S, K, n_shards):
+    """N = 3, 6, 45, 42, 180 rows: tail tiles, tail wavefronts, one neighbour, nine neighbours."""
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    scene = make_scene_batch(bs, K=K, S=S, seed=100 + S, invalid_lane_frac=0.3, stlp_mode="wide")
+    _both(dev, scene, S, 6, seed=S, rect_head=True, multi_cands=3, n_shards=n_shards,
+          guidance=dict(enabled=True, before=2, niters=1, lr=0.01))
+
+
+def test_all_lanes_invalid(dev):
+    """Every lane of every scene invalid: all-zero waypoints (degenerate-segment branch of the lane distance), valid = 0
+    everywhere; mask_mean clips the empty denominator, acc = 0, and guidance leaves mu untouched (zero gradient scale)."""
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    scene = make_scene_batch(4, K=2, S=8, seed=9, invalid_lane_frac=0.0, stlp_mode="wide")
+    for k in ("curr", "left", "right"):
+        scene["%slane_wpts" % k].zero_()
+        scene["%s_id" % k].zero_()
+    out, ref = _both(dev, scene, 8, 6, seed=3, rect_head=True, multi_cands=2, guidance=dict(enabled=True, before=3, niters=2, lr=0.02))
+    assert out["counts"].tolist()[:2] == [0, 0]
+
+
+@pytest.mark.parametrize("steps", [2, 3, 150])
+def test_shortest_and_longest_schedule(dev, steps):
+    """steps = 2: a single denoiser evaluation, no noise added at all; steps = 150: the 149-step segment is split over
+    launches of at most 128 reverse steps."""
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    scene = make_scene_batch(2, K=2, S=8, seed=steps, stlp_mode="wide")
+    _both(dev, scene, 8, steps, seed=steps, rect_head=(steps != 150), multi_cands=2 if steps == 3 else None)
+
+
+def test_abi_rejects_bad_arguments_with_status_codes(dev):
+    from pstl_diffusion_policy_amd import ffi
+    L = ffi.lib()
+    hp = _hp()
+    null = ctypes.c_void_p(0)
+    buf = torch.zeros(4096, device=dev)
+    p = ffi.ptr(buf)
+    st = ffi.stream()
+    ok_cfg = ffi.make_cfg(2, 24, 8, 2, 10, hp)
+    assert L.pstl_generate_trajs(ctypes.byref(ok_cfg), null, p, p, st) == -1                     # null s0
+    assert L.pstl_generate_trajs(null, p, p, p, st) == -1                                        # null cfg
+    for bad in (ffi.make_cfg(0, 24, 8, 2, 10, hp), ffi.make_cfg(2, 0, 8, 2, 10, hp), ffi.make_cfg(2, 24, 8, 0, 10, hp),
+                ffi.make_cfg(2, 24, 8, 2, 1, hp)):
+        assert L.pstl_generate_trajs(ctypes.byref(bad), p, p, p, st) == -1
+    # merge pooling needs S % n_shards == 0 and rows_per_scene == 3*S: shape errors, not crashes
+    odd = ffi.make_cfg(2, 24, 8, 2, 10, dict(hp, n_shards=3))
+    assert L.pstl_refine(ctypes.byref(odd), p, p, p, p, p, p, p, p, st) == -2
+    dense = ffi.make_cfg(48, 1, 1, 2, 10, hp)
+    assert L.pstl_reduce_metrics(ctypes.byref(dense), p, p, ffi.ptr(torch.zeros(8, dtype=torch.int64, device=dev), torch.int64),
+                                 null, st) == -2
+    big = ffi.make_cfg(1, 3 * 128, 128, 2, 10, hp)                                                # S > 64 lanes
+    assert L.pstl_diversity(ctypes.byref(big), p, p, 6, p, p, p, p, ffi.ptr(torch.zeros(64, dtype=torch.float64, device=dev),
+                                                                            torch.float64), p, null, st) == -2
+    nodes = torch.zeros(1, 8, dtype=torch.int32, device=dev)
+    assert L.pstl_stl_program_forward(ffi.ptr(nodes, torch.int32), 1, null, ctypes.c_int64(4), 2000, p, ctypes.c_float(1.0), 0,
+                                      p, p, st) == -1                                             # T > PSTL_STL_MAX_T
+    assert L.pstl_trajopt(ctypes.byref(ok_cfg), p, p, p, p, p, p, ctypes.c_float(0.01), ctypes.c_float(1.0), ctypes.c_float(0.0),
+                          0, p, p, 0, p, p, p, st) == -1                                          # iters < 1
+    assert L.pstl_error_string(-1).decode() and L.pstl_error_string(-3).decode()
+    torch.cuda.synchronize()    # nothing was launched, nothing is pending, the device is healthy
+    assert float(buf.sum()) == 0.0
