@@ -20,15 +20,16 @@ def short(name):
 
 
 def load(tag):
-    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    """kernel -> {dispatch id -> {counter: value, "dur_ns": duration}} (the csv holds one row per dispatch and counter)"""
+    per = collections.defaultdict(lambda: collections.defaultdict(dict))
     try:
         rows = csv.DictReader(open("%s/pmc_%s_counter_collection.csv" % (d, tag)))
     except FileNotFoundError:
         return per
     for r in rows:
-        k = short(r["Kernel_Name"])
-        per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        per[k]["dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+        e = per[short(r["Kernel_Name"])][r["Dispatch_Id"]]
+        e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        e["dur_ns"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     return per
 
 
@@ -36,20 +37,16 @@ out = {"per_kernel": {}}
 passes = {t: load(t) for t in ("FETCH_SIZE", "WRITE_SIZE", "SQ")}
 for tag, per in passes.items():
     out["per_kernel"][tag] = {}
-    for k, c in per.items():
-        if k.startswith("k_") or "k_chain" in k:
-            # the longest dispatches of a kernel are the ones of interest (k_chain: the multi-step launch)
-            if "k_chain<8,false>" == k:
-                n = len(c["dur_ns"])
-                idx = [i for i in range(n) if c["dur_ns"][i] > 0.5 * max(c["dur_ns"])]
-            else:
-                idx = list(range(len(c["dur_ns"])))
-            ent = {}
-            for name, vals in c.items():
-                m = len(vals) // len(c["dur_ns"]) if name != "dur_ns" else 1
-                sel = [vals[i] for i in idx] if len(vals) == len(c["dur_ns"]) else vals
-                ent[name] = sum(sel) / max(len(sel), 1)
-            out["per_kernel"][tag][k] = ent
+    for k, disp in per.items():
+        if not (k.startswith("k_") or "k_chain" in k):
+            continue
+        ds = list(disp.values())
+        if k == "k_chain<8,false>":   # the multi-step launch only (the single-step launches of the guided steps are 30x shorter)
+            top = max(e["dur_ns"] for e in ds)
+            ds = [e for e in ds if e["dur_ns"] > 0.5 * top]
+        keys = sorted(set().union(*[set(e) for e in ds]))
+        out["per_kernel"][tag][k] = {name: sum(e.get(name, 0.0) for e in ds) / len(ds) for name in keys}
+        out["per_kernel"][tag][k]["launches_averaged"] = len(ds)
 dom = "k_chain<8,false>"
 f = out["per_kernel"]["FETCH_SIZE"].get(dom, {})
 w = out["per_kernel"]["WRITE_SIZE"].get(dom, {})
