@@ -148,6 +148,7 @@ def main():
     for _ in range(a.warmup):
         counts, div_totals = one_step()
     sampler.trace = []
+    sampler.trace_stl = {}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -184,6 +185,22 @@ def main():
     flop = float(nrows) * nst * F_STEP_MIN
     achieved = flop / (k_ms * 1e-3) / 1e12
     acc, sacc = acc_from_counts(counts)
+    # the STL kernels (one row per lane): row-evaluations/s and what that means against the HBM roofline.  Algorithmic
+    # bytes per row-evaluation in the scene-shared layout: 160 B controls + 16 B s0 + 24 B stlp + 4 B score + scene
+    # tables amortised over the 192 rows of a scene -- these kernels are VALU-bound, not HBM-bound.
+    K = a.neighbors
+    stl_bytes = 160 + 16 + 24 + 4 + (K * 20 * 7 * 4 + 540) / (3.0 * S)
+    stl_info = {}
+    for kind, evs in (sampler.trace_stl or {}).items():
+        ms_k = sum(e0.elapsed_time(e1) for (e0, e1, _) in evs)
+        evals = sum(n for (_, _, n) in evs)
+        if ms_k > 0:
+            rate = evals / (ms_k * 1e-3)
+            stl_info[kind] = {"kernel": "k_guidance_iter (forward + adjoint + Adam)" if kind == "guidance" else "k_stl_forward",
+                              "row_evals_per_s": rate, "ms_per_step": ms_k / a.steps,
+                              "algorithmic_bytes_per_row_eval": stl_bytes * (2 if kind == "guidance" else 1),
+                              "achieved_GBps": rate * stl_bytes * (2 if kind == "guidance" else 1) / 1e9,
+                              "frac_of_hbm_peak": rate * stl_bytes * (2 if kind == "guidance" else 1) / 8e12}
     # HBM bytes of that launch from the committed PMC passes (FETCH_SIZE/WRITE_SIZE cannot be read inside this process);
     # only quoted when this run is the configuration those passes were collected on
     traffic = None
@@ -215,7 +232,7 @@ def main():
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
                          "traffic_source": "profiles/r1/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
                                            if traffic else None,
-                         "kernel_ms": k_ms, "flop_per_launch": flop,
+                         "kernel_ms": k_ms, "flop_per_launch": flop, "stl_kernels": stl_info,
                          "note": "algorithmic FLOP = rows x steps x 172032 (hoisted layer-1 columns not counted)"},
         }
         if not a.no_cpu_baseline:

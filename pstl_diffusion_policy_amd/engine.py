@@ -132,7 +132,18 @@ class Sampler:
         # when set to a list, every multi-step rollout launch appends (start_event, end_event, n_steps, n_rows):
         # HIP events recorded on the launch stream, used by bench.py to time the dominant kernel live
         self.trace = None
+        # when set to a dict, STL launches append (start_event, end_event, row_evaluations) under "guidance" / "score"
+        self.trace_stl = None
         self.debug_buf = None   # diagnostic builds only (chain_waves 708): receives the kernel's cycle stamps
+
+    def _stl_event(self, kind, row_evals):
+        """HIP events (recorded on the launch stream) around one STL launch, kept for bench.py; None when not tracing."""
+        if self.trace_stl is None:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), int(row_evals))
+        ev[0].record()
+        self.trace_stl.setdefault(kind, []).append(ev)
+        return ev
 
     # ---- A1 ----
     def encode(self, sb, need_rect=True):
@@ -209,11 +220,14 @@ class Sampler:
                 plain(i, i, mu_only=1)
                 z = noise[steps - 1 - i] if (noise is not None and i > 1) else None
                 eo = emit[n_emit - i] if (n_emit > 0 and i <= n_emit) else None
+                gev = self._stl_event("guidance", sb.N * nit)
                 ffi.check(self.L.pstl_guidance_step(ctypes.byref(cfg), ffi.ptr(sb.s0), ffi.ptr(sb.nei_prep),
                                                     ffi.ptr(sb.lane_prep), ffi.ptr(sb.stlp), ffi.ptr(sb.hl),
                                                     ffi.ptr(sb.valid), ctypes.c_float(sb.grad_scale), nit, neg_step, bc2,
                                                     ctypes.c_float(float(beta_host[i])), int(i), ffi.ptr(z), ffi.ptr(x),
                                                     ffi.ptr(work), ffi.ptr(eo), ffi.stream()), "guidance_step")
+                if gev is not None:
+                    gev[1].record()
                 i -= 1
         return emit[:n_emit]
 
@@ -229,10 +243,13 @@ class Sampler:
         sel_s = torch.empty(sb.N, dtype=torch.float32, device=dev) if select else None
         sel_i = torch.empty(sb.N, dtype=torch.int32, device=dev) if select else None
         cfg = sb.cfg(2)
+        sev = self._stl_event("score", sb.N * reps)
         ffi.check(self.L.pstl_stl_forward(ctypes.byref(cfg), ffi.ptr(sb.s0), ffi.ptr(controls), ffi.ptr(states), int(reps),
                                           ffi.ptr(sb.nei_prep), ffi.ptr(sb.lane_prep), ffi.ptr(sb.stlp), ffi.ptr(sb.hl),
                                           ffi.ptr(scores), ffi.ptr(s3), ffi.ptr(sel_c), ffi.ptr(sel_s),
                                           ffi.ptr(sel_i, torch.int32), ffi.stream()), "stl_forward")
+        if sev is not None:
+            sev[1].record()
         out = {"scores": scores}
         if all3:
             out["scores3"] = s3

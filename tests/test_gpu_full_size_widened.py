@@ -1,0 +1,128 @@
+"""BASELINE.json's single-GPU size (4096 scenes x 64 samples x 3 modes = 786432 rows) for the widened rows, checked
+through size-independent properties (the oracle cannot run at this size): shard additivity and bitwise reproducibility of
+the diversity totals; the traj-opt loop split over calls and over scene shards; a generic formula tree against the fused
+STL kernel on the same rows; the DPP loss invariant under a permutation of the groups."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_weights
+
+pytestmark = pytest.mark.gpu
+BS, S, K = 4096, 64, 2
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    dev = torch.device("cuda:0")
+    hp = default_hparams()
+    scene = {k: v.to(dev) for k, v in make_scene_batch(BS, K=K, S=S, seed=3, invalid_lane_frac=0.2, stlp_mode="wide").items()
+             if k not in ("pre_stlp", "tj_scores_prior")}
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    sb = SceneBatch(scene, S, hp, dev)
+    out = sm.sampling_region(sb, 12, None, None, rect_head=True, multi_cands=3, seed=5, want_scores3=True, diversity=True)
+    torch.cuda.synchronize()
+    return dict(dev=dev, hp=hp, scene=scene, sm=sm, sb=sb, out=out)
+
+
+def _sub(ctx, lo, hi, **kw):
+    from pstl_diffusion_policy_amd.engine import SceneBatch
+    sub = {k: v[lo:hi].contiguous() for k, v in ctx["scene"].items()}
+    return SceneBatch(sub, S, ctx["hp"], ctx["dev"], **kw)
+
+
+def test_diversity_totals_full_size(ctx):
+    from pstl_diffusion_policy_amd.engine import diversity_from_totals
+    sm, sb, out = ctx["sm"], ctx["sb"], ctx["out"]
+    N = sb.N
+    assert N == 786432
+    pm, ps, tot = out["div_per_mode"], out["div_per_scene"], out["div_totals"]
+    pm2, ps2, tot2 = sm.diversity(sb, out["final_controls"], out["final_scores"])
+    assert torch.equal(pm, pm2) and torch.equal(ps, ps2) and torch.equal(tot, tot2)          # bitwise reproducible
+    assert torch.isfinite(pm).all() and torch.isfinite(ps).all()
+    acc = torch.zeros(12, dtype=torch.float64, device=ctx["dev"])
+    for q in range(4):                                                                        # four shards, as four GPUs
+        lo, hi = q * BS // 4, (q + 1) * BS // 4
+        r0, r1 = lo * S * 3, hi * S * 3
+        p, s_, t = sm.diversity(_sub(ctx, lo, hi), out["final_controls"][r0:r1].contiguous(), out["final_scores"][r0:r1].contiguous())
+        assert torch.equal(p, pm[lo:hi]) and torch.equal(s_, ps[lo:hi])
+        acc += t
+    np.testing.assert_allclose(acc.cpu().numpy(), tot.cpu().numpy(), rtol=1e-12)
+    d = diversity_from_totals(tot)
+    sat = (out["final_scores"] > 0).reshape(BS, S, 3).sum(dim=1)
+    assert torch.equal(pm[:, :, 6].long(), sat)                                              # satisfied-sample counts
+    assert torch.equal(pm[:, :, 7], sb.valid.reshape(BS, S, 3)[:, 0].double())
+    assert (pm[:, :, 1][pm[:, :, 6] < 3] == 0).all()                                         # no hull below 3 points
+    assert 0 <= d["ent_s"] <= np.log2(10) + 1e-6 and 0 <= d["ent_w"] <= np.log2(10) + 1e-6
+    assert d["std"] > 0 and d["vol"] > 0 and d["area"] > 0 and d["fde"] >= 0
+
+
+def test_generic_formulas_agree_with_the_fused_kernel_full_size(ctx):
+    """build_stl_cache's formula objects (generic program kernel) on signals from pstl_stl_signals reproduce the three
+    scores of the fused kernel on all 786432 rows."""
+    from pstl_diffusion_policy_amd import nusc_train as nt
+    sm, sb, out = ctx["sm"], ctx["sb"], ctx["out"]
+    args = nt.generate_parser(["--diffusion", "--load_stlp"])
+    traj = sm.trajs(sb, out["final_controls"])[:, :-1].contiguous()
+    x = nt.prep_stl_cache({"ego_traj": traj, "_pstl": sb}, args)
+    stls = nt.build_stl_cache(args)
+    for m in range(3):
+        got = stls[m](x, args.smoothing_factor)[:, 0]
+        want = out["final_scores3"][m]
+        err = (got - want).abs()
+        assert err.max().item() <= 5e-4 + 1e-4 * want.abs().max().item(), (m, err.max().item())
+        assert ((got > 0) == (want > 0))[want.abs() > 1e-3].all()
+
+
+def test_trajopt_full_size_split_and_sharded(ctx):
+    sm, sb = ctx["sm"], ctx["sb"]
+    N = sb.N
+    p0 = ctx["scene"]["params"].reshape(N, 40).contiguous()
+    vsum = float(sb.valid.sum())
+    a = p0.clone()
+    sc_a, _ = sm.trajopt(sb, a, 6, 0.01)
+    b = p0.clone()                                                      # same run split over two calls
+    _, work = sm.trajopt(sb, b, 2, 0.01)
+    sc_b, _ = sm.trajopt(sb, b, 4, 0.01, work=work, first_iter=2)
+    assert torch.equal(a, b) and torch.equal(sc_a, sc_b)
+    for q in (0, 3):                                                    # a quarter of the scenes alone, global constants
+        lo, hi = q * BS // 4, (q + 1) * BS // 4
+        r0, r1 = lo * S * 3, hi * S * 3
+        c = p0[r0:r1].clone()
+        sc_c, _ = sm.trajopt(_sub(ctx, lo, hi), c, 6, 0.01, global_valid_sum=vsum, global_rows=N)
+        assert torch.equal(c, a[r0:r1]) and torch.equal(sc_c, sc_a[r0:r1])
+    # Adam's bias-corrected step is bounded by lr * (1 - beta1) / sqrt(1 - beta2) ~ 3.2 lr (typically ~lr)
+    assert torch.isfinite(a).all() and (a - p0).abs().max().item() <= 6 * 0.01 * 3.2
+
+
+def test_dpp_loss_full_size_is_invariant_to_scene_order(ctx):
+    """Reversing the order of the scenes permutes the groups: group diversities and gradients permute with them."""
+    from pstl_diffusion_policy_amd import ffi
+    sm, sb, out = ctx["sm"], ctx["sb"], ctx["out"]
+    dev, N = ctx["dev"], sb.N
+    cfg = sb.cfg(2)
+    G = BS * 3 * cfg.n_shards
+    rect, scores = out["final_controls"], out["final_scores"]
+
+    def run(rc, sc):
+        o = dict(div=torch.empty(G, device=dev), dc=torch.empty(N, 40, device=dev), ds=torch.empty(N, device=dev))
+        ffi.check(ffi.lib().pstl_diversity_loss(ctypes.byref(cfg), ffi.ptr(rc), ffi.ptr(None), ffi.ptr(sc), ctypes.c_float(1.0),
+                                                ctypes.c_float(1.0), 0, ctypes.c_float(0.0), ffi.ptr(o["div"]), ffi.ptr(None),
+                                                ffi.ptr(None, torch.float64), ffi.ptr(o["dc"]), ffi.ptr(o["ds"]), ffi.stream()),
+                  "diversity_loss")
+        return o
+    a = run(rect, scores)
+    rrev = rect.reshape(BS, S * 3, 40).flip(0).reshape(N, 40).contiguous()
+    srev = scores.reshape(BS, S * 3).flip(0).reshape(N).contiguous()
+    b = run(rrev, srev)
+    torch.cuda.synchronize()
+    assert torch.equal(a["div"].reshape(BS, -1).flip(0), b["div"].reshape(BS, -1))
+    assert torch.equal(a["dc"].reshape(BS, -1).flip(0), b["dc"].reshape(BS, -1))
+    assert torch.equal(a["ds"].reshape(BS, -1).flip(0), b["ds"].reshape(BS, -1))
+    n = S // cfg.n_shards
+    assert torch.isfinite(a["div"]).all() and (a["div"] >= -1e-5).all() and (a["div"] <= n + 1e-4).all()
