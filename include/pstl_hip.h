@@ -282,8 +282,8 @@ int pstl_stl_program_backward(const pstl_stl_node* nodes, int n_nodes, const int
  * for all N rows in ONE launch; params (N,40) are controls in physical units (the dataset's `params`, (bs,M,3,nt,2)).
  * grad_scale = (1/clip(mean(valid),1e-3))/N_global; reg_scale = reg_loss/(N_global*nt);
  * adam_neg_step / adam_bc2_sqrt: DEVICE arrays [iters] = float(-lr/(1-0.9^k)), float(sqrt(1-0.999^k)), k = first
- * iteration number (1-based) ... ; work (2,N,40) holds Adam's m and v: written always, read when resume != 0 (a run can be
- * split over several calls).  scores (N,) or null: robustness of the iterate the last update started from (what the
+ * iteration number (1-based) ... ; work: 3*N*40 floats of scratch the kernel owns for the run (the iterate and Adam's m and
+ * v, element-major); m and v are read back when resume != 0, so a run can be split over several calls.  scores (N,) or null: robustness of the iterate the last update started from (what the
  * reference saves as scores_*.npy).  thres = --stl_trajopt_thres. */
 int pstl_trajopt(const pstl_cfg* cfg, const float* s0, const float* nei_prep, const float* lane_prep, const float* stlp,
                  const float* hl, const float* valid, float thres, float grad_scale, float reg_scale, int iters,

@@ -52,12 +52,12 @@ constexpr int kNseg = 15;     // lane waypoints
 constexpr int kFwin = 10;     // Eventually(0, nt//2)
 constexpr int kNeiPrep = 12;  // floats per prepared (neighbour, t)
 // per-lane scratch floats: forward needs the first 10 values of the two "reach" signals per evaluated side lane;
-// the adjoint additionally keeps x_t, y_t (heading and speed are re-derived from the controls, see stl_eval_grad)
+// the adjoint additionally keeps the state (x, y, heading, speed) at every 4th step (see stl_eval_grad)
 constexpr int kScratchFwd = 2 * kFwin;       // selected formula only
 constexpr int kScratchFwd3 = 4 * kFwin;      // all three formulas (left and right lane)
-constexpr int kCkStride = 4;                     // heading/speed checkpoints every 4 steps (adjoint replays <= 3 steps)
-constexpr int kCk = kT / kCkStride;               // 5 checkpoints
-constexpr int kScratchGrad = 2 * kT + 2 * kFwin + 2 * kCk;
+constexpr int kCkStride = 4;                     // state checkpoints every 4 steps (the adjoint re-derives blocks of 4 states)
+constexpr int kCk = kT / kCkStride;               // 5 checkpoints of (x, y, th, v)
+constexpr int kScratchGrad = 4 * kCk + 2 * kFwin;
 
 struct alignas(16) f4 {
   float x, y, z, w;
@@ -280,13 +280,14 @@ struct DynSrc {
   float x, y, th, v;
   const float* u;
   float ws, as, dt;
-  PSTL_HD DynSrc(const float* s0, const float* u_, float ws_, float as_, float dt_)
-      : x(s0[0]), y(s0[1]), th(s0[2]), v(s0[3]), u(u_), ws(ws_), as(as_), dt(dt_) {}
+  long us;  // distance (in floats) between consecutive control values of this row: 1, or N for an element-major buffer
+  PSTL_HD DynSrc(const float* s0, const float* u_, float ws_, float as_, float dt_, long us_ = 1)
+      : x(s0[0]), y(s0[1]), th(s0[2]), v(s0[3]), u(u_), ws(ws_), as(as_), dt(dt_), us(us_) {}
   PSTL_HD void get(int t, float& X, float& Y, float& TH, float& V, float& c, float& s) {
     X = x, Y = y, TH = th, V = v;
     PSTL_SINCOS(th, &s, &c);
-    const float w = u[2 * t] * ws;
-    const float a = u[2 * t + 1] * as;
+    const float w = u[(2 * t) * us] * ws;
+    const float a = u[(2 * t + 1) * us] * as;
     const float dx = v * c;
     const float dy = v * s;
     x = x + dx * dt;
@@ -371,7 +372,7 @@ struct FwdOut {  // what the adjoint needs from the forward sweep
 // Evaluates the formulas of one row.
 //   ALL3 = true : all three formulas -> out3[0..2]; returns the mode-selected score   (scratch: kScratchFwd3)
 //   ALL3 = false: only the formula of r.mode                                           (scratch: kScratchFwd)
-//   XY != -1    : additionally parks x_t, y_t at scratch[XY + t], scratch[XY + T + t]  (adjoint)
+//   XY != -1    : additionally parks the state of every 4th step at scratch[XY ...] (x, y, th, v; 5 each)  (adjoint)
 template <bool ALL3, int XY, class Src>
 PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Src src, Scratch st,
                        int tab, float* out3, FwdOut* fo) {
@@ -392,13 +393,12 @@ PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, cons
   for (int t = 0; t < kT; ++t) {
     float x, y, th, v, c, s;
     src.get(t, x, y, th, v, c, s);
-    if (XY >= 0) {
-      st.at(XY + t) = x;
-      st.at(XY + kT + t) = y;
-      if ((t & (kCkStride - 1)) == 0) {   // checkpoints of heading and speed for the adjoint's replay
-        st.at(XY + 2 * kT + 2 * kFwin + t / kCkStride) = th;
-        st.at(XY + 2 * kT + 2 * kFwin + kCk + t / kCkStride) = v;
-      }
+    if (XY >= 0 && (t & (kCkStride - 1)) == 0) {   // state checkpoints for the adjoint (every 4th step)
+      const int k = t / kCkStride;
+      st.at(XY + k) = x;
+      st.at(XY + kCk + k) = y;
+      st.at(XY + 2 * kCk + k) = th;
+      st.at(XY + 3 * kCk + k) = v;
     }
     gv1.add(-(v - r.vmin) * tau);
     gv2.add(-(-v + r.vmax) * tau);
@@ -466,14 +466,21 @@ PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, cons
 // Forward + adjoint of one row: returns the score and calls emit(t, gw, ga) once for every t in [0,T) with
 // (gw, ga) = dscore_fn(score) * d score / d (u[2t], u[2t+1])  (u = the 40 control values, scaled by wscale/ascale
 // inside the dynamics).  Only the formula of r.mode carries gradient (the others are multiplied by a 0 mask in the
-// reference).  Scratch: kScratchGrad floats per lane = x_t, y_t (2T) + the two suffix tables (2*10) + heading/speed
-// checkpoints every 4th step (2*5).  Heading and speed at time t are re-derived from the last checkpoint by the very
-// same additions the forward sweep performed (<= 3 steps, 30 in total per row instead of 190 from t = 0), which keeps
-// them bit-identical to the forward values at 30 % of the LDS a full (th_t, v_t) table would take.
+// reference).  Scratch: kScratchGrad = 40 floats per lane = the state (x, y, th, v) at every 4th step (4*5) + the two
+// suffix tables (2*10).  The states in between are re-derived block by block from the checkpoint with the forward
+// sweep's own operations -- bit-identical, and the sin/cos they need are the ones the adjoint needs anyway -- instead of
+// being stored (80 floats): 10 KB of LDS per wavefront instead of 25.6 KB, i.e. 12 resident wavefronts per CU, not 6.
+// (These kernels are latency-bound at that occupancy: measured 0.94 / 1.02 / 1.32 / 1.65 ms at 7 / 6 / 4 / 3 per CU.)
 // ---------------------------------------------------------------------------------------------------------------
+PSTL_HD float pick4(const float (&a)[kCkStride], int i) {   // register array, dynamic index: three selects
+  static_assert(kCkStride == 4, "pick4");
+  return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
+}
+
 template <class DScoreFn, class EmitFn>
 PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, const float* s0,
-                            const float* u, Scratch st, float wscale, float ascale, DScoreFn dscore_fn, EmitFn emit) {
+                            const float* u, Scratch st, float wscale, float ascale, DScoreFn dscore_fn, EmitFn emit,
+                            long us = 1) {
   const float tau = env.tau;
   const int mode = r.mode;
   if (mode >= 3) {
@@ -482,10 +489,10 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     return 1.0f;
   }
   const f4* lane = lanes + mode * kNseg;
-  const int XY = 0, LB = 2 * kT, LT = 2 * kT + kFwin, CKP = 2 * kT + 2 * kFwin;
+  const int CKP = 0, LB = 4 * kCk, LT = 4 * kCk + kFwin;
   // ---- forward sweep ------------------------------------------------------------------------------------------
   FwdOut fo;
-  const float score = stl_eval<false, 0>(env, r, lanes, nei, K, DynSrc(s0, u, wscale, ascale, env.dt), st, LB, nullptr, &fo);
+  const float score = stl_eval<false, 0>(env, r, lanes, nei, K, DynSrc(s0, u, wscale, ascale, env.dt, us), st, LB, nullptr, &fo);
   const float Lv1 = fo.Lv1, Lv2 = fo.Lv2, Ls = fo.Ls, L1 = fo.L1, L2 = fo.L2, L3 = fo.L3, Lfb = fo.Lfb, Lft = fo.Lft;
   float V[6];
   int n;
@@ -523,18 +530,37 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   // ---- adjoint, backwards in time -----------------------------------------------------------------------------
   float lx = 0.0f, ly = 0.0f, lth = 0.0f, lv = 0.0f;  // lambda_{t+1}
   const float dt = env.dt;
+  // The states are not stored per step: block by block (4 steps), they are re-derived from the block's checkpoint with the
+  // forward sweep's own operations (bit-identical), kept in registers, and consumed in reverse order.  The controls a
+  // block reads (steps < its last one) have not been rewritten yet by emit(), which has only reached later steps.
   PSTL_NOUNROLL
-  for (int t = kT - 1; t >= 1; --t) {
-    const float x = st.at(XY + t), y = st.at(XY + kT + t);
-    const int ck = t / kCkStride;
-    float th = st.at(CKP + ck), v = st.at(CKP + kCk + ck);
-    PSTL_NOUNROLL
-    for (int q = ck * kCkStride; q < t; ++q) {  // the forward sweep's own additions, replayed from the last checkpoint
-      th = th + (u[2 * q] * wscale) * dt;
-      v = v + (u[2 * q + 1] * ascale) * dt;
+  for (int blk = kCk - 1; blk >= 0; --blk) {
+    float bx[kCkStride], by[kCkStride], bth[kCkStride], bv[kCkStride], bc[kCkStride], bs[kCkStride];
+    {
+      float x = st.at(CKP + blk), y = st.at(CKP + kCk + blk), th = st.at(CKP + 2 * kCk + blk), v = st.at(CKP + 3 * kCk + blk);
+      PSTL_UNROLL
+      for (int i = 0; i < kCkStride; ++i) {
+        float c, s;
+        PSTL_SINCOS(th, &s, &c);
+        bx[i] = x, by[i] = y, bth[i] = th, bv[i] = v, bc[i] = c, bs[i] = s;
+        if (i + 1 < kCkStride) {
+          const int q = blk * kCkStride + i;
+          const float w = u[(2 * q) * us] * wscale;
+          const float a = u[(2 * q + 1) * us] * ascale;
+          const float dx = v * c;
+          const float dy = v * s;
+          x = x + dx * dt;
+          y = y + dy * dt;
+          th = th + w * dt;
+          v = v + a * dt;
+        }
+      }
     }
-    float c, s;
-    PSTL_SINCOS(th, &s, &c);
+  PSTL_NOUNROLL
+  for (int i = kCkStride - 1; i >= 0; --i) {
+    const int t = blk * kCkStride + i;
+    if (t == 0) break;
+    const float x = pick4(bx, i), y = pick4(by, i), th = pick4(bth, i), v = pick4(bv, i), c = pick4(bc, i), s = pick4(bs, i);
     // direct partials of the score w.r.t. state t
     float gx, gy, gth, gv;
     gv = o_v1 * PSTL_EXP(-(v - r.vmin) * tau - Lv1) - o_v2 * PSTL_EXP(-(-v + r.vmax) * tau - Lv2);
@@ -574,6 +600,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     lv = nlv;
     // state_t = f(state_{t-1}, u_{t-1}):  th_t = th_{t-1} + w dt ; v_t = v_{t-1} + a dt
     emit(t - 1, lth * dt * wscale, lv * dt * ascale);
+  }
   }
   return score;
 }

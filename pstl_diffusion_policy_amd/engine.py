@@ -138,7 +138,7 @@ class Sampler:
 
     def _stl_event(self, kind, row_evals):
         """HIP events (recorded on the launch stream) around one STL launch, kept for bench.py; None when not tracing."""
-        if self.trace_stl is None:
+        if getattr(self, "trace_stl", None) is None:
             return None
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), int(row_evals))
         ev[0].record()
@@ -316,7 +316,7 @@ class Sampler:
         bc2 = torch.tensor([math.sqrt(1 - 0.999 ** k) for k in ks], dtype=torch.float32, device=dev)
         resume = 1 if work is not None else 0
         if work is None:
-            work = torch.empty(2, N, ffi.CTRL, dtype=torch.float32, device=dev)
+            work = torch.empty(3, ffi.CTRL, N, dtype=torch.float32, device=dev)
         scores = torch.empty(N, dtype=torch.float32, device=dev)
         cfg = sb.cfg(2)
         ffi.check(self.L.pstl_trajopt(ctypes.byref(cfg), ffi.ptr(sb.s0), ffi.ptr(sb.nei_prep), ffi.ptr(sb.lane_prep),

@@ -46,7 +46,8 @@ def test_formula_matches_reference_golden(dev, key):
 @pytest.mark.parametrize("name", sorted(stl_specs.SPECS))
 def test_formula_matches_oracle_fresh_inputs(dev, name):
     from oracle import stl_lib_oracle as so
-    g = torch.Generator().manual_seed(abs(hash(name)) % 1000)
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)    # hash() is salted per process: not reproducible
     n, T = 300, 17
     x = torch.randn(4, n, T, generator=g) * 1.5
     W = torch.randn(n, T, generator=g)
