@@ -235,7 +235,7 @@ def main():
                          "kernel_ms": k_ms, "flop_per_launch": flop, "stl_kernels": stl_info,
                          "note": "algorithmic FLOP = rows x steps x 172032 (hoisted layer-1 columns not counted)"},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
             line["cpu_baseline"] = cpu_baseline(a, hp, sd, guidance, rect_head)
         print(json.dumps(line), flush=True)
     if world > 1:
