@@ -396,7 +396,9 @@ def rect_forward(sd, feature, rows, init_controls, scores, n_shards, diverse=Tru
 # A12 the whole timed region (reference nusc_train.py:957-1105)
 # ------------------------------------------------------------------------------------------------
 def sampling_region(sd, scene, S, steps, hp, x_T, z, rect_head=False, multi_cands=None, refinenet=True,
-                    guidance=None, n_rolls=None, diverse=True, n_shards=4):
+                    guidance=None, n_rolls=None, diverse=True, n_shards=4, clip_rect=False, use_rect=True):
+    """use_rect=False is --not_use_rect: --rect_head's side effects (clip, full list) stay, the RefineNet block is skipped
+    (nusc_train.py:993 `if args.rect_head and not args.not_use_rect`)."""
     rows = Rows(scene, S, hp)
     out = {}
     with torch.no_grad():
@@ -406,7 +408,7 @@ def sampling_region(sd, scene, S, steps, hp, x_T, z, rect_head=False, multi_cand
         out["controls_list"] = torch.stack(clist, dim=0)
         out["feature_scene"] = feature
         controls = clist[-1]
-        if rect_head:
+        if rect_head and use_rect:
             if multi_cands is not None:
                 cands = torch.stack(clist[-multi_cands:], dim=0)
                 _, cs, _ = rows.score(cands.reshape(-1, cands.shape[2], 2), reps=multi_cands)
@@ -416,11 +418,11 @@ def sampling_region(sd, scene, S, steps, hp, x_T, z, rect_head=False, multi_cand
             else:
                 _, best, _ = rows.score(controls)
             if refinenet:
-                controls = rect_forward(sd, feature, rows, controls, best, n_shards, diverse)
+                controls = rect_forward(sd, feature, rows, controls, best, n_shards, diverse, clip_rect)
                 out["rect_controls"] = controls
             for ri in range(n_rolls or 0):
                 _, sc, _ = rows.score(controls)
-                controls = rect_forward(sd, feature, rows, controls, sc, n_shards, diverse)
+                controls = rect_forward(sd, feature, rows, controls, sc, n_shards, diverse, clip_rect)
                 out["roll%d_scores" % ri] = sc
                 out["roll%d_controls" % ri] = controls
         s3, score, sig = rows.score(controls)

@@ -347,7 +347,7 @@ class Sampler:
     # ---- A12: the timed region ----
     def sampling_region(self, sb, steps, x_T, noise, rect_head=False, multi_cands=None, refinenet=True, guidance=None,
                         n_rolls=None, diverse=True, full_list=False, coeffs=None, want_scores3=True, seed=None,
-                        diversity=False):
+                        diversity=False, clip_rect=False, use_rect=True):
         """x_T (N,40) and noise (steps-1,N,40) supplied by the caller (parity), or seed != None: x_T and all noise are
         drawn by the kernels (x_T / noise arguments ignored)."""
         out = {}
@@ -364,7 +364,7 @@ class Sampler:
         if full_list:
             out["controls_list"] = emit
         controls = emit[-1]
-        if rect_head:
+        if rect_head and use_rect:      # use_rect=False: --not_use_rect (clip / candidate list of --rect_head stay)
             if mc > 0:
                 r = self.score(sb, emit[-mc:].contiguous(), select=True)
                 out.update(cand_scores=r["scores"], sel_scores=r["sel_scores"], sel_idx=r["sel_idx"],
@@ -373,11 +373,11 @@ class Sampler:
             else:
                 best = self.score(sb, controls.reshape(1, sb.N, ffi.CTRL))["scores"][0]
             if refinenet:
-                controls = self.refine(sb, base_r, controls, best, diverse=diverse)
+                controls = self.refine(sb, base_r, controls, best, diverse=diverse, clip_rect=clip_rect)
                 out["rect_controls"] = controls
             for ri in range(n_rolls or 0):
                 sc = self.score(sb, controls.reshape(1, sb.N, ffi.CTRL))["scores"][0]
-                controls = self.refine(sb, base_r, controls, sc, diverse=diverse)
+                controls = self.refine(sb, base_r, controls, sc, diverse=diverse, clip_rect=clip_rect)
                 out["roll%d_scores" % ri] = sc
                 out["roll%d_controls" % ri] = controls
         fin = self.score(sb, controls.reshape(1, sb.N, ffi.CTRL), all3=want_scores3)

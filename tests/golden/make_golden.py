@@ -145,6 +145,11 @@ def sampling_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=
                             -1 if args.n_rolls is None else args.n_rolls, int(zero_net_out), int(maximize)],
                            dtype=np.int64)
     out["meta_f"] = np.array([args.guidance_lr, args.stl_nn_thres, args.smoothing_factor], dtype=np.float64)
+    # flag variants (read with defaults by conftest.golden_meta when absent)
+    out["meta_x"] = np.array([int(args.diverse_loss and not args.no_arch), int(args.clip_rect), int(not args.no_refinenet),
+                              int(not args.not_use_rect), int(args.guidance_reverse),
+                              -1 if args.guidance_freq is None else args.guidance_freq], dtype=np.int64)
+    out["guid_sets"] = np.array(args.guidance_sets if args.guidance_sets is not None else [], dtype=np.int64)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print("%-28s N=%d acc=%.4f scene_acc=%.4f sat=%d/%d -> %s (%.1f KB)" % (
@@ -226,7 +231,7 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags")):
     main()
 
 
@@ -550,3 +555,23 @@ def main_norm_stl():
 
 if __name__ == "__main__" and "--norm-stl" in sys.argv:
     main_norm_stl()
+
+
+def main_flags():
+    """Flag variants of the sampling harness that no other fixture exercises end to end."""
+    ref = ref_harness.load_reference()
+    sd = dict(np.load(WEIGHTS_FILE))
+    e7 = ["--diffusion", "--load_stlp", "--rect_head", "--flex", "--diverse_loss", "--multi_cands", "3"]
+    e8 = ["--diffusion", "--load_stlp", "--rect_head", "--flex", "--multi_cands", "3"]
+    gd = ["--guidance", "--guidance_niters", "1", "--guidance_lr", "0.01"]
+    kw = dict(bs=2, S=8, K=3, steps=10, stlp_mode="wide", invalid_lane_frac=0.25)
+    sampling_case(ref, sd, "fl_e8_clip_rect", e8 + ["--clip_rect"], seed=71, **kw)
+    sampling_case(ref, sd, "fl_no_arch", e7 + ["--no_arch"], seed=72, **kw)
+    sampling_case(ref, sd, "fl_no_refinenet", e7 + ["--no_refinenet"], seed=73, **kw)
+    sampling_case(ref, sd, "fl_not_use_rect", e7 + ["--not_use_rect"], seed=74, **kw)
+    sampling_case(ref, sd, "fl_guid_sets", e7 + gd + ["--guidance_sets", "2", "5", "7"], seed=75, **kw)
+    sampling_case(ref, sd, "fl_guid_freq_rev", e7 + gd + ["--guidance_freq", "3", "--guidance_reverse"], seed=76, **kw)
+
+
+if __name__ == "__main__" and "--flags" in sys.argv:
+    main_flags()

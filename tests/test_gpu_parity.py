@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (SAMPLING_CASES, STL_CASES, golden_meta, golden_weights, load_golden, scene_from_golden)
+from conftest import (SAMPLING_CASES, STL_CASES, golden_meta, golden_weights, load_golden, region_kwargs,
+                      scene_from_golden)
 
 pytestmark = pytest.mark.gpu
 
@@ -117,14 +118,8 @@ def _run_region(dev, name, chain_waves=0):
     w, _ = _weights(dev, zero_out=bool(meta["zero_net_out"]))
     sb = _scene_batch(d, meta["S"], dev)
     sm = Sampler(w, _hp(), chain_waves=chain_waves)
-    g = None
-    if meta["guidance"]:
-        g = dict(enabled=True, before=meta["guidance_before"], niters=meta["guidance_niters"], lr=meta["guidance_lr"],
-                 maximize=bool(meta["maximize"]))
     out = sm.sampling_region(sb, meta["steps"], torch.from_numpy(d["x_T"]).to(dev), torch.from_numpy(d["z"]).to(dev),
-                             rect_head=bool(meta["rect_head"]),
-                             multi_cands=None if meta["multi_cands"] < 0 else meta["multi_cands"], guidance=g,
-                             n_rolls=None if meta["n_rolls"] < 0 else meta["n_rolls"], full_list=True)
+                             full_list=True, **region_kwargs(meta))
     return d, meta, sb, out
 
 

@@ -3,7 +3,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (SAMPLING_CASES, STL_CASES, golden_meta, golden_weights, load_golden, scene_from_golden)
+from conftest import (SAMPLING_CASES, STL_CASES, golden_meta, golden_weights, load_golden, region_kwargs,
+                      scene_from_golden)
 from oracle import pstl_oracle as orc
 from pstl_diffusion_policy_amd.synthetic import default_hparams
 
@@ -38,9 +39,7 @@ def test_sampling_region_matches_reference(name):
     meta = golden_meta(d)
     hp = default_hparams()
     out = orc.sampling_region(_weights_for(meta), scene_from_golden(d), meta["S"], meta["steps"], hp, d["x_T"], d["z"],
-                              rect_head=bool(meta["rect_head"]),
-                              multi_cands=None if meta["multi_cands"] < 0 else meta["multi_cands"],
-                              guidance=_guidance_cfg(meta), n_rolls=None if meta["n_rolls"] < 0 else meta["n_rolls"])
+                              **region_kwargs(meta))
     np.testing.assert_allclose(out["feature_scene"].numpy(), d["feature_scene"], rtol=0, atol=2e-6)
     # sampled trajectories: the north-star tolerance is 1e-4; the oracle itself sits far inside it
     tol = 5e-6 if not meta["guidance"] else 2e-5
