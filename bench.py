@@ -82,6 +82,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    # host-side scalars (the global valid-row statistics of the guidance loss) travel over a gloo side group, so that a
+    # step never has to wait for the GPU: batches are enqueued back to back
+    cpu_group = dist.new_group(backend="gloo") if (world > 1 and backend == "nccl") else None
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -100,7 +103,8 @@ def main():
     S, steps, bs = a.sampling_size, a.diffusion_steps, a.scenes
     # every rank owns its own contiguous block of scenes (seeded by the global scene offset); no data-path collective
     scene = make_scene_batch(bs, K=a.neighbors, S=S, seed=1000 + rank, invalid_lane_frac=0.2, stlp_mode="wide")
-    scene = {k: v.to(dev) for k, v in scene.items() if k not in ("pre_stlp", "tj_scores_prior")}
+    ids_host = float(sum(scene[k].sum().item() for k in ("curr_id", "left_id", "right_id")))   # from the CPU copy, as a
+    scene = {k: v.to(dev) for k, v in scene.items() if k not in ("pre_stlp", "tj_scores_prior")}   # data loader would
     sampler = Sampler(PackedWeights(sd, dev), hp, chain_waves=a.chain_waves)
     if train:
         from pstl_diffusion_policy_amd.engine import RectTrainer
@@ -115,8 +119,8 @@ def main():
 
     def one_step():
         # global mean(valid) of the guidance loss (one tiny all-reduce; the shard split must not change results)
-        ids = torch.stack([scene["curr_id"], scene["left_id"], scene["right_id"]]).sum().item()
-        vsum, vrows = global_valid_stats(ids * S, N, dev)
+        vsum, vrows = global_valid_stats(ids_host * S, N, torch.device("cpu") if (cpu_group or world == 1) else dev,
+                                         group=cpu_group)
         sb = SceneBatch(scene, S, hp, dev, global_valid_sum=vsum, global_rows=vrows, row_offset=rank * N)
         if a.noise == "torch":
             x_T = torch.randn(N, 40, device=dev, generator=gen)

@@ -174,7 +174,14 @@ class Sampler:
         Returns emit (n_emit,N,40): the last n_emit entries of the reference's normalised diff_full list."""
         dev = sb.device
         beta, alpha, alpha_hat = coeffs if coeffs is not None else diffusion_coeffs(steps, dev)
-        beta_host = beta.detach().cpu()
+        # host copy of beta (sqrt(beta_i) is a by-value argument of the guidance launch); taking it from the device tensor
+        # would block the host on the GPU at every rollout, so it is cached per schedule
+        cache = self.__dict__.setdefault("_beta_host", {})
+        key = (int(steps), beta.data_ptr())
+        if key not in cache:
+            cache.clear()
+            cache[key] = beta.detach().cpu()
+        beta_host = cache[key]
         flags = ffi.PSTL_FLAG_CLIP if clip else 0
         if guidance and guidance.get("maximize", False):
             flags |= ffi.PSTL_FLAG_MAXIMIZE
