@@ -84,7 +84,12 @@ def main():
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     # host-side scalars (the global valid-row statistics of the guidance loss) travel over a gloo side group, so that a
     # step never has to wait for the GPU: batches are enqueued back to back
-    cpu_group = dist.new_group(backend="gloo") if (world > 1 and backend == "nccl") else None
+    cpu_group = None
+    if world > 1 and backend == "nccl":
+        try:
+            cpu_group = dist.new_group(backend="gloo")
+        except Exception as e:      # no gloo transport on this node: fall back to the device all-reduce (one sync per step)
+            print("bench: gloo side group unavailable (%s); host scalars go through RCCL" % e, file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
