@@ -276,18 +276,85 @@ PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, f
 // caller (what compute_stl_dense receives).  get() returns state t and cos/sin of its heading (shared by the dynamics
 // and by the ego circle row).
 // ---------------------------------------------------------------------------------------------------------------
+struct alignas(8) f2 {
+  float x, y;
+};
+PSTL_HD void store_pair(float* p, float x, float y) {   // one 8-byte store
+#if defined(__HIPCC__)
+  typedef float st2 __attribute__((ext_vector_type(2)));
+  st2 v;
+  v.x = x;
+  v.y = y;
+  *reinterpret_cast<st2*>(p) = v;
+#else
+  p[0] = x;
+  p[1] = y;
+#endif
+}
+
+// (w, a) of time step t from a row's control buffer: contiguous rows (us == 1, 16-byte aligned: 160 B per row) are read
+// 16 bytes = two time steps at a time -- every per-lane access is a gather over 64 cache lines whatever its width, so
+// wider accesses are proportionally fewer gathers; element-major buffers (us = N) are coalesced and read one by one.
+#if defined(__HIPCC__)
+typedef float ctrl4 __attribute__((ext_vector_type(4)));   // a native vector type: the 16-byte load stays in registers
+typedef float ctrl2 __attribute__((ext_vector_type(2)));
+#else
+struct alignas(16) ctrl4 {
+  float x, y, z, w;
+};
+struct alignas(8) ctrl2 {
+  float x, y;
+};
+#endif
+
+struct CtrlReader {
+  const float* u;
+  long us;
+  float w1, a1;   // the second time step of the last 16-byte read
+  PSTL_HD CtrlReader(const float* u_, long us_) : u(u_), us(us_), w1(0.0f), a1(0.0f) {}
+  PSTL_HD void get(int t, float& w, float& a) {   // t must be visited in increasing order, starting at an even step
+    if (us == 1) {
+      if ((t & 1) == 0) {
+        const ctrl4 c = *reinterpret_cast<const ctrl4*>(u + 2 * t);
+        w = c.x;
+        a = c.y;
+        w1 = c.z;
+        a1 = c.w;
+      } else {
+        w = w1;
+        a = a1;
+      }
+    } else {
+      w = u[(2 * t) * us];
+      a = u[(2 * t + 1) * us];
+    }
+  }
+};
+PSTL_HD void ctrl_pair(const float* u, long us, int t, float& w, float& a) {   // one (w, a) pair, any order
+  if (us == 1) {
+    const ctrl2 p = *reinterpret_cast<const ctrl2*>(u + 2 * t);
+    w = p.x;
+    a = p.y;
+  } else {
+    w = u[(2 * t) * us];
+    a = u[(2 * t + 1) * us];
+  }
+}
+
 struct DynSrc {
   float x, y, th, v;
-  const float* u;
+  CtrlReader rd;
   float ws, as, dt;
-  long us;  // distance (in floats) between consecutive control values of this row: 1, or N for an element-major buffer
+  // us: distance (in floats) between consecutive control values of this row: 1, or N for an element-major buffer
   PSTL_HD DynSrc(const float* s0, const float* u_, float ws_, float as_, float dt_, long us_ = 1)
-      : x(s0[0]), y(s0[1]), th(s0[2]), v(s0[3]), u(u_), ws(ws_), as(as_), dt(dt_), us(us_) {}
+      : x(s0[0]), y(s0[1]), th(s0[2]), v(s0[3]), rd(u_, us_), ws(ws_), as(as_), dt(dt_) {}
   PSTL_HD void get(int t, float& X, float& Y, float& TH, float& V, float& c, float& s) {
     X = x, Y = y, TH = th, V = v;
     PSTL_SINCOS(th, &s, &c);
-    const float w = u[(2 * t) * us] * ws;
-    const float a = u[(2 * t + 1) * us] * as;
+    float wr, ar;
+    rd.get(t, wr, ar);
+    const float w = wr * ws;
+    const float a = ar * as;
     const float dx = v * c;
     const float dy = v * s;
     x = x + dx * dt;
@@ -463,8 +530,9 @@ PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Forward + adjoint of one row: returns the score and calls emit(t, gw, ga) once for every t in [0,T) with
-// (gw, ga) = dscore_fn(score) * d score / d (u[2t], u[2t+1])  (u = the 40 control values, scaled by wscale/ascale
+// Forward + adjoint of one row: returns the score and calls emit(t, gw, ga, w, a) once for every t in [0,T) with
+// (gw, ga) = dscore_fn(score) * d score / d (u[2t], u[2t+1]) and (w, a) = the stored values u[2t], u[2t+1] themselves
+// (the adjoint has them in registers, so an optimiser step needs no further read; u = the 40 control values, scaled by wscale/ascale
 // inside the dynamics).  Only the formula of r.mode carries gradient (the others are multiplied by a 0 mask in the
 // reference).  Scratch: kScratchGrad = 40 floats per lane = the state (x, y, th, v) at every 4th step (4*5) + the two
 // suffix tables (2*10).  The states in between are re-derived block by block from the checkpoint with the forward
@@ -485,7 +553,11 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   const int mode = r.mode;
   if (mode >= 3) {
     PSTL_NOUNROLL
-    for (int t = 0; t < kT; ++t) emit(t, 0.0f, 0.0f);
+    for (int t = 0; t < kT; ++t) {
+      float w, a;
+      ctrl_pair(u, us, t, w, a);
+      emit(t, 0.0f, 0.0f, w, a);
+    }
     return 1.0f;
   }
   const f4* lane = lanes + mode * kNseg;
@@ -509,7 +581,11 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   PSTL_UNROLL
   for (int i = 0; i < 6; ++i) om[i] = i < n ? PSTL_EXP(-V[i] * tau - Lout) * dscore_in : 0.0f;  // d score / d V_i
   const float o_v1 = om[0], o_v2 = om[1], o_s = (mode == 0) ? om[5] : om[4];
-  emit(kT - 1, 0.0f, 0.0f);  // the last control never reaches a scored state
+  {
+    float w, a;
+    ctrl_pair(u, us, kT - 1, w, a);
+    emit(kT - 1, 0.0f, 0.0f, w, a);  // the last control never reaches a scored state
+  }
   if (mode != 0) {
     // d F10(G s) / d s_u = sum_{k <= m} q_k exp(a_u - L_k), m = min(u, 9), q_k = exp(tau g_k - Lf).  With
     // S_m = sum_{k<=m} q_k exp(L_m - L_k) (a 10-step recurrence; L_k decreases with k so every exponent is <= 0)
@@ -536,17 +612,22 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   PSTL_NOUNROLL
   for (int blk = kCk - 1; blk >= 0; --blk) {
     float bx[kCkStride], by[kCkStride], bth[kCkStride], bv[kCkStride], bc[kCkStride], bs[kCkStride];
+    float bw[kCkStride], ba[kCkStride];   // stored controls of steps 4blk-1, 4blk, 4blk+1, 4blk+2: the ones emit() is called for
     {
       float x = st.at(CKP + blk), y = st.at(CKP + kCk + blk), th = st.at(CKP + 2 * kCk + blk), v = st.at(CKP + 3 * kCk + blk);
+      CtrlReader rd(u, us);
+      if (blk > 0) ctrl_pair(u, us, blk * kCkStride - 1, bw[0], ba[0]);
       PSTL_UNROLL
       for (int i = 0; i < kCkStride; ++i) {
         float c, s;
         PSTL_SINCOS(th, &s, &c);
         bx[i] = x, by[i] = y, bth[i] = th, bv[i] = v, bc[i] = c, bs[i] = s;
         if (i + 1 < kCkStride) {
-          const int q = blk * kCkStride + i;
-          const float w = u[(2 * q) * us] * wscale;
-          const float a = u[(2 * q + 1) * us] * ascale;
+          float wr, ar;
+          rd.get(blk * kCkStride + i, wr, ar);
+          bw[i + 1] = wr, ba[i + 1] = ar;
+          const float w = wr * wscale;
+          const float a = ar * ascale;
           const float dx = v * c;
           const float dy = v * s;
           x = x + dx * dt;
@@ -599,7 +680,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     lth = nlth;
     lv = nlv;
     // state_t = f(state_{t-1}, u_{t-1}):  th_t = th_{t-1} + w dt ; v_t = v_{t-1} + a dt
-    emit(t - 1, lth * dt * wscale, lv * dt * ascale);
+    emit(t - 1, lth * dt * wscale, lv * dt * ascale, pick4(bw, i), pick4(ba, i));
   }
   }
   return score;

@@ -158,9 +158,8 @@ __global__ __launch_bounds__(kWave) void k_stl_backward(GradArgs a) {
   float* out = a.dcontrols + row * (2 * kT);
   const float score = stl_eval_grad(
       a.env, r, lanes, nei, a.K, a.s0 + b * 4, a.u + row * (2 * kT), st, a.wscale, a.ascale, [=](float) { return ds; },
-      [=](int t, float gw, float ga) {
-        out[2 * t] = gw;
-        out[2 * t + 1] = ga;
+      [=](int t, float gw, float ga, float, float) {
+        store_pair(out + 2 * t, gw, ga);   // one 8-byte gather store per time step
       });
   if (a.scores) a.scores[row] = score;
 }
@@ -214,7 +213,8 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
   float* wm = MULTI ? a.work + row * (2 * kT) : nullptr;
   const float* zr = a.z ? a.z + row * (2 * kT) : nullptr;
   float* er = a.emit_out ? a.emit_out + row * (2 * kT) : nullptr;
-  auto update = [=](int e, float g, float nscale, float zdrawn) {
+  // one element of the Adam update; returns the value that goes back to mu (and, through *emit_v, to emit_out)
+  auto update = [=](int e, float p0, float g, float nscale, float zdrawn, float* emit_v) -> float {
     // torch.optim.Adam, single-tensor path, betas (0.9, 0.999), eps 1e-8 (see oracle guidance_update)
     float m = 0.0f, v = 0.0f;
     if (MULTI && a.iter > 0) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
     m = m + 0.1f * (g - m);
     v = v * 0.999f + (0.001f * g) * g;
     const float denom = sqrtf(v) / a.bc2_sqrt + 1e-8f;
-    float p = mu[e] + (a.neg_step * m) / denom;
+    float p = p0 + (a.neg_step * m) / denom;
     if (MULTI) {
       wm[e] = m;
       wm[plane + e] = v;
@@ -235,31 +235,29 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
         p = an + fminf(fabsf(p - an), a.beta_i);
       }
     }
-    if (last) {
-      const float zv = a.rng ? zdrawn : (zr ? zr[e] : 0.0f);
-      const float x = p + a.sqrt_beta * zv;
-      mu[e] = x;
-      if (er) {
-        float c = x * nscale;
-        if (a.clip) c = fminf(fmaxf(c, -nscale), nscale);
-        er[e] = c;
-      }
-    } else {
-      mu[e] = p;
-    }
+    if (!last) return p;
+    const float zv = a.rng ? zdrawn : (zr ? zr[e] : 0.0f);
+    const float x = p + a.sqrt_beta * zv;
+    float c = x * nscale;
+    if (a.clip) c = fminf(fmaxf(c, -nscale), nscale);
+    *emit_v = c;
+    return x;
   };
-  // mu[2t], mu[2t+1] are rewritten by emit(t) while the adjoint walks t = T-1 ... 0; the sweep re-reads only entries
-  // of earlier time steps, which are still the original values
+  // mu[2t], mu[2t+1] are rewritten by emit(t) while the adjoint walks t = T-1 ... 0; the adjoint has already taken every
+  // value it still needs from earlier time steps only (and hands the current one to emit, so mu is not read here)
   stl_eval_grad(
       a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
       [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
-      [=](int t, float gw, float ga) {
+      [=](int t, float gw, float ga, float w0, float a0) {
         // elements 2t, 2t+1 share one noise quad: one Philox draw per time step
         float z4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (a.rng && a.step > 1 && last) normal4(a.seed, a.row_offset + row, t >> 1, a.step, z4);
         const int o = (t & 1) * 2;
-        update(2 * t, gw, a.wscale, o ? z4[2] : z4[0]);
-        update(2 * t + 1, ga, a.ascale, o ? z4[3] : z4[1]);
+        float ew = 0.0f, ea = 0.0f;
+        const float nw = update(2 * t, w0, gw, a.wscale, o ? z4[2] : z4[0], &ew);
+        const float na = update(2 * t + 1, a0, ga, a.ascale, o ? z4[3] : z4[1], &ea);
+        store_pair(mu + 2 * t, nw, na);                      // 8-byte gather stores: (w, a) of a step together
+        if (last && er) store_pair(er + 2 * t, ew, ea);
       });
 }
 
@@ -292,8 +290,10 @@ struct TrajoptArgs {
   int resume;
 };
 
+// amdgpu_waves_per_eu(3, 4): the register allocation is held to the 3 wavefronts per SIMD that the 10 KB of LDS per
+// wavefront allows (the kernel is latency-bound; at 169 registers = 2 per SIMD it ran 10 % slower)
 template <bool STAGED>
-__global__ __launch_bounds__(kWave) void k_trajopt(TrajoptArgs a) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_trajopt(TrajoptArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const long row = (long)blockIdx.x * kWave + threadIdx.x;
   const f4* lanes;
@@ -323,8 +323,7 @@ __global__ __launch_bounds__(kWave) void k_trajopt(TrajoptArgs a) {
   for (int it = 0; it < a.iters; ++it) {
     const float neg_step = a.neg_step[it], bc2 = a.bc2_sqrt[it];
     const bool fresh = (it == 0 && !a.resume);
-    auto update = [=](int e, float g, float lim2) {
-      const float p0 = u[e * N];
+    auto update = [=](int e, float p0, float g, float lim2) {
       // d reg / d p: relu'(p^2 - lim^2) * 2p * reg_scale   (pow backward: grad * (2 * p))
       if (p0 * p0 - lim2 > 0.0f) g = g + a.reg_scale * (2.0f * p0);
       float m = fresh ? 0.0f : wm[e * N], v = fresh ? 0.0f : wm[plane + e * N];
@@ -338,9 +337,9 @@ __global__ __launch_bounds__(kWave) void k_trajopt(TrajoptArgs a) {
     score = stl_eval_grad(
         a.env, r, lanes, nei, a.K, a.s0 + b * 4, u, st, 1.0f, 1.0f,
         [=](float sc) { return (thres - sc > 0.0f) ? -gs : 0.0f; },
-        [=](int t, float gw, float ga) {
-          update(2 * t, gw, a.w_max2);
-          update(2 * t + 1, ga, a.a_max2);
+        [=](int t, float gw, float ga, float w0, float a0) {
+          update(2 * t, w0, gw, a.w_max2);
+          update(2 * t + 1, a0, ga, a.a_max2);
         },
         N);
   }

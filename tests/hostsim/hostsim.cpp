@@ -67,7 +67,7 @@ void hostsim_stl_grad(int N, int rows_per_scene, int K, float tau, float dt, flo
     const float ds = dscore ? dscore[r] : 1.0f;
     const float vr = valid ? valid[r] : 1.0f;
     auto dfn = [=](float score) { return relu_mode ? ((thres - score > 0.0f) ? -(gscale * vr) : 0.0f) : ds; };
-    auto emit = [=](int t, float gw, float ga) {
+    auto emit = [=](int t, float gw, float ga, float, float) {
       out[2 * t] = gw;
       out[2 * t + 1] = ga;
     };

@@ -43,7 +43,7 @@ int main() {
       }
       const float scale = (rep % 5 == 0) ? 50.0f : (rep % 5 == 1) ? 1e-6f : 0.2f;
       float s0[4] = {urand(), urand() - 0.5f, 0.05f * (urand() - 0.5f), 5 + 3 * urand()};
-      float u[2 * kT];
+      alignas(16) float u[2 * kT];   // contiguous control rows are read 16 bytes at a time
       for (int i = 0; i < 2 * kT; ++i) u[i] = scale * (urand() - 0.5f);
       const StlEnv env = make_env(100.0f, 0.5f, 4.084f, 1.73f);
       for (int mode = 0; mode <= 3; ++mode) {
@@ -57,7 +57,7 @@ int main() {
         float du[2 * kT];
         const float ag = stl_eval_grad(
             env, r, lanes.data(), nei_prep.data(), K, s0, u, Scratch{scg.data(), 1}, 1.0f, 1.0f, [](float) { return 1.0f; },
-            [&](int t, float gw, float ga) {
+            [&](int t, float gw, float ga, float, float) {
               du[2 * t] = gw;
               du[2 * t + 1] = ga;
             });
