@@ -13,6 +13,8 @@
  *  - rows: N = bs * rows_per_scene, row r belongs to scene r / rows_per_scene.  The reference's row order is
  *    r = (b*S + s)*3 + mode (nusc_train.py:20,724-754) => rows_per_scene = 3*S.  Passing rows_per_scene = 1 and
  *    bs = N gives the reference's "dense" (row-replicated) layout for the scene tensors.
+ *  - row buffers ((N,40) controls, (N,T,4) states and the like) are accessed 16 bytes at a time and must be 16-byte
+ *    aligned (PSTL_ERR_ARG otherwise); every torch allocation and every row-wise slice of one is;
  *  - thread-safe for distinct streams; no global mutable state.
  */
 #ifndef PSTL_HIP_H

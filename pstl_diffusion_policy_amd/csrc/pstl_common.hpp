@@ -13,6 +13,10 @@ inline int check_cfg(const pstl_cfg* c) {
   return PSTL_OK;
 }
 
+// Row buffers of 40 controls / (T,4) states are read and written 16 bytes at a time: they must be 16-byte aligned (every
+// torch allocation and every row-wise slice of one is).
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 inline long n_rows(const pstl_cfg* c) { return (long)c->bs * c->rows_per_scene; }
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? PSTL_OK : PSTL_ERR_LAUNCH; }

@@ -519,6 +519,7 @@ extern "C" int pstl_stl_forward(const pstl_cfg* cfg, const float* s0, const floa
                                 float* sel_scores, int32_t* sel_idx, void* stream) {
   if (int e = check_cfg(cfg)) return e;
   if ((!states && (!s0 || !controls)) || !lane_prep || !stlp || !hl || !scores || reps < 1) return PSTL_ERR_ARG;
+  if (!aligned16(controls) || !aligned16(states) || !aligned16(sel_controls)) return PSTL_ERR_ARG;
   if (cfg->K > 0 && !nei_prep) return PSTL_ERR_ARG;
   if (sel_controls && (!sel_scores || !sel_idx)) return PSTL_ERR_ARG;
   StlArgs a;
@@ -559,6 +560,7 @@ extern "C" int pstl_stl_backward(const pstl_cfg* cfg, const float* s0, const flo
                                  float* dcontrols, float* scores, void* stream) {
   if (int e = check_cfg(cfg)) return e;
   if (!s0 || !controls || !lane_prep || !stlp || !hl || !dcontrols) return PSTL_ERR_ARG;
+  if (!aligned16(controls) || !aligned16(dcontrols)) return PSTL_ERR_ARG;
   if (cfg->K > 0 && !nei_prep) return PSTL_ERR_ARG;
   GradArgs a;
   a.N = n_rows(cfg);
@@ -593,6 +595,7 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
     return PSTL_ERR_ARG;
   if (cfg->K > 0 && !nei_prep) return PSTL_ERR_ARG;
   if (niters > 1 && !work) return PSTL_ERR_ARG;
+  if (!aligned16(mu_x_inout) || !aligned16(emit_out) || !aligned16(z)) return PSTL_ERR_ARG;
   GuideArgs a;
   a.N = n_rows(cfg);
   a.rows_per_scene = cfg->rows_per_scene;
@@ -680,6 +683,7 @@ extern "C" int pstl_stl_signals(const pstl_cfg* cfg, const float* s0, const floa
                                 const float* nei_prep, const float* lane_prep, float* signals, void* stream) {
   if (int e = check_cfg(cfg)) return e;
   if (!lane_prep || !signals || (!states && (!s0 || !controls)) || (cfg->K > 0 && !nei_prep)) return PSTL_ERR_ARG;
+  if (!aligned16(controls) || !aligned16(states)) return PSTL_ERR_ARG;
   const long N = n_rows(cfg);
   hipLaunchKernelGGL(k_stl_signals, dim3((unsigned)((N + kWave - 1) / kWave)), dim3(kWave), 0, as_stream(stream), N,
                      cfg->rows_per_scene, cfg->K, make_env(cfg->tau, cfg->dt, cfg->ego_L, cfg->ego_W), s0, controls, states,

@@ -107,6 +107,9 @@ def test_abi_rejects_bad_arguments_with_status_codes(dev):
                                       p, p, st) == -1                                             # T > PSTL_STL_MAX_T
     assert L.pstl_trajopt(ctypes.byref(ok_cfg), p, p, p, p, p, p, ctypes.c_float(0.01), ctypes.c_float(1.0), ctypes.c_float(0.0),
                           0, p, p, 0, p, p, p, st) == -1                                          # iters < 1
+    off4 = ctypes.c_void_p(buf.data_ptr() + 4)                                                     # not 16-byte aligned
+    assert L.pstl_stl_backward(ctypes.byref(ok_cfg), p, off4, p, p, p, p, null, p, null, st) == -1
+    assert L.pstl_stl_forward(ctypes.byref(ok_cfg), p, off4, null, 1, p, p, p, p, p, null, null, null, null, st) == -1
     assert L.pstl_error_string(-1).decode() and L.pstl_error_string(-3).decode()
     torch.cuda.synchronize()    # nothing was launched, nothing is pending, the device is healthy
     assert float(buf.sum()) == 0.0
