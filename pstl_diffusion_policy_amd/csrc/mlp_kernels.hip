@@ -435,32 +435,35 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   }
 
   // ---- per-row constants and the initial state into the B-operand image ----
-  for (int e = tid; e < G * kTileRows * kKx; e += NT) {
-    const int tl = e / (kTileRows * kKx), rem = e % (kTileRows * kKx);
-    const int c = rem / kKx, k = rem % kKx;
+  // Four consecutive input columns k = 4j .. 4j+3 of one tile column sit in one 16-byte LDS slot of the B-operand image,
+  // so a row is moved as 12 quads: 10 straight from the 160-byte state row (16-byte global loads), 2 assembled from
+  // hl | stlp | 0.  (One scalar load per element made this prologue a visible part of the single-step launches.)
+  for (int e = tid; e < G * kTileRows * (kKx / 4); e += NT) {
+    const int tl = e / (kTileRows * (kKx / 4)), rem = e % (kTileRows * (kKx / 4));
+    const int c = rem / (kKx / 4), j = rem % (kKx / 4);
     long row = (tile0 + tl) * kTileRows + c;
     if (row >= a.N) row = a.N - 1;
-    float v;
-    if (k < kCtrl) {
+    f32x4 v;
+    if (j < kCtrl / 4) {
       if (REFINE) {
-        v = a.init[row * kCtrl + k];
+        v = *reinterpret_cast<const f32x4*>(a.init + row * kCtrl + 4 * j);
         if (a.pooled) {  // fused = init + pooled[scene][mode][shard]   (nusc_model.py:186-200)
           const long b = row / a.rows_per_scene;
           const int rr = (int)(row % a.rows_per_scene), s = rr / 3, m = rr % 3;
           const int sh = s / (a.S / a.n_shards);
-          v += a.pooled[((b * 3 + m) * a.n_shards + sh) * kCtrl + k];
+          v += *reinterpret_cast<const f32x4*>(a.pooled + ((b * 3 + m) * a.n_shards + sh) * kCtrl + 4 * j);
         }
       } else {
-        v = a.x_inout[row * kCtrl + k];
+        v = *reinterpret_cast<const f32x4*>(a.x_inout + row * kCtrl + 4 * j);
       }
-    } else if (k == 40) {
-      v = a.hl[row];
-    } else if (k < 47) {
-      v = a.stlp[row * 6 + (k - 41)];
+    } else if (j == kCtrl / 4) {
+      const float* sp = a.stlp + row * 6;
+      v = f32x4{a.hl[row], sp[0], sp[1], sp[2]};
     } else {
-      v = 0.0f;
+      const float* sp = a.stlp + row * 6;
+      v = f32x4{sp[3], sp[4], sp[5], 0.0f};
     }
-    xs[tl * 768 + xs_addr(k, c)] = v;
+    *reinterpret_cast<f32x4*>(xs + tl * 768 + xs_addr(4 * j, c)) = v;
   }
   if (!REFINE && a.n_emit >= a.steps && a.step_hi == a.steps - 1) {  // x_T itself is entry 0 of the full list
     for (int e = tid; e < G * kTileRows * kCtrl; e += NT) {
