@@ -571,6 +571,11 @@ def main_flags():
     sampling_case(ref, sd, "fl_not_use_rect", e7 + ["--not_use_rect"], seed=74, **kw)
     sampling_case(ref, sd, "fl_guid_sets", e7 + gd + ["--guidance_sets", "2", "5", "7"], seed=75, **kw)
     sampling_case(ref, sd, "fl_guid_freq_rev", e7 + gd + ["--guidance_freq", "3", "--guidance_reverse"], seed=76, **kw)
+    # the reference's default sampling_size: 192 rows per scene = whole 16-row tiles and whole wavefronts per scene, i.e.
+    # the uniform-tile chain path and the LDS-staged scene tables of the STL kernels, against the reference itself
+    e7c5 = e7[:-1] + ["5"]
+    sampling_case(ref, sd, "e7_s64_guid", e7c5 + gd + ["--guidance_before", "3"], bs=2, S=64, K=2, steps=8, seed=77,
+                  stlp_mode="wide", invalid_lane_frac=0.25)
 
 
 if __name__ == "__main__" and "--flags" in sys.argv:
