@@ -157,7 +157,7 @@ def sampling_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=
         os.path.getsize(path) / 1024))
 
 
-def stl_case(ref, name, bs, S, K, seed, invalid_lane_frac, stlp_mode, ctrl_scale, norm_stl=False):
+def stl_case(ref, name, bs, S, K, seed, invalid_lane_frac, stlp_mode, ctrl_scale, norm_stl=False, lean=False):
     """STL robustness + gradients w.r.t. the controls, on small random controls (mixed satisfied/violated rows)."""
     nt = ref.nusc_train
     args = ref_harness.parse_reference_args(
@@ -193,6 +193,8 @@ def stl_case(ref, name, bs, S, K, seed, invalid_lane_frac, stlp_mode, ctrl_scale
            "grad_loss": np_(g_loss), "grad_sum": np_(g_sum)}
     for k in ["x2curr_d", "x2curr_th", "x2left_d", "x2left_th", "x2right_d", "x2right_th", "min_nei_d"]:
         out["sig_" + k] = np_(stl_in[k])
+    if lean:    # a large case: keep only what the score / mask comparison needs
+        out = {k: v for k, v in out.items() if k in ("controls", "scores3", "scores", "acc", "scene_acc", "loss", "grad_loss")}
     for k in ["ego_traj", "neighbors", "neighbors_traj", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
               "curr_id", "left_id", "right_id", "stlp_modes"]:
         out["in_" + k] = np_(batch[k])
@@ -231,7 +233,7 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big")):
     main()
 
 
@@ -580,3 +582,13 @@ def main_flags():
 
 if __name__ == "__main__" and "--flags" in sys.argv:
     main_flags()
+
+
+def main_stl_big():
+    """6144 rows at the reference's default sampling_size: score signs (satisfaction masks) against the reference at scale."""
+    ref = ref_harness.load_reference()
+    stl_case(ref, "stl_big", bs=32, S=64, K=3, seed=25, invalid_lane_frac=0.25, stlp_mode="wide", ctrl_scale=0.03, lean=True)
+
+
+if __name__ == "__main__" and "--stl-big" in sys.argv:
+    main_stl_big()

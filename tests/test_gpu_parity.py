@@ -317,3 +317,30 @@ def test_full_size_properties(dev):
     assert torch.equal(total, full["counts"])
     acc, sacc = acc_from_counts(full["counts"])
     assert 0.0 < acc < 1.0 and 0.0 < sacc <= 1.0
+
+
+def test_stl_masks_at_scale_match_reference(dev):
+    """6144 rows (32 scenes x the reference's sampling_size 64 x 3 modes; LDS-staged scene tables): the three formula
+    scores and the satisfaction mask against the reference's own compute_stl_dense, plus the loss gradient."""
+    from pstl_diffusion_policy_amd.engine import Sampler, acc_from_counts
+    d = load_golden("stl_big")
+    bs, S, K, seed = [int(v) for v in d["meta"]]
+    w, _ = _weights(dev)
+    sb = _scene_batch(d, S, dev)
+    sm = Sampler(w, _hp())
+    c = torch.from_numpy(d["controls"]).reshape(1, sb.N, 40).to(dev)
+    r = sm.score(sb, c, all3=True)
+    np.testing.assert_allclose(r["scores3"][:, 0].cpu().numpy(), d["scores3"], rtol=5e-5, atol=5e-4)
+    got = r["scores"][0].cpu().numpy()
+    np.testing.assert_allclose(got, d["scores"], rtol=5e-5, atol=5e-4)
+    np.testing.assert_array_equal(got > 0, d["scores"] > 0)                  # 6144 masks, bit for bit
+    print("rows with |score| < 1e-3 in the reference: %d of %d" % (int((np.abs(d["scores"]) < 1e-3).sum()), sb.N))
+    counts, _ = sm.metrics(sb, r["scores"][0])
+    acc, sacc = acc_from_counts(counts)
+    assert acc == float(d["acc"]) and sacc == float(d["scene_acc"])
+    # d loss / d controls of the guidance loss (what pstl_guidance_step feeds Adam with)
+    dscore = torch.where((_hp()["stl_nn_thres"] - r["scores"][0]) > 0, -sb.grad_scale * sb.valid, torch.zeros_like(sb.valid))
+    _, g = sm.score_grad(sb, c[0], dscore=dscore.contiguous())
+    ref = d["grad_loss"].reshape(-1, 40)
+    scale = np.abs(ref).max() + 1e-20
+    np.testing.assert_allclose(g.cpu().numpy() / scale, ref / scale, rtol=5e-3, atol=2e-4)
