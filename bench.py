@@ -44,25 +44,40 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(a, hp, sd, guidance, rect_head):
+def cpu_baseline(a, hp, sd, guidance, rect_head, sampler=None, dev=None):
     """The CPU oracle (a float32 torch restatement of the reference path; the reference itself cannot travel to the
-    GPU box) timed on the host cores on a bounded sample of the same workload."""
+    GPU box) timed on the host cores on a bounded sample of the same workload.  The HIP path is then run on the very same
+    scenes and noise, so that the line also carries the satisfaction rate of both and their largest control difference."""
     from oracle import pstl_oracle as orc
     from pstl_diffusion_policy_amd.synthetic import make_scene_batch
     bs, S, steps = a.cpu_scenes, a.sampling_size, a.diffusion_steps
-    scene = {k: v.numpy() for k, v in make_scene_batch(bs, K=a.neighbors, S=S, seed=77, stlp_mode="wide").items()}
+    scene_t = make_scene_batch(bs, K=a.neighbors, S=S, seed=77, stlp_mode="wide")
+    scene = {k: v.numpy() for k, v in scene_t.items()}
     N = bs * S * 3
     g = torch.Generator().manual_seed(5)
     sdn = {k: v.cpu().numpy() for k, v in sd.items()}
     t0 = time.time()
     x_T = torch.randn(N, 40, generator=g)
     z = torch.randn(steps - 1, N, 40, generator=g)
-    orc.sampling_region(sdn, scene, S, steps, hp, x_T, z, rect_head=rect_head,
-                        multi_cands=a.multi_cands if rect_head else None, guidance=guidance)
+    mc = a.multi_cands if rect_head else None
+    ref = orc.sampling_region(sdn, scene, S, steps, hp, x_T, z, rect_head=rect_head, multi_cands=mc, guidance=guidance)
     dt = time.time() - t0
-    return {"value": N / dt, "unit": "trajectories/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%s, %d scenes x %d samples x 3 modes = %d rows, %d diffusion steps, K=%d, %.1f s, torch %s CPU"
-                      % (a.workload, bs, S, N, steps, a.neighbors, dt, torch.__version__)}
+    out = {"value": N / dt, "unit": "trajectories/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "%s, %d scenes x %d samples x 3 modes = %d rows, %d diffusion steps, K=%d, %.1f s, torch %s CPU"
+                     % (a.workload, bs, S, N, steps, a.neighbors, dt, torch.__version__),
+           "stl_sat_rate": float(ref["final_acc"])}
+    if sampler is not None:
+        from pstl_diffusion_policy_amd.engine import SceneBatch, acc_from_counts
+        sb = SceneBatch(scene_t, S, hp, dev)
+        got = sampler.sampling_region(sb, steps, x_T.to(dev), z.to(dev), rect_head=rect_head, multi_cands=mc, guidance=guidance,
+                                      want_scores3=False)
+        torch.cuda.synchronize()
+        acc, _ = acc_from_counts(got["counts"])
+        err = (got["final_controls"].reshape(N, 20, 2).cpu() - ref["final_controls"]).abs()
+        out.update(gpu_same_inputs={"stl_sat_rate": acc, "max_abs_dcontrols": float(err.max()),
+                                    "frac_controls_within_1e-4": float((err <= 1e-4).float().mean()),
+                                    "masks_differing": int(((got["final_scores"].cpu() > 0) != (ref["final_scores"] > 0)).sum())})
+    return out
 
 
 def main():
@@ -245,7 +260,7 @@ def main():
                          "note": "algorithmic FLOP = rows x steps x 172032 (hoisted layer-1 columns not counted)"},
         }
         if not a.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
-            line["cpu_baseline"] = cpu_baseline(a, hp, sd, guidance, rect_head)
+            line["cpu_baseline"] = cpu_baseline(a, hp, sd, guidance, rect_head, None if (train or trajopt) else sampler, dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
