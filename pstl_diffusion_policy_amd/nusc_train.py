@@ -13,8 +13,8 @@ Differences that are deliberate:
     `compute_stl_dense` also accepts a purely dense `stl_input` (rows_per_scene = 1) as the reference passes it.
   * data comes from the seeded synthetic scene generator (synthetic.py): the nuScenes cache / devkit are out of scope.
   * the metrics the reference computes on the CPU after its timer stops (diversity std / hull volume / entropies /
-    occupancy area, ADE/FDE; nusc_train.py:1107-1140) come from one HIP kernel (pstl_diversity); the traj-opt "TJ"
-    columns need the dataset's stored traj-opt solutions and are printed as nan.
+    occupancy area, ADE/FDE; nusc_train.py:1107-1140) come from one HIP kernel (pstl_diversity), for the sampled
+    trajectories and for the dataset's stored traj-opt solutions (the "TJ" columns, :918-957).
 """
 import argparse
 import ctypes
@@ -238,6 +238,33 @@ def prep_stl_cache(x, args):
     return x
 
 
+def infer_gt_stlp(batch_cuda, gt_trajs, args, data_loader=None):
+    """STL parameters (vmin, vmax, dmin, dmax, dsafe, thmax) that the ground-truth future itself satisfies (reference
+    nusc_train.py:210-251): extrema of the GT speed, of its lane distance / heading error w.r.t. the lane of its
+    high-level label (side lanes: from step nt/2 - 1 on) and of its clearance, widened by the --flex margins.  The signals
+    come from pstl_stl_signals (dense layout: one row per scene)."""
+    bs = gt_trajs.shape[0]
+    x = {"ego_traj": gt_trajs[..., :4], "neighbors": batch_cuda["neighbor_trajs_aug"],
+         "currlane_wpts": batch_cuda["currlane_wpts"], "leftlane_wpts": batch_cuda["leftlane_wpts"],
+         "rightlane_wpts": batch_cuda["rightlane_wpts"], "stlp": torch.zeros(bs, 1, 6, device=gt_trajs.device)}
+    x = prep_stl_cache(x, argparse.Namespace(**dict(vars(args), norm_stl=False)))
+    v = gt_trajs[..., 3]
+    hl = batch_cuda["gt_high_level"][:, 0]
+    h = args.nt // 2 - 1
+    sel = lambda a0, a1, a2, dflt: (a0 * (hl == 0).float() + a1 * (hl == 1).float() + a2 * (hl == 2).float()
+                                    + dflt * (hl == 3).float())
+    mn = lambda t: torch.min(t, dim=-1)[0]
+    mx = lambda t: torch.max(t, dim=-1)[0]
+    dmin = sel(mn(x["x2curr_d"]), mn(x["x2left_d"][:, h:]), mn(x["x2right_d"][:, h:]), -5)
+    dmax = sel(mx(x["x2curr_d"]), mx(x["x2left_d"][:, h:]), mx(x["x2right_d"][:, h:]), 5)
+    thmax = sel(mx(x["x2curr_th"]), mx(x["x2left_th"][:, h:]), mx(x["x2right_th"][:, h:]), 0.5)
+    dsafe = mn(x["min_nei_d"])
+    if args.flex:
+        return torch.stack([torch.clip(mn(v) - 1, -0.3), mx(v) + 1, dmin - 0.3, dmax + 0.3, torch.clip(dsafe - 0.1, 0),
+                            thmax + 0.1], dim=-1)
+    return torch.stack([mn(v) - 0.1, mx(v) + 0.1, dmin - 0.1, dmax + 0.1, dsafe - 0.1, thmax + 0.05], dim=-1)
+
+
 def compute_stl_dense(stl_input, stls_cac, stl_idx, mask, args, debug=False, tj_scores=None, scene=False):
     """Scores trajectories stl_input["ego_traj"] (R,T,4) (reference nusc_train.py:318-345).
     Returns (scores_list [curr, left, right, ones], scores (R,), acc[, scene_acc]).
@@ -404,8 +431,23 @@ def run_sampling_test(stls_cac, data_loader, net, coeffs, args, result_queue=Non
         gt_trajs = batch_cuda["ego_traj"][..., :4]
         states = gt_trajs[..., 0, :4]
         bs = states.shape[0]
-        gt_stlp = batch_cuda["stlp_modes"][:, 0]
+        batch_cuda["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
+        gt_stlp = infer_gt_stlp(batch_cuda, gt_trajs, args)
         N = bs * args.sampling_size * 3
+        # the dataset's traj-opt solutions ("TJ" columns of the printed line; reference nusc_train.py:918-957)
+        if "params" in batch_cuda:
+            tj_batch = augment_batch_data({k: batch_cuda[k] for k in batch_cuda if not k.startswith("_")}, gt_stlp, args)
+            tsb = tj_batch["_pstl"]
+            tj_controls = batch_cuda["params"].reshape(tsb.N, -1).float().contiguous()
+            tsm = Sampler(net.packed(), net.hparams())
+            tj_scores = tsm.score(tsb, tj_controls.reshape(1, tsb.N, -1))["scores"][0]
+            tcounts, _ = tsm.metrics(tsb, tj_scores)
+            tacc, tsacc = acc_from_counts(tcounts)
+            md.update("tj_acc", tacc)
+            md.update("tj_scene_acc", tsacc)
+            _, _, tj_tot = tsm.diversity(tsb, tj_controls, tj_scores)
+            for k, v in diversity_from_totals(tj_tot).items():
+                md.update("tj_" + k, v)
         torch.cuda.synchronize()
         tttt1 = time.time()
         if myt:
@@ -464,7 +506,8 @@ def run_sampling_test(stls_cac, data_loader, net, coeffs, args, result_queue=Non
         nan = float("nan")
         print("###[%02d] TJ acc:%.3f scene_acc:%.3f ade:%.3f fde:%.3f std:%.3f vol:%.3f area:%.3f s:%.3f u:%.3f| "
               "NN acc:%.3f scene_acc:%.3f ade:%.3f fde:%.3f std:%.3f vol:%.3f area:%.3f s:%.3f u:%.3f ||| T:%.3f" % (
-                  bi, nan, nan, nan, nan, nan, nan, nan, nan, nan, md("acc"), md("scene_acc"), md("ade"), md("fde"),
+                  bi, md("tj_acc"), md("tj_scene_acc"), md("tj_ade"), md("tj_fde"), md("tj_std"), md("tj_vol"), md("tj_area"),
+                  md("tj_ent_s"), md("tj_ent_wa"), md("acc"), md("scene_acc"), md("ade"), md("fde"),
                   md("std"), md("vol"), md("area"), md("ent_s"), md("ent_wa"), md("time")))
     if myt:
         myt.print_profile()

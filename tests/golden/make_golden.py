@@ -233,7 +233,7 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp")):
     main()
 
 
@@ -592,3 +592,24 @@ def main_stl_big():
 
 if __name__ == "__main__" and "--stl-big" in sys.argv:
     main_stl_big()
+
+
+def main_gt_stlp():
+    """infer_gt_stlp (reference nusc_train.py:210-251) on synthetic scenes with all four high-level labels, --flex on/off."""
+    ref = ref_harness.load_reference()
+    batch = make_scene_batch(12, K=4, S=8, seed=81, invalid_lane_frac=0.3)
+    g = torch.Generator().manual_seed(4)
+    batch["gt_high_level"] = torch.randint(0, 4, (12, 1), generator=g).float()
+    out = {"in_" + k: np_(batch[k]) for k in ["ego_traj", "neighbors_traj", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
+                                               "gt_high_level"]}
+    bc = dict(batch)
+    bc["neighbor_trajs_aug"] = batch["neighbors_traj"][..., :7]
+    for flex in (False, True):
+        args = ref_harness.parse_reference_args(["--diffusion", "--load_stlp"] + (["--flex"] if flex else []))
+        out["stlp_flex%d" % int(flex)] = np_(ref.nusc_train.infer_gt_stlp(bc, batch["ego_traj"][..., :4], args))
+    np.savez_compressed(os.path.join(HERE, "gt_stlp.npz"), **out)
+    print("gt_stlp.npz", out["stlp_flex1"][:3])
+
+
+if __name__ == "__main__" and "--gt-stlp" in sys.argv:
+    main_gt_stlp()

@@ -144,3 +144,17 @@ def test_cli_runs_the_sampling_test(capsys):
     out = capsys.readouterr().out
     assert "###[00]" in out and "NN acc:" in out and "T:" in out and "end_diffusion-start_diffusion" in out
     assert 0.0 <= md("acc") <= 1.0 and md("time") > 0
+
+
+def test_infer_gt_stlp_matches_reference():
+    """infer_gt_stlp through pstl_stl_signals against the reference's own function (all four high-level labels)."""
+    import os
+    from pstl_diffusion_policy_amd import nusc_train as nt
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "gt_stlp.npz")))
+    dev = torch.device("cuda:0")
+    bc = {k[3:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("in_")}
+    bc["neighbor_trajs_aug"] = bc["neighbors_traj"][..., :7]
+    for flex in (0, 1):
+        args = nt.generate_parser(["--diffusion", "--load_stlp"] + (["--flex"] if flex else []))
+        got = nt.infer_gt_stlp(bc, bc["ego_traj"][..., :4], args).cpu().numpy()
+        np.testing.assert_allclose(got, g["stlp_flex%d" % flex], rtol=1e-5, atol=2e-4)
