@@ -23,7 +23,8 @@ def test_sampling_test_and_trajopt_from_files(tmp_path, capsys):
     nd.save_checkpoint(init_state_dict(1007), os.path.join(root, "models"))
     md = nt.main(base + ["--rect_head", "--multi_cands", "3", "--run_sampling_test", "--test", "-P", nd.smart_path(root)])
     out = capsys.readouterr().out
-    assert "NN acc:" in out and "nan" not in out.split("| NN")[1]
+    line = [l for l in out.splitlines() if l.startswith("###[")][-1]
+    assert "TJ acc:" in line and "NN acc:" in line and "nan" not in line, line      # every column of the reference's line
     assert 0.0 <= md("acc") <= 1.0 and np.isfinite(md("std")) and np.isfinite(md("ade"))
     # the data-augmentation pass over the train split rewrites params_*.npy / scores_*.npy
     before = np.load(nd.trajopt_paths(os.path.join(root, "models"), 0, 1)["params"])
