@@ -761,6 +761,11 @@ def main(argv=None):
         return run_trajopt(loader_for("train", n_batches=min(args.n_trials, 2)), args)
     if args.sampling_size != args.n_randoms:
         raise SystemExit("--sampling_size must equal --n_randoms (merge_net pooling, reference nusc_model.py:187-196)")
+    if args.norm_stl and (args.rect_head or args.guidance or not args.run_sampling_test):
+        # compute_stl_dense / prep_stl_cache / the formula objects honour --norm_stl (generic evaluator); the fused kernels
+        # that score candidates, drive guidance and train RefineNet evaluate the un-normalised formulas only
+        raise SystemExit("--norm_stl is supported for scoring (compute_stl_dense), not together with --rect_head / --guidance "
+                         "/ training: the fused STL kernels evaluate the default (un-normalised) formulas")
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     loader = loader_for("val")
