@@ -440,7 +440,12 @@ def run_sampling_test(stls_cac, data_loader, net, coeffs, args, result_queue=Non
             tsb = tj_batch["_pstl"]
             tj_controls = batch_cuda["params"].reshape(tsb.N, -1).float().contiguous()
             tsm = Sampler(net.packed(), net.hparams())
-            tj_scores = tsm.score(tsb, tj_controls.reshape(1, tsb.N, -1))["scores"][0]
+            if args.norm_stl:   # the generic evaluator honours the normalised formulas
+                tj_in = pre_prepare_stl_cache(tj_batch, dense_trajs=tsm.trajs(tsb, tj_controls)[:, :-1].contiguous())
+                tj_scores = compute_stl_dense(tj_in, stls_cac, tj_batch["highlevel_dense"], tj_in["dense_valids"], args)[1]
+                tj_scores = tj_scores.contiguous()
+            else:
+                tj_scores = tsm.score(tsb, tj_controls.reshape(1, tsb.N, -1))["scores"][0]
             tcounts, _ = tsm.metrics(tsb, tj_scores)
             tacc, tsacc = acc_from_counts(tcounts)
             md.update("tj_acc", tacc)
