@@ -548,10 +548,12 @@ PSTL_HD float pick4(const float (&a)[kCkStride], int i) {   // register array, d
 template <class DScoreFn, class EmitFn>
 PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, const float* s0,
                             const float* u, Scratch st, float wscale, float ascale, DScoreFn dscore_fn, EmitFn emit,
-                            long us = 1) {
+                            long us = 1, bool inert = false) {
   const float tau = env.tau;
   const int mode = r.mode;
-  if (mode >= 3) {
+  // inert: the caller knows that this row's score cannot reach the result (its loss weight is zero -- an invalid lane):
+  // every gradient is exactly zero, so neither sweep is needed (the returned score is then meaningless).
+  if (mode >= 3 || inert) {
     PSTL_NOUNROLL
     for (int t = 0; t < kT; ++t) {
       float w, a;
@@ -577,6 +579,15 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   }
   const float Lout = -score * tau;  // logsumexp of (-V_i tau)
   const float dscore_in = dscore_fn(score);
+  if (dscore_in == 0.0f) {   // e.g. a hinge loss on a satisfied row: the adjoint would produce exact zeros
+    PSTL_NOUNROLL
+    for (int t = kT - 1; t >= 0; --t) {
+      float w, a;
+      ctrl_pair(u, us, t, w, a);
+      emit(t, 0.0f, 0.0f, w, a);
+    }
+    return score;
+  }
   float om[6];
   PSTL_UNROLL
   for (int i = 0; i < 6; ++i) om[i] = i < n ? PSTL_EXP(-V[i] * tau - Lout) * dscore_in : 0.0f;  // d score / d V_i

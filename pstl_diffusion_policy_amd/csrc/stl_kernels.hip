@@ -125,10 +125,30 @@ __global__ __launch_bounds__(kWave) void k_stl_forward(StlArgs a) {
   }
 }
 
+// Row handled by this lane.  by_mode (scene-indexed rows r = (b*S + s)*3 + mode with S a multiple of 64): a wavefront
+// takes 64 samples of ONE (scene, mode) instead of 64 consecutive rows.  Rows of a (scene, mode) share their lane, their
+// validity and mostly their fate (satisfied or not), so whole wavefronts take the cheap exits of stl_eval_grad -- an
+// invalid lane skips both sweeps, a satisfied row the adjoint -- instead of idling beside the lanes that cannot.
+// The workgroup -> scene map is unchanged (blockIdx.x * 64 / rows_per_scene), which is what scene_tables relies on.
+__device__ __forceinline__ long map_row(int by_mode, int rows_per_scene) {
+  const long blk = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (!by_mode) return blk * kWave + lane;
+  const int gps = rows_per_scene / kWave;   // workgroups per scene = 3 * (S / 64)
+  const long b = blk / gps;
+  const int g = (int)(blk % gps);
+  const int mode = g % 3, chunk = g / 3, S = rows_per_scene / 3;
+  return (b * S + chunk * kWave + lane) * 3 + mode;
+}
+static bool rows_by_mode(const pstl_cfg* cfg, bool staged) {
+  return staged && cfg->rows_per_scene == 3 * cfg->S && cfg->S % kWave == 0;
+}
+
 struct GradArgs {
   long N;
   int rows_per_scene;
   int K;
+  int by_mode;
   StlEnv env;
   float wscale, ascale;
   const float* s0;
@@ -145,7 +165,7 @@ struct GradArgs {
 template <bool STAGED>
 __global__ __launch_bounds__(kWave) void k_stl_backward(GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const long row = (long)blockIdx.x * kWave + threadIdx.x;
+  const long row = map_row(a.by_mode, a.rows_per_scene);
   const f4* lanes;
   const float* nei;
   scene_tables<STAGED>(lds, kScratchGrad, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes,
@@ -160,7 +180,8 @@ __global__ __launch_bounds__(kWave) void k_stl_backward(GradArgs a) {
       a.env, r, lanes, nei, a.K, a.s0 + b * 4, a.u + row * (2 * kT), st, a.wscale, a.ascale, [=](float) { return ds; },
       [=](int t, float gw, float ga, float, float) {
         store_pair(out + 2 * t, gw, ga);   // one 8-byte gather store per time step
-      });
+      },
+      1, ds == 0.0f && !a.scores);
   if (a.scores) a.scores[row] = score;
 }
 
@@ -169,6 +190,7 @@ struct GuideArgs {
   long N;
   int rows_per_scene;
   int K;
+  int by_mode;
   StlEnv env;
   float wscale, ascale;    // mul_w_max, mul_a_max
   float thres;             // stl_nn_thres, or 100 with PSTL_FLAG_MAXIMIZE
@@ -195,7 +217,7 @@ struct GuideArgs {
 template <bool MULTI, bool STAGED>
 __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const long row = (long)blockIdx.x * kWave + threadIdx.x;
+  const long row = map_row(a.by_mode, a.rows_per_scene);
   const f4* lanes;
   const float* nei;
   scene_tables<STAGED>(lds, kScratchGrad, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes,
@@ -258,7 +280,8 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
         const float na = update(2 * t + 1, a0, ga, a.ascale, o ? z4[3] : z4[1], &ea);
         store_pair(mu + 2 * t, nw, na);                      // 8-byte gather stores: (w, a) of a step together
         if (last && er) store_pair(er + 2 * t, ew, ea);
-      });
+      },
+      1, gs == 0.0f);   // an invalid lane has zero loss weight: Adam sees exact zeros, only the noise is added
 }
 
 // ---- trajectory optimisation (nusc_train.py:1302-1325 with compute_trajopt_loss_lite :287-316) --------
@@ -271,6 +294,7 @@ struct TrajoptArgs {
   long N;
   int rows_per_scene;
   int K;
+  int by_mode;
   StlEnv env;
   float thres, grad_scale;   // (1/clip(mean(valid),1e-3))/N
   float reg_scale;           // reg_loss / (N * nt): d reg / d relu-term
@@ -295,7 +319,8 @@ struct TrajoptArgs {
 template <bool STAGED>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_trajopt(TrajoptArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const long row = (long)blockIdx.x * kWave + threadIdx.x;
+  const long row = map_row(a.by_mode, a.rows_per_scene);
+  const long slot = (long)blockIdx.x * kWave + threadIdx.x;   // position in the element-major work buffer (lane-contiguous)
   const f4* lanes;
   const float* nei;
   scene_tables<STAGED>(lds, kScratchGrad, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes,
@@ -310,8 +335,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) v
   // over 786 432 rows at 12 resident wavefronts per CU; 1.7 ms at 7).
   const long N = a.N;
   const long plane = N * (2 * kT);
-  float* u = a.work + row;            // plane 0: the iterate
-  float* wm = a.work + plane + row;   // plane 1: m, plane 2: v
+  float* u = a.work + slot;            // plane 0: the iterate
+  float* wm = a.work + plane + slot;   // plane 1: m, plane 2: v
   {
     const float* src = a.params + row * (2 * kT);
     PSTL_NOUNROLL
@@ -579,6 +604,7 @@ extern "C" int pstl_stl_backward(const pstl_cfg* cfg, const float* s0, const flo
   a.dcontrols = dcontrols;
   a.scores = scores;
   const bool staged = scene_staged(cfg);
+  a.by_mode = rows_by_mode(cfg, staged) ? 1 : 0;
   const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged);
   void (*fn)(GradArgs) = staged ? k_stl_backward<true> : k_stl_backward<false>;
   if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
@@ -625,6 +651,7 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
   a.emit_out = emit_out;
   const dim3 grid((unsigned)((a.N + kWave - 1) / kWave));
   const bool staged = scene_staged(cfg);
+  a.by_mode = rows_by_mode(cfg, staged) ? 1 : 0;
   const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged);
   void (*fn)(GuideArgs) = niters > 1 ? (staged ? k_guidance_iter<true, true> : k_guidance_iter<true, false>)
                                      : (staged ? k_guidance_iter<false, true> : k_guidance_iter<false, false>);
@@ -672,6 +699,7 @@ extern "C" int pstl_trajopt(const pstl_cfg* cfg, const float* s0, const float* n
   a.scores = scores;
   a.resume = resume;
   const bool staged = scene_staged(cfg);
+  a.by_mode = rows_by_mode(cfg, staged) ? 1 : 0;
   const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged);
   void (*fn)(TrajoptArgs) = staged ? k_trajopt<true> : k_trajopt<false>;
   if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
