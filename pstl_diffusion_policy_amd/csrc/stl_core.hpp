@@ -555,7 +555,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   // every gradient is exactly zero, so neither sweep is needed (the returned score is then meaningless).
   if (mode >= 3 || inert) {
     PSTL_NOUNROLL
-    for (int t = 0; t < kT; ++t) {
+    for (int t = kT - 1; t >= 0; --t) {   // emit() is always called for t = T-1 ... 0, in that order
       float w, a;
       ctrl_pair(u, us, t, w, a);
       emit(t, 0.0f, 0.0f, w, a);

@@ -270,14 +270,18 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
   stl_eval_grad(
       a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
       [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
-      [=](int t, float gw, float ga, float w0, float a0) {
-        // elements 2t, 2t+1 share one noise quad: one Philox draw per time step
-        float z4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (a.rng && a.step > 1 && last) normal4(a.seed, a.row_offset + row, t >> 1, a.step, z4);
+      [=, z4 = f4{0.0f, 0.0f, 0.0f, 0.0f}](int t, float gw, float ga, float w0, float a0) mutable {
+        // a noise quad covers two time steps (elements 4q .. 4q+3); emit() comes in the order t = T-1 ... 0, so the quad is
+        // drawn at the odd step and kept for the even one: one Philox draw per two time steps
+        if (a.rng && a.step > 1 && last && (t & 1)) {
+          float zz[4];
+          normal4(a.seed, a.row_offset + row, t >> 1, a.step, zz);
+          z4 = f4{zz[0], zz[1], zz[2], zz[3]};
+        }
         const int o = (t & 1) * 2;
         float ew = 0.0f, ea = 0.0f;
-        const float nw = update(2 * t, w0, gw, a.wscale, o ? z4[2] : z4[0], &ew);
-        const float na = update(2 * t + 1, a0, ga, a.ascale, o ? z4[3] : z4[1], &ea);
+        const float nw = update(2 * t, w0, gw, a.wscale, o ? z4.z : z4.x, &ew);
+        const float na = update(2 * t + 1, a0, ga, a.ascale, o ? z4.w : z4.y, &ea);
         store_pair(mu + 2 * t, nw, na);                      // 8-byte gather stores: (w, a) of a step together
         if (last && er) store_pair(er + 2 * t, ew, ea);
       },
