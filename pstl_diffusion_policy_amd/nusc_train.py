@@ -133,6 +133,46 @@ def get_stl_scores(scores_list, stl_i):
 # ---------------------------------------------------------------------------------------------------------------
 # batch construction
 # ---------------------------------------------------------------------------------------------------------------
+def get_dense_stlp(batch_cuda, the_stlp, args, n_randoms=None):
+    """Per-row STL parameters of the traj-opt / data-generation pass (reference nusc_train.py:657-722): the mode that
+    matches the scene's ground-truth label keeps the GT parameters `the_stlp`; the other modes get the fixed prior
+    (0, 20, -2.5, 2.5, 0.1, 0.5), or with --flex parameters drawn around the GT ones (torch's CPU generator, in the
+    reference's order of draws, so a seeded run reproduces the reference's parameters).  -> (bs*n_randoms*3, 1, 6)."""
+    bs = the_stlp.shape[0]
+    if n_randoms is None:
+        n_randoms = args.n_randoms
+    dev = the_stlp.device
+    hl = batch_cuda["gt_high_level"].reshape(bs, 1, 1)
+    mid = the_stlp.unsqueeze(1).repeat(1, n_randoms, 1)                       # (bs, n_randoms, 6)
+    U = lambda a, b: (torch.rand(bs, 1) * (b - a) + a).repeat(1, n_randoms).to(dev)
+
+    def flex_params(level):
+        vd0, vd1 = U(1.3, 3), U(1.3, 3)
+        vmin = torch.clip(mid[:, :, 0] - vd0, -0.3)
+        vmax = torch.clip(mid[:, :, 1] + vd1, -0.3)
+        if level == 0:
+            l0, l1 = U(0, 1), U(0, 1)
+            dmin = l0 * mid[:, :, 2] + (1 - l0) * (mid[:, :, 2] - 2.5)
+            dmax = l1 * mid[:, :, 2] + (1 - l1) * (mid[:, :, 2] + 2.5)          # (the reference blends dmin here too)
+        else:
+            dmin, dmax = U(-2.5, -0.5), U(0.5, 2.5)
+        l2 = U(0, 1)
+        dsafe = torch.clip(l2 * mid[:, :, 4] + (1 - l2) * (mid[:, :, 4] - 1.5), 0)
+        l3 = U(0, 1)
+        thmax = l3 * mid[:, :, 5] + (1 - l3) * (mid[:, :, 5] + 0.3)
+        return torch.stack([vmin, vmax, dmin, dmax, dsafe, thmax], dim=-1)
+
+    if args.flex:
+        d0, d1, d2 = flex_params(0), flex_params(1), flex_params(2)
+        keep0 = (hl * (3 - hl) == 0).float()                                   # labels 0 and 3 keep the GT set in mode 0
+        per_mode = [keep0 * mid + (1 - keep0) * d0, (hl == 1).float() * mid + (hl != 1).float() * d1,
+                    (hl == 2).float() * mid + (hl != 2).float() * d2]
+    else:
+        prior = torch.tensor([0.0, 20.0, -2.5, 2.5, 0.1, 0.5], device=dev).reshape(1, 1, 6).repeat(bs, n_randoms, 1)
+        per_mode = [(hl == m).float() * mid + (hl != m).float() * prior for m in range(3)]
+    return torch.stack(per_mode, dim=-2).reshape(bs * n_randoms * 3, 1, 6)
+
+
 def augment_batch_data(batch, the_stlp, args, n_randoms=None, stlp_dense=None, dense=False):
     """Adds the per-row constants of the sampling harness (reference nusc_train.py:724-754).  `batch["_pstl"]` holds
     the scene-indexed device tensors the kernels read; dense replicas are only built with dense=True."""
@@ -153,7 +193,7 @@ def augment_batch_data(batch, the_stlp, args, n_randoms=None, stlp_dense=None, d
         else:
             batch["stlp_dense"] = batch["pre_stlp"].reshape(bs * m, 1, 6)
     else:
-        raise NotImplementedError("sampling test runs with --load_stlp (README commands); get_dense_stlp is data tooling")
+        batch["stlp_dense"] = get_dense_stlp(batch, the_stlp, args, n_randoms=n_randoms)
     valids = torch.cat([batch["curr_id"], batch["left_id"], batch["right_id"]], dim=-1)
     batch["valids_dense"] = dup(valids, n_randoms).reshape(bs * n_randoms, 3)
     batch["highlevel_dense"] = torch.tensor([0, 1.0, 2.0], device=dev).reshape(1, 3, 1).repeat(bs * n_randoms, 1, 1).reshape(bs * m, 1)
@@ -459,7 +499,7 @@ def run_sampling_test(stls_cac, data_loader, net, coeffs, args, result_queue=Non
             myt.next_batch()
         new_batch = {k: batch_cuda[k] for k in ("ego_traj", "neighbors", "currlane_wpts", "leftlane_wpts",
                                                 "rightlane_wpts", "curr_id", "left_id", "right_id", "gt_high_level",
-                                                "pre_stlp")}
+                                                "pre_stlp") if k in batch_cuda}
         new_batch["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
         new_batch = augment_batch_data(new_batch, gt_stlp, args, n_randoms=args.sampling_size)
         highlevel_new = new_batch["highlevel_dense"]
@@ -564,11 +604,10 @@ def run_trajopt(data_loader, args):
         N = bs * S * 3
         new_batch = {k: batch_cuda[k] for k in ("ego_traj", "neighbors", "currlane_wpts", "leftlane_wpts",
                                                 "rightlane_wpts", "curr_id", "left_id", "right_id", "gt_high_level",
-                                                "pre_stlp")}
+                                                "pre_stlp") if k in batch_cuda}
         new_batch["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
-        load_stlp, args.load_stlp = args.load_stlp, True        # synthetic scenes carry their per-row parameters
-        new_batch = augment_batch_data(new_batch, batch_cuda["stlp_modes"][:, 0], args)
-        args.load_stlp = load_stlp
+        gt_stlp = infer_gt_stlp(new_batch, batch_cuda["ego_traj"][..., :4], args)   # reference :1279, then get_dense_stlp
+        new_batch = augment_batch_data(new_batch, gt_stlp, args)
         sb = new_batch["_pstl"]
         traj_i = batch_cuda.get("traj_i", torch.full((bs,), bi))
         ti = batch_cuda.get("ti", torch.arange(bs))
@@ -616,7 +655,7 @@ def run_training(data_loader, net, coeffs, args):
             batch_cuda = dict_to_cuda(batch)
             new_batch = {k: batch_cuda[k] for k in ("ego_traj", "neighbors", "currlane_wpts", "leftlane_wpts",
                                                     "rightlane_wpts", "curr_id", "left_id", "right_id", "gt_high_level",
-                                                    "pre_stlp")}
+                                                    "pre_stlp") if k in batch_cuda}
             new_batch["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
             new_batch = augment_batch_data(new_batch, batch_cuda["stlp_modes"][:, 0], args)
             sb = new_batch["_pstl"]
@@ -739,6 +778,14 @@ def generate_parser(argv=None):
     if args.run_sampling_test:
         args.test = True
         args.extra_diversity = True
+    if args.trajopt_only:      # reference nusc_train.py:1794-1801
+        args.opt_epochs = 1
+        args.epochs = 1
+        args.batch_size = 1024
+        args.diffusion = True
+        args.flex = True
+    if args.opt_epochs > 0:
+        args.epochs = args.opt_epochs
     if args.load_stlp:
         args.load_tj = True
     if args.rect_head:

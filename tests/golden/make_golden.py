@@ -233,7 +233,7 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp")):
     main()
 
 
@@ -613,3 +613,25 @@ def main_gt_stlp():
 
 if __name__ == "__main__" and "--gt-stlp" in sys.argv:
     main_gt_stlp()
+
+
+def main_dense_stlp():
+    """get_dense_stlp (reference nusc_train.py:657-722): fixed-prior branch and the --flex branch under a seeded generator."""
+    ref = ref_harness.load_reference()
+    bs, S = 9, 4
+    g = torch.Generator().manual_seed(8)
+    the_stlp = torch.randn(bs, 6, generator=g) * 0.5 + torch.tensor([5.0, 8.0, -1.0, 1.0, 0.5, 0.4])
+    hl = torch.randint(0, 4, (bs, 1), generator=g).float()
+    out = {"in_stlp": np_(the_stlp), "in_gt_high_level": np_(hl), "S": np.int32(S)}
+    for flex in (0, 1):
+        # --trajopt_only forces --flex in the reference's parser (nusc_train.py:1794-1801)
+        args = ref_harness.parse_reference_args((["--trajopt_only"] if flex else ["--diffusion"]) + ["--n_randoms", str(S)])
+        assert bool(args.flex) == bool(flex)
+        torch.manual_seed(123)
+        out["dense_flex%d" % flex] = np_(ref.nusc_train.get_dense_stlp({"gt_high_level": hl}, the_stlp, args))
+    np.savez_compressed(os.path.join(HERE, "dense_stlp.npz"), **out)
+    print("dense_stlp.npz", out["dense_flex0"].shape, out["dense_flex1"][:3, 0])
+
+
+if __name__ == "__main__" and "--dense-stlp" in sys.argv:
+    main_dense_stlp()

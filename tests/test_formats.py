@@ -73,3 +73,18 @@ def test_trajopt_files_and_checkpoint(tmp_path):
     nd.save_checkpoint(sd, str(tmp_path / "models"))
     back = torch.load(nd.smart_path(str(tmp_path)), map_location="cpu")
     assert set(back) == set(sd) and all(torch.equal(back[k], sd[k].cpu()) for k in sd)
+
+
+def test_get_dense_stlp_matches_reference():
+    """Host-side parameter expansion of the traj-opt pass against the reference's get_dense_stlp: exact in the fixed-prior
+    branch, and in the --flex branch under the same torch seed (same draws in the same order)."""
+    g = dict(np.load(os.path.join(GOLD, "dense_stlp.npz")))
+    S = int(g["S"])
+    the_stlp = torch.from_numpy(g["in_stlp"])
+    batch = {"gt_high_level": torch.from_numpy(g["in_gt_high_level"])}
+    for flex in (0, 1):
+        args = _args((["--trajopt_only"] if flex else []) + ["--n_randoms", str(S), "--sampling_size", str(S)])
+        assert bool(args.flex) == bool(flex)        # --trajopt_only forces --flex, as in the reference's parser
+        torch.manual_seed(123)
+        got = nt.get_dense_stlp(batch, the_stlp, args).numpy()
+        np.testing.assert_array_equal(got, g["dense_flex%d" % flex])
