@@ -104,9 +104,33 @@ def closed_loop(state_dict, n_sim_steps=20, K=8, S=64, diffusion_steps=100, mult
     return records
 
 
-if __name__ == "__main__":
+def main(argv=None):
+    """The reference's nusc_sim command lines (README: `nusc_sim.py -e e7_ours --diffusion ... --test -P e7_ours
+    --filter_traj 0 --test_scenes --viz_last [--guidance --guidance_before 10 --guidance_niters 1 --guidance_lr 0.04]
+    --suffix sim`) on the synthetic world: same flags (nusc_train's parser), a checkpoint from -P when it exists,
+    random-init weights under --seed otherwise.  The devkit replay / rendering flags are accepted and ignored."""
+    import os
+    from . import nusc_train as nt
     from .nusc_model import init_state_dict
-    recs = closed_loop(init_state_dict(1007))
-    lats = sorted(r["latency_s"] for r in recs[2:])
-    print("median latency per simulation step: %.2f ms (192 rows, 100 diffusion steps, guidance on the last 10)"
-          % (lats[len(lats) // 2] * 1e3))
+    args = nt.generate_parser(argv)
+    sd = init_state_dict(args.seed, rect_head=True, diverse_loss=True)
+    if args.net_pretrained_path:
+        path = args.net_pretrained_path
+        if not os.path.isfile(path):
+            path = os.path.join("exps", path, "models", "model_last.ckpt")
+        if os.path.isfile(path):
+            sd.update(torch.load(path, map_location="cpu"))
+        else:
+            print("checkpoint %s not found: random-init weights (seed %d)" % (path, args.seed))
+    recs = closed_loop(sd, n_sim_steps=max(args.n_trials, 1) if args.n_trials < 100 else 20, K=args.n_neighbors,
+                       S=args.n_randoms, diffusion_steps=args.diffusion_steps, multi_cands=args.multi_cands or 5,
+                       guidance=args.guidance, guidance_before=args.guidance_before, guidance_lr=args.guidance_lr,
+                       seed=args.seed)
+    lats = sorted(r["latency_s"] for r in recs[min(2, len(recs) - 1):])
+    print("median latency per simulation step: %.2f ms (%d rows, %d diffusion steps, guidance %s)"
+          % (lats[len(lats) // 2] * 1e3, args.n_randoms * 3, args.diffusion_steps, "on" if args.guidance else "off"))
+    return recs
+
+
+if __name__ == "__main__":
+    main()

@@ -772,6 +772,41 @@ def generate_parser(argv=None):
         help="experiment directory holding cache.npz, *_split.txt and models/ (nusc_dataset.write_synthetic_experiment); "
              "without it batches come straight from the synthetic scene generator")
     add("--test_t1", action="store_true", default=False)
+    # the rest of the reference's flags (nusc_train.py:1635-1778), accepted so that its command lines parse unchanged;
+    # the ones that select functionality outside this path are refused in main() with a message
+    add("--anno_path", type=str, default="annotated_data_trainval")
+    add("--backup", action="store_true", default=False)
+    add("--bc_weight", type=float, default=0.0)
+    add("--check_stl_params", action="store_true", default=False)
+    add("--collect_data", action="store_true", default=False)
+    add("--debug", action="store_true", default=False)
+    add("--diffusion_weight", type=float, default=1.0)
+    add("--epi_print_freq", type=int, default=1)
+    add("--extra_rect_reg", type=float, default=0.0)
+    add("--filter_traj", type=int, nargs="+", default=None)
+    add("--generate_split_on_the_fly", action="store_true", default=False)
+    add("--gt_nei", action="store_true", default=False)
+    add("--lite_refine", action="store_true", default=False)
+    add("--n_expands", type=int, default=4)
+    add("--no_viz", action="store_true", default=False)
+    add("--num_viz", type=int, default=10)
+    add("--params_load_path", "-P2", type=str, default="e1_nusc_trajopt")
+    add("--raw_refinement", action="store_true", default=False)
+    add("--refined_safety", action="store_true", default=False)
+    add("--refinement", action="store_true", default=False)
+    add("--replace_hint", action="store_true", default=False)
+    add("--save_freq", type=int, default=100)
+    add("--stl_bc_mask", action="store_true", default=False)
+    add("--test_aggressive", action="store_true", default=False)
+    add("--test_scenes", action="store_true", default=False)
+    add("--train_ratio", type=float, default=0.7)
+    add("--trajopt_save_freq", type=int, default=1000)
+    add("--use_gt_stlp", action="store_true", default=False)
+    add("--vae_dim", type=int, default=64)
+    add("--viz_freq", type=int, default=50)
+    add("--viz_last", action="store_true", default=False)
+    add("--weight_vae_bc", type=float, default=1.0)
+    add("--weight_vae_kl", type=float, default=1.0)
     args = parser.parse_args(argv)
     args.cos = True
     args.measure_diversity = True
@@ -799,6 +834,12 @@ def generate_parser(argv=None):
 
 def main(argv=None):
     args = generate_parser(argv)
+    for flag, why in (("collect_data", "dataset extraction needs the nuScenes devkit"), ("bc", "the BC baseline"),
+                      ("vae", "the VAE baseline"), ("refinement", "the mixing-weight optimiser (nusc_train.py:1034-1071)"),
+                      ("gt_data_training", "the mono (GT-data) training mode"), ("check_stl_params", "a data-inspection tool")):
+        if getattr(args, flag, False):
+            raise SystemExit("--%s selects %s, which is outside the path this package implements" % (flag, why))
+
     def loader_for(split, n_batches=None):
         if args.cache_path:      # from files, as the reference does (cache.npz + split file + models/*.npy)
             from . import nusc_dataset

@@ -21,3 +21,13 @@ def test_receding_horizon_loop_runs_and_is_reproducible():
         assert all(math.isfinite(ra[k]) for k in ("best_score", "x", "y", "v", "latency_s"))
         assert (ra["best_score"], ra["x"], ra["y"], ra["v"]) == (rb["best_score"], rb["x"], rb["y"], rb["v"])
     assert a[-1]["x"] > a[0]["x"]                      # the ego moves forward
+
+
+def test_reference_command_line_runs(capsys):
+    """README command of the guided closed-loop run, through the mirror's main()."""
+    from pstl_diffusion_policy_amd import nusc_sim
+    recs = nusc_sim.main("-e e7_ours --diffusion --stl_weight 0.0 --rect_head --flex --diverse_loss --multi_cands 5 --test "
+                         "-P e7_ours --filter_traj 0 --test_scenes --viz_last --guidance --guidance_before 10 "
+                         "--guidance_niters 1 --guidance_lr 0.04 --suffix sim_guide --n_trials 3 --diffusion_steps 20 "
+                         "--n_neighbors 4".split())
+    assert len(recs) == 3 and "median latency" in capsys.readouterr().out
