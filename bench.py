@@ -22,6 +22,10 @@ sys.path.insert(0, ROOT)
 
 F_STEP_MIN = 2 * (40 * 256 + 256 * 256 + 256 * 40)   # algorithmic FLOP per row per denoiser evaluation
 PEAK_FP32_MATRIX_TFLOPS = 157.3                       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_BF16_MATRIX_TFLOPS = 16 * 157.3                  # same guide: the f32 MFMA rate is 1/16 of the dense BF16 rate (~2.5 PF)
+# split-bf16 chain kernel: MFMA FLOP issued per row and denoiser evaluation (69 v_mfma_f32_16x16x32_bf16 per wave and
+# 16-row tile, 8 waves): 3 bf16 products per fp32 product, layer 1 padded 40 -> 64 columns, layer 3 padded 40 -> 48 rows
+F_STEP_ISSUED_BF16 = 8 * 69 * (2 * 16 * 16 * 32) / 16
 
 
 def parse():
@@ -208,6 +212,10 @@ def main():
     k_ms = float(np.mean(ms))
     flop = float(nrows) * nst * F_STEP_MIN
     achieved = flop / (k_ms * 1e-3) / 1e12
+    split_bf16 = a.chain_waves in (0, 16)
+    peak = PEAK_BF16_MATRIX_TFLOPS if split_bf16 else PEAK_FP32_MATRIX_TFLOPS
+    dtype = ("bf16x3 (every f32 operand split into two bf16 pieces, 3 bf16 MFMA products per f32 product, f32 accumulate; "
+             "STL and rect_net in f32)") if split_bf16 else "f32"
     acc, sacc = acc_from_counts(counts)
     # the STL kernels (one row per lane): row-evaluations/s and what that means against the HBM roofline.  Algorithmic
     # bytes per row-evaluation in the scene-shared layout: 160 B controls + 16 B s0 + 24 B stlp + 4 B score + scene
@@ -239,7 +247,7 @@ def main():
             "metric": "sampled trajectories/sec (%d DDPM steps, multi_cands=%d) + STL-sat rate" % (steps, a.multi_cands),
             "value": world * N * a.steps / dt, "unit": "trajectories/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "%s: %d scenes/GPU x sampling_size %d x 3 modes = %d rows/GPU, T=20, K=%d neighbours, "
                                    "diffusion_steps=%d (%d denoiser evals), multi_cands=%s, guidance=%s, RefineNet=%s, "
                                    "random-init weights (seed 1007)"
@@ -247,17 +255,21 @@ def main():
                                       a.multi_cands if rect_head else None,
                                       "before=10,niters=1,lr=0.01" if guidance else None, rect_head),
                        "rows_per_gpu": N, "parallelism": "scene shards x%d, no data-path collective" % world,
-                       "chain_waves": a.chain_waves or 8,
+                       "chain_waves": a.chain_waves or 16,
                        "noise": "in-kernel Philox4x32-10" if a.noise == "kernel" else "torch.randn tensors"},
             "stl_sat_rate": acc, "scene_sat_rate": sacc,
             "diversity": None if train else diversity_from_totals(div_totals),
             "roofline": {"bound": "mfma", "kernel": "k_chain (denoiser MLP chain, %d reverse steps per launch)" % nst,
-                         "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "achieved_over_f32_mfma_peak": achieved / PEAK_FP32_MATRIX_TFLOPS,
+                         "matrix_pipe_frac_issued": (achieved * F_STEP_ISSUED_BF16 / F_STEP_MIN / peak) if split_bf16
+                                                    else achieved / peak,
                          "traffic_source": "profiles/r1/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
                                            if traffic else None,
                          "kernel_ms": k_ms, "flop_per_launch": flop, "stl_kernels": stl_info,
-                         "note": "algorithmic FLOP = rows x steps x 172032 (hoisted layer-1 columns not counted)"},
+                         "note": "algorithmic FLOP = rows x steps x 172032 (hoisted layer-1 columns not counted); achieved "
+                                 "counts every f32 multiply-add once, whatever the kernel issues for it"},
         }
         if not a.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
             line["cpu_baseline"] = cpu_baseline(a, hp, sd, guidance, rect_head, None if (train or trajopt) else sampler, dev)

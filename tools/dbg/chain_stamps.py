@@ -1,0 +1,32 @@
+"""Cycle stamps of the MLP-chain kernel's diagnostic build (chain_waves 708 = fp32, 716 = split-bf16): where one
+workgroup's waves spend an iteration.  GPU only:  python tools/dbg/chain_stamps.py [716]"""
+import sys, os
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pstl_diffusion_policy_amd.engine import Sampler, PackedWeights, SceneBatch  # noqa: E402
+from pstl_diffusion_policy_amd.nusc_model import init_state_dict  # noqa: E402
+from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch  # noqa: E402
+
+cw = int(sys.argv[1]) if len(sys.argv) > 1 else 716
+dev = torch.device("cuda:0")
+hp = default_hparams()
+bs, S, K, steps = 1024, 64, 2, 50
+sd = init_state_dict(1007)
+sm = Sampler(PackedWeights(sd, dev), hp, chain_waves=cw)
+scene = make_scene_batch(bs, K=K, S=S, seed=3, stlp_mode="wide")
+scene = {k: v.to(dev) for k, v in scene.items() if k not in ("pre_stlp", "tj_scores_prior")}
+sb = SceneBatch(scene, S, hp, dev)
+_, base_p, _ = Sampler(sm.w, hp).encode(sb, need_rect=False)
+x = torch.randn(sb.N, 40, device=dev)
+sm.debug_buf = torch.zeros(32 * 8 * 8, dtype=torch.int64, device=dev)
+sm.rollout(sb, base_p, x, None, steps, n_emit=0, seed=11)
+torch.cuda.synchronize()
+t = sm.debug_buf.cpu().numpy().reshape(32, 8, 8).astype(np.int64)   # [iteration][wave][slot], 100 MHz ticks
+names = ["epilogue", "layer1", "layer2", "layer3+part", "barrier"]
+per_it = (t[1:, :, 0] - t[:-1, :, 0]).mean()
+print("iteration: %.1f ticks (x24 = %.0f shader cycles at 2.4 GHz)" % (per_it, per_it * 24))
+for w in range(8):
+    d = [(t[:, w, s + 1] - t[:, w, s]).mean() for s in range(5)]
+    print("wave %d: " % w + "  ".join("%s %.1f" % (n, v) for n, v in zip(names, d)))
