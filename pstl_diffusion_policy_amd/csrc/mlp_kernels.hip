@@ -459,6 +459,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   float* b3s = b2s + 256;
   float* coef = b3s + 48;                   // [kMaxLaunchSteps][4] c1, 1/sqrt(alpha), sqrt(beta) of step s_hi - n
   float* crow = coef + 4 * kMaxLaunchSteps; // [3][2][256] UT only: base[scene] row and tbias[step] row of a tile-step
+  // BF: waves 4..6 (the SIMD partners of the epilogue waves 0..2) draw the noise and hand it over through LDS.  The
+  // split-bf16 kernel is bound by the instructions its longest wave has to issue, not by the matrix pipe, so the ~130
+  // instructions of Philox + Box-Muller are taken off the epilogue waves.  (In the fp32 kernel the same move was slower.)
+  constexpr bool NOISE_SPLIT = BF;
+  f32x4* zbuf = reinterpret_cast<f32x4*>(crow + 3 * 512);   // [2][160] noise quads of a tile-step
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
   const long tile0 = (long)blockIdx.x * a.tiles_per_group;
@@ -580,24 +585,39 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // registers), issued by one wave a whole iteration before layer 1 needs them.  A plain global load here costs every
   // wave ~1400 stalled cycles per tile-step (measured with the stamp build), because nothing else of the wave can
   // issue while it waits.
-  auto stage_cst = [&](int j) {
-    const int tl = j % G, i = s_hi - j / G;
+  // A tile-step is named by its position (tile tl of the workgroup, n-th reverse step of the launch) and its ring slot
+  // (tile-step index mod 3); both are advanced with counters -- divisions by G here cost every wave ~100 scalar
+  // instructions per iteration, which the split-bf16 kernel (issue-bound, not MFMA-bound) cannot hide.
+  struct Pos {
+    int tl, n;
+  };
+  auto next_pos = [&](Pos p) {
+    ++p.tl;
+    if (p.tl == G) {
+      p.tl = 0;
+      ++p.n;
+    }
+    return p;
+  };
+  auto stage_cst = [&](Pos p, int slot3) {
+    const int tl = p.tl, i = s_hi - p.n;
     long row = (tile0 + tl) * kTileRows;
     if (row >= a.N) row = a.N - 1;
-    float* dst = crow + (j % 3) * 512;
+    float* dst = crow + slot3 * 512;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
-    __builtin_amdgcn_global_load_lds((glb_ptr)(a.base + (row / a.rows_per_scene) * kHid + lane * 4), (lds_ptr)dst, 16, 0, 0);
+    const unsigned scene = (unsigned)row / (unsigned)a.rows_per_scene;   // N < 2^31 (checked by the host)
+    __builtin_amdgcn_global_load_lds((glb_ptr)(a.base + (long)scene * kHid + lane * 4), (lds_ptr)dst, 16, 0, 0);
     if (!REFINE)
       __builtin_amdgcn_global_load_lds((glb_ptr)(a.tbias + (long)i * kHid + lane * 4), (lds_ptr)(dst + 256), 16, 0, 0);
   };
 
-  auto layer1 = [&](int it, int buf) {
-    const int tl = it % G, i = s_hi - it / G;
+  auto layer1 = [&](Pos p, int buf) {   // buf = tile-step index mod 3: the h1 buffer written and the crow slot read
+    const int tl = p.tl, i = s_hi - p.n;
     // the scene/timestep constant part of the pre-activation: fetched now, added after the MFMAs
     f32x4 cst[OT];
     if (UT) {
-      const f32x4* cb = reinterpret_cast<const f32x4*>(crow + (it % 3) * 512);
+      const f32x4* cb = reinterpret_cast<const f32x4*>(crow + buf * 512);
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) {
         cst[ot] = cb[4 * (w * OT + ot) + g];
@@ -667,12 +687,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // Hazards: it reads part[it & 1] (complete since the barrier that ended iteration `it`; rewritten only in iteration
   // it + 2, after another barrier) and rewrites xs[tile], which layer1 reads again G - 3 iterations later -- at least
   // one barrier later as long as G >= 4.
-  auto epilogue = [&](int it, const f32x4& z4) {
-    const int tl = it % G, i = s_hi - it / G;
+  auto epilogue = [&](Pos p, int par, const f32x4& z4) {   // par = tile-step index & 1
+    const int tl = p.tl, i = s_hi - p.n;
     const long row0 = (tile0 + tl) * kTileRows;
     float c1 = 0.0f, inv_sa = 0.0f, sbeta = 0.0f;
     if (!REFINE) {
-      const f32x4 cf = reinterpret_cast<const f32x4*>(coef)[it / G];
+      const f32x4 cf = reinterpret_cast<const f32x4*>(coef)[p.n];
       c1 = cf.x;
       inv_sa = cf.y;
       sbeta = cf.z;
@@ -683,7 +703,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     if (et < 160) {
       const int qd = et >> 4, c = et & 15;
       const int j = qd >> 2, gq = qd & 3, slot = gq * 16 + c, f0 = 4 * qd;
-      const f32x4* pp = reinterpret_cast<const f32x4*>(part + (it & 1) * (NW * 768));
+      const f32x4* pp = reinterpret_cast<const f32x4*>(part + par * (NW * 768));
       f32x4 o = reinterpret_cast<const f32x4*>(b3s)[qd];
 #pragma unroll
       for (int ww = 0; ww < NW; ++ww) o += pp[(ww * 3 + j) * 64 + slot];
@@ -729,10 +749,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // Noise of tile-step `it`, fetched/drawn by the epilogue waves one iteration before its epilogue runs.  (Drawing it on
   // the partner waves instead was measured slower: with "older wave first" arbitration of both the matrix pipe and
   // VALU issue their Philox work is starved behind the epilogue waves' MFMA streams wherever it is placed.)
-  auto fetch_noise = [&](int it, int et, f32x4& z4) {
+  auto fetch_noise = [&](Pos p, int et, f32x4& z4) {
     z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (REFINE || (!a.noise && !a.rng) || a.mu_only) return;
-    const int tl = it % G, i = s_hi - it / G;
+    const int tl = p.tl, i = s_hi - p.n;
     if (i <= 1) return;  // the reference adds zeros at the last step
     if (et < 160) {
       const long row = (tile0 + tl) * kTileRows + (et & 15);
@@ -748,8 +768,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
   };
 
+  Pos pm1{0, 0}, p0{0, 0};                   // tile-steps it - 1, it, it + 1, it + 2, it + 3
+  Pos p1 = next_pos(p0), p2 = next_pos(p1), p3 = next_pos(p2);
   if (UT && w == kStager) {
-    for (int j = 0; j < 3 && j < total; ++j) stage_cst(j);
+    stage_cst(p0, 0);
+    if (total > 1) stage_cst(p1, 1);
+    if (total > 2) stage_cst(p2, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();  // xs image, bias/coefficient tables and the first three constant rows are in LDS
@@ -766,29 +790,41 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     __builtin_amdgcn_sched_barrier(0);                                                          \
   }
 
-  layer1(0, 0);
-  if (total > 1) layer1(1, 1);
+  layer1(p0, 0);
+  if (total > 1) layer1(p1, 1);
   __syncthreads();
   int hbuf = 0;  // it % 3
   for (int it = 0; it < total; ++it) {
     PSTL_STAMP(0)
-    if (UT && w == kStager && it + 3 < total) stage_cst(it + 3);
-    if (epi_wave && (ABL == 0 || ABL == 7)) {
+    if (UT && w == kStager && it + 3 < total) stage_cst(p3, hbuf);
+    if (NOISE_SPLIT && (ABL == 0 || ABL == 7)) {
+      if (w >= NW / 2 && w < NW / 2 + NCW) {
+        const int nt = tid - NT / 2;
+        f32x4 z;
+        fetch_noise(p0, nt, z);
+        if (nt < 160) zbuf[(it & 1) * 160 + nt] = z;
+      }
+      if (epi_wave && it > 0) {
+        const f32x4 z = tid < 160 ? zbuf[((it - 1) & 1) * 160 + tid] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        epilogue(pm1, (it - 1) & 1, z);
+      }
+    } else if (epi_wave && (ABL == 0 || ABL == 7)) {
       // While this half finishes the previous tile-step, the partner wave on the same SIMD already issues MFMAs: the
       // matrix pipe never waits for the epilogue (the stagger of MI355X_MICROARCH.md "Two waves per SIMD", item 9).
       const int et = EPI_FIRST ? tid : tid - (NT - NCT);
       const f32x4 zprev = zreg;
-      fetch_noise(it, et, zreg);             // HBM read of this tile-step's noise first: a full iteration to land
-      if (it > 0) epilogue(it - 1, zprev);
+      fetch_noise(p0, et, zreg);             // HBM read of this tile-step's noise first: a full iteration to land
+      if (it > 0) epilogue(pm1, (it - 1) & 1, zprev);
     }
     if (ABL == 5 && w >= NW / 2) {  // solo-rate probe: one wave per SIMD issues MFMAs, its partner only joins barriers
       __syncthreads();
       hbuf = hbuf == 2 ? 0 : hbuf + 1;
+      pm1 = p0, p0 = p1, p1 = p2, p2 = p3, p3 = next_pos(p3);
       continue;
     }
     PSTL_STAMP(1)
     // ---------------- layer 1 of tile-step it + 2 (two ahead) ------------------------------------------------------
-    if (it + 2 < total && (ABL < 2 || ABL == 5 || ABL == 7)) layer1(it + 2, hbuf == 0 ? 2 : hbuf - 1);
+    if (it + 2 < total && (ABL < 2 || ABL == 5 || ABL == 7)) layer1(p2, hbuf == 0 ? 2 : hbuf - 1);
     PSTL_STAMP(2)
     // ---------------- layer 2: 256 -> 256 (B from LDS), layer 3: this wave's 16*OT features -> 48 ----------------
     f32x4 acc[OT];
@@ -862,7 +898,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     for (int ot = 0; ot < OT; ++ot) {
       const f32x4 h = relu4(acc[ot]);
       if (REFINE && a.h2_save) {
-        const long row = (tile0 + it % G) * kTileRows + col;
+        const long row = (tile0 + p0.tl) * kTileRows + col;
         if (row < a.N) *reinterpret_cast<f32x4*>(a.h2_save + row * kHid + 16 * (w * OT + ot) + 4 * g) = h;
       }
 #pragma unroll
@@ -879,9 +915,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     if (ABL < 3 || ABL == 5 || ABL == 7) __syncthreads();
     PSTL_STAMP(5)
     hbuf = hbuf == 2 ? 0 : hbuf + 1;
+    pm1 = p0, p0 = p1, p1 = p2, p2 = p3, p3 = next_pos(p3);
   }
-  if (epi_wave && (ABL == 0 || ABL == 7)) epilogue(total - 1, zreg);
-  if (ABL != 0 && a.N < 0) epilogue(0, zreg);  // keep the code reachable for the compiler, never executed
+  if (NOISE_SPLIT && epi_wave && tid < 160) zreg = zbuf[((total - 1) & 1) * 160 + tid];
+  if (epi_wave && (ABL == 0 || ABL == 7)) epilogue(pm1, (total - 1) & 1, zreg);
+  if (ABL != 0 && a.N < 0) epilogue(p0, 0, zreg);  // keep the code reachable for the compiler, never executed
 }
 
 // ---- merge_net + shard max-pool (nusc_model.py:186-196) -----------------------------------------------------------
@@ -983,7 +1021,8 @@ inline int tiles_per_group(long N) {
 
 template <int NW>
 size_t chain_lds_bytes() {
-  return (size_t)(kG * 768 + 3 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps + 3 * 512) * sizeof(float);
+  return (size_t)(kG * 768 + 3 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps + 3 * 512 + 2 * 160 * 4) *
+         sizeof(float);
 }
 
 template <int NW, bool REFINE, int ABL = 0, bool UT = false, bool BF = false>
@@ -1178,6 +1217,7 @@ extern "C" int pstl_rollout(const pstl_cfg* cfg, const float* packed, const floa
   if (n_emit < 0 || n_emit > cfg->steps || (n_emit > 0 && !emit_out)) return PSTL_ERR_ARG;
   ChainArgs a = {};
   a.N = n_rows(cfg);
+  if (a.N >= (1L << 31)) return PSTL_ERR_SHAPE;   // row indices are 32-bit inside the kernel (a shard of 2^31 rows is 344 GB)
   a.tiles_per_group = tiles_per_group(a.N);
   a.rows_per_scene = cfg->rows_per_scene;
   a.steps = cfg->steps;
@@ -1259,6 +1299,7 @@ static int refine_impl(const pstl_cfg* cfg, const float* packed, const float* ba
   }
   ChainArgs a = {};
   a.N = n_rows(cfg);
+  if (a.N >= (1L << 31)) return PSTL_ERR_SHAPE;   // row indices are 32-bit inside the kernel (a shard of 2^31 rows is 344 GB)
   a.tiles_per_group = tiles_per_group(a.N);
   a.rows_per_scene = cfg->rows_per_scene;
   a.steps = cfg->steps;

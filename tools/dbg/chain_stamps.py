@@ -20,10 +20,10 @@ scene = {k: v.to(dev) for k, v in scene.items() if k not in ("pre_stlp", "tj_sco
 sb = SceneBatch(scene, S, hp, dev)
 _, base_p, _ = Sampler(sm.w, hp).encode(sb, need_rect=False)
 x = torch.randn(sb.N, 40, device=dev)
-sm.debug_buf = torch.zeros(32 * 8 * 8, dtype=torch.int64, device=dev)
+sm.debug_buf = torch.zeros(2 * 32 * 8 * 8, dtype=torch.float32, device=dev)   # 64-bit ticks
 sm.rollout(sb, base_p, x, None, steps, n_emit=0, seed=11)
 torch.cuda.synchronize()
-t = sm.debug_buf.cpu().numpy().reshape(32, 8, 8).astype(np.int64)   # [iteration][wave][slot], 100 MHz ticks
+t = sm.debug_buf.cpu().numpy().view(np.int64).reshape(32, 8, 8)   # [iteration][wave][slot], 100 MHz ticks
 names = ["epilogue", "layer1", "layer2", "layer3+part", "barrier"]
 per_it = (t[1:, :, 0] - t[:-1, :, 0]).mean()
 print("iteration: %.1f ticks (x24 = %.0f shader cycles at 2.4 GHz)" % (per_it, per_it * 24))
