@@ -19,6 +19,10 @@
 #include "pstl_common.hpp"
 #include "rng.hpp"
 
+#ifndef PSTL_EXP
+#define PSTL_EXP 0
+#endif
+
 namespace pstl {
 namespace {
 
@@ -612,10 +616,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       __builtin_amdgcn_global_load_lds((glb_ptr)(a.tbias + (long)i * kHid + lane * 4), (lds_ptr)(dst + 256), 16, 0, 0);
   };
 
-  auto layer1 = [&](Pos p, int buf) {   // buf = tile-step index mod 3: the h1 buffer written and the crow slot read
-    const int tl = p.tl, i = s_hi - p.n;
-    // the scene/timestep constant part of the pre-activation: fetched now, added after the MFMAs
-    f32x4 cst[OT];
+  // the scene/timestep constant part of layer 1's pre-activation for this lane's 4*OT outputs
+  auto l1_const = [&](Pos p, int buf, f32x4 (&cst)[OT]) {
+    const int tl = p.tl;
+    int i = s_hi - p.n;
+    if (i < 0) i = 0;   // a tile-step past the end of the launch (computed and discarded by the fused split-bf16 loop)
     if (UT) {
       const f32x4* cb = reinterpret_cast<const f32x4*>(crow + buf * 512);
 #pragma unroll
@@ -634,15 +639,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         if (!REFINE) cst[ot] += *reinterpret_cast<const f32x4*>(a.tbias + (long)i * kHid + f0);
       }
     }
+  };
+
+  auto layer1 = [&](Pos p, int buf) {   // buf = tile-step index mod 3: the h1 buffer written and the crow slot read
+    const int tl = p.tl;
+    // fetched now, added after the MFMAs
+    f32x4 cst[OT];
+    l1_const(p, buf, cst);
     f32x4 acc[OT];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) acc[ot] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const f32x4* xb = reinterpret_cast<const f32x4*>(xs + tl * 768) + lane;
     if constexpr (BF) {
       // the fp32 image [q][lane][4] already holds slots 0..3 (q = 2 kb) and 4..7 (q = 2 kb + 1) of this lane's k-block
-      f32x4 cor[OT];
-#pragma unroll
-      for (int ot = 0; ot < OT; ++ot) cor[ot] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      // (same operation order as the fused loop below: results do not depend on which of the two computed a tile-step)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const f32x4 x0 = xb[2 * kb * 64];
@@ -650,14 +660,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         bf16x8 bh, bl;
         split8(x0, x1, bh, bl);
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-          acc[ot] = mfma_bf(w1h[ot][kb], bh, acc[ot]);
-          cor[ot] = mfma_bf(w1l[ot][kb], bh, cor[ot]);
-          cor[ot] = mfma_bf(w1h[ot][kb], bl, cor[ot]);
-        }
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w1h[ot][kb], bh, acc[ot]);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w1l[ot][kb], bh, acc[ot]);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w1h[ot][kb], bl, acc[ot]);
       }
       bf16x8 hh, hl2;
-      split8(relu4(acc[0] + cor[0] + cst[0]), relu4(acc[OT - 1] + cor[OT - 1] + cst[OT - 1]), hh, hl2);
+      split8(relu4(acc[0] + cst[0]), relu4(acc[OT - 1] + cst[OT - 1]), hh, hl2);
       u32x4* hwb = reinterpret_cast<u32x4*>(h1 + buf * 4096);   // [kb = producing wave][hi | lo][lane]
       hwb[(w * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
       hwb[(w * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, hl2);
@@ -824,7 +834,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
     PSTL_STAMP(1)
     // ---------------- layer 1 of tile-step it + 2 (two ahead) ------------------------------------------------------
-    if (it + 2 < total && (ABL < 2 || ABL == 5 || ABL == 7)) layer1(p2, hbuf == 0 ? 2 : hbuf - 1);
+    // (BF: woven into layers 2 + 3 below)
+    if (!BF && it + 2 < total && (ABL < 2 || ABL == 5 || ABL == 7)) layer1(p2, hbuf == 0 ? 2 : hbuf - 1);
     PSTL_STAMP(2)
     // ---------------- layer 2: 256 -> 256 (B from LDS), layer 3: this wave's 16*OT features -> 48 ----------------
     f32x4 acc[OT];
@@ -835,46 +846,91 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc3[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if constexpr (BF) {
+      // Layer 1 of tile-step it + 2 is woven into layers 2 + 3 of tile-step it: the kernel is bound by what one wave can
+      // issue, and a wave cannot issue past its own MFMA while the matrix pipe is busy, so the conversions of layer 1
+      // (independent work) go into the 8 issue cycles each 16-cycle MFMA leaves free.  Layer 1 is computed for the
+      // two tile-steps past the end as well (results never read) to keep the loop body one basic block.
+      const int b1 = hbuf == 0 ? 2 : hbuf - 1;
+      const f32x4* xb = reinterpret_cast<const f32x4*>(xs + p2.tl * 768) + lane;
       const u32x4* hbb = reinterpret_cast<const u32x4*>(h1 + hbuf * 4096) + lane;
-      f32x4 cor[OT];
-#pragma unroll
-      for (int ot = 0; ot < OT; ++ot) cor[ot] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       u32x4 ch = hbb[0], cl = hbb[64];
+      const f32x4 xa = xb[0], xc = xb[64], xe = xb[128];
+      f32x4 a1[OT], cst[OT];
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) a1[ot] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      bf16x8 x0h, x0l, x1h, x1l;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
         u32x4 nh = ch, nl = cl;
-        if (kb < 7) {
+        if (kb < 7 && PSTL_EXP != 3) {
           nh = hbb[(2 * kb + 2) * 64];
           nl = hbb[(2 * kb + 3) * 64];
         }
         const bf16x8 bh = __builtin_bit_cast(bf16x8, ch), bl = __builtin_bit_cast(bf16x8, cl);
+        if (PSTL_EXP != 1 || kb == 0) {
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-          acc[ot] = mfma_bf(w2h[ot][kb], bh, acc[ot]);
-          cor[ot] = mfma_bf(w2l[ot][kb], bh, cor[ot]);
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2h[ot][kb], bh, acc[ot]);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2l[ot][kb], bh, acc[ot]);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2h[ot][kb], bl, acc[ot]);
         }
+        if (kb == 0) split8(xa, xc, x0h, x0l);
+        if (kb == 1) split8(xe, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, x1h, x1l);
+        if (kb == 2 || kb == 3) {
+          const bf16x8 vh = kb == 2 ? x0h : x1h, vl = kb == 2 ? x0l : x1l;
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) cor[ot] = mfma_bf(w2h[ot][kb], bl, cor[ot]);
+          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vh, a1[ot]);
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1l[ot][kb - 2], vh, a1[ot]);
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vl, a1[ot]);
+        }
+        if (kb == 5) l1_const(p2, b1, cst);
         ch = nh;
         cl = nl;
+        // issue order of this k-block: the two LDS reads of the next one, then its MFMAs with the conversions between
         if (kb < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * OT, 0);
+        if (kb == 0) {
+#pragma unroll
+          for (int m = 0; m < 3 * OT; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          }
+        } else if (kb == 1) {
+#pragma unroll
+          for (int m = 0; m < 3 * OT; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          }
+        } else if (kb == 2 || kb == 3) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 6 * OT, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3 * OT, 0);
+          if (UT && kb == 5) __builtin_amdgcn_sched_group_barrier(0x100, 2 * OT, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       PSTL_STAMP(3)
-      bf16x8 bh, bl;
-      split8(relu4(acc[0] + cor[0]), relu4(acc[OT - 1] + cor[OT - 1]), bh, bl);
-      f32x4 cor3[3];
+      // layer 3 of tile-step it; the ReLU + split of layer 1's output sits between its MFMAs
+      bf16x8 bh, bl, hh, hl2;
+      split8(relu4(acc[0]), relu4(acc[OT - 1]), bh, bl);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        acc3[j] = mfma_bf(w3h[j], bh, acc3[j]);
-        cor3[j] = mfma_bf(w3l[j], bh, f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+      for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bh, acc3[j]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3l[j], bh, acc3[j]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bl, acc3[j]);
+      split8(relu4(a1[0] + cst[0]), relu4(a1[OT - 1] + cst[OT - 1]), hh, hl2);
+      u32x4* hwb = reinterpret_cast<u32x4*>(h1 + b1 * 4096);
+      hwb[(w * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
+      hwb[(w * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, hl2);
+#pragma unroll
+      for (int m = 0; m < 9; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
       }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) cor3[j] = mfma_bf(w3h[j], bl, cor3[j]);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc3[j] += cor3[j];
     } else {
     f32x4 bq = hb[0];
     __builtin_amdgcn_sched_barrier(0);  // the pipelined region starts here
@@ -912,7 +968,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     for (int j = 0; j < 3; ++j) pw[(w * 3 + j) * 64 + lane] = acc3[j];
     PSTL_STAMP(4)
     if (UT && w == kStager) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged rows have landed
-    if (ABL < 3 || ABL == 5 || ABL == 7) __syncthreads();
+    if ((ABL < 3 || ABL == 5 || ABL == 7) && PSTL_EXP != 2) __syncthreads();
     PSTL_STAMP(5)
     hbuf = hbuf == 2 ? 0 : hbuf + 1;
     pm1 = p0, p0 = p1, p1 = p2, p2 = p3, p3 = next_pos(p3);
