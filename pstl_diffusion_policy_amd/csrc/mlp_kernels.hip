@@ -135,8 +135,9 @@ __global__ void k_pack_a(const float* W, int ld, int rows_valid, int n_tiles, in
 }
 
 // Split-bf16 A-operand layout.  Every fp32 weight is stored as two bf16 pieces, hi = bf16(w) and lo = bf16(w - hi)
-// (w = hi + lo to ~2^-17 relative).  Word m of lane l for (tile Tt, k-block kb) sits at
-// dst[((Tt*nkb + kb)*8 + m)*64 + l]: m < 4 are the hi pieces of slots 2m, 2m+1 (low half first), m >= 4 the lo pieces.
+// (w = hi + lo to ~2^-17 relative).  Word m of lane l for block blk = Tt*nkb + kb (tile Tt, k-block kb) sits at
+// dst[((blk*2 + (m>>2))*64 + l)*4 + (m&3)]: one 16-byte load per lane fetches the four hi words (m < 4: slots 2m, 2m+1,
+// low half first), a second one the four lo words (m >= 4).
 // Slot s of lane group g = l>>4 is column k = 32 kb + 16 (s>>2) + 4 g + (s&3): with this order the accumulator
 // registers of two neighbouring 16-feature tiles ARE one k-block of the next layer's B operand (see k_chain).
 __device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
@@ -144,7 +145,7 @@ __device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__buil
 __global__ void k_pack_a_bf(const float* W, int ld, int rows_valid, int n_tiles, int nkb, int mode, unsigned* dst) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)n_tiles * nkb * 512) return;
-  const int lane = (int)(i & 63), m = (int)((i >> 6) & 7);
+  const int lane = (int)((i >> 2) & 63), m = (int)((i & 3) | (((i >> 8) & 1) << 2));
   const long tk = i >> 9;
   const int kb = (int)(tk % nkb), Tt = (int)(tk / nkb);
   const int row = 16 * Tt + (lane & 15), g = lane >> 4;
@@ -416,13 +417,14 @@ __device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, bf16x8& h
   }
 }
 
+// max(v, 0) as a signed-integer max on the bit patterns: one instruction per value (fmaxf costs two: the compiler first
+// canonicalises an operand it cannot prove free of signalling NaNs); identical to fmaxf for every non-NaN input
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
-  f32x4 r;
-  r.x = fmaxf(v.x, 0.0f);
-  r.y = fmaxf(v.y, 0.0f);
-  r.z = fmaxf(v.z, 0.0f);
-  r.w = fmaxf(v.w, 0.0f);
-  return r;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 b = __builtin_bit_cast(i32x4, v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = b[i] > 0 ? b[i] : 0;
+  return __builtin_bit_cast(f32x4, b);
 }
 
 // LDS address (in floats) of activation element k (0..47) of tile column c in the B-operand image [q][lane][r]
@@ -489,14 +491,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       const unsigned* q2 = reinterpret_cast<const unsigned*>(a.packed + a.off.w2b);
       const unsigned* q3 = reinterpret_cast<const unsigned*>(a.packed + a.off.w3b);
       auto load_pair = [&](const unsigned* q, long blk, bf16x8& hi, bf16x8& lo) {
-        u32x4 h, l;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          h[m] = q[(blk * 8 + m) * 64 + lane];
-          l[m] = q[(blk * 8 + 4 + m) * 64 + lane];
-        }
-        hi = __builtin_bit_cast(bf16x8, h);
-        lo = __builtin_bit_cast(bf16x8, l);
+        const u32x4* q4 = reinterpret_cast<const u32x4*>(q);
+        hi = __builtin_bit_cast(bf16x8, q4[(blk * 2 + 0) * 64 + lane]);
+        lo = __builtin_bit_cast(bf16x8, q4[(blk * 2 + 1) * 64 + lane]);
       };
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) {
@@ -654,6 +651,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       // the fp32 image [q][lane][4] already holds slots 0..3 (q = 2 kb) and 4..7 (q = 2 kb + 1) of this lane's k-block
       // (same operation order as the fused loop below: results do not depend on which of the two computed a tile-step)
 #pragma unroll
+      for (int ot = 0; ot < OT; ++ot) acc[ot] = cst[ot];
+#pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const f32x4 x0 = xb[2 * kb * 64];
         const f32x4 x1 = kb == 0 ? xb[64] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -667,7 +666,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w1h[ot][kb], bl, acc[ot]);
       }
       bf16x8 hh, hl2;
-      split8(relu4(acc[0] + cst[0]), relu4(acc[OT - 1] + cst[OT - 1]), hh, hl2);
+      split8(relu4(acc[0]), relu4(acc[OT - 1]), hh, hl2);
       u32x4* hwb = reinterpret_cast<u32x4*>(h1 + buf * 4096);   // [kb = producing wave][hi | lo][lane]
       hwb[(w * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
       hwb[(w * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, hl2);
@@ -855,9 +854,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       const u32x4* hbb = reinterpret_cast<const u32x4*>(h1 + hbuf * 4096) + lane;
       u32x4 ch = hbb[0], cl = hbb[64];
       const f32x4 xa = xb[0], xc = xb[64], xe = xb[128];
-      f32x4 a1[OT], cst[OT];
-#pragma unroll
-      for (int ot = 0; ot < OT; ++ot) a1[ot] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      f32x4 a1[OT];   // starts from the scene/timestep constant part (fetched at k-block 1, used from k-block 2 on)
       bf16x8 x0h, x0l, x1h, x1l;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -887,7 +884,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 #pragma unroll
           for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vl, a1[ot]);
         }
-        if (kb == 5) l1_const(p2, b1, cst);
+        if (kb == 1) l1_const(p2, b1, a1);
         ch = nh;
         cl = nl;
         // issue order of this k-block: the two LDS reads of the next one, then its MFMAs with the conversions between
@@ -899,6 +896,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
           }
         } else if (kb == 1) {
+          if (UT) __builtin_amdgcn_sched_group_barrier(0x100, 2 * OT, 0);
 #pragma unroll
           for (int m = 0; m < 3 * OT; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -908,7 +906,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           __builtin_amdgcn_sched_group_barrier(0x008, 6 * OT, 0);
         } else {
           __builtin_amdgcn_sched_group_barrier(0x008, 3 * OT, 0);
-          if (UT && kb == 5) __builtin_amdgcn_sched_group_barrier(0x100, 2 * OT, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -922,7 +919,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3l[j], bh, acc3[j]);
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bl, acc3[j]);
-      split8(relu4(a1[0] + cst[0]), relu4(a1[OT - 1] + cst[OT - 1]), hh, hl2);
+      split8(relu4(a1[0]), relu4(a1[OT - 1]), hh, hl2);
       u32x4* hwb = reinterpret_cast<u32x4*>(h1 + b1 * 4096);
       hwb[(w * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
       hwb[(w * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, hl2);
