@@ -445,7 +445,7 @@ __device__ __forceinline__ int xs_addr(int k, int c) { return (((k >> 4) * 64) +
 // the final controls (tools/dbg/bf16_split_study.py), against the 1e-4 gate.
 template <int NW, bool REFINE, int ABL = 0, bool UT = false, bool BF = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
-  static_assert(!BF || (NW == 8 && !REFINE), "the split-bf16 variant is the 8-wave rollout kernel");
+  static_assert(!BF || NW == 8, "the split-bf16 variant is an 8-wave kernel");
   constexpr int OT = 16 / NW;       // 16-feature output tiles per wave
   constexpr int NT = NW * 64;
   // The first NCW waves also run the epilogue (8 waves: waves 0..3, the older wave of each SIMD pair; measured 1.8 %
@@ -1091,16 +1091,17 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
   return launch_status();
 }
 
-// cfg->chain_waves: 0/16 = the rollout on split-bf16 MFMA (eight waves x 32 output features), rect_net on fp32 MFMA,
+// cfg->chain_waves: 0/16 = policy_net and rect_net on split-bf16 MFMA (eight waves x 32 output features),
 //                   8    = eight waves x 32 output features on fp32 MFMA (2 waves/SIMD, <=256 registers each),
 //                   4    = four waves x 64 output features on fp32 MFMA (1 wave/SIMD, weights partly in AGPRs)
 template <bool REFINE>
 int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   const bool ut = (a.rows_per_scene % kTileRows == 0);  // every 16-row tile lies inside one scene
-  if (REFINE && (chain_waves == 0 || chain_waves == 16)) chain_waves = 8;     // rect_net stays on fp32 MFMA
-  if constexpr (!REFINE)
-    if (chain_waves == 0 || chain_waves == 16)   // the default rollout: split-bf16 products on the 8-wave layout
-      return ut ? launch_chain<8, false, 0, true, true>(a, st) : launch_chain<8, false, 0, false, true>(a, st);
+  // the default: split-bf16 products on the 8-wave layout.  The training forward pass (activations saved for the
+  // hand-written backward pass) stays on the fp32 kernel.
+  if (REFINE && a.h1_save && (chain_waves == 0 || chain_waves == 16)) chain_waves = 8;
+  if (chain_waves == 0 || chain_waves == 16)
+    return ut ? launch_chain<8, REFINE, 0, true, true>(a, st) : launch_chain<8, REFINE, 0, false, true>(a, st);
   if (chain_waves == 8) return ut ? launch_chain<8, REFINE, 0, true>(a, st) : launch_chain<8, REFINE>(a, st);
   if (chain_waves == 4) return launch_chain<4, REFINE>(a, st);
   if (REFINE) return chain_waves > 100 ? launch_chain<8, true>(a, st) : PSTL_ERR_SHAPE;
@@ -1114,7 +1115,6 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
     case 1008: return launch_chain<8, false>(a, st);   // force the general (non-uniform-tile) path
     case 116: return launch_chain<8, false, 1, true, true>(a, st);
     case 716: return launch_chain<8, false, 7, true, true>(a, st);
-    case 1016: return launch_chain<8, false, 0, false, true>(a, st);
     default: return PSTL_ERR_SHAPE;
   }
 }
