@@ -11,6 +11,7 @@ mkdir -p "$out"
 cd "$root"
 b() { name=$1; shift; python3 bench.py "$@" 2> "$out/$name.err" | tail -1 > "$out/$name.json"; cut -c1-230 "$out/$name.json"; }
 b bench_default
+b bench_fp32_mfma --chain_waves 8 --no_cpu_baseline
 b bench_e5 --workload e5 --no_cpu_baseline
 b bench_e7 --workload e7 --no_cpu_baseline
 b bench_k8_s100 --neighbors 8 --diffusion_steps 100 --no_cpu_baseline
