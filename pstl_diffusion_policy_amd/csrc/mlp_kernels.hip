@@ -1,4 +1,5 @@
-// mlp_kernels.hip -- the denoiser / RefineNet MLP chain on gfx950 fp32 MFMA, the scene encoder and weight packing.
+// mlp_kernels.hip -- the denoiser / RefineNet MLP chain on gfx950 MFMA (split-bf16 by default, exact fp32 on request),
+// the scene encoder and weight packing.
 //
 // Design:
 //  * Both 3-layer MLPs of the hot path (policy_net 303->256->256->40, rect_net 271->256->256->40) see only 47
@@ -14,6 +15,9 @@
 //  * A workgroup owns G tiles (192 rows = one scene at S = 64) for ALL reverse steps of a launch: x never leaves
 //    LDS between steps; HBM traffic is the noise read (parity mode) and the emitted candidates.
 //  * f32 MFMA is bit-for-bit a k-ordered fmaf chain, so results match an fp32 torch path to rounding (1e-4 gate).
+//  * Default arithmetic (template parameter BF): every fp32 operand is two bf16 pieces, every product three
+//    v_mfma_f32_16x16x32_bf16 products accumulated in fp32 -- 8e-6 from the reference after 99 chained steps, 2.7x the
+//    speed of the fp32 form.  See the comment above k_chain.
 #include <stdlib.h>
 
 #include "pstl_common.hpp"
