@@ -26,6 +26,9 @@ PEAK_BF16_MATRIX_TFLOPS = 16 * 157.3                  # same guide: the f32 MFMA
 # split-bf16 chain kernel: MFMA FLOP issued per row and denoiser evaluation (69 v_mfma_f32_16x16x32_bf16 per wave and
 # 16-row tile, 8 waves): 3 bf16 products per fp32 product, layer 1 padded 40 -> 64 columns, layer 3 padded 40 -> 48 rows
 F_STEP_ISSUED_BF16 = 8 * 69 * (2 * 16 * 16 * 32) / 16
+# what v_mfma_f32_16x16x32_bf16 sustains on this part, measured (tools/dbg/mfma_rate.hip, profiles/r1/mfma_rate_*.txt):
+# 8.6 ns per instruction and SIMD with two waves per SIMD
+SUSTAINED_BF16_MFMA_TFLOPS = 2 * 16 * 16 * 32 / 8.6e-9 * 1024 / 1e12
 
 
 def parse():
@@ -265,6 +268,8 @@ def main():
                          "achieved_over_f32_mfma_peak": achieved / PEAK_FP32_MATRIX_TFLOPS,
                          "matrix_pipe_frac_issued": (achieved * F_STEP_ISSUED_BF16 / F_STEP_MIN / peak) if split_bf16
                                                     else achieved / peak,
+                         "matrix_pipe_frac_of_sustained_rate": (achieved * F_STEP_ISSUED_BF16 / F_STEP_MIN
+                                                                / SUSTAINED_BF16_MFMA_TFLOPS) if split_bf16 else None,
                          "traffic_source": "profiles/r1/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
                                            if traffic else None,
                          "kernel_ms": k_ms, "flop_per_launch": flop, "stl_kernels": stl_info,

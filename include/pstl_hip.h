@@ -62,8 +62,9 @@ typedef struct pstl_cfg {
   int32_t n_shards;        /* --n_shards (merge_net max-pool groups)                      */
   int32_t flags;           /* PSTL_FLAG_*                                                 */
   int32_t chain_waves;     /* MLP-chain kernel variant: 0 = default (denoiser on split-bf16
-                              MFMA, 3 bf16 products per fp32 product, fp32 accumulate), 8 or
-                              4 = everything on fp32 MFMA with 8 / 4 waves per workgroup     */
+                              MFMA, 3 bf16 products per fp32 product, fp32 accumulate;
+                              rect_net on fp32 MFMA), 16 = both on split-bf16, 8 or 4 =
+                              everything on fp32 MFMA with 8 / 4 waves per workgroup         */
   float tau;               /* --smoothing_factor                                          */
   float thres;             /* --stl_nn_thres                                              */
   float w_max, a_max;      /* --mul_w_max, --mul_a_max                                    */

@@ -1095,15 +1095,19 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
   return launch_status();
 }
 
-// cfg->chain_waves: 0/16 = policy_net and rect_net on split-bf16 MFMA (eight waves x 32 output features),
+// cfg->chain_waves: 0    = policy_net on split-bf16 MFMA (eight waves x 32 output features), rect_net on fp32 MFMA,
+//                   16   = both on split-bf16 MFMA,
 //                   8    = eight waves x 32 output features on fp32 MFMA (2 waves/SIMD, <=256 registers each),
 //                   4    = four waves x 64 output features on fp32 MFMA (1 wave/SIMD, weights partly in AGPRs)
 template <bool REFINE>
 int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   const bool ut = (a.rows_per_scene % kTileRows == 0);  // every 16-row tile lies inside one scene
-  // the default: split-bf16 products on the 8-wave layout.  The training forward pass (activations saved for the
-  // hand-written backward pass) stays on the fp32 kernel.
-  if (REFINE && a.h1_save && (chain_waves == 0 || chain_waves == 16)) chain_waves = 8;
+  // the default: the denoiser on split-bf16 products (8-wave layout).  rect_net stays on fp32 MFMA: its interval head
+  // scales tanh(output) by the remaining headroom of a control (up to 2 x mul_a_max), and measured at full size one pass
+  // through it on split-bf16 products moves a refined control by up to 9e-5 -- the whole parity budget -- for 0.7 ms.
+  // chain_waves = 16 forces the split-bf16 form for both networks.
+  if (REFINE && chain_waves == 0) chain_waves = 8;
+  if (REFINE && a.h1_save && chain_waves == 16) chain_waves = 8;   // the training forward pass saves fp32 activations
   if (chain_waves == 0 || chain_waves == 16)
     return ut ? launch_chain<8, REFINE, 0, true, true>(a, st) : launch_chain<8, REFINE, 0, false, true>(a, st);
   if (chain_waves == 8) return ut ? launch_chain<8, REFINE, 0, true>(a, st) : launch_chain<8, REFINE>(a, st);
