@@ -51,30 +51,88 @@ __global__ void k_head_bwd(long N, float w_max, float a_max, const float* dctrl,
   if (f < 6) x47[row * kX47 + 1 + f] = stlp[row * 6 + f];
 }
 
-// G *= [H > 0] (in place, skipped when H == nullptr) and partial[b][c] = sum over the block's rows of G[.][c]
-__global__ void k_mask_colsum(long N, int ncol, float* G, const float* H, float* partial) {
-  const int c = threadIdx.x;
-  if (c >= ncol) return;
-  const long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+// G *= [H > 0] in place and partial[b][c] = sum over the block's rows of G[.][c], for the 256-column activations, 16 bytes
+// per lane: a block is 4 row-lanes x 64 column quads, four rows per
+// row-lane in flight; the four row-lanes are added in a fixed order (deterministic, like everything else here).
+__global__ __launch_bounds__(256) void k_mask_colsum256(long N, float* G, const float* H, float* partial) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+  rows_per_block = (rows_per_block + 15) / 16 * 16;
   const long r0 = blockIdx.x * rows_per_block, r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
-  float acc = 0.0f;
-  for (long r = r0; r < r1; ++r) {
-    float g = G[r * ncol + c];
-    if (H) {
-      g = H[r * ncol + c] > 0.0f ? g : 0.0f;
-      G[r * ncol + c] = g;
+  f4 acc = f4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (long r = r0 + rl; r < r1; r += 16) {
+    f4 g[4], h[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long rr = r + 4 * u;
+      if (rr < r1) {
+        g[u] = *reinterpret_cast<const f4*>(G + rr * kHid + 4 * q);
+        h[u] = *reinterpret_cast<const f4*>(H + rr * kHid + 4 * q);
+      }
     }
-    acc += g;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long rr = r + 4 * u;
+      if (rr < r1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[u][i] = h[u][i] > 0.0f ? g[u][i] : 0.0f;
+        *reinterpret_cast<f4*>(G + rr * kHid + 4 * q) = g[u];
+        acc += g[u];
+      }
+    }
   }
-  partial[(long)blockIdx.x * ncol + c] = acc;
+  __shared__ f4 red[4][64];
+  red[rl][q] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    const f4 t = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+    *reinterpret_cast<f4*>(partial + (long)blockIdx.x * kHid + 4 * q) = t;
+  }
 }
 
-__global__ void k_colsum_final(int nblocks, int ncol, const float* partial, float* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncol) return;
+// Column sums of the 40-column head gradient (no mask): 25 row-lanes x 10 column quads per block, four rows per row-lane
+// in flight, row-lanes added in a fixed order.
+__global__ __launch_bounds__(256) void k_colsum40(long N, const float* G, float* partial) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int q = threadIdx.x % 10, rl = threadIdx.x / 10;
+  long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+  rows_per_block = (rows_per_block + 99) / 100 * 100;
+  const long r0 = blockIdx.x * rows_per_block, r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
+  f4 acc = f4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (rl < 25)
+    for (long r = r0 + rl; r < r1; r += 100) {
+      f4 g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        g[u] = (r + 25 * u < r1) ? *reinterpret_cast<const f4*>(G + (r + 25 * u) * kCtrl + 4 * q) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += g[u];
+    }
+  __shared__ f4 red[25][10];
+  if (rl < 25) red[rl][q] = acc;
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    f4 t = red[0][q];
+    for (int i = 1; i < 25; ++i) t += red[i][q];
+    *reinterpret_cast<f4*>(partial + (long)blockIdx.x * kCtrl + 4 * q) = t;
+  }
+}
+
+// out[c] = sum over the blocks of partial[b][c]: one 64-lane block per column, lane l adds blocks l, l+64, ... and the
+// 64 lane sums are added in lane order (fixed order: deterministic)
+__global__ __launch_bounds__(64) void k_colsum_final(int nblocks, int ncol, const float* partial, float* out) {
+  const int c = blockIdx.x, l = threadIdx.x;
   float acc = 0.0f;
-  for (int b = 0; b < nblocks; ++b) acc += partial[(long)b * ncol + c];
-  out[c] = acc;
+  for (int b = l; b < nblocks; b += 64) acc += partial[(long)b * ncol + c];
+  __shared__ float red[64];
+  red[l] = acc;
+  __syncthreads();
+  if (l == 0) {
+    float t = red[0];
+    for (int i = 1; i < 64; ++i) t += red[i];
+    out[c] = t;
+  }
 }
 
 // S[scene][f] = sum over the scene's rows of G[row][f]
@@ -496,18 +554,18 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
                      dcontrols, pre, init_controls, prev_scores, hl, stlp, merge ? pooled : (const float*)nullptr, cfg->S,
                      cfg->n_shards, dO, x47);
   // layer 3
-  hipLaunchKernelGGL(k_mask_colsum, dim3(nb), dim3(64), 0, st, N, kCtrl, dO, (const float*)nullptr, part);
-  hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(64), 0, st, nb, kCtrl, part, db3);
+  hipLaunchKernelGGL(k_colsum40, dim3(nb), dim3(256), 0, st, N, dO, part);
+  hipLaunchKernelGGL(k_colsum_final, dim3(kCtrl), dim3(64), 0, st, nb, kCtrl, part, db3);
   if (int e = wgrad<3, 16, 1, 8>(N, dO, kCtrl, kCtrl, h2, kHid, kHid, slabs, dw3, kHid, st)) return e;  // dW3 = dO^T h2
   if (int e = gemm_rm(c->h, false, false, (int)N, kHid, kCtrl, dO, kCtrl, w3, kHid, dH2, kHid)) return e;  // dH2 = dO W3
   // layer 2
-  hipLaunchKernelGGL(k_mask_colsum, dim3(nb), dim3(256), 0, st, N, kHid, dH2, h2, part);
-  hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(256), 0, st, nb, kHid, part, db2);
+  hipLaunchKernelGGL(k_mask_colsum256, dim3(nb), dim3(256), 0, st, N, dH2, h2, part);
+  hipLaunchKernelGGL(k_colsum_final, dim3(kHid), dim3(64), 0, st, nb, kHid, part, db2);
   if (int e = wgrad<16, 16, 4, 2>(N, dH2, kHid, kHid, h1, kHid, kHid, slabs, dw2, kHid, st)) return e;  // dW2 = dH2^T h1
   if (int e = gemm_rm(c->h, false, false, (int)N, kHid, kHid, dH2, kHid, w2, kHid, dH1, kHid)) return e;  // dH1 = dH2 W2
   // layer 1
-  hipLaunchKernelGGL(k_mask_colsum, dim3(nb), dim3(256), 0, st, N, kHid, dH1, h1, part);
-  hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(256), 0, st, nb, kHid, part, db1);
+  hipLaunchKernelGGL(k_mask_colsum256, dim3(nb), dim3(256), 0, st, N, dH1, h1, part);
+  hipLaunchKernelGGL(k_colsum_final, dim3(kHid), dim3(64), 0, st, nb, kHid, part, db1);
   hipLaunchKernelGGL(k_scene_sum, dim3(cfg->bs), dim3(256), 0, st, cfg->rows_per_scene, dH1, S);
   if (int e = gemm_rm(c->h, true, false, kHid, kFeat, cfg->bs, S, kHid, feature, kFeat, dw1, kIn)) return e;
   if (int e = wgrad<16, 3, 8, 1>(N, dH1, kHid, kHid, x47, kX47, kX47, slabs, dw1 + kFeat, kIn, st)) return e;
