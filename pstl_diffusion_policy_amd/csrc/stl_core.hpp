@@ -229,6 +229,30 @@ PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, f
     const float valid = a.x, r = a.y;
     const float nx[4] = {a.z, a.w, b.x, b.y};
     const float ny[4] = {b.z, b.w, cc.x, cc.y};
+    // Exact shortcuts (the result is a hard minimum over neighbours and circle pairs, so a neighbour that cannot be the
+    // strict minimum changes nothing): an invalid neighbour contributes exactly 100 whatever its distance, and a valid
+    // one whose lower bound -- distance of the ego reference point to its nearest circle centre, minus the longest ego
+    // offset and both radii, minus a margin far above the rounding of these few operations -- already reaches the
+    // current minimum is skipped without looking at the 16 pairs.  (All 64 lanes of a wave are samples of one scene
+    // and mode: the skip is usually wave-uniform.)
+    if (valid == 0.0f) {
+      if (100.0f < best) {
+        best = 100.0f;
+        if (GRAD) gx = gy = gth = 0.0f;
+      }
+      continue;
+    }
+    if (valid == 1.0f && best < INFINITY) {
+      float m2 = INFINITY;
+      PSTL_UNROLL
+      for (int j = 0; j < 4; ++j) {
+        const float dx = x - nx[j], dy = y - ny[j];
+        m2 = fminf(m2, dx * dx + dy * dy);
+      }
+      const float emax = fmaxf(fmaxf(fabsf(env.eoff[0]), fabsf(env.eoff[1])), fmaxf(fabsf(env.eoff[2]), fabsf(env.eoff[3])));
+      const float lb = sqrtf(m2) * 0.99999f - (emax + env.er + r) - 1e-3f;
+      if (fminf(fmaxf(lb, -5.0f), 20.0f) >= best) continue;
+    }
     float q = INFINITY;
     float bdx = 0.0f, bdy = 0.0f, boff = 0.0f;  // the closest circle pair (first one on ties)
     PSTL_UNROLL
