@@ -23,6 +23,8 @@
 #include "pstl_common.hpp"
 #include "rng.hpp"
 
+// PSTL_EXP != 0: timing-only builds of the split-bf16 loop (wrong results; tools/dbg/build_variants.sh): 1 = layer 2
+// issues its MFMAs for the first k-block only, 2 = no barrier, 3 = no LDS reads inside layer 2's loop
 #ifndef PSTL_EXP
 #define PSTL_EXP 0
 #endif
@@ -758,10 +760,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
   };
 
-  // noise of tile-step `it`, fetched one iteration before its epilogue runs
-  // Noise of tile-step `it`, fetched/drawn by the epilogue waves one iteration before its epilogue runs.  (Drawing it on
-  // the partner waves instead was measured slower: with "older wave first" arbitration of both the matrix pipe and
-  // VALU issue their Philox work is starved behind the epilogue waves' MFMA streams wherever it is placed.)
+  // Noise of tile-step `it`, fetched/drawn one iteration before its epilogue runs: by the epilogue waves themselves in
+  // the fp32 kernel (drawing it on the partner waves was measured slower there: with "older wave first" arbitration of
+  // both the matrix pipe and VALU issue their Philox work is starved behind the epilogue waves' MFMA streams), by the
+  // partner waves 4..6 in the split-bf16 kernel (see zbuf above).
   auto fetch_noise = [&](Pos p, int et, f32x4& z4) {
     z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (REFINE || (!a.noise && !a.rng) || a.mu_only) return;
