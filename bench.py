@@ -26,9 +26,9 @@ PEAK_BF16_MATRIX_TFLOPS = 16 * 157.3                  # same guide: the f32 MFMA
 # split-bf16 chain kernel: MFMA FLOP issued per row and denoiser evaluation (69 v_mfma_f32_16x16x32_bf16 per wave and
 # 16-row tile, 8 waves): 3 bf16 products per fp32 product, layer 1 padded 40 -> 64 columns, layer 3 padded 40 -> 48 rows
 F_STEP_ISSUED_BF16 = 8 * 69 * (2 * 16 * 16 * 32) / 16
-# what v_mfma_f32_16x16x32_bf16 sustains on this part, measured (tools/dbg/mfma_rate.hip, profiles/r1/mfma_rate_*.txt):
-# 8.6 ns per instruction and SIMD with two waves per SIMD
-SUSTAINED_BF16_MFMA_TFLOPS = 2 * 16 * 16 * 32 / 8.6e-9 * 1024 / 1e12
+# what the kernel's layer-2 MFMA pattern sustains in isolation, measured (tools/dbg/mfma_rate2.hip,
+# profiles/r1/mfma_rate_*.txt): 8.0 ns per v_mfma_f32_16x16x32_bf16 and SIMD with two waves per SIMD
+SUSTAINED_BF16_MFMA_TFLOPS = 2 * 16 * 16 * 32 / 8.0e-9 * 1024 / 1e12
 
 
 def parse():

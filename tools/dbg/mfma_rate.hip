@@ -6,7 +6,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int NACC>
-__global__ __launch_bounds__(512) void k(const float* in, float* out, int iters) {
+__global__ __launch_bounds__(1024) void k(const float* in, float* out, int iters) {
   bf16x8 a[8], b;
   for (int i = 0; i < 8; ++i)
     for (int j = 0; j < 8; ++j) a[i][j] = (__bf16)in[(threadIdx.x + i * 8 + j) & 1023];
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(512) void k(const float* in, float* out, int iters)
   }
   f32x4 s = acc[0];
   for (int i = 1; i < NACC; ++i) s += acc[i];
-  out[blockIdx.x * 512 + threadIdx.x] = s.x + s.y + s.z + s.w;
+  out[blockIdx.x * 1024 + threadIdx.x] = s.x + s.y + s.z + s.w;
 }
 
 template <int NACC>
@@ -43,9 +43,9 @@ void run(int threads, const float* in, float* out) {
 int main() {
   float *in, *out;
   hipMalloc(&in, 4096);
-  hipMalloc(&out, 256 * 512 * 4);
+  hipMalloc(&out, 256 * 1024 * 4);
   hipMemset(in, 0, 4096);
-  for (int t : {256, 512}) {
+  for (int t : {256, 512, 1024}) {
     run<1>(t, in, out);
     run<2>(t, in, out);
     run<3>(t, in, out);
