@@ -4,6 +4,7 @@
 Host code only sequences launches; all arithmetic on rows happens in the HIP kernels.
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -126,7 +127,11 @@ def guidance_triggered(i, steps, g):
 
 
 class Sampler:
-    def __init__(self, weights, hp, chain_waves=0):
+    def __init__(self, weights, hp, chain_waves=None):
+        # chain_waves: arithmetic of the MLP chains (include/pstl_hip.h): 0 = denoiser on split-bf16 MFMA (default),
+        # 8 = exact fp32 MFMA.  Callers that go through the reference's CLI surface choose with PSTL_CHAIN_WAVES.
+        if chain_waves is None:
+            chain_waves = int(os.environ.get("PSTL_CHAIN_WAVES", "0"))
         self.w, self.hp, self.chain_waves = weights, hp, int(chain_waves)
         self.L = ffi.lib()
         # when set to a list, every multi-step rollout launch appends (start_event, end_event, n_steps, n_rows):
