@@ -449,7 +449,10 @@ __device__ __forceinline__ int xs_addr(int k, int c) { return (((k >> 4) * 64) +
 // between layers of the fp32 kernel carries over: lane (g, c) holds features 16 ot + 4 g + r of row c in acc[ot][r],
 // which is slot s = 4 ot + r of its B operand.  Measured on the reference's 100-step fixture the split costs 8e-6 in
 // the final controls (tools/dbg/bf16_split_study.py), against the 1e-4 gate.
-template <int NW, bool REFINE, int ABL = 0, bool UT = false, bool BF = false>
+// PERSIST: one workgroup per CU walks the 12-tile groups blockIdx.x, blockIdx.x + gridDim.x, ... with the weights loaded
+// into registers once (used for the single-step launches of the guided phase, where the 344 KB weight fetch and the
+// workgroup turnover are ~10 % of a 12-iteration workgroup).
+template <int NW, bool REFINE, int ABL = 0, bool UT = false, bool BF = false, bool PERSIST = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   static_assert(!BF || NW == 8, "the split-bf16 variant is an 8-wave kernel");
   constexpr int OT = 16 / NW;       // 16-feature output tiles per wave
@@ -478,12 +481,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   f32x4* zbuf = reinterpret_cast<f32x4*>(crow + 3 * 512);   // [2][160] noise quads of a tile-step
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
-  const long tile0 = (long)blockIdx.x * a.tiles_per_group;
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
-  int G = (int)((n_tiles - tile0) < a.tiles_per_group ? (n_tiles - tile0) : a.tiles_per_group);
-  // Layer 1 runs two tile-steps ahead and the epilogue one behind, so >= 4 tiles must be in flight (see the hazard
-  // notes below); short tail blocks process phantom tiles whose rows are clamped on load and masked on store.
-  if (G < 4) G = 4;
+  const long n_groups = (n_tiles + a.tiles_per_group - 1) / a.tiles_per_group;
 
   // ---- weights -> registers (A operands), once per launch ----
   float w1x[BF ? 1 : OT][12], w2[BF ? 1 : OT][64], w3[3][BF ? 1 : OT][4];
@@ -536,6 +535,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
   }
 
+  for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {   // one pass unless PERSIST (gridDim.x == n_groups)
+  if (PERSIST && grp != blockIdx.x) __syncthreads();   // the previous group's last epilogue has left xs / part
+  const long tile0 = grp * a.tiles_per_group;
+  int G = (int)((n_tiles - tile0) < a.tiles_per_group ? (n_tiles - tile0) : a.tiles_per_group);
+  // Layer 1 runs two tile-steps ahead and the epilogue one behind, so >= 4 tiles must be in flight (see the hazard
+  // notes below); short tail blocks process phantom tiles whose rows are clamped on load and masked on store.
+  if (G < 4) G = 4;
   // ---- per-row constants and the initial state into the B-operand image ----
   // Four consecutive input columns k = 4j .. 4j+3 of one tile column sit in one 16-byte LDS slot of the B-operand image,
   // so a row is moved as 12 quads: 10 straight from the 160-byte state row (16-byte global loads), 2 assembled from
@@ -979,6 +985,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   if (NOISE_SPLIT && epi_wave && tid < 160) zreg = zbuf[((total - 1) & 1) * 160 + tid];
   if (epi_wave && (ABL == 0 || ABL == 7)) epilogue(pm1, (total - 1) & 1, zreg);
   if (ABL != 0 && a.N < 0) epilogue(p0, 0, zreg);  // keep the code reachable for the compiler, never executed
+  if (!PERSIST) break;
+  }
 }
 
 // ---- merge_net + shard max-pool (nusc_model.py:186-196) -----------------------------------------------------------
@@ -1084,12 +1092,24 @@ size_t chain_lds_bytes() {
          sizeof(float);
 }
 
-template <int NW, bool REFINE, int ABL = 0, bool UT = false, bool BF = false>
+inline int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+    n = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <int NW, bool REFINE, int ABL = 0, bool UT = false, bool BF = false, bool PERSIST = false>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
-  const dim3 grid((unsigned)((n_tiles + a.tiles_per_group - 1) / a.tiles_per_group));
+  const long n_groups = (n_tiles + a.tiles_per_group - 1) / a.tiles_per_group;
+  const dim3 grid((unsigned)(PERSIST && n_groups > cu_count() ? cu_count() : n_groups));
   const size_t lds = chain_lds_bytes<NW>();
-  auto fn = k_chain<NW, REFINE, ABL, UT, BF>;
+  auto fn = k_chain<NW, REFINE, ABL, UT, BF, PERSIST>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return PSTL_ERR_LAUNCH;
@@ -1110,8 +1130,11 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   // chain_waves = 16 forces the split-bf16 form for both networks.
   if (REFINE && chain_waves == 0) chain_waves = 8;
   if (REFINE && a.h1_save && chain_waves == 16) chain_waves = 8;   // the training forward pass saves fp32 activations
-  if (chain_waves == 0 || chain_waves == 16)
+  if (chain_waves == 0 || chain_waves == 16) {
+    if constexpr (!REFINE)
+      if (ut && a.step_hi == a.step_lo) return launch_chain<8, false, 0, true, true, true>(a, st);   // single step: persistent
     return ut ? launch_chain<8, REFINE, 0, true, true>(a, st) : launch_chain<8, REFINE, 0, false, true>(a, st);
+  }
   if (chain_waves == 8) return ut ? launch_chain<8, REFINE, 0, true>(a, st) : launch_chain<8, REFINE>(a, st);
   if (chain_waves == 4) return launch_chain<4, REFINE>(a, st);
   if (REFINE) return chain_waves > 100 ? launch_chain<8, true>(a, st) : PSTL_ERR_SHAPE;
