@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256) void k_encode(EncArgs a, int SCN) {
       float acc[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc[u] = b0v;
+#pragma unroll 4
       for (int k = 0; k < nin; ++k) {
         const float w = w0t[k * kHid + tid];
 #pragma unroll
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256) void k_encode(EncArgs a, int SCN) {
       float acc[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc[u] = b1v;
+#pragma unroll 4   // 16 weight loads in flight: with one workgroup (4 waves) per CU nothing else hides their latency
       for (int k = 0; k < kHid; k += 4) {   // 4 weights per step, activations as one 16-byte LDS broadcast per token
         const float w0 = w1t[k * kHid + tid], w1 = w1t[(k + 1) * kHid + tid], w2 = w1t[(k + 2) * kHid + tid],
                     w3 = w1t[(k + 3) * kHid + tid];
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(256) void k_encode(EncArgs a, int SCN) {
     const int o = tid & 31;
     for (int tk = t0 + (tid >> 5); tk < t1; tk += 8) {
       float acc = a.packed[a.L.enc[e].b2 + o];
+#pragma unroll 4
       for (int k = 0; k < kHid; k += 4) {
         const f32x4 h = *reinterpret_cast<const f32x4*>(&h_b[tk][k]);
         acc += w2t[k * 32 + o] * h.x + w2t[(k + 1) * 32 + o] * h.y + w2t[(k + 2) * 32 + o] * h.z + w2t[(k + 3) * 32 + o] * h.w;
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(256) void k_encode(EncArgs a, int SCN) {
     float acc[kMaxScn];
 #pragma unroll
     for (int u = 0; u < kMaxScn; ++u) acc[u] = bias;
+#pragma unroll 8
     for (int k = 0; k < kFeat; ++k) {
       const float wv = w[k * kHid + tid];
 #pragma unroll
