@@ -871,7 +871,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       u32x4 ch = hbb[0], cl = hbb[64];
       const f32x4 xa = xb[0], xc = xb[64], xe = xb[128];
       f32x4 a1[OT];   // starts from the scene/timestep constant part (fetched at k-block 1, used from k-block 2 on)
-      bf16x8 x0h, x0l, x1h, x1l;
+      bf16x8 x0h, x0l, x1h, x1l, hh, hl2;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
@@ -901,6 +901,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vl, a1[ot]);
         }
         if (kb == 1) l1_const(p2, b1, a1);
+        if (kb == 5) split8(relu4(a1[0]), relu4(a1[OT - 1]), hh, hl2);   // layer 1's output, in the shadow of layer 2's MFMAs
         ch = nh;
         cl = nl;
         // issue order of this k-block: the two LDS reads of the next one, then its MFMAs with the conversions between
@@ -920,6 +921,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           }
         } else if (kb == 2 || kb == 3) {
           __builtin_amdgcn_sched_group_barrier(0x008, 6 * OT, 0);
+        } else if (kb == 5) {
+#pragma unroll
+          for (int m = 0; m < 3 * OT; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          }
         } else {
           __builtin_amdgcn_sched_group_barrier(0x008, 3 * OT, 0);
         }
@@ -927,7 +934,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       PSTL_STAMP(3)
       // layer 3 of tile-step it; the ReLU + split of layer 1's output sits between its MFMAs
-      bf16x8 bh, bl, hh, hl2;
+      bf16x8 bh, bl;
       split8(relu4(acc[0]), relu4(acc[OT - 1]), bh, bl);
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bh, acc3[j]);
@@ -935,7 +942,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3l[j], bh, acc3[j]);
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bl, acc3[j]);
-      split8(relu4(a1[0]), relu4(a1[OT - 1]), hh, hl2);
       u32x4* hwb = reinterpret_cast<u32x4*>(h1 + b1 * 4096);
       hwb[(w * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
       hwb[(w * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, hl2);
