@@ -931,7 +931,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           __builtin_amdgcn_sched_group_barrier(0x008, 3 * OT, 0);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      // (no scheduling fence here: left free, the compiler starts layer 3's conversions under layer 2's last MFMAs, -4 %)
       PSTL_STAMP(3)
       // layer 3 of tile-step it; the ReLU + split of layer 1's output sits between its MFMAs
       bf16x8 bh, bl;
