@@ -20,6 +20,8 @@
 //    speed of the fp32 form.  See the comment above k_chain.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pstl_common.hpp"
 #include "rng.hpp"
 
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // split-bf16 kernel is bound by the instructions its longest wave has to issue, not by the matrix pipe, so the ~130
   // instructions of Philox + Box-Muller are taken off the epilogue waves.  (In the fp32 kernel the same move was slower.)
   constexpr bool NOISE_SPLIT = BF;
-  f32x4* zbuf = reinterpret_cast<f32x4*>(crow + 3 * 512);   // [2][160] noise quads of a tile-step
+  f32x4* zbuf = reinterpret_cast<f32x4*>(crow + 3 * 512);   // [2][192] noise quads of a tile-step (160 used)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
@@ -818,19 +820,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   layer1(p0, 0);
   if (total > 1) layer1(p1, 1);
   __syncthreads();
+  // BF, in-kernel noise: waves 4..6 draw it INSIDE their layer-2 MFMA stream (branch-free, one basic block) instead of in
+  // a phase of their own in front of it
+  const bool woven_noise = BF && !REFINE && ABL == 0 && a.rng && !a.mu_only && w >= NW / 2 && w < NW / 2 + 3;
   int hbuf = 0;  // it % 3
   for (int it = 0; it < total; ++it) {
     PSTL_STAMP(0)
     if (UT && w == kStager && it + 3 < total) stage_cst(p3, hbuf);
     if (NOISE_SPLIT && (ABL == 0 || ABL == 7)) {
-      if (w >= NW / 2 && w < NW / 2 + NCW) {
+      if (w >= NW / 2 && w < NW / 2 + NCW && !woven_noise) {
         const int nt = tid - NT / 2;
         f32x4 z;
         fetch_noise(p0, nt, z);
-        if (nt < 160) zbuf[(it & 1) * 160 + nt] = z;
+        if (nt < 160) zbuf[(it & 1) * 192 + nt] = z;
       }
       if (epi_wave && it > 0) {
-        const f32x4 z = tid < 160 ? zbuf[((it - 1) & 1) * 160 + tid] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const f32x4 z = tid < 160 ? zbuf[((it - 1) & 1) * 192 + tid] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         epilogue(pm1, (it - 1) & 1, z);
       }
     } else if (epi_wave && (ABL == 0 || ABL == 7)) {
@@ -861,6 +866,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc3[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if constexpr (BF) {
+      auto bf_block = [&](auto noise_tag) {
+      constexpr bool NOISE = decltype(noise_tag)::value;
       // Layer 1 of tile-step it + 2 is woven into layers 2 + 3 of tile-step it: the kernel is bound by what one wave can
       // issue, and a wave cannot issue past its own MFMA while the matrix pipe is busy, so the conversions of layer 1
       // (independent work) go into the 8 issue cycles each 16-cycle MFMA leaves free.  Layer 1 is computed for the
@@ -872,6 +879,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       const f32x4 xa = xb[0], xc = xb[64], xe = xb[128];
       f32x4 a1[OT];   // starts from the scene/timestep constant part (fetched at k-block 1, used from k-block 2 on)
       bf16x8 x0h, x0l, x1h, x1l, hh, hl2;
+      f32x4 zv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
@@ -902,6 +910,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         }
         if (kb == 1) l1_const(p2, b1, a1);
         if (kb == 5) split8(relu4(a1[0]), relu4(a1[OT - 1]), hh, hl2);   // layer 1's output, in the shadow of layer 2's MFMAs
+        if (NOISE && kb == 6) {   // this wave's share of the noise of tile-step it (rows past N and the quads 10, 11 are never read)
+          const int nt = tid - NT / 2;
+          const int i = s_hi - p0.n;
+          float z[4];
+          normal4(a.seed, a.row_offset + (tile0 + p0.tl) * kTileRows + (nt & 15), nt >> 4, i, z);
+          zv = i > 1 ? f32x4{z[0], z[1], z[2], z[3]} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
         ch = nh;
         cl = nl;
         // issue order of this k-block: the two LDS reads of the next one, then its MFMAs with the conversions between
@@ -927,6 +942,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
           }
+        } else if (NOISE && (kb == 6 || kb == 7)) {
+#pragma unroll
+          for (int m = 0; m < 3 * OT; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          }
         } else {
           __builtin_amdgcn_sched_group_barrier(0x008, 3 * OT, 0);
         }
@@ -950,6 +971,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
       }
+      if (NOISE) zbuf[(it & 1) * 192 + (tid - NT / 2)] = zv;
+      };
+      if (woven_noise) bf_block(std::true_type{});
+      else bf_block(std::false_type{});
     } else {
     f32x4 bq = hb[0];
     __builtin_amdgcn_sched_barrier(0);  // the pipelined region starts here
@@ -992,7 +1017,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     hbuf = hbuf == 2 ? 0 : hbuf + 1;
     pm1 = p0, p0 = p1, p1 = p2, p2 = p3, p3 = next_pos(p3);
   }
-  if (NOISE_SPLIT && epi_wave && tid < 160) zreg = zbuf[((total - 1) & 1) * 160 + tid];
+  if (NOISE_SPLIT && epi_wave && tid < 160) zreg = zbuf[((total - 1) & 1) * 192 + tid];
   if (epi_wave && (ABL == 0 || ABL == 7)) epilogue(pm1, (total - 1) & 1, zreg);
   if (ABL != 0 && a.N < 0) epilogue(p0, 0, zreg);  // keep the code reachable for the compiler, never executed
   if (!PERSIST) break;
@@ -1098,7 +1123,7 @@ inline int tiles_per_group(long N) {
 
 template <int NW>
 size_t chain_lds_bytes() {
-  return (size_t)(kG * 768 + 3 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps + 3 * 512 + 2 * 160 * 4) *
+  return (size_t)(kG * 768 + 3 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps + 3 * 512 + 2 * 192 * 4) *
          sizeof(float);
 }
 
