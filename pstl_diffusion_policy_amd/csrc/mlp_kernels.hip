@@ -946,7 +946,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 #pragma unroll
           for (int m = 0; m < 3 * OT; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4-5 per MFMA measured best (2: +3 %, 6: +1.5 %)
           }
         } else {
           __builtin_amdgcn_sched_group_barrier(0x008, 3 * OT, 0);
