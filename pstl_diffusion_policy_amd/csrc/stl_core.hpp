@@ -255,15 +255,32 @@ PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, f
     }
     float q = INFINITY;
     float bdx = 0.0f, bdy = 0.0f, boff = 0.0f;  // the closest circle pair (first one on ties)
-    PSTL_UNROLL
-    for (int i = 0; i < 4; ++i) {
+    if (!GRAD) {
+      // value only: a tree of plain minima over the 16 independent pair distances (the same number as the sequential
+      // "if (qq < q)" scan for any non-NaN input, without its compare -> select -> compare chain and the wait states
+      // that go with it)
+      float qs[16];
       PSTL_UNROLL
-      for (int j = 0; j < 4; ++j) {
-        const float dx = ex[i] - nx[j], dy = ey[i] - ny[j];
-        const float qq = dx * dx + dy * dy;
-        if (qq < q) {
-          q = qq;
-          if (GRAD) {
+      for (int i = 0; i < 4; ++i) {
+        PSTL_UNROLL
+        for (int j = 0; j < 4; ++j) {
+          const float dx = ex[i] - nx[j], dy = ey[i] - ny[j];
+          qs[4 * i + j] = dx * dx + dy * dy;
+        }
+      }
+      q = fminf(fminf(fminf(qs[0], qs[1]), fminf(qs[2], qs[3])), fminf(fminf(qs[4], qs[5]), fminf(qs[6], qs[7])));
+      q = fminf(q, fminf(fminf(fminf(qs[8], qs[9]), fminf(qs[10], qs[11])), fminf(fminf(qs[12], qs[13]), fminf(qs[14], qs[15]))));
+    } else {
+      // with the gradient the winning pair has to be tracked (finding it afterwards by equality with the tree minimum
+      // was measured slower: 16 compares and 48 selects)
+      PSTL_UNROLL
+      for (int i = 0; i < 4; ++i) {
+        PSTL_UNROLL
+        for (int j = 0; j < 4; ++j) {
+          const float dx = ex[i] - nx[j], dy = ey[i] - ny[j];
+          const float qq = dx * dx + dy * dy;
+          if (qq < q) {
+            q = qq;
             bdx = dx;
             bdy = dy;
             boff = env.eoff[i];
