@@ -8,8 +8,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpstl_hip.so")
 ARCH = "gfx950"
 
-# (source, extra flags).  stl_kernels must not contract mul+add into fma: see csrc/stl_core.hpp.
-UNITS = [("stl_kernels.hip", ["-ffp-contract=off"]), ("mlp_kernels.hip", []), ("train_kernels.hip", []),
+# (source, extra flags).  stl_kernels must not contract mul+add into fma: see csrc/stl_core.hpp.  Its device code is
+# scheduled with the ILP-oriented machine scheduler: the default one serialises chains of packed-fp32 operations through
+# one temporary and pays an s_nop between every two of them (a third of the issue slots of the circle-pair loop);
+# results are bit-identical, the guidance kernel is 3 % faster.
+UNITS = [("stl_kernels.hip", ["-ffp-contract=off", "-Xarch_device", "-mllvm=-misched=gcn-iterative-ilp"]),
+         ("mlp_kernels.hip", []), ("train_kernels.hip", []),
          ("diversity_kernels.hip", ["-ffp-contract=off"]), ("stl_program.hip", ["-ffp-contract=off"])]
 # rocBLAS only serves the plain fp32 GEMMs of the RefineNet backward pass (train_kernels.hip)
 LINK_LIBS = ["-lrocblas"]
