@@ -26,9 +26,6 @@ PEAK_BF16_MATRIX_TFLOPS = 16 * 157.3                  # same guide: the f32 MFMA
 # split-bf16 chain kernel: MFMA FLOP issued per row and denoiser evaluation (69 v_mfma_f32_16x16x32_bf16 per wave and
 # 16-row tile, 8 waves): 3 bf16 products per fp32 product, layer 1 padded 40 -> 64 columns, layer 3 padded 40 -> 48 rows
 F_STEP_ISSUED_BF16 = 8 * 69 * (2 * 16 * 16 * 32) / 16
-# what the kernel's layer-2 MFMA pattern sustains in isolation, measured (tools/dbg/mfma_rate2.hip,
-# profiles/r1/mfma_rate_*.txt): 8.0 ns per v_mfma_f32_16x16x32_bf16 and SIMD with two waves per SIMD
-SUSTAINED_BF16_MFMA_TFLOPS = 2 * 16 * 16 * 32 / 8.0e-9 * 1024 / 1e12
 
 
 def parse():
@@ -215,10 +212,15 @@ def main():
     k_ms = float(np.mean(ms))
     flop = float(nrows) * nst * F_STEP_MIN
     achieved = flop / (k_ms * 1e-3) / 1e12
-    split_bf16 = a.chain_waves in (0, 16)
-    peak = PEAK_BF16_MATRIX_TFLOPS if split_bf16 else PEAK_FP32_MATRIX_TFLOPS
-    dtype = ("bf16x3 (every f32 operand split into two bf16 pieces, 3 bf16 MFMA products per f32 product, f32 accumulate; "
-             "STL and rect_net in f32)") if split_bf16 else "f32"
+    split_f16 = a.chain_waves in (0, 16)
+    split_bf16 = a.chain_waves == 32
+    # split forms: three 16-bit MFMA products per fp32 product, so the roofline of the fp32 work they deliver is the
+    # dense 16-bit matrix peak / 3
+    peak = PEAK_BF16_MATRIX_TFLOPS / 3 if (split_f16 or split_bf16) else PEAK_FP32_MATRIX_TFLOPS
+    dtype = ("f32 (MLP products formed from two f16 pieces per operand, 2^-23 per operand, 3 v_mfma_f32_16x16x32_f16 per f32 "
+             "product, f32 accumulate; everything else plain f32)") if split_f16 else (
+        "bf16x3 (two bf16 pieces per f32 operand, 2^-17 per operand, 3 bf16 MFMA products per f32 product, f32 accumulate; "
+        "STL and rect_net in f32)") if split_bf16 else "f32"
     acc, sacc = acc_from_counts(counts)
     # the STL kernels (one row per lane): row-evaluations/s and what that means against the HBM roofline.  Algorithmic
     # bytes per row-evaluation in the scene-shared layout: 160 B controls + 16 B s0 + 24 B stlp + 4 B score + scene
@@ -258,18 +260,17 @@ def main():
                                       a.multi_cands if rect_head else None,
                                       "before=10,niters=1,lr=0.01" if guidance else None, rect_head),
                        "rows_per_gpu": N, "parallelism": "scene shards x%d, no data-path collective" % world,
-                       "chain_waves": a.chain_waves or 16,
+                       "chain_waves": a.chain_waves,
                        "noise": "in-kernel Philox4x32-10" if a.noise == "kernel" else "torch.randn tensors"},
             "stl_sat_rate": acc, "scene_sat_rate": sacc,
             "diversity": None if train else diversity_from_totals(div_totals),
             "roofline": {"bound": "mfma", "kernel": "k_chain (denoiser MLP chain, %d reverse steps per launch)" % nst,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "achieved_over_f32_mfma_peak": achieved / PEAK_FP32_MATRIX_TFLOPS,
-                         "matrix_pipe_frac_issued": (achieved * F_STEP_ISSUED_BF16 / F_STEP_MIN / peak) if split_bf16
-                                                    else achieved / peak,
-                         "matrix_pipe_frac_of_sustained_rate": (achieved * F_STEP_ISSUED_BF16 / F_STEP_MIN
-                                                                / SUSTAINED_BF16_MFMA_TFLOPS) if split_bf16 else None,
+                         "peak_note": ("dense f16/bf16 MFMA peak 2516.8 TFLOP/s / 3 products per f32 product"
+                                       if (split_f16 or split_bf16) else "dense f32 MFMA peak"),
+                         "matrix_pipe_frac_issued": (achieved * F_STEP_ISSUED_BF16 / F_STEP_MIN / PEAK_BF16_MATRIX_TFLOPS)
+                                                    if (split_f16 or split_bf16) else achieved / peak,
                          "traffic_source": "profiles/r1/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
                                            if traffic else None,
                          "kernel_ms": k_ms, "flop_per_launch": flop, "stl_kernels": stl_info,

@@ -37,6 +37,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kHid = PSTL_HID;     // 256
 constexpr int kFeat = PSTL_FEAT;   // 224
@@ -63,6 +64,8 @@ struct ChainOff {       // one of policy_net / rect_net
   long w1xb;            // [16 T][2 kb][8][64]
   long w2b;             // [16 T][8 kb][8][64]
   long w3b;             // [3 j][8 kb][8][64]
+  // split-f16 A operands (v_mfma_f32_16x16x32_f16), same shapes: pieces of kSplitW * w (see k_pack_a_split)
+  long w1xh, w2h, w3h;
 };
 struct MergeOff {
   long w0t, b0, w1t, b1, w2t, b2;  // [40][32],[32],[32][32],[32],[32][40],[40]
@@ -100,6 +103,9 @@ __host__ __device__ inline PackLayout make_layout() {
     cs[c]->w1xb = o; o += 16L * 2 * 8 * 64;
     cs[c]->w2b = o;  o += 16L * 8 * 8 * 64;
     cs[c]->w3b = o;  o += 3L * 8 * 8 * 64;
+    cs[c]->w1xh = o; o += 16L * 2 * 8 * 64;
+    cs[c]->w2h = o;  o += 16L * 8 * 8 * 64;
+    cs[c]->w3h = o;  o += 3L * 8 * 8 * 64;
   }
   L.mrg.w0t = o; o += 40 * 32;
   L.mrg.b0 = o;  o += 32;
@@ -142,15 +148,25 @@ __global__ void k_pack_a(const float* W, int ld, int rows_valid, int n_tiles, in
   dst[i] = (row < rows_valid && col >= 0) ? W[(long)row * ld + col] : 0.0f;
 }
 
-// Split-bf16 A-operand layout.  Every fp32 weight is stored as two bf16 pieces, hi = bf16(w) and lo = bf16(w - hi)
-// (w = hi + lo to ~2^-17 relative).  Word m of lane l for block blk = Tt*nkb + kb (tile Tt, k-block kb) sits at
+// Split A-operand layout (two 16-bit pieces per fp32 weight).  F16 = false: hi = bf16(w), lo = bf16(w - hi) (w = hi + lo to
+// ~2^-17 relative).  F16 = true (the default arithmetic of the chains): the pieces are IEEE half, of ws = kSplitW * w:
+// hi = f16(ws), lo = f16(ws - hi), so that ws = hi + lo to ~2^-23 relative -- an fp32 operand to within one bit.  The
+// power-of-two factor keeps the pieces of ordinary weights (|w| ~ 1e-3 .. 1) inside half's normal range (|ws| >= 0.25
+// leaves lo normal; below that the error is 2^-25 / kSplitW absolute); it is exact and is divided out of the
+// accumulators by the kernel.  |w| must stay below 65504 / kSplitW = 64.
+// Word m of lane l for block blk = Tt*nkb + kb (tile Tt, k-block kb) sits at
 // dst[((blk*2 + (m>>2))*64 + l)*4 + (m&3)]: one 16-byte load per lane fetches the four hi words (m < 4: slots 2m, 2m+1,
 // low half first), a second one the four lo words (m >= 4).
 // Slot s of lane group g = l>>4 is column k = 32 kb + 16 (s>>2) + 4 g + (s&3): with this order the accumulator
 // registers of two neighbouring 16-feature tiles ARE one k-block of the next layer's B operand (see k_chain).
-__device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+constexpr float kSplitW = 1024.0f;   // weights are split as pieces of 2^10 w
+constexpr float kSplitX = 16.0f;     // activations as pieces of 2^4 x (|x| < 4094; absolute error floor 2^-29)
 
-__global__ void k_pack_a_bf(const float* W, int ld, int rows_valid, int n_tiles, int nkb, int mode, unsigned* dst) {
+__device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ unsigned f16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); }
+
+template <bool F16>
+__global__ void k_pack_a_split(const float* W, int ld, int rows_valid, int n_tiles, int nkb, int mode, unsigned* dst) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)n_tiles * nkb * 512) return;
   const int lane = (int)((i >> 2) & 63), m = (int)((i & 3) | (((i >> 8) & 1) << 2));
@@ -164,10 +180,17 @@ __global__ void k_pack_a_bf(const float* W, int ld, int rows_valid, int n_tiles,
     int col = k;
     if (mode == 1) col = k < 40 ? 224 + k : k == 40 ? 296 : k < 47 ? 297 + (k - 41) : -1;
     if (mode == 2) col = k < 40 ? 231 + k : k == 40 ? 224 : k < 47 ? 225 + (k - 41) : -1;
-    const float wv = (row < rows_valid && col >= 0) ? W[(long)row * ld + col] : 0.0f;
-    const __bf16 hi = (__bf16)wv;
-    const float piece = m < 4 ? (float)hi : wv - (float)hi;
-    word |= bf16_bits(piece) << (16 * e);
+    float wv = (row < rows_valid && col >= 0) ? W[(long)row * ld + col] : 0.0f;
+    if (F16) {
+      wv *= kSplitW;
+      const _Float16 hi = (_Float16)wv;
+      const float piece = m < 4 ? (float)hi : wv - (float)hi;
+      word |= f16_bits(piece) << (16 * e);
+    } else {
+      const __bf16 hi = (__bf16)wv;
+      const float piece = m < 4 ? (float)hi : wv - (float)hi;
+      word |= bf16_bits(piece) << (16 * e);
+    }
   }
   dst[i] = word;
 }
@@ -414,18 +437,24 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma_bf(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
-// eight fp32 values -> their bf16 hi pieces and the bf16 of what the hi pieces miss (v_cvt_pk_bf16_f32, RNE)
-__device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, bf16x8& hi, bf16x8& lo) {
+// eight fp32 values -> their 16-bit hi pieces and the 16-bit rounding of what the hi pieces miss
+// (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, RNE)
+template <typename PV>
+__device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, PV& hi, PV& lo) {
+  typedef std::remove_reference_t<decltype(hi[0])> E;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    hi[i] = (__bf16)u[i];
-    hi[4 + i] = (__bf16)v[i];
+    hi[i] = (E)u[i];
+    hi[4 + i] = (E)v[i];
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    lo[i] = (__bf16)(u[i] - (float)hi[i]);
-    lo[4 + i] = (__bf16)(v[i] - (float)hi[4 + i]);
+    lo[i] = (E)(u[i] - (float)hi[i]);
+    lo[4 + i] = (E)(v[i] - (float)hi[4 + i]);
   }
 }
 
@@ -458,9 +487,16 @@ __device__ __forceinline__ int xs_addr(int k, int c) { return (((k >> 4) * 64) +
 // PERSIST: one workgroup per CU walks the 12-tile groups blockIdx.x, blockIdx.x + gridDim.x, ... with the weights loaded
 // into registers once (used for the single-step launches of the guided phase, where the 344 KB weight fetch and the
 // workgroup turnover are ~10 % of a 12-iteration workgroup).
-template <int NW, bool REFINE, int ABL = 0, bool UT = false, bool BF = false, bool PERSIST = false>
+template <int NW, bool REFINE, int ABL = 0, bool UT = false, int PT = 0, bool PERSIST = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
-  static_assert(!BF || NW == 8, "the split-bf16 variant is an 8-wave kernel");
+  constexpr bool BF = PT != 0;      // the operands are split into two 16-bit pieces
+  constexpr bool F16 = PT == 2;     // ... of IEEE half (scaled, see k_pack_a_split); PT == 1: bfloat16 pieces
+  typedef std::conditional_t<F16, f16x8, bf16x8> pv8;
+  // F16: layer inputs are held as kSX * x, weights as kSW * w, so every accumulator is kSW * kSX times its value; a
+  // hidden layer's output relu(acc) / kSW is the next layer's kSX-scaled input.  All factors are powers of two (exact).
+  constexpr float kSX = F16 ? kSplitX : 1.0f, kSW = F16 ? kSplitW : 1.0f;
+  constexpr float kAcc = kSX * kSW, kInvSW = 1.0f / kSW, kInvAcc = 1.0f / kAcc, kInvSX = 1.0f / kSX;
+  static_assert(!BF || NW == 8, "the split variants are 8-wave kernels");
   constexpr int OT = 16 / NW;       // 16-feature output tiles per wave
   constexpr int NT = NW * 64;
   // The first NCW waves also run the epilogue (8 waves: waves 0..3, the older wave of each SIMD pair; measured 1.8 %
@@ -492,19 +528,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 
   // ---- weights -> registers (A operands), once per launch ----
   float w1x[BF ? 1 : OT][12], w2[BF ? 1 : OT][64], w3[3][BF ? 1 : OT][4];
-  bf16x8 w1h[OT][2], w1l[OT][2], w2h[OT][8], w2l[OT][8], w3h[3], w3l[3];
+  pv8 w1h[OT][2], w1l[OT][2], w2h[OT][8], w2l[OT][8], w3h[3], w3l[3];
   {
     const float* p1 = a.packed + a.off.w1x;
     const float* p2 = a.packed + a.off.w2;
     const float* p3 = a.packed + a.off.w3;
     if constexpr (BF) {
-      const unsigned* q1 = reinterpret_cast<const unsigned*>(a.packed + a.off.w1xb);
-      const unsigned* q2 = reinterpret_cast<const unsigned*>(a.packed + a.off.w2b);
-      const unsigned* q3 = reinterpret_cast<const unsigned*>(a.packed + a.off.w3b);
-      auto load_pair = [&](const unsigned* q, long blk, bf16x8& hi, bf16x8& lo) {
+      const unsigned* q1 = reinterpret_cast<const unsigned*>(a.packed + (F16 ? a.off.w1xh : a.off.w1xb));
+      const unsigned* q2 = reinterpret_cast<const unsigned*>(a.packed + (F16 ? a.off.w2h : a.off.w2b));
+      const unsigned* q3 = reinterpret_cast<const unsigned*>(a.packed + (F16 ? a.off.w3h : a.off.w3b));
+      auto load_pair = [&](const unsigned* q, long blk, pv8& hi, pv8& lo) {
         const u32x4* q4 = reinterpret_cast<const u32x4*>(q);
-        hi = __builtin_bit_cast(bf16x8, q4[(blk * 2 + 0) * 64 + lane]);
-        lo = __builtin_bit_cast(bf16x8, q4[(blk * 2 + 1) * 64 + lane]);
+        hi = __builtin_bit_cast(pv8, q4[(blk * 2 + 0) * 64 + lane]);
+        lo = __builtin_bit_cast(pv8, q4[(blk * 2 + 1) * 64 + lane]);
       };
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) {
@@ -529,7 +565,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) w3[j][BF ? 0 : ot][r] = p3[(((long)j * 16 + T) * 4 + r) * 64 + lane];
     }
-    if (tid < 256) b2s[tid] = a.packed[a.off.b2 + tid];
+    if (tid < 256) b2s[tid] = a.packed[a.off.b2 + tid] * kAcc;
     if (tid < 48) b3s[tid] = a.packed[a.off.b3 + tid];
     if (!REFINE && tid <= a.step_hi - a.step_lo) {   // reverse-step coefficients (nusc_train.py:580-587), once per launch
       const int i = a.step_hi - tid;
@@ -577,7 +613,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       const float* sp = a.stlp + row * 6;
       v = f32x4{sp[3], sp[4], sp[5], 0.0f};
     }
-    *reinterpret_cast<f32x4*>(xs + tl * 768 + xs_addr(4 * j, c)) = v;
+    *reinterpret_cast<f32x4*>(xs + tl * 768 + xs_addr(4 * j, c)) = v * kSX;
   }
   if (!REFINE && a.n_emit >= a.steps && a.step_hi == a.steps - 1) {  // x_T itself is entry 0 of the full list
     for (int e = tid; e < G * kTileRows * kCtrl; e += NT) {
@@ -642,6 +678,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       for (int ot = 0; ot < OT; ++ot) {
         cst[ot] = cb[4 * (w * OT + ot) + g];
         if (!REFINE) cst[ot] += cb[64 + 4 * (w * OT + ot) + g];
+        if (F16) cst[ot] *= kAcc;
       }
     } else {
       long rowc = (tile0 + tl) * kTileRows + col;
@@ -652,10 +689,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         const int f0 = 16 * (w * OT + ot) + 4 * g;
         cst[ot] = *reinterpret_cast<const f32x4*>(bp + f0);
         if (!REFINE) cst[ot] += *reinterpret_cast<const f32x4*>(a.tbias + (long)i * kHid + f0);
+        if (F16) cst[ot] *= kAcc;
       }
     }
   };
 
+  // a hidden layer's output as the next layer's input: relu, and (F16) the accumulator's weight factor divided out
+  auto hidden = [&](const f32x4& acc_v) {
+    f32x4 h = relu4(acc_v);
+    if (F16) h *= kInvSW;
+    return h;
+  };
   auto layer1 = [&](Pos p, int buf) {   // buf = tile-step index mod 3: the h1 buffer written and the crow slot read
     const int tl = p.tl;
     // fetched now, added after the MFMAs
@@ -674,7 +718,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       for (int kb = 0; kb < 2; ++kb) {
         const f32x4 x0 = xb[2 * kb * 64];
         const f32x4 x1 = kb == 0 ? xb[64] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        bf16x8 bh, bl;
+        pv8 bh, bl;
         split8(x0, x1, bh, bl);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w1h[ot][kb], bh, acc[ot]);
@@ -683,8 +727,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w1h[ot][kb], bl, acc[ot]);
       }
-      bf16x8 hh, hl2;
-      split8(relu4(acc[0]), relu4(acc[OT - 1]), hh, hl2);
+      pv8 hh, hl2;
+      split8(hidden(acc[0]), hidden(acc[OT - 1]), hh, hl2);
       u32x4* hwb = reinterpret_cast<u32x4*>(h1 + buf * 4096);   // [kb = producing wave][hi | lo][lane]
       hwb[(w * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
       hwb[(w * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, hl2);
@@ -732,17 +776,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       const int j = qd >> 2, gq = qd & 3, slot = gq * 16 + c, f0 = 4 * qd;
       const f32x4* pp = reinterpret_cast<const f32x4*>(part + par * (NW * 768));
       f32x4 o = reinterpret_cast<const f32x4*>(b3s)[qd];
+      if (F16) {   // the partial sums carry the factor kAcc
+        f32x4 ps = pp[j * 64 + slot];
 #pragma unroll
-      for (int ww = 0; ww < NW; ++ww) o += pp[(ww * 3 + j) * 64 + slot];
+        for (int ww = 1; ww < NW; ++ww) ps += pp[(ww * 3 + j) * 64 + slot];
+        o += ps * kInvAcc;
+      } else {
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) o += pp[(ww * 3 + j) * 64 + slot];
+      }
       const long row = row0 + c;
       const f32x4 sc = f32x4{a.w_max, a.a_max, a.w_max, a.a_max};
       if (!REFINE) {
         f32x4* xp = reinterpret_cast<f32x4*>(xs + tl * 768) + j * 64 + slot;
-        const f32x4 x = *xp;
+        const f32x4 x = F16 ? *xp * kInvSX : *xp;
         const f32x4 eps = o + x;
         const f32x4 mu = inv_sa * (x - c1 * eps);
         const f32x4 xn = a.mu_only == 2 ? eps : a.mu_only ? mu : mu + sbeta * z4;
-        *xp = xn;
+        *xp = F16 ? xn * kSX : xn;
         if (row < a.N) {
           if (i == s_lo) *reinterpret_cast<f32x4*>(a.x_inout + row * kCtrl + f0) = xn;
           if (i <= a.n_emit && !a.mu_only) {
@@ -878,7 +929,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       u32x4 ch = hbb[0], cl = hbb[64];
       const f32x4 xa = xb[0], xc = xb[64], xe = xb[128];
       f32x4 a1[OT];   // starts from the scene/timestep constant part (fetched at k-block 1, used from k-block 2 on)
-      bf16x8 x0h, x0l, x1h, x1l, hh, hl2;
+      pv8 x0h, x0l, x1h, x1l, hh, hl2;
       f32x4 zv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -888,7 +939,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           nh = hbb[(2 * kb + 2) * 64];
           nl = hbb[(2 * kb + 3) * 64];
         }
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, ch), bl = __builtin_bit_cast(bf16x8, cl);
+        const pv8 bh = __builtin_bit_cast(pv8, ch), bl = __builtin_bit_cast(pv8, cl);
         if (PSTL_EXP != 1 || kb == 0) {
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2h[ot][kb], bh, acc[ot]);
@@ -900,7 +951,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         if (kb == 0) split8(xa, xc, x0h, x0l);
         if (kb == 1) split8(xe, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, x1h, x1l);
         if (kb == 2 || kb == 3) {
-          const bf16x8 vh = kb == 2 ? x0h : x1h, vl = kb == 2 ? x0l : x1l;
+          const pv8 vh = kb == 2 ? x0h : x1h, vl = kb == 2 ? x0l : x1l;
 #pragma unroll
           for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vh, a1[ot]);
 #pragma unroll
@@ -909,7 +960,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vl, a1[ot]);
         }
         if (kb == 1) l1_const(p2, b1, a1);
-        if (kb == 5) split8(relu4(a1[0]), relu4(a1[OT - 1]), hh, hl2);   // layer 1's output, in the shadow of layer 2's MFMAs
+        if (kb == 5) split8(hidden(a1[0]), hidden(a1[OT - 1]), hh, hl2);   // layer 1's output, in the shadow of layer 2's MFMAs
         if (NOISE && kb == 6) {   // this wave's share of the noise of tile-step it (rows past N and the quads 10, 11 are never read)
           const int nt = tid - NT / 2;
           const int i = s_hi - p0.n;
@@ -955,8 +1006,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       // (no scheduling fence here: left free, the compiler starts layer 3's conversions under layer 2's last MFMAs, -4 %)
       PSTL_STAMP(3)
       // layer 3 of tile-step it; the ReLU + split of layer 1's output sits between its MFMAs
-      bf16x8 bh, bl;
-      split8(relu4(acc[0]), relu4(acc[OT - 1]), bh, bl);
+      pv8 bh, bl;
+      split8(hidden(acc[0]), hidden(acc[OT - 1]), bh, bl);
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bh, acc3[j]);
 #pragma unroll
@@ -1138,13 +1189,13 @@ inline int cu_count() {
   return n;
 }
 
-template <int NW, bool REFINE, int ABL = 0, bool UT = false, bool BF = false, bool PERSIST = false>
+template <int NW, bool REFINE, int ABL = 0, bool UT = false, int PT = 0, bool PERSIST = false>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
   const long n_groups = (n_tiles + a.tiles_per_group - 1) / a.tiles_per_group;
   const dim3 grid((unsigned)(PERSIST && n_groups > cu_count() ? cu_count() : n_groups));
   const size_t lds = chain_lds_bytes<NW>();
-  auto fn = k_chain<NW, REFINE, ABL, UT, BF, PERSIST>;
+  auto fn = k_chain<NW, REFINE, ABL, UT, PT, PERSIST>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return PSTL_ERR_LAUNCH;
@@ -1152,23 +1203,29 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
   return launch_status();
 }
 
-// cfg->chain_waves: 0    = policy_net on split-bf16 MFMA (eight waves x 32 output features), rect_net on fp32 MFMA,
-//                   16   = both on split-bf16 MFMA,
+// cfg->chain_waves: 0, 16 = both networks on split-f16 MFMA: every fp32 operand as two half pieces, three
+//                          v_mfma_f32_16x16x32_f16 products per fp32 product, fp32 accumulation (operands good to 2^-23:
+//                          results sit as close to the reference as an fp32 fmaf chain in another summation order does),
+//                   32   = policy_net on split-bf16 MFMA (operands good to 2^-17; the round-1 default, kept for
+//                          comparison), rect_net on fp32 MFMA,
 //                   8    = eight waves x 32 output features on fp32 MFMA (2 waves/SIMD, <=256 registers each),
 //                   4    = four waves x 64 output features on fp32 MFMA (1 wave/SIMD, weights partly in AGPRs)
 template <bool REFINE>
 int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   const bool ut = (a.rows_per_scene % kTileRows == 0);  // every 16-row tile lies inside one scene
-  // the default: the denoiser on split-bf16 products (8-wave layout).  rect_net stays on fp32 MFMA: its interval head
-  // scales tanh(output) by the remaining headroom of a control (up to 2 x mul_a_max), and measured at full size one pass
-  // through it on split-bf16 products moves a refined control by up to 9e-5 -- the whole parity budget -- for 0.7 ms.
-  // chain_waves = 16 forces the split-bf16 form for both networks.
-  if (REFINE && chain_waves == 0) chain_waves = 8;
-  if (REFINE && a.h1_save && chain_waves == 16) chain_waves = 8;   // the training forward pass saves fp32 activations
-  if (chain_waves == 0 || chain_waves == 16) {
+  if (chain_waves == 16) chain_waves = 0;
+  if (REFINE && chain_waves == 32) chain_waves = 8;    // bf16 pieces cost the interval head up to 9e-5 per pass
+  if (REFINE && a.h1_save) chain_waves = chain_waves == 4 ? 4 : 8;   // the training forward pass saves fp32 activations
+  if (chain_waves == 0) {
     if constexpr (!REFINE)
-      if (ut && a.step_hi == a.step_lo) return launch_chain<8, false, 0, true, true, true>(a, st);   // single step: persistent
-    return ut ? launch_chain<8, REFINE, 0, true, true>(a, st) : launch_chain<8, REFINE, 0, false, true>(a, st);
+      if (ut && a.step_hi == a.step_lo) return launch_chain<8, false, 0, true, 2, true>(a, st);   // single step: persistent
+    return ut ? launch_chain<8, REFINE, 0, true, 2>(a, st) : launch_chain<8, REFINE, 0, false, 2>(a, st);
+  }
+  if (chain_waves == 32) {
+    if constexpr (!REFINE) {
+      if (ut && a.step_hi == a.step_lo) return launch_chain<8, false, 0, true, 1, true>(a, st);
+      return ut ? launch_chain<8, false, 0, true, 1>(a, st) : launch_chain<8, false, 0, false, 1>(a, st);
+    }
   }
   if (chain_waves == 8) return ut ? launch_chain<8, REFINE, 0, true>(a, st) : launch_chain<8, REFINE>(a, st);
   if (chain_waves == 4) return launch_chain<4, REFINE>(a, st);
@@ -1181,8 +1238,8 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
     case 508: return launch_chain<8, false, 5>(a, st);
     case 708: return ut ? launch_chain<8, false, 7, true>(a, st) : launch_chain<8, false, 7>(a, st);
     case 1008: return launch_chain<8, false>(a, st);   // force the general (non-uniform-tile) path
-    case 116: return launch_chain<8, false, 1, true, true>(a, st);
-    case 716: return launch_chain<8, false, 7, true, true>(a, st);
+    case 116: return launch_chain<8, false, 1, true, 2>(a, st);
+    case 716: return launch_chain<8, false, 7, true, 2>(a, st);
     default: return PSTL_ERR_SHAPE;
   }
 }
@@ -1243,9 +1300,12 @@ static int pack_chain(const pstl_mlp3& m, int in, int kext_mode, bool with_time,
   hipLaunchKernelGGL(k_pack_a, dim3(3 * 16), dim3(256), 0, st, m.w2, kHid, kCtrl, 3, 16, 0, packed + o.w3);
   hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, st, m.b2, kCtrl, 48, packed + o.b3);
   unsigned* pw = reinterpret_cast<unsigned*>(packed);
-  hipLaunchKernelGGL(k_pack_a_bf, dim3(16 * 2 * 2), dim3(256), 0, st, m.w0, in, kHid, 16, 2, kext_mode, pw + o.w1xb);
-  hipLaunchKernelGGL(k_pack_a_bf, dim3(16 * 8 * 2), dim3(256), 0, st, m.w1, kHid, kHid, 16, 8, 0, pw + o.w2b);
-  hipLaunchKernelGGL(k_pack_a_bf, dim3(3 * 8 * 2), dim3(256), 0, st, m.w2, kHid, kCtrl, 3, 8, 0, pw + o.w3b);
+  hipLaunchKernelGGL(k_pack_a_split<false>, dim3(16 * 2 * 2), dim3(256), 0, st, m.w0, in, kHid, 16, 2, kext_mode, pw + o.w1xb);
+  hipLaunchKernelGGL(k_pack_a_split<false>, dim3(16 * 8 * 2), dim3(256), 0, st, m.w1, kHid, kHid, 16, 8, 0, pw + o.w2b);
+  hipLaunchKernelGGL(k_pack_a_split<false>, dim3(3 * 8 * 2), dim3(256), 0, st, m.w2, kHid, kCtrl, 3, 8, 0, pw + o.w3b);
+  hipLaunchKernelGGL(k_pack_a_split<true>, dim3(16 * 2 * 2), dim3(256), 0, st, m.w0, in, kHid, 16, 2, kext_mode, pw + o.w1xh);
+  hipLaunchKernelGGL(k_pack_a_split<true>, dim3(16 * 8 * 2), dim3(256), 0, st, m.w1, kHid, kHid, 16, 8, 0, pw + o.w2h);
+  hipLaunchKernelGGL(k_pack_a_split<true>, dim3(3 * 8 * 2), dim3(256), 0, st, m.w2, kHid, kCtrl, 3, 8, 0, pw + o.w3h);
   return launch_status();
 }
 

@@ -124,7 +124,7 @@ def _run_region(dev, name, chain_waves=0):
     return d, meta, sb, out
 
 
-@pytest.mark.parametrize("chain_waves", [8, 4, 16])
+@pytest.mark.parametrize("chain_waves", [8, 4, 0, 32])
 @pytest.mark.parametrize("name", SAMPLING_CASES)
 def test_sampling_region_matches_reference(dev, name, chain_waves):
     from pstl_diffusion_policy_amd.engine import acc_from_counts
