@@ -11,6 +11,8 @@ Unit: sampled trajectories per second = rows (scenes x sampling_size x 3 modes) 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -84,23 +86,69 @@ def cpu_baseline(a, hp, sd, guidance, rect_head, sampler=None, dev=None):
     return out
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: this process starts the N ranks itself (one per GPU, rendezvous on
+    127.0.0.1) BEFORE anything here touches the GPU, waits for them and exits with their status.  Rank 0 prints the JSON
+    line on the inherited stdout.  Children are separate processes started with Popen -- never an exec of this one."""
+    n = a.gpus
+    backend = os.environ.get("PSTL_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()          # counts devices without initialising the GPU
+    if backend == "nccl" and ndev < n:
+        print("bench: --gpus %d but only %d GPU(s) visible; refusing to measure fewer ranks than asked for" % (n, ndev),
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in live:               # a rank died: its peers would wait in a collective for ever
+                    q.terminate()
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        sys.exit("bench: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit("bench: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (a.gpus, world))
     import torch.distributed as dist
     # PSTL_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs than ranks (ranks then
     # share devices); the real runs use nccl (= RCCL over xGMI), one process per GPU.
     backend = os.environ.get("PSTL_BENCH_BACKEND", "nccl")
-    local = local % max(torch.cuda.device_count(), 1)
+    ndev = max(torch.cuda.device_count(), 1)
+    if backend == "nccl" and world > ndev:
+        sys.exit("bench: %d ranks but %d GPU(s): one process per GPU" % (world, ndev))
+    local = local % ndev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+        if dist.get_world_size() != a.gpus:
+            sys.exit("bench: the process group has %d ranks, --gpus %d" % (dist.get_world_size(), a.gpus))
     # host-side scalars (the global valid-row statistics of the guidance loss) travel over a gloo side group, so that a
     # step never has to wait for the GPU: batches are enqueued back to back
     cpu_group = None

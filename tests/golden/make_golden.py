@@ -75,11 +75,13 @@ def sampling_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=
     torch.manual_seed(seed + 17)
     noise = torch.normal(0, 1, (N, args.nt * 2)).float()
     gextras = (new_batch, states_flat, stls) if args.guidance else None
-    draws = []
-    with ref_harness.record_randn_like(draws):
+    draws, ggrads = [], []
+    with ref_harness.record_randn_like(draws), ref_harness.record_adam_grads(ggrads):
         controls, feature, clist = nt.diffusion_rollout(noise, net, new_batch, hl, None, args, coeffs,
                                                         fastforward=False, n_randoms=S, return_feature=True,
                                                         guidance_extras=gextras, maximize=maximize)
+    if ggrads:   # d loss / d mu_opt of every guidance iteration (reference :622), guided steps in rollout order
+        out["guid_grads"] = np_(torch.stack(ggrads, dim=0))            # (n_guided * niters, N, nt, 2)
     E = steps - 1
     assert len(draws) == 1 + (E - 1), len(draws)
     out["x_T"] = np_(draws[0])
@@ -233,7 +235,7 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided")):
     main()
 
 
@@ -580,6 +582,44 @@ def main_flags():
                   stlp_mode="wide", invalid_lane_frac=0.25)
 
 
+def main_baseline_shape():
+    """The BASELINE hyper-parameters end to end (README.md:114,120): 50 diffusion steps, K=2, sampling_size 64,
+    multi_cands 5, guidance on the last 10 steps (1 Adam iteration, lr 0.01) -- ten guided steps compounding."""
+    ref = ref_harness.load_reference()
+    sd = dict(np.load(WEIGHTS_FILE))
+    e7c5 = ["--diffusion", "--load_stlp", "--rect_head", "--flex", "--diverse_loss", "--multi_cands", "5"]
+    gd = ["--guidance", "--guidance_before", "10", "--guidance_niters", "1", "--guidance_lr", "0.01"]
+    sampling_case(ref, sd, "e7_guid_c4", e7c5 + gd, bs=2, S=64, K=2, steps=50, seed=78, stlp_mode="wide",
+                  invalid_lane_frac=0.25)
+
+
+if __name__ == "__main__" and "--baseline-shape" in sys.argv:
+    main_baseline_shape()
+
+
+def main_regen_guided():
+    """Re-runs every guided fixture (same seeds => same bits) so that each carries `guid_grads`."""
+    ref = ref_harness.load_reference()
+    sd = dict(np.load(WEIGHTS_FILE))
+    e5 = ["--diffusion", "--load_stlp", "--flex"]
+    e7 = ["--diffusion", "--load_stlp", "--rect_head", "--flex", "--diverse_loss", "--multi_cands", "5"]
+    gd = ["--guidance", "--guidance_before", "4", "--guidance_niters", "1", "--guidance_lr", "0.01"]
+    sampling_case(ref, sd, "e7_guid", e7 + gd, bs=2, S=8, K=3, steps=12, seed=16, stlp_mode="wide")
+    sampling_case(ref, sd, "e7_guid_n2_rolls", e7[:-1] + ["3"] + gd[:4] + ["2", "--guidance_lr", "0.02", "--n_rolls", "2"],
+                  bs=2, S=8, K=3, steps=10, seed=17, zero_net_out=True)
+    sampling_case(ref, sd, "e5_guid_all", e5 + ["--guidance", "--guidance_niters", "3"], bs=2, S=8, K=2, steps=8, seed=18,
+                  zero_net_out=True)
+    main_closed_loop()
+    e7f = e7[:-1] + ["3"]
+    gdf = ["--guidance", "--guidance_niters", "1", "--guidance_lr", "0.01"]
+    kw = dict(bs=2, S=8, K=3, steps=10, stlp_mode="wide", invalid_lane_frac=0.25)
+    sampling_case(ref, sd, "fl_guid_sets", e7f + gdf + ["--guidance_sets", "2", "5", "7"], seed=75, **kw)
+    sampling_case(ref, sd, "fl_guid_freq_rev", e7f + gdf + ["--guidance_freq", "3", "--guidance_reverse"], seed=76, **kw)
+    sampling_case(ref, sd, "e7_s64_guid", e7 + gdf + ["--guidance_before", "3"], bs=2, S=64, K=2, steps=8, seed=77,
+                  stlp_mode="wide", invalid_lane_frac=0.25)
+    main_baseline_shape()
+
+
 if __name__ == "__main__" and "--flags" in sys.argv:
     main_flags()
 
@@ -635,3 +675,7 @@ def main_dense_stlp():
 
 if __name__ == "__main__" and "--dense-stlp" in sys.argv:
     main_dense_stlp()
+
+
+if __name__ == "__main__" and "--regen-guided" in sys.argv:
+    main_regen_guided()

@@ -106,3 +106,24 @@ def record_randn_like(store):
         yield store
     finally:
         torch.randn_like = orig
+
+
+@contextlib.contextmanager
+def record_adam_grads(store):
+    """Record the gradient every torch.optim.Adam.step() consumes (the guidance block builds a fresh Adam over mu_opt
+    per guided step, reference nusc_train.py:606-623): one tensor per step() call, in call order."""
+    import torch
+    orig = torch.optim.Adam.step
+
+    def tapped(self, *a, **k):
+        for grp in self.param_groups:
+            for p in grp["params"]:
+                if p.grad is not None:
+                    store.append(p.grad.detach().clone())
+        return orig(self, *a, **k)
+
+    torch.optim.Adam.step = tapped
+    try:
+        yield store
+    finally:
+        torch.optim.Adam.step = orig

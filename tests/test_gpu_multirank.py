@@ -1,0 +1,131 @@
+"""N > 1 on the HIP path: ranks own contiguous scene shards, run the whole
+sampling region through libpstl_hip.so with in-kernel noise keyed by the GLOBAL row, and meet only in the two tiny
+exchanges of shard.py.  The sharded run must reproduce the single-process run over the whole batch: satisfaction
+counters exactly, per-row results bit for bit, diversity totals to summation order.
+
+ * gloo, two ranks sharing GPU 0: runs on the 1-GPU box (RCCL refuses two ranks on one device);
+ * nccl (= RCCL), one rank per GPU: runs where >= 2 GPUs are visible, skipped otherwise;
+ * `python bench.py --gpus 2` starts its own ranks and reports n_gpus = 2 (or refuses when the GPUs are not there)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+BS, S, K, STEPS, SEED = 6, 16, 2, 12, 4242
+GUID = dict(enabled=True, before=3, niters=1, lr=0.01)
+
+
+def _region(scene, lo, hi, vsum, vrows, dev):
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.nusc_model import init_state_dict
+    from pstl_diffusion_policy_amd.synthetic import default_hparams
+    hp = default_hparams()
+    sub = {k: v[lo:hi].to(dev) for k, v in scene.items() if k not in ("pre_stlp", "tj_scores_prior")}
+    sb = SceneBatch(sub, S, hp, dev, global_valid_sum=vsum, global_rows=vrows, row_offset=lo * S * 3)
+    sm = Sampler(PackedWeights(init_state_dict(1007), dev), hp)
+    return sm.sampling_region(sb, STEPS, None, None, rect_head=True, multi_cands=3, guidance=GUID, seed=SEED,
+                              diversity=True, want_scores3=False)
+
+
+def _scene():
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    return make_scene_batch(BS, K=K, S=S, seed=77, invalid_lane_frac=0.3, stlp_mode="wide")
+
+
+def _worker(rank, world, port, backend, out_path):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pstl_diffusion_policy_amd.shard import gather_final, global_valid_stats, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    local = rank % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = _scene()
+    lo, hi = shard_range(BS, rank, world)
+    ids = float(sum(scene[k][lo:hi].sum().item() for k in ("curr_id", "left_id", "right_id")))
+    vsum, vrows = global_valid_stats(ids * S, (hi - lo) * S * 3, dev if backend == "nccl" else torch.device("cpu"))
+    out = _region(scene, lo, hi, vsum, vrows, dev)
+    counts, totals = out["counts"], out["div_totals"]
+    if backend != "nccl":       # gloo moves host tensors
+        counts, totals = counts.cpu(), totals.cpu()
+    counts, totals = gather_final(counts, totals)
+    torch.save({"vsum": vsum, "vrows": vrows, "counts": counts.cpu(), "totals": totals.cpu(), "lo": lo, "hi": hi,
+                "final_controls": out["final_controls"].cpu(), "final_scores": out["final_scores"].cpu()},
+               out_path + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check(tmp_path, backend, world):
+    out_path = str(tmp_path / "rank")
+    port = 23000 + (os.getpid() % 4000)
+    mp.spawn(_worker, args=(world, port, backend, out_path), nprocs=world, join=True)
+    parts = [torch.load(out_path + ".%d" % r) for r in range(world)]
+    dev = torch.device("cuda:0")
+    scene = _scene()
+    ids = float(sum(scene[k].sum().item() for k in ("curr_id", "left_id", "right_id")))
+    assert parts[0]["vsum"] == ids * S and parts[0]["vrows"] == BS * S * 3
+    ref = _region(scene, 0, BS, ids * S, BS * S * 3, dev)
+    torch.cuda.synchronize()
+    for p in parts:       # every rank holds the same global numbers
+        assert torch.equal(p["counts"], ref["counts"].cpu())
+        assert torch.equal(p["counts"], parts[0]["counts"]) and torch.equal(p["totals"], parts[0]["totals"])
+        np.testing.assert_allclose(p["totals"].numpy(), ref["div_totals"].cpu().numpy(), rtol=1e-12)
+        rows = slice(p["lo"] * S * 3, p["hi"] * S * 3)    # shard invariance: a shard's rows are the whole batch's rows
+        assert torch.equal(p["final_controls"], ref["final_controls"].cpu()[rows])
+        assert torch.equal(p["final_scores"], ref["final_scores"].cpu()[rows])
+
+
+def test_two_gloo_ranks_on_one_gpu_reproduce_the_single_process_run(tmp_path):
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    _check(tmp_path, "gloo", 2)
+
+
+def test_rccl_ranks_reproduce_the_single_process_run(tmp_path):
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one GPU visible: RCCL needs one device per rank")
+    _check(tmp_path, "nccl", 2)
+
+
+def _bench(args, env=None):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None), e.pop("RANK", None), e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True,
+                          timeout=900)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2`: two ranks (gloo + shared device here when only one GPU is visible, RCCL otherwise),
+    n_gpus = 2 in the line, twice the rows of the one-rank run; with RCCL and too few GPUs it refuses."""
+    small = ["--scenes", "48", "--steps", "2", "--warmup", "1", "--no_cpu_baseline"]
+    one = _bench(["--gpus", "1"] + small)
+    assert one.returncode == 0, one.stderr[-2000:]
+    l1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert l1["n_gpus"] == 1
+    ndev = torch.cuda.device_count()
+    two = _bench(["--gpus", "2"] + small, None if ndev >= 2 else {"PSTL_BENCH_BACKEND": "gloo"})
+    assert two.returncode == 0, two.stderr[-2000:]
+    l2 = json.loads(two.stdout.strip().splitlines()[-1])
+    assert l2["n_gpus"] == 2 and l2["scaling"] == "weak"
+    assert l2["config"]["rows_per_gpu"] == l1["config"]["rows_per_gpu"]
+    assert abs(l2["stl_sat_rate"] - l1["stl_sat_rate"]) < 0.2
+    if ndev < 2:
+        refused = _bench(["--gpus", "2"] + small)
+        assert refused.returncode != 0 and "refusing" in refused.stderr

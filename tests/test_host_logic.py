@@ -88,3 +88,19 @@ def test_metric_arithmetic_matches_mask_mean():
     a, s = acc_from_counts(counts)
     assert a == float(acc) and s == float(scene_acc) if False else True
     assert a == float(acc) and s == float(sacc)
+
+
+def test_bench_refuses_to_measure_fewer_ranks_than_asked_for():
+    """`python bench.py --gpus N` must never print a 1-rank number.  Without GPUs it exits non-zero before
+    anything is measured; a launcher that started a different number of ranks is an error too."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "launcher started 1 rank" in r.stderr
