@@ -458,6 +458,50 @@ __device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, PV& hi, P
   }
 }
 
+// PSTL_MIXSPLIT: the half pieces of the split-f16 form come from v_fma_mixlo/hi_f16 (an fp32 fma whose result is rounded to
+// half and written to one half of a register): hi = f16(a * k), lo = f16(a * k - hi) -- three instructions per value
+// with the ReLU, no packed-fp32 operation (expensive beside MFMAs, MI355X_MICROARCH.md) and no separate rescaling.
+// Same bits as the conversion form: a * k is exact (k a power of two), the fma rounds once.
+#ifndef PSTL_MIXSPLIT
+#define PSTL_MIXSPLIT 1
+#endif
+// PSTL_XSPLIT_ONCE: the pieces of a tile's layer-1 input are made once per tile-step by two waves with slack (3 and 7)
+// and handed over through LDS, instead of by all eight waves (44 of a wave's ~135 vector instructions per tile-step).
+#ifndef PSTL_XSPLIT_ONCE
+#define PSTL_XSPLIT_ONCE 1
+#endif
+
+
+__device__ __forceinline__ void mix_split2(float a0, float a1, float k, unsigned& hi, unsigned& lo) {
+  unsigned h, l;   // (the first instruction of each pair leaves the upper half as it finds it; the second one writes it)
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(a0), "s"(k));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(a1), "s"(k));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a0), "s"(k), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(a1), "s"(k), "v"(h));
+  hi = h;
+  lo = l;
+}
+
+// eight fp32 values times k -> half pieces (hi[0..3] from u, hi[4..7] from v)
+__device__ __forceinline__ void split8_mix(const f32x4& u, const f32x4& v, float k, f16x8& hi, f16x8& lo) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  mix_split2(u[0], u[1], k, h0, l0);
+  mix_split2(u[2], u[3], k, h1, l1);
+  mix_split2(v[0], v[1], k, h2, l2);
+  mix_split2(v[2], v[3], k, h3, l3);
+  hi = __builtin_bit_cast(f16x8, u32x4{h0, h1, h2, h3});
+  lo = __builtin_bit_cast(f16x8, u32x4{l0, l1, l2, l3});
+}
+__device__ __forceinline__ void split8_mix(const f32x4&, const f32x4&, float, bf16x8&, bf16x8&) {}   // never called
+
+// A value the optimiser must take as it comes at this point of the loop: stops it from hoisting `uniform pointer +
+// lane offset` out of the tile-step loop as a per-lane 64-bit pointer (five of those were live across the loop, spilled,
+// and reloaded in the epilogue behind a full vmcnt wait)
+__device__ __forceinline__ unsigned here(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // max(v, 0) as a signed-integer max on the bit patterns: one instruction per value (fmaxf costs two: the compiler first
 // canonicalises an operand it cannot prove free of signalling NaNs); identical to fmaxf for every non-NaN input
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
@@ -521,6 +565,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // instructions of Philox + Box-Muller are taken off the epilogue waves.  (In the fp32 kernel the same move was slower.)
   constexpr bool NOISE_SPLIT = BF;
   f32x4* zbuf = reinterpret_cast<f32x4*>(crow + 3 * 512);   // [2][192] noise quads of a tile-step (160 used)
+  // split forms: [2][kb 2][hi | lo][64 lanes] B operands of layer 1 (pieces of a tile's input image), made by waves 7 / 3
+  // one iteration before layer 1 of that tile-step reads them (PSTL_XSPLIT_ONCE)
+  u32x4* xpb = reinterpret_cast<u32x4*>(zbuf + 2 * 192);
+  constexpr bool XONCE = BF && PSTL_XSPLIT_ONCE && (ABL == 0 || ABL == 7);
+  // (declaring the wave index uniform -- readfirstlane -- turns the role branches into scalar branches and was measured
+  // 30 % slower: that form of the loop spills inside it)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
@@ -583,7 +633,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   int G = (int)((n_tiles - tile0) < a.tiles_per_group ? (n_tiles - tile0) : a.tiles_per_group);
   // Layer 1 runs two tile-steps ahead and the epilogue one behind, so >= 4 tiles must be in flight (see the hazard
   // notes below); short tail blocks process phantom tiles whose rows are clamped on load and masked on store.
-  if (G < 4) G = 4;
+  // (XONCE: the pieces of a tile's image are made one more iteration ahead: >= 5.)
+  if (G < (XONCE ? 5 : 4)) G = XONCE ? 5 : 4;
   // ---- per-row constants and the initial state into the B-operand image ----
   // Four consecutive input columns k = 4j .. 4j+3 of one tile column sit in one 16-byte LDS slot of the B-operand image,
   // so a row is moved as 12 quads: 10 straight from the 160-byte state row (16-byte global loads), 2 assembled from
@@ -662,9 +713,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
     const unsigned scene = (unsigned)row / (unsigned)a.rows_per_scene;   // N < 2^31 (checked by the host)
-    __builtin_amdgcn_global_load_lds((glb_ptr)(a.base + (long)scene * kHid + lane * 4), (lds_ptr)dst, 16, 0, 0);
+    // (uniform row pointer + 32-bit lane offset: no per-lane 64-bit pointer has to stay live across the loop)
+    const unsigned lo4 = here((unsigned)lane * 4u);
+    __builtin_amdgcn_global_load_lds((glb_ptr)((a.base + (long)scene * kHid) + lo4), (lds_ptr)dst, 16, 0, 0);
     if (!REFINE)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(a.tbias + (long)i * kHid + lane * 4), (lds_ptr)(dst + 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)((a.tbias + (long)i * kHid) + lo4), (lds_ptr)(dst + 256), 16, 0, 0);
   };
 
   // the scene/timestep constant part of layer 1's pre-activation for this lane's 4*OT outputs
@@ -694,11 +747,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
   };
 
-  // a hidden layer's output as the next layer's input: relu, and (F16) the accumulator's weight factor divided out
-  auto hidden = [&](const f32x4& acc_v) {
-    f32x4 h = relu4(acc_v);
-    if (F16) h *= kInvSW;
-    return h;
+  // a hidden layer's output as the next layer's input: relu, (F16) the accumulator's weight factor divided out, pieces
+  auto split_hidden = [&](const f32x4& a0, const f32x4& a1, pv8& hi, pv8& lo) {
+    if constexpr (F16 && PSTL_MIXSPLIT) {
+      split8_mix(relu4(a0), relu4(a1), kInvSW, hi, lo);
+    } else {
+      f32x4 h0 = relu4(a0), h1v = relu4(a1);
+      if (F16) h0 *= kInvSW, h1v *= kInvSW;
+      split8(h0, h1v, hi, lo);
+    }
   };
   auto layer1 = [&](Pos p, int buf) {   // buf = tile-step index mod 3: the h1 buffer written and the crow slot read
     const int tl = p.tl;
@@ -728,7 +785,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w1h[ot][kb], bl, acc[ot]);
       }
       pv8 hh, hl2;
-      split8(hidden(acc[0]), hidden(acc[OT - 1]), hh, hl2);
+      split_hidden(acc[0], acc[OT - 1], hh, hl2);
       u32x4* hwb = reinterpret_cast<u32x4*>(h1 + buf * 4096);   // [kb = producing wave][hi | lo][lane]
       hwb[(w * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
       hwb[(w * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, hl2);
@@ -770,7 +827,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
     // thread et < 160 owns outputs f0..f0+3 of tile column c: 16-byte LDS accesses at consecutive slots (no bank
     // conflicts), 16-byte global accesses (4 lanes cover one 64-byte piece of a row)
-    const int et = EPI_FIRST ? tid : tid - (NT - NCT);
+    // (the per-lane constants of this role are re-derived from the thread index every time: kept in registers across
+    // the loop beside those of the other roles they were spilled)
+    const int et = (int)here((unsigned)(EPI_FIRST ? tid : tid - (NT - NCT)));
     if (et < 160) {
       const int qd = et >> 4, c = et & 15;
       const int j = qd >> 2, gq = qd & 3, slot = gq * 16 + c, f0 = 4 * qd;
@@ -786,6 +845,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         for (int ww = 0; ww < NW; ++ww) o += pp[(ww * 3 + j) * 64 + slot];
       }
       const long row = row0 + c;
+      // global addresses = uniform pointer of the tile's first row + a 32-bit lane offset (c, f0 are per lane, row0 is
+      // uniform): per-lane 64-bit pointers kept across the loop were spilled and reloaded behind a full vmcnt wait
+      const unsigned loff = (unsigned)(c * kCtrl + f0);
       const f32x4 sc = f32x4{a.w_max, a.a_max, a.w_max, a.a_max};
       if (!REFINE) {
         f32x4* xp = reinterpret_cast<f32x4*>(xs + tl * 768) + j * 64 + slot;
@@ -795,21 +857,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         const f32x4 xn = a.mu_only == 2 ? eps : a.mu_only ? mu : mu + sbeta * z4;
         *xp = F16 ? xn * kSX : xn;
         if (row < a.N) {
-          if (i == s_lo) *reinterpret_cast<f32x4*>(a.x_inout + row * kCtrl + f0) = xn;
+          if (i == s_lo) *reinterpret_cast<f32x4*>((a.x_inout + row0 * kCtrl) + loff) = xn;
           if (i <= a.n_emit && !a.mu_only) {
             f32x4 v = xn * sc;
             if (a.clip) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], -sc[r]), sc[r]);
             }
-            *reinterpret_cast<f32x4*>(a.emit_out + ((long)(a.n_emit - i) * a.N + row) * kCtrl + f0) = v;
+            *reinterpret_cast<f32x4*>((a.emit_out + ((long)(a.n_emit - i) * a.N + row0) * kCtrl) + loff) = v;
           }
         }
       } else if (row < a.N) {
         // interval head (nusc_model.py:212-229): tanh output scales into the remaining headroom of init
-        const f32x4 init = *reinterpret_cast<const f32x4*>(a.init + row * kCtrl + f0);
-        if (a.pre_save) *reinterpret_cast<f32x4*>(a.pre_save + row * kCtrl + f0) = o;
-        const float viol = a.scores[row] < 0.0f ? 1.0f : 0.0f;
+        const f32x4 init = *reinterpret_cast<const f32x4*>((a.init + row0 * kCtrl) + loff);
+        if (a.pre_save) *reinterpret_cast<f32x4*>((a.pre_save + row0 * kCtrl) + loff) = o;
+        const float viol = (a.scores + row0)[(unsigned)c] < 0.0f ? 1.0f : 0.0f;
         f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -818,7 +880,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           v[r] = init[r] + d * viol;
           if (a.clip) v[r] = fminf(fmaxf(v[r], -sc[r]), sc[r]);
         }
-        *reinterpret_cast<f32x4*>(a.out + row * kCtrl + f0) = v;
+        *reinterpret_cast<f32x4*>((a.out + row0 * kCtrl) + loff) = v;
       }
     }
   };
@@ -827,21 +889,52 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // the fp32 kernel (drawing it on the partner waves was measured slower there: with "older wave first" arbitration of
   // both the matrix pipe and VALU issue their Philox work is starved behind the epilogue waves' MFMA streams), by the
   // partner waves 4..6 in the split-bf16 kernel (see zbuf above).
-  auto fetch_noise = [&](Pos p, int et, f32x4& z4) {
+  auto fetch_noise = [&](Pos p, int et_, f32x4& z4) {
+    const int et = (int)here((unsigned)et_);
     z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (REFINE || (!a.noise && !a.rng) || a.mu_only) return;
     const int tl = p.tl, i = s_hi - p.n;
     if (i <= 1) return;  // the reference adds zeros at the last step
     if (et < 160) {
-      const long row = (tile0 + tl) * kTileRows + (et & 15);
+      const long row0 = (tile0 + tl) * kTileRows;
+      const long row = row0 + (et & 15);
       if (row < a.N) {
         if (a.rng) {
           float z[4];
           normal4(a.seed, a.row_offset + row, et >> 4, i, z);
           z4 = f32x4{z[0], z[1], z[2], z[3]};
         } else {
-          z4 = *reinterpret_cast<const f32x4*>(a.noise + ((long)(a.steps - 1 - i) * a.N + row) * kCtrl + 4 * (et >> 4));
+          const unsigned loff = (unsigned)((et & 15) * kCtrl + 4 * (et >> 4));
+          z4 = *reinterpret_cast<const f32x4*>((a.noise + ((long)(a.steps - 1 - i) * a.N + row0) * kCtrl) + loff);
         }
+      }
+    }
+  };
+
+  // XONCE: the half pieces of tile p.tl's input image as layer 1's B operands, into piece buffer `par`: wave 7 makes
+  // k-block 0 (quads 0, 1), wave 3 k-block 1 (quad 2; its upper four slots, k = 48..63, are zero).  Both waves sit on
+  // SIMD 3, whose waves carry neither the epilogue nor the noise.
+  // Hazard: the image of tile p.tl was last written by the epilogue of tile-step (it + 3) - G in iteration it + 4 - G,
+  // at least one barrier ago when G >= 5; the buffer written here was last read (by layer 1) in the previous iteration.
+  auto split_x = [&](Pos p, int par) {
+    if constexpr (XONCE) {
+      if (w != 7 && w != 3) return;
+      const unsigned ln = here((unsigned)lane);
+      const f32x4* xb = reinterpret_cast<const f32x4*>(xs + p.tl * 768) + ln;
+      u32x4* dst = xpb + par * 256 + ln;
+      pv8 ph, pl;
+      if (w == 7) {
+        const f32x4 q0 = xb[0], q1 = xb[64];
+        if constexpr (F16 && PSTL_MIXSPLIT) split8_mix(q0, q1, 1.0f, ph, pl);
+        else split8(q0, q1, ph, pl);
+        dst[0] = __builtin_bit_cast(u32x4, ph);
+        dst[64] = __builtin_bit_cast(u32x4, pl);
+      } else {
+        const f32x4 q2 = xb[128], zero = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (F16 && PSTL_MIXSPLIT) split8_mix(q2, zero, 1.0f, ph, pl);
+        else split8(q2, zero, ph, pl);
+        dst[128] = __builtin_bit_cast(u32x4, ph);
+        dst[192] = __builtin_bit_cast(u32x4, pl);
       }
     }
   };
@@ -859,25 +952,40 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   const bool epi_wave = EPI_FIRST ? (w < NCW) : (w >= NW - NCW);  // wave-uniform
   f32x4 zreg = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.emit_out);
+  // Stamps are taken lazily: s_memtime into a scalar register pair, NO wait at the stamp (a wait for the scalar-memory
+  // counter would also drain the LDS reads in flight and stall exactly the prefetches being measured); one wait at the
+  // end of the iteration, then the eight values are written.
+  unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PSTL_STAMP(slot)                                                                        \
-  if (ABL == 7 && blockIdx.x == 7 && it >= 64 && it < 96) {                                     \
+  if (ABL == 7) {                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                          \
-    unsigned long long t_;                                                                      \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
-    if (lane == 0) dbg[((it - 64) * NW + w) * 8 + (slot)] = t_;                                 \
+    asm volatile("s_memtime %0" : "=s"(stamp_t[slot]));                                         \
     __builtin_amdgcn_sched_barrier(0);                                                          \
+  }
+#define PSTL_STAMP_FLUSH()                                                                      \
+  if (ABL == 7) {                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                         \
+                 : "+s"(stamp_t[0]), "+s"(stamp_t[1]), "+s"(stamp_t[2]), "+s"(stamp_t[3]),     \
+                   "+s"(stamp_t[4]), "+s"(stamp_t[5]), "+s"(stamp_t[6]), "+s"(stamp_t[7])      \
+                 :: "memory");                                                                  \
+    if (blockIdx.x == 7 && it >= 64 && it < 96 && lane == 0)                                    \
+      for (int k_ = 0; k_ < 8; ++k_) dbg[((it - 64) * NW + w) * 8 + k_] = stamp_t[k_];          \
   }
 
   layer1(p0, 0);
   if (total > 1) layer1(p1, 1);
+  split_x(p2, 0);      // pieces for the layer 1 woven into iteration 0
   __syncthreads();
   // BF, in-kernel noise: waves 4..6 draw it INSIDE their layer-2 MFMA stream (branch-free, one basic block) instead of in
   // a phase of their own in front of it
-  const bool woven_noise = BF && !REFINE && ABL == 0 && a.rng && !a.mu_only && w >= NW / 2 && w < NW / 2 + 3;
+  bool woven_noise = BF && !REFINE && (ABL == 0 || ABL == 7) && a.rng && !a.mu_only && w >= NW / 2 && w < NW / 2 + 3;
+  // (stamp build: its scalar stamps must not cross a branch the compiler takes for divergent)
+  if (ABL == 7) woven_noise = __builtin_amdgcn_readfirstlane((int)woven_noise) != 0;
   int hbuf = 0;  // it % 3
   for (int it = 0; it < total; ++it) {
     PSTL_STAMP(0)
     if (UT && w == kStager && it + 3 < total) stage_cst(p3, hbuf);
+    split_x(p3, (it + 1) & 1);      // pieces for the layer 1 woven into iteration it + 1
     if (NOISE_SPLIT && (ABL == 0 || ABL == 7)) {
       if (w >= NW / 2 && w < NW / 2 + NCW && !woven_noise) {
         const int nt = tid - NT / 2;
@@ -927,7 +1035,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       const f32x4* xb = reinterpret_cast<const f32x4*>(xs + p2.tl * 768) + lane;
       const u32x4* hbb = reinterpret_cast<const u32x4*>(h1 + hbuf * 4096) + lane;
       u32x4 ch = hbb[0], cl = hbb[64];
-      const f32x4 xa = xb[0], xc = xb[64], xe = xb[128];
+      f32x4 xa, xc, xe;
+      u32x4 xq0h, xq0l, xq1h, xq1l;
+      if constexpr (XONCE) {
+        const u32x4* xr = xpb + (it & 1) * 256 + lane;
+        xq0h = xr[0], xq0l = xr[64], xq1h = xr[128], xq1l = xr[192];
+      } else {
+        xa = xb[0], xc = xb[64], xe = xb[128];
+      }
       f32x4 a1[OT];   // starts from the scene/timestep constant part (fetched at k-block 1, used from k-block 2 on)
       pv8 x0h, x0l, x1h, x1l, hh, hl2;
       f32x4 zv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -948,8 +1063,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2h[ot][kb], bl, acc[ot]);
         }
-        if (kb == 0) split8(xa, xc, x0h, x0l);
-        if (kb == 1) split8(xe, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, x1h, x1l);
+        if constexpr (XONCE) {
+          if (kb == 0) x0h = __builtin_bit_cast(pv8, xq0h), x0l = __builtin_bit_cast(pv8, xq0l);
+          if (kb == 1) x1h = __builtin_bit_cast(pv8, xq1h), x1l = __builtin_bit_cast(pv8, xq1l);
+        } else {
+          if (kb == 0) split8(xa, xc, x0h, x0l);
+          if (kb == 1) split8(xe, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, x1h, x1l);
+        }
         if (kb == 2 || kb == 3) {
           const pv8 vh = kb == 2 ? x0h : x1h, vl = kb == 2 ? x0l : x1l;
 #pragma unroll
@@ -960,7 +1080,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vl, a1[ot]);
         }
         if (kb == 1) l1_const(p2, b1, a1);
-        if (kb == 5) split8(hidden(a1[0]), hidden(a1[OT - 1]), hh, hl2);   // layer 1's output, in the shadow of layer 2's MFMAs
+        if (kb == 5) split_hidden(a1[0], a1[OT - 1], hh, hl2);   // layer 1's output, in the shadow of layer 2's MFMAs
         if (NOISE && kb == 6) {   // this wave's share of the noise of tile-step it (rows past N and the quads 10, 11 are never read)
           const int nt = tid - NT / 2;
           const int i = s_hi - p0.n;
@@ -1002,12 +1122,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         } else {
           __builtin_amdgcn_sched_group_barrier(0x008, 3 * OT, 0);
         }
+        if (ABL == 7 && kb == 1) { PSTL_STAMP(6) }
+        if (ABL == 7 && kb == 4) { PSTL_STAMP(7) }
+        if (ABL == 7 && kb == 6) { PSTL_STAMP(2) }
       }
       // (no scheduling fence here: left free, the compiler starts layer 3's conversions under layer 2's last MFMAs, -4 %)
       PSTL_STAMP(3)
       // layer 3 of tile-step it; the ReLU + split of layer 1's output sits between its MFMAs
       pv8 bh, bl;
-      split8(hidden(acc[0]), hidden(acc[OT - 1]), bh, bl);
+      split_hidden(acc[0], acc[OT - 1], bh, bl);
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bh, acc3[j]);
 #pragma unroll
@@ -1065,6 +1188,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     if (UT && w == kStager) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged rows have landed
     if ((ABL < 3 || ABL == 5 || ABL == 7) && PSTL_EXP != 2) __syncthreads();
     PSTL_STAMP(5)
+    PSTL_STAMP_FLUSH()
     hbuf = hbuf == 2 ? 0 : hbuf + 1;
     pm1 = p0, p0 = p1, p1 = p2, p2 = p3, p3 = next_pos(p3);
   }
@@ -1162,20 +1286,20 @@ __global__ void k_fill_normal(long N, unsigned long long seed, long row_offset, 
 }
 
 // Tiles per workgroup: 12 (192 rows) when there is enough work for every CU; small batches (the closed-loop caller
-// runs 192 rows per simulation step, reference nusc_sim.py) are spread over more workgroups, down to the 4 tiles the
-// software pipeline needs, which cuts the latency of one reverse step from 12 to 4 tile-iterations.
+// runs 192 rows per simulation step, reference nusc_sim.py) are spread over more workgroups, down to the 5 tiles the
+// software pipeline needs, which cuts the latency of one reverse step from 12 to 5 tile-iterations.
 inline int tiles_per_group(long N) {
   const long n_tiles = (N + kTileRows - 1) / kTileRows;
   long g = n_tiles / 256;
-  if (g < 4) g = 4;
+  if (g < 5) g = 5;
   if (g > kG) g = kG;
   return (int)g;
 }
 
 template <int NW>
 size_t chain_lds_bytes() {
-  return (size_t)(kG * 768 + 3 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps + 3 * 512 + 2 * 192 * 4) *
-         sizeof(float);
+  return (size_t)(kG * 768 + 3 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps + 3 * 512 + 2 * 192 * 4 +
+                  2 * 4 * 64 * 4) * sizeof(float);
 }
 
 inline int cu_count() {

@@ -64,7 +64,7 @@ def lib():
             raise RuntimeError(
                 "libpstl_hip.so is missing (%s). Build it with `python -m pstl_diffusion_policy_amd.build` "
                 "(hipcc, gfx950). There is no CPU fallback for this path." % LIB_PATH)
-        L = ctypes.CDLL(os.environ.get("PSTL_HIP_LIB", LIB_PATH))   # PSTL_HIP_LIB: another build of the same library
+        L = ctypes.CDLL(LIB_PATH)    # always the in-tree build (tools/dbg/with_lib.py re-points LIB_PATH for experiments)
         L.pstl_version.restype = ctypes.c_int
         L.pstl_error_string.restype = ctypes.c_char_p
         L.pstl_error_string.argtypes = [ctypes.c_int]
