@@ -61,10 +61,12 @@ typedef struct pstl_cfg {
   int32_t steps;           /* --diffusion_steps                                           */
   int32_t n_shards;        /* --n_shards (merge_net max-pool groups)                      */
   int32_t flags;           /* PSTL_FLAG_*                                                 */
-  int32_t chain_waves;     /* MLP-chain kernel variant: 0 = default (denoiser on split-bf16
-                              MFMA, 3 bf16 products per fp32 product, fp32 accumulate;
-                              rect_net on fp32 MFMA), 16 = both on split-bf16, 8 or 4 =
-                              everything on fp32 MFMA with 8 / 4 waves per workgroup         */
+  int32_t chain_waves;     /* arithmetic of the MLP chains (policy_net, rect_net): 0 (= 16) = default: every fp32
+                              operand as two IEEE-half pieces (2^-23 per operand), three
+                              v_mfma_f32_16x16x32_f16 products per fp32 product, fp32 accumulate -- as close to
+                              the reference as an fp32 fmaf chain in another summation order; 8 or 4 = fp32
+                              MFMA (v_mfma_f32_16x16x4_f32) with 8 / 4 waves per workgroup; 32 = policy_net
+                              on bfloat16 pieces (2^-17 per operand), rect_net on fp32 MFMA                  */
   float tau;               /* --smoothing_factor                                          */
   float thres;             /* --stl_nn_thres                                              */
   float w_max, a_max;      /* --mul_w_max, --mul_a_max                                    */

@@ -446,37 +446,44 @@ class RectTrainer:
         except Exception:
             pass
 
-    def loss_and_grads(self, sb, feature, base_rect, w2, w3, init_controls, prev_scores, e7=None, stl_weight=1.0):
+    def loss_and_grads(self, sb, feature, base_rect, w2, w3, init_controls, prev_scores, e7=None, stl_weight=1.0, merge=None,
+                       clip_rect=False):
         """init_controls (N,40) physical units, prev_scores (N,) (both detached in the reference).  w2, w3: the live
         rect_net.2.weight / rect_net.4.weight tensors.  Returns (loss tensor, rect_controls, scores, {name: grad}).
         e7 = None: config 5, loss = mask_mean(relu(thres - score), valid), plain rect_net input.
         e7 = dict(stl_weight, diversity_weight[, diversity_scale, rect_reg_loss, detach]): the --diverse_loss objective
         loss_stl*stl_weight + loss_reg*rect_reg_loss + loss_diversity (reference nusc_train.py:442-467) with the
-        merge_net architecture; self.last holds the individual terms."""
+        merge_net architecture; self.last holds the individual terms.
+        merge: rect_net sees init + merge_net max-pool (the reference: --diverse_loss without --no_arch, nusc_model.py:185);
+        default = (e7 is not None).  clip_rect: --clip_rect (nusc_model.py:230-233); the interval head already keeps a
+        refined control inside its bounds, so the clip is the identity up to rounding and passes the gradient through."""
         dev = sb.device
         N = sb.N
-        merge = e7 is not None
+        objective_e7 = e7 is not None
+        merge = objective_e7 if merge is None else bool(merge)
         cfg = sb.cfg(2, 0 if merge else ffi.PSTL_FLAG_NO_MERGE, self.sm.chain_waves)
+        cfg_fwd = sb.cfg(2, (0 if merge else ffi.PSTL_FLAG_NO_MERGE) | (ffi.PSTL_FLAG_CLIP_RECT if clip_rect else 0),
+                         self.sm.chain_waves)
         h1 = torch.empty(N, ffi.HID, dtype=torch.float32, device=dev)
         h2 = torch.empty(N, ffi.HID, dtype=torch.float32, device=dev)
         pre = torch.empty(N, ffi.CTRL, dtype=torch.float32, device=dev)
         rect = torch.empty(N, ffi.CTRL, dtype=torch.float32, device=dev)
         pooled = torch.empty(sb.bs, 3, cfg.n_shards, ffi.CTRL, dtype=torch.float32, device=dev) if merge else None
-        ffi.check(self.L.pstl_refine_train_forward(ctypes.byref(cfg), ffi.ptr(self.sm.w.packed), ffi.ptr(base_rect),
+        ffi.check(self.L.pstl_refine_train_forward(ctypes.byref(cfg_fwd), ffi.ptr(self.sm.w.packed), ffi.ptr(base_rect),
                                                    ffi.ptr(sb.stlp), ffi.ptr(sb.hl), ffi.ptr(init_controls),
                                                    ffi.ptr(prev_scores), ffi.ptr(pooled), ffi.ptr(rect), ffi.ptr(h1),
                                                    ffi.ptr(h2), ffi.ptr(pre), ffi.stream()), "refine_train_forward")
         scores = self.sm.score(sb, rect.reshape(1, N, ffi.CTRL))["scores"][0]
         dscore = torch.empty(N, dtype=torch.float32, device=dev)
         parts = torch.empty(256, dtype=torch.float32, device=dev)
-        stl_w = float(e7["stl_weight"]) if merge else float(stl_weight)
+        stl_w = float(e7["stl_weight"]) if objective_e7 else float(stl_weight)
         ffi.check(self.L.pstl_loss_grad(ctypes.byref(cfg), ffi.ptr(scores), ffi.ptr(sb.valid),
                                         ctypes.c_float(sb.grad_scale * stl_w), ffi.ptr(dscore), ffi.ptr(parts), ffi.stream()),
                   "loss_grad")
         # loss = mean(relu(thres - score) * valid) / clip(mean(valid), 1e-2): grad_scale is exactly (1/clip)/N
         loss = parts.sum() * (sb.grad_scale * stl_w)
         dctrl_extra = None
-        if merge:
+        if objective_e7:
             groups = sb.bs * 3 * cfg.n_shards
             group_div = torch.empty(groups, dtype=torch.float32, device=dev)
             reg_out = torch.empty(2, dtype=torch.float32, device=dev)
@@ -513,7 +520,7 @@ class RectTrainer:
         return loss, rect, scores, g
 
     def train_step(self, sb, params, optimizer, steps, x_T=None, noise=None, seed=None, multi_cands=5, coeffs=None,
-                   group=None, e7=None, stl_weight=1.0):
+                   group=None, e7=None, stl_weight=1.0, merge=None, clip_rect=False):
         """One optimisation step of config 5 on one batch shard: sampling under no-grad (rollout, candidate scoring and
         selection), RefineNet forward/backward under the STL loss, gradient all-reduce over the ranks (the loss is a
         mean over the GLOBAL batch, so per-rank gradients simply add), optimizer.step() on the caller's parameters.
@@ -533,7 +540,7 @@ class RectTrainer:
                       rect_reg_loss=float(e7.get("rect_reg_loss", 0.0)) / world)
         loss, rect, scores, g = self.loss_and_grads(sb, feature, base_r, params["rect_net.2.weight"],
                                                     params["rect_net.4.weight"], r["sel_controls"], r["sel_scores"], e7=e7,
-                                                    stl_weight=stl_weight)
+                                                    stl_weight=stl_weight, merge=merge, clip_rect=clip_rect)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             flat = torch.cat([g[k].reshape(-1) for k in self.NAMES] + [loss.reshape(1)])
             dist.all_reduce(flat, group=group)          # 145 704 gradients + the loss: one 583 KB all-reduce

@@ -120,8 +120,10 @@ def main(argv=None):
             path = os.path.join("exps", path, "models", "model_last.ckpt")
         if os.path.isfile(path):
             sd.update(torch.load(path, map_location="cpu"))
-        else:
+        elif args.allow_random_init:
             print("checkpoint %s not found: random-init weights (seed %d)" % (path, args.seed))
+        else:
+            raise SystemExit("checkpoint %s not found (pass --allow_random_init to run with random-init weights)" % path)
     recs = closed_loop(sd, n_sim_steps=max(args.n_trials, 1) if args.n_trials < 100 else 20, K=args.n_neighbors,
                        S=args.n_randoms, diffusion_steps=args.diffusion_steps, multi_cands=args.multi_cands or 5,
                        guidance=args.guidance, guidance_before=args.guidance_before, guidance_lr=args.guidance_lr,

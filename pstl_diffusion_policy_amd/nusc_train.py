@@ -657,12 +657,16 @@ def run_training(data_loader, net, coeffs, args):
                                                     "rightlane_wpts", "curr_id", "left_id", "right_id", "gt_high_level",
                                                     "pre_stlp") if k in batch_cuda}
             new_batch["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
-            new_batch = augment_batch_data(new_batch, batch_cuda["stlp_modes"][:, 0], args)
+            # STL parameters of the ground-truth mode, as the sampling harness and the traj-opt loop get them (reference
+            # :1279): from the file format's own keys, not from anything only the synthetic generator writes
+            gt_stlp = infer_gt_stlp(new_batch, batch_cuda["ego_traj"][..., :4], args)
+            new_batch = augment_batch_data(new_batch, gt_stlp, args)
             sb = new_batch["_pstl"]
             tr = RectTrainer(Sampler(net.packed(), net.hparams()))     # packed() re-packs after the optimiser moved weights
             step += 1
             loss, scores = tr.train_step(sb, params, optimizer, args.diffusion_steps, seed=args.seed * 100003 + step,
-                                         multi_cands=args.multi_cands or 1, coeffs=coeffs, e7=e7, stl_weight=args.stl_weight)
+                                         multi_cands=args.multi_cands or 1, coeffs=coeffs, e7=e7, stl_weight=args.stl_weight,
+                                         merge=bool(args.diverse_loss and not args.no_arch), clip_rect=bool(args.clip_rect))
             counts, _ = tr.sm.metrics(sb, scores)
             acc, _ = acc_from_counts(counts)
             md.update("loss", float(loss))
@@ -685,6 +689,7 @@ def generate_parser(argv=None):
     add("--epochs", type=int, default=500)
     add("--test", action="store_true", default=False)
     add("--net_pretrained_path", "-P", type=str, default=None)
+    add("--allow_random_init", action="store_true", default=False)   # not a reference flag: -P may name a missing file
     add("--num_workers", type=int, default=8)
     add("--batch_size", "-b", type=int, default=128)
     add("--lr", type=float, default=3e-4)
@@ -871,8 +876,10 @@ def main(argv=None):
             path = os.path.join("exps", path, "models", "model_last.ckpt")
         if os.path.isfile(path):
             net.load_state_dict(torch.load(path, map_location="cuda"), strict=(not args.rect_head))
-        else:
+        elif args.allow_random_init:
             print("checkpoint %s not found: running with random-init weights (seed %d)" % (path, args.seed))
+        else:   # the reference fails in torch.load here; numbers from an untrained net must not pass for a run of -P
+            raise SystemExit("checkpoint %s not found (pass --allow_random_init to run with random-init weights)" % path)
     coeffs = get_diffusion_coeffs(args)
     if not args.run_sampling_test:
         if args.test:

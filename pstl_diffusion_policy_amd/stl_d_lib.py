@@ -26,29 +26,6 @@ def clip(x, a, b):
     return max(min(x, b), a)
 
 
-# the four helper functions of the reference module (stl_d_lib.py:6-26): thin torch expressions, kept for callers
-def softmax(x, tau, d, dim=1):
-    if x.shape[1] == 0:
-        return torch.ones(x.shape[0], 1).to(x.device) * -float("inf")
-    if d is not None and d.get("hard", False):
-        return torch.max(x, dim=dim, keepdim=True)[0]
-    return torch.logsumexp(x * tau, dim=dim, keepdim=True) / tau
-
-
-def softmin(x, tau, d, dim=1):
-    if x.shape[1] == 0:
-        return torch.ones(x.shape[0], 1).to(x.device) * -float("inf")
-    return -softmax(-x, tau, d, dim)
-
-
-def softmax_pairs(x, y, tau, d):
-    return softmax(torch.stack([x, y], dim=1), tau, d).squeeze(1)
-
-
-def softmin_pairs(x, y, tau, d):
-    return -softmax_pairs(-x, -y, tau, d)
-
-
 # ---------------------------------------------------------------------------------------------------------------
 # program = flattened formula
 # ---------------------------------------------------------------------------------------------------------------
@@ -291,3 +268,40 @@ class Until(STLFormula):
             self.eval = UntimedUntil(lhs, rhs)
         else:
             self.eval = And(Eventually(ts, te, rhs), Always(0, ts, UntimedUntil(lhs, rhs)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the four module-level helpers of the reference (stl_d_lib.py:6-26): the same kernel, as one-node programs
+# ---------------------------------------------------------------------------------------------------------------
+_ROW_MAX, _PAIR_MAX = {}, None
+
+
+def softmax(x, tau, d, dim=1):
+    """Soft (d['hard']: hard) maximum of x (n, m) over its second axis -> (n, 1): an Eventually node spanning the whole
+    row, read at t = 0.  An empty row gives -inf, as in the reference."""
+    if x.dim() != 2 or dim != 1:
+        raise NotImplementedError("softmax is evaluated by the STL kernel for (n, m) inputs over dim 1")
+    m = x.shape[1]
+    if m == 0:
+        return torch.ones(x.shape[0], 1).to(x.device) * -float("inf")
+    if m not in _ROW_MAX:
+        _ROW_MAX[m] = Eventually(0, m, AP(lambda s: s, comment="x"))
+    return _evaluate(_ROW_MAX[m], x, tau, d)[:, :1]
+
+
+def softmin(x, tau, d, dim=1):
+    if x.shape[1] == 0:
+        return torch.ones(x.shape[0], 1).to(x.device) * -float("inf")
+    return -softmax(-x, tau, d, dim)
+
+
+def softmax_pairs(x, y, tau, d):
+    """Elementwise soft maximum of two (n, T) signals: an Or node."""
+    global _PAIR_MAX
+    if _PAIR_MAX is None:
+        _PAIR_MAX = Or(AP(lambda s: s[0], comment="x"), AP(lambda s: s[1], comment="y"))
+    return _evaluate(_PAIR_MAX, (x, y), tau, d)
+
+
+def softmin_pairs(x, y, tau, d):
+    return -softmax_pairs(-x, -y, tau, d)

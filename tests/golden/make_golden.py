@@ -254,7 +254,8 @@ def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None):
                 "--diverse_loss", "--multi_cands", "5", "--diversity_weight", str(e7["diversity_weight"]),
                 "--diversity_scale", str(e7.get("diversity_scale", 1.0)), "--rect_reg_loss", str(e7.get("rect_reg_loss", 0.0)),
                 "--diffusion_steps", str(steps), "--n_randoms", str(S), "--sampling_size", str(S), "--n_neighbors", str(K),
-                "--lr", str(lr)] + (["--diverse_detach"] if e7.get("detach") else [])
+                "--lr", str(lr)] + (["--diverse_detach"] if e7.get("detach") else []) + (
+                    ["--no_arch"] if e7.get("no_arch") else []) + (["--clip_rect"] if e7.get("clip_rect") else [])
     args = ref_harness.parse_reference_args(argv)
     args.measure_diversity = False        # CPU-side metric (scipy hull), not part of the loss
     net = ref.nusc_model.Net(args)
@@ -317,7 +318,8 @@ def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None):
         out["loss_diversity"] = np.float32(rd["loss_diversity"].item())
         out["loss_reg"] = np.float32(rd["loss_reg"].item())
         out["meta_e7"] = np.array([e7["stl_weight"], e7["diversity_weight"], e7.get("diversity_scale", 1.0),
-                                   e7.get("rect_reg_loss", 0.0), 1.0 if e7.get("detach") else 0.0, args.n_shards],
+                                   e7.get("rect_reg_loss", 0.0), 1.0 if e7.get("detach") else 0.0, args.n_shards,
+                                   1.0 if e7.get("no_arch") else 0.0, 1.0 if e7.get("clip_rect") else 0.0],
                                   dtype=np.float64)
     for k in grads:
         out["grad_rect_net." + k] = np_(grads[k])
@@ -364,6 +366,9 @@ def main_train_e7(ref=None, sd=None):
                e7=dict(stl_weight=1.0, diversity_weight=0.5, diversity_scale=2.0, rect_reg_loss=0.3))
     train_case(ref, sd, "train_e7_step_c", bs=3, S=8, K=3, steps=8, seed=35,
                e7=dict(stl_weight=0.5, diversity_weight=1.0, detach=True))
+    # --diverse_loss --no_arch (the DPP objective through the PLAIN rect_net input, nusc_model.py:185) and --clip_rect
+    train_case(ref, sd, "train_e7_noarch", bs=3, S=8, K=3, steps=8, seed=36,
+               e7=dict(stl_weight=1.0, diversity_weight=0.5, no_arch=True, clip_rect=True))
 
 
 if __name__ == "__main__" and "--train-e7" in sys.argv:

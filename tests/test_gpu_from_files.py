@@ -49,7 +49,8 @@ def test_refinenet_training_from_files_updates_the_checkpoint(tmp_path, capsys):
             "--lr", "1e-3", "--print_freq", "1"]
     nd.write_synthetic_experiment(root, 12, nt.generate_parser(base), seed=6)
     sd0 = init_state_dict(1007)
-    for extra in (["--diverse_loss", "--stl_weight", "0.0"], ["--stl_weight", "1.0", "--diversity_weight", "0.0"]):
+    for extra in (["--diverse_loss", "--stl_weight", "0.0"], ["--stl_weight", "1.0", "--diversity_weight", "0.0"],
+                  ["--diverse_loss", "--no_arch", "--clip_rect", "--stl_weight", "1.0"]):
         nd.save_checkpoint(sd0, os.path.join(root, "models"))
         md = nt.main(base + extra + ["-P", nd.smart_path(root)])
         assert np.isfinite(md("loss"))
@@ -57,3 +58,8 @@ def test_refinenet_training_from_files_updates_the_checkpoint(tmp_path, capsys):
         moved = {k for k in sd1 if k in sd0 and not torch.equal(sd1[k], sd0[k].cpu())}
         assert moved and all(k.startswith("rect_net.") for k in moved), moved
     assert "epoch 001" in capsys.readouterr().out
+    # a -P that names no file is an error (the reference fails in torch.load), unless random init is asked for
+    with pytest.raises(SystemExit):
+        nt.main(base + ["--stl_weight", "1.0", "-P", str(tmp_path / "no_such.ckpt")])
+    md = nt.main(base + ["--stl_weight", "1.0", "--epochs", "1", "--allow_random_init", "-P", str(tmp_path / "no_such.ckpt")])
+    assert np.isfinite(md("loss"))

@@ -72,6 +72,32 @@ def test_listand_full_returns_children(dev):
     np.testing.assert_allclose(v.cpu().numpy(), G["listand_full_v"], rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("hard", [False, True])
+def test_module_level_soft_helpers_run_on_the_kernel(dev, hard):
+    """softmax / softmin / softmax_pairs / softmin_pairs of the reference module (stl_d_lib.py:6-26): evaluated by the STL
+    program kernel, values and gradients against the reference's torch expressions."""
+    from pstl_diffusion_policy_amd import stl_d_lib as sl
+    g = torch.Generator().manual_seed(3)
+    tau, d = 7.0, {"hard": hard}
+    x = (torch.randn(37, 11, generator=g) * 0.5).to(dev).requires_grad_()
+    y = (torch.randn(37, 11, generator=g) * 0.5).to(dev).requires_grad_()
+
+    def ref_max(v, dim=1):
+        return torch.max(v, dim=dim, keepdim=True)[0] if hard else torch.logsumexp(v * tau, dim=dim, keepdim=True) / tau
+
+    for mine, ref in [(sl.softmax(x, tau, d), ref_max(x)), (sl.softmin(x, tau, d), -ref_max(-x)),
+                      (sl.softmax_pairs(x, y, tau, d), ref_max(torch.stack([x, y], dim=1)).squeeze(1)),
+                      (sl.softmin_pairs(x, y, tau, d), -ref_max(torch.stack([-x, -y], dim=1)).squeeze(1))]:
+        assert mine.shape == ref.shape
+        np.testing.assert_allclose(mine.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=0, atol=2e-6)
+        gm = torch.autograd.grad(mine.sum(), [x, y], allow_unused=True, retain_graph=True)
+        gr = torch.autograd.grad(ref.sum(), [x, y], allow_unused=True, retain_graph=True)
+        for a, b in zip(gm, gr):
+            if b is not None:
+                np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert torch.isinf(sl.softmax(x[:, :0], tau, d)).all() and sl.softmax(x[:, :0], tau, d).shape == (37, 1)
+
+
 def test_cpu_tensors_are_rejected(dev):
     from pstl_diffusion_policy_amd import stl_d_lib
     f = stl_specs.build(stl_specs.SPECS["alw_ap"], stl_d_lib)

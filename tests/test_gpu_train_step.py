@@ -105,20 +105,21 @@ def test_train_step_reduces_the_loss_and_repacks_weights():
     assert all(np.isfinite(losses))
 
 
-@pytest.mark.parametrize("name", ["train_e7_step", "train_e7_step_b", "train_e7_step_c"])
+@pytest.mark.parametrize("name", ["train_e7_step", "train_e7_step_b", "train_e7_step_c", "train_e7_noarch"])
 def test_e7_diversity_train_step_matches_reference(name):
-    """e7 training objective (--diverse_loss): DPP diversity loss + merge_net architecture, gradients of rect_net."""
+    """e7 training objective (--diverse_loss): DPP diversity loss + merge_net architecture, gradients of rect_net;
+    train_e7_noarch: the same objective with --no_arch (plain rect_net input, nusc_model.py:185) and --clip_rect."""
     dev = torch.device("cuda:0")
     d = load_golden(name)
     lr = float(d["meta_f"][0])
-    stl_w, div_w, scale, reg_w, detach, n_shards = [float(v) for v in d["meta_e7"]]
+    stl_w, div_w, scale, reg_w, detach, n_shards, no_arch, clip_rect = [float(v) for v in d["meta_e7"]]
     e7 = dict(stl_weight=stl_w, diversity_weight=div_w, diversity_scale=scale, rect_reg_loss=reg_w, detach=bool(detach))
     sm, sb, sd, tr = _setup(d, dev)
     feature, _, base_r = sm.encode(sb)
     init = torch.from_numpy(d["sel_controls"]).reshape(sb.N, 40).to(dev)
     prev = torch.from_numpy(d["sel_scores"]).to(dev)
     loss, rect, scores, g = tr.loss_and_grads(sb, feature, base_r, sd["rect_net.2.weight"], sd["rect_net.4.weight"], init,
-                                              prev, e7=e7)
+                                              prev, e7=e7, merge=not no_arch, clip_rect=bool(clip_rect))
     np.testing.assert_allclose(rect.reshape(sb.N, 20, 2).cpu().numpy(), d["rect_controls"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(scores.cpu().numpy(), d["scores"], rtol=1e-4, atol=2e-3)
     np.testing.assert_allclose(float(tr.last["loss_diversity"]), float(d["loss_diversity"]), rtol=2e-4, atol=1e-5)

@@ -23,17 +23,18 @@ def test_rect_train_step_matches_reference(name):
         np.testing.assert_allclose(out["after"][k].numpy(), d["after_" + k], rtol=0, atol=2e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["train_e7_step", "train_e7_step_b", "train_e7_step_c"])
+@pytest.mark.parametrize("name", ["train_e7_step", "train_e7_step_b", "train_e7_step_c", "train_e7_noarch"])
 def test_e7_diversity_train_step_matches_reference(name):
-    """e7 training objective (--diverse_loss): DPP diversity + merge_net architecture (reference nusc_train.py:442-467)."""
+    """e7 training objective (--diverse_loss): DPP diversity + merge_net architecture (reference nusc_train.py:442-467);
+    train_e7_noarch: the same objective with --no_arch (plain rect_net input) and --clip_rect."""
     d = load_golden(name)
     bs, S, K, steps, seed, mc = [int(v) for v in d["meta"]]
     lr = float(d["meta_f"][0])
-    stl_w, div_w, scale, reg_w, detach, n_shards = [float(v) for v in d["meta_e7"]]
+    stl_w, div_w, scale, reg_w, detach, n_shards, no_arch, clip_rect = [float(v) for v in d["meta_e7"]]
     e7 = dict(stl_weight=stl_w, diversity_weight=div_w, diversity_scale=scale, rect_reg_loss=reg_w, detach=bool(detach))
     sd = {k: v for k, v in golden_weights().items()}
     out = orc.rect_train_step(sd, scene_from_golden(d), S, default_hparams(), d["sel_controls"], d["sel_scores"], lr,
-                              n_shards=int(n_shards), e7=e7)
+                              n_shards=int(n_shards), e7=e7, merge=not no_arch, clip_rect=bool(clip_rect))
     np.testing.assert_allclose(out["rect_controls"].numpy(), d["rect_controls"], rtol=0, atol=5e-6)
     np.testing.assert_allclose(float(out["loss_diversity"]), float(d["loss_diversity"]), rtol=2e-5)
     np.testing.assert_allclose(float(out["loss_reg"]), float(d["loss_reg"]), rtol=2e-5)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # README command lines of the reference through the CLI mirror (synthetic scenes), one line of output each
-base="python -m pstl_diffusion_policy_amd.nusc_train --batch_size 8 --n_trials 1 --diffusion_steps 20 --n_neighbors 3"
+base="python -m pstl_diffusion_policy_amd.nusc_train --batch_size 8 --n_trials 1 --diffusion_steps 20 --n_neighbors 3 --allow_random_init"
 run() { echo "== $*"; $base "$@" 2>&1 | grep -E "^###|Error|error|Traceback|trajopt batch|epoch" | tail -2; }
 run -e e5_ddpm --diffusion --stl_weight 0.0 --load_stlp --flex --run_sampling_test --test -P e5_ddpm --skip_nusc_load --viz_correct
 run -e e5_ddpm --diffusion --stl_weight 0.0 --load_stlp --flex --run_sampling_test --test -P e5_ddpm --skip_nusc_load --viz_correct --guidance
