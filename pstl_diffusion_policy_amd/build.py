@@ -17,8 +17,7 @@ UNITS = [("stl_kernels.hip", ["-ffp-contract=off", "-Xarch_device", "-mllvm=-mis
          # closely (multi-step launch -1.4 %, single-step -1.9 %, nothing else in the unit changes)
          ("mlp_kernels.hip", ["-Xarch_device", "-mllvm=-misched-prera-direction=topdown"]), ("train_kernels.hip", []),
          ("diversity_kernels.hip", ["-ffp-contract=off"]), ("stl_program.hip", ["-ffp-contract=off"])]
-# rocBLAS only serves the plain fp32 GEMMs of the RefineNet backward pass (train_kernels.hip)
-LINK_LIBS = ["-lrocblas"]
+LINK_LIBS = []   # no vendor BLAS: every kernel of the library is in csrc/
 
 
 def _newer(target, deps):

@@ -6,9 +6,10 @@
 //   here: interval/tanh head backward (fused elementwise kernel), ReLU masks + column sums (fused, deterministic
 //   two-stage reduction), per-scene reduction for the 224 scene-constant input columns, the three weight-gradient
 //   contractions over the rows (dW3 = dO^T h2, dW2 = dH2^T h1, dW1x = dH1^T [hl|stlp|init]) as a hand-written split-K
-//   fp32-MFMA kernel (k_wgrad: rocBLAS ran these K = 786 432, tiny-M-by-N shapes at 22 TFLOP/s, 4.7 ms each), and
-//   three PLAIN fp32 GEMMs left to rocBLAS (dH2 = dO W3, dH1 = dH2 W2, dW1f = S^T feature).
-#include <rocblas/rocblas.h>
+//   fp32-MFMA kernel (k_wgrad: rocBLAS ran these K = 786 432, tiny-M-by-N shapes at 22 TFLOP/s, 4.7 ms each), and the two
+//   activation-gradient products dH2 = (dO W3) * [h2 > 0], dH1 = (dH2 W2) * [h1 > 0] as k_dgrad: the transposed weights
+//   register-stationary as split-bf16 MFMA A operands (the layout of the forward chain), the gradient rows staged
+//   through LDS as B operands, ReLU mask and bias-gradient column sums fused into the epilogue.  No vendor BLAS.
 
 #include "pstl_common.hpp"
 
@@ -20,7 +21,7 @@ constexpr int kX47 = 47;   // hl 1 | stlp 6 | init 40  = input columns 224..270 
 constexpr int kIn = kFeat + kX47;  // 271
 
 struct TrainCtx {
-  rocblas_handle h;
+  int unused;   // (the context once held a rocBLAS handle; the entry points keep their signatures)
 };
 
 // dO = dcontrols * [prev_score < 0] * d interval / d raw * (1 - raw^2), raw = tanh(pre)   (nusc_model.py:212-229)
@@ -49,46 +50,6 @@ __global__ void k_head_bwd(long N, float w_max, float a_max, const float* dctrl,
   x47[row * kX47 + 7 + f] = fused;
   if (f == 0) x47[row * kX47] = hl[row];
   if (f < 6) x47[row * kX47 + 1 + f] = stlp[row * 6 + f];
-}
-
-// G *= [H > 0] in place and partial[b][c] = sum over the block's rows of G[.][c], for the 256-column activations, 16 bytes
-// per lane: a block is 4 row-lanes x 64 column quads, four rows per
-// row-lane in flight; the four row-lanes are added in a fixed order (deterministic, like everything else here).
-__global__ __launch_bounds__(256) void k_mask_colsum256(long N, float* G, const float* H, float* partial) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
-  rows_per_block = (rows_per_block + 15) / 16 * 16;
-  const long r0 = blockIdx.x * rows_per_block, r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
-  f4 acc = f4{0.0f, 0.0f, 0.0f, 0.0f};
-  for (long r = r0 + rl; r < r1; r += 16) {
-    f4 g[4], h[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long rr = r + 4 * u;
-      if (rr < r1) {
-        g[u] = *reinterpret_cast<const f4*>(G + rr * kHid + 4 * q);
-        h[u] = *reinterpret_cast<const f4*>(H + rr * kHid + 4 * q);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long rr = r + 4 * u;
-      if (rr < r1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g[u][i] = h[u][i] > 0.0f ? g[u][i] : 0.0f;
-        *reinterpret_cast<f4*>(G + rr * kHid + 4 * q) = g[u];
-        acc += g[u];
-      }
-    }
-  }
-  __shared__ f4 red[4][64];
-  red[rl][q] = acc;
-  __syncthreads();
-  if (rl == 0) {
-    const f4 t = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
-    *reinterpret_cast<f4*>(partial + (long)blockIdx.x * kHid + 4 * q) = t;
-  }
 }
 
 // Column sums of the 40-column head gradient (no mask): 25 row-lanes x 10 column quads per block, four rows per row-lane
@@ -330,17 +291,8 @@ __global__ void k_reg_grad(long N, float weight, const float* rect, const float*
 }
 
 // row-major C(m x n) = op(A) op(B) through column-major rocBLAS
-int gemm_rm(rocblas_handle h, bool ta, bool tb, int m, int n, long k, const float* A, int lda, const float* B, int ldb,
-            float* C, int ldc) {
-  const float one = 1.0f, zero = 0.0f;
-  const rocblas_status st =
-      rocblas_sgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
-                    ta ? rocblas_operation_transpose : rocblas_operation_none, n, m, (rocblas_int)k, &one, B, ldb, A, lda,
-                    &zero, C, ldc);
-  return st == rocblas_status_success ? PSTL_OK : PSTL_ERR_LAUNCH;
-}
-
 constexpr int kRedBlocks = 512;
+constexpr long kWtPackWords = 16L * 8 * 8 * 64;   // split-bf16 A operands of one transposed 256 x 256 weight matrix (k_dgrad)
 
 // ---- weight gradient: D[f][c] = sum over rows of G[row][f] * H[row][c]  (split-K over workgroups) -------------------
 // v_mfma_f32_16x16x4_f32 with the ROW index as the contraction: A[i = f][k = row], B[k = row][j = c], 16 rows (4 k-steps)
@@ -482,6 +434,163 @@ int wgrad(long N, const float* G, int ldg, int fvalid, const float* H, int ldh, 
   return launch_status();
 }
 
+
+// ---- activation gradients: out[row][f] = [H[row][f] > 0] * sum_k G[row][k] * W[k][f],  f < 256 -----------------------
+// (dH2 = dO W3 with K = 40, dH1 = dH2 W2 with K = 256; W is the layer's (out = K, in = 256) weight matrix, so the product
+// runs over the layer's OUTPUT index.)  Same scheme as the forward chain kernel (mlp_kernels.hip): eight waves, wave w
+// owns output features [32 w, 32 w + 32) and keeps its slice of W^T in registers as MFMA A operands for the whole
+// launch; a tile of 16 gradient rows is the B operand.  Arithmetic: every fp32 operand as two bfloat16 pieces
+// (hi = bf16(v), lo = bf16(v - hi)), three v_mfma_f32_16x16x32_bf16 products per fp32 product, fp32 accumulation --
+// operands good to 2^-17, far inside the 5e-3 the gradients are held to, and bfloat16 keeps fp32's exponent range
+// (gradients here are ~1e-7: half pieces would underflow).  The tile's pieces are made once (each thread splits the
+// 16-byte quads it loaded) and laid out in LDS in B-operand order, double buffered: the loads of tile t + 1 are in
+// flight during the MFMAs of tile t.  Epilogue per lane: four consecutive features of one row -- the ReLU mask from H
+// (16-byte load), the 16-byte store, and a running column sum whose 16 row-lanes are added in a fixed order at the end
+// (partial[block][f]; k_colsum_final adds the blocks: deterministic).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned bf16_pair(float a, float b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+}
+
+// A operands of W^T: word m of lane l for block (T, kb) at dst[(((T*nkb + kb)*2 + (m>>2))*64 + l)*4 + (m&3)], m < 4 the hi
+// pieces of slots 2m, 2m+1, m >= 4 the lo pieces; slot s of lane group g = l>>4 is k = 32 kb + 16 (s>>2) + 4 g + (s&3),
+// the lane's feature is f = 16 T + (l&15); element = W[k][f] (k < kvalid, else 0)
+__global__ void k_pack_wt_bf(const float* W, int ld, int kvalid, int nkb, unsigned* dst) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 16L * nkb * 512) return;
+  const int lane = (int)((i >> 2) & 63), m = (int)((i & 3) | (((i >> 8) & 1) << 2));
+  const long tk = i >> 9;
+  const int kb = (int)(tk % nkb), T = (int)(tk / nkb);
+  const int f = 16 * T + (lane & 15), g = lane >> 4;
+  float v[2];
+  for (int e = 0; e < 2; ++e) {
+    const int sl = 2 * (m & 3) + e;
+    const int k = 32 * kb + 16 * (sl >> 2) + 4 * g + (sl & 3);
+    const float wv = k < kvalid ? W[(long)k * ld + f] : 0.0f;
+    const float hi = (float)(__bf16)wv;
+    v[e] = m < 4 ? hi : wv - hi;
+  }
+  dst[i] = bf16_pair(v[0], v[1]);
+}
+
+template <int NKB>
+__global__ __launch_bounds__(512, 2) void k_dgrad(long N, const float* G, int ldg, int kvalid, const unsigned* Wp,
+                                                  const float* H, float* out, float* partial) {
+  static_assert(NKB <= 8, "one staging wave per k-block");
+  __shared__ __attribute__((aligned(16))) u32x4 pieces[2][NKB * 2 * 64];   // [buffer][kb][hi | lo][lane]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  bf16x8 wh[2][NKB], wl[2][NKB];
+  {
+    const u32x4* q4 = reinterpret_cast<const u32x4*>(Wp);
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const long blk = (long)(2 * w + ot) * NKB + kb;
+        wh[ot][kb] = __builtin_bit_cast(bf16x8, q4[(blk * 2 + 0) * 64 + lane]);
+        wl[ot][kb] = __builtin_bit_cast(bf16x8, q4[(blk * 2 + 1) * 64 + lane]);
+      }
+  }
+  const long n_tiles = (N + 15) / 16;
+  // Staging: wave kb (< NKB) makes k-block kb of the tile; its lane (g, c) loads the two 16-byte quads of row c that
+  // are the lane's own B operand -- columns 32 kb + 4 g .. +3 (slots 0..3) and 32 kb + 16 + 4 g .. +3 (slots 4..7) --
+  // and writes its hi and lo pieces as two lane-linear 16-byte LDS stores (conflict-free).
+  f32x4 rq[2];
+  auto load_tile = [&](long t) {
+    rq[0] = rq[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (w < NKB) {
+      const long row = t * 16 + c;
+      if (row < N) {
+        const int k0 = 32 * w + 4 * g;
+        if (k0 < kvalid) rq[0] = *reinterpret_cast<const f32x4*>(G + row * ldg + k0);
+        if (k0 + 16 < kvalid) rq[1] = *reinterpret_cast<const f32x4*>(G + row * ldg + k0 + 16);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    if (w < NKB) {
+      float hi[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hi[q] = (float)(__bf16)rq[0][q], hi[4 + q] = (float)(__bf16)rq[1][q];
+      const u32x4 ph = u32x4{bf16_pair(hi[0], hi[1]), bf16_pair(hi[2], hi[3]), bf16_pair(hi[4], hi[5]), bf16_pair(hi[6], hi[7])};
+      const u32x4 pl = u32x4{bf16_pair(rq[0][0] - hi[0], rq[0][1] - hi[1]), bf16_pair(rq[0][2] - hi[2], rq[0][3] - hi[3]),
+                             bf16_pair(rq[1][0] - hi[4], rq[1][1] - hi[5]), bf16_pair(rq[1][2] - hi[6], rq[1][3] - hi[7])};
+      pieces[buf][(2 * w) * 64 + lane] = ph;
+      pieces[buf][(2 * w + 1) * 64 + lane] = pl;
+    }
+  };
+  f32x4 cs[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+  long t = blockIdx.x;
+  if (t < n_tiles) {
+    load_tile(t);
+    store_tile(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; t < n_tiles; t += gridDim.x) {
+    const long tn = t + gridDim.x;
+    if (tn < n_tiles) load_tile(tn);               // in flight during the MFMAs below
+    // this lane's mask source: features 16 (2w + ot) + 4g .. +3 of row t*16 + c
+    const long row = t * 16 + c;
+    f32x4 hm[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+      hm[ot] = row < N ? *reinterpret_cast<const f32x4*>(H + row * kHid + 16 * (2 * w + ot) + 4 * g) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+    const u32x4* pb = &pieces[buf][lane];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, pb[(2 * kb) * 64]), bl = __builtin_bit_cast(bf16x8, pb[(2 * kb + 1) * 64]);
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ot][kb], bh, acc[ot], 0, 0, 0);
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ot][kb], bh, acc[ot], 0, 0, 0);
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ot][kb], bl, acc[ot], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = hm[ot][r] > 0.0f ? acc[ot][r] : 0.0f;
+      if (row < N) {
+        *reinterpret_cast<f32x4*>(out + row * kHid + 16 * (2 * w + ot) + 4 * g) = o;
+        cs[ot] += o;
+      }
+    }
+    if (tn < n_tiles) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // column sums of this workgroup: the 16 row-lanes of a feature quad are added in a fixed (butterfly) order
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = cs[ot][r];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+      cs[ot][r] = v;
+    }
+    if (c == 0) *reinterpret_cast<f32x4*>(partial + (long)blockIdx.x * kHid + 16 * (2 * w + ot) + 4 * g) = cs[ot];
+  }
+}
+
+template <int NKB>
+int dgrad(long N, const float* G, int ldg, int kvalid, const float* W, unsigned* wpack, const float* H, float* out,
+          float* partial, float* colsum, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_wt_bf, dim3(16 * NKB * 2), dim3(256), 0, st, W, kHid, kvalid, NKB, wpack);
+  const long n_tiles = (N + 15) / 16;
+  const int nb = (int)(n_tiles < 256 ? n_tiles : 256);
+  hipLaunchKernelGGL(k_dgrad<NKB>, dim3(nb), dim3(512), 0, st, N, G, ldg, kvalid, (const unsigned*)wpack, H, out, partial);
+  hipLaunchKernelGGL(k_colsum_final, dim3(kHid), dim3(64), 0, st, nb, kHid, partial, colsum);
+  return launch_status();
+}
+
 }  // namespace
 }  // namespace pstl
 
@@ -489,20 +598,13 @@ using namespace pstl;
 
 extern "C" int pstl_train_create(void** ctx) {
   if (!ctx) return PSTL_ERR_ARG;
-  TrainCtx* c = new TrainCtx();
-  if (rocblas_create_handle(&c->h) != rocblas_status_success) {
-    delete c;
-    return PSTL_ERR_LAUNCH;
-  }
-  *ctx = c;
+  *ctx = new TrainCtx();
   return PSTL_OK;
 }
 
 extern "C" int pstl_train_destroy(void* ctx) {
   if (!ctx) return PSTL_ERR_ARG;
-  TrainCtx* c = static_cast<TrainCtx*>(ctx);
-  rocblas_destroy_handle(c->h);
-  delete c;
+  delete static_cast<TrainCtx*>(ctx);
   return PSTL_OK;
 }
 
@@ -510,7 +612,7 @@ extern "C" size_t pstl_train_work_floats(const pstl_cfg* cfg) {
   if (check_cfg(cfg)) return 0;
   const long N = n_rows(cfg);
   return (size_t)(N * (kCtrl + kX47 + 2L * kHid) + (long)cfg->bs * kHid + (long)kRedBlocks * kHid +
-                  (long)kRedBlocks * kHid * kHid + 64);
+                  (long)kRedBlocks * kHid * kHid + kWtPackWords + 64);
 }
 
 extern "C" int pstl_loss_grad(const pstl_cfg* cfg, const float* scores, const float* valid, float grad_scale, float* dscore,
@@ -537,9 +639,7 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
   const bool merge = !(cfg->flags & PSTL_FLAG_NO_MERGE);
   if (merge && (!pooled || cfg->rows_per_scene != 3 * cfg->S || cfg->n_shards < 1 || cfg->S % cfg->n_shards != 0))
     return PSTL_ERR_ARG;
-  TrainCtx* c = static_cast<TrainCtx*>(ctx);
   hipStream_t st = as_stream(stream);
-  if (rocblas_set_stream(c->h, st) != rocblas_status_success) return PSTL_ERR_LAUNCH;
   const long N = n_rows(cfg);
   float* dO = work;                       // (N,40)
   float* x47 = dO + N * kCtrl;            // (N,47)
@@ -548,6 +648,7 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
   float* S = dH1 + N * kHid;              // (bs,256)
   float* part = S + (long)cfg->bs * kHid; // (kRedBlocks,256)
   float* slabs = part + (long)kRedBlocks * kHid;  // (kRedBlocks,256,256) split-K partials of k_wgrad
+  unsigned* wpack = reinterpret_cast<unsigned*>(slabs + (long)kRedBlocks * kHid * kHid);   // kWtPackWords
   const int nb = (int)(N < kRedBlocks ? N : kRedBlocks);
 
   hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)((N * kCtrl + 255) / 256)), dim3(256), 0, st, N, cfg->w_max, cfg->a_max,
@@ -557,17 +658,14 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
   hipLaunchKernelGGL(k_colsum40, dim3(nb), dim3(256), 0, st, N, dO, part);
   hipLaunchKernelGGL(k_colsum_final, dim3(kCtrl), dim3(64), 0, st, nb, kCtrl, part, db3);
   if (int e = wgrad<3, 16, 1, 8>(N, dO, kCtrl, kCtrl, h2, kHid, kHid, slabs, dw3, kHid, st)) return e;  // dW3 = dO^T h2
-  if (int e = gemm_rm(c->h, false, false, (int)N, kHid, kCtrl, dO, kCtrl, w3, kHid, dH2, kHid)) return e;  // dH2 = dO W3
-  // layer 2
-  hipLaunchKernelGGL(k_mask_colsum256, dim3(nb), dim3(256), 0, st, N, dH2, h2, part);
-  hipLaunchKernelGGL(k_colsum_final, dim3(kHid), dim3(64), 0, st, nb, kHid, part, db2);
+  // layer 2: dH2 = (dO W3) * [h2 > 0], db2 = column sums of dH2
+  if (int e = dgrad<2>(N, dO, kCtrl, kCtrl, w3, wpack, h2, dH2, part, db2, st)) return e;
   if (int e = wgrad<16, 16, 4, 2>(N, dH2, kHid, kHid, h1, kHid, kHid, slabs, dw2, kHid, st)) return e;  // dW2 = dH2^T h1
-  if (int e = gemm_rm(c->h, false, false, (int)N, kHid, kHid, dH2, kHid, w2, kHid, dH1, kHid)) return e;  // dH1 = dH2 W2
-  // layer 1
-  hipLaunchKernelGGL(k_mask_colsum256, dim3(nb), dim3(256), 0, st, N, dH1, h1, part);
-  hipLaunchKernelGGL(k_colsum_final, dim3(kHid), dim3(64), 0, st, nb, kHid, part, db1);
+  // layer 1: dH1 = (dH2 W2) * [h1 > 0], db1 = column sums of dH1
+  if (int e = dgrad<8>(N, dH2, kHid, kHid, w2, wpack, h1, dH1, part, db1, st)) return e;
   hipLaunchKernelGGL(k_scene_sum, dim3(cfg->bs), dim3(256), 0, st, cfg->rows_per_scene, dH1, S);
-  if (int e = gemm_rm(c->h, true, false, kHid, kFeat, cfg->bs, S, kHid, feature, kFeat, dw1, kIn)) return e;
+  // the 224 scene-constant input columns: dW1[:, :224] = S^T feature (contraction over the scenes)
+  if (int e = wgrad<16, 14, 4, 2>(cfg->bs, S, kHid, kHid, feature, kFeat, kFeat, slabs, dw1, kIn, st)) return e;
   if (int e = wgrad<16, 3, 8, 1>(N, dH1, kHid, kHid, x47, kX47, kX47, slabs, dw1 + kFeat, kIn, st)) return e;
   return launch_status();
 }

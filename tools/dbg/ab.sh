@@ -14,6 +14,6 @@ python3 bench.py --no_cpu_baseline $bargs 2>/dev/null | tail -1 | line base
 for v in "$@"; do
   n=${v%%:*}; flags=${v#*:}
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xarch_device -mllvm=-misched-prera-direction=topdown $flags -c $c/mlp_kernels.hip -o $out/mlp_$n.o || { echo "$n: build failed"; continue; }
-  hipcc --offload-arch=gfx950 -shared -fPIC $c/stl_kernels.o $out/mlp_$n.o $c/train_kernels.o $c/diversity_kernels.o $c/stl_program.o -lrocblas -o $out/libpstl_$n.so
+  hipcc --offload-arch=gfx950 -shared -fPIC $c/stl_kernels.o $out/mlp_$n.o $c/train_kernels.o $c/diversity_kernels.o $c/stl_program.o -o $out/libpstl_$n.so
   python3 tools/dbg/with_lib.py $out/libpstl_$n.so bench.py --no_cpu_baseline $bargs 2>/dev/null | tail -1 | line $n
 done
