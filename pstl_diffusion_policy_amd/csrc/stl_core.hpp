@@ -70,6 +70,42 @@ struct Scratch {
   PSTL_HD float& at(int i) const { return p[i * stride]; }
 };
 
+// Winners of the forward sweep's hard minima, one entry per time step, for the adjoint -- which would otherwise rank the 14
+// segment pairs of the lane and the 16 circle pairs of every neighbour a second time at the very same state:
+//   ln: 4 bits per step = index of the winning waypoint pair (compute_t2l_dist's argmin);
+//   cl: 8 bits per step = neighbour (4 bits; 15 = no neighbour, the constant 100) | circle pair 4 i + j (4 bits).
+// Eight registers per lane.  Neighbour indices need K <= kRecMaxK; beyond that the adjoint ranks again.
+constexpr int kRecMaxK = 14;
+struct Rec {
+  unsigned ln[3], cl[5];
+};
+PSTL_HD void rec_clear(Rec& r) {
+  r.ln[0] = r.ln[1] = r.ln[2] = 0u;
+  r.cl[0] = r.cl[1] = r.cl[2] = r.cl[3] = r.cl[4] = 0u;
+}
+PSTL_HD void rec_put(Rec& r, int t, unsigned seg, unsigned win) {   // t dynamic: the words are picked by selects
+  const unsigned a = seg << (4 * (t & 7)), b = win << (8 * (t & 3));
+  const int wa = t >> 3, wb = t >> 2;
+  r.ln[0] |= wa == 0 ? a : 0u;
+  r.ln[1] |= wa == 1 ? a : 0u;
+  r.ln[2] |= wa == 2 ? a : 0u;
+  r.cl[0] |= wb == 0 ? b : 0u;
+  r.cl[1] |= wb == 1 ? b : 0u;
+  r.cl[2] |= wb == 2 ? b : 0u;
+  r.cl[3] |= wb == 3 ? b : 0u;
+  r.cl[4] |= wb == 4 ? b : 0u;
+}
+PSTL_HD unsigned rec_seg(const Rec& r, int t) {
+  const int wa = t >> 3;
+  const unsigned x = wa == 0 ? r.ln[0] : (wa == 1 ? r.ln[1] : r.ln[2]);
+  return (x >> (4 * (t & 7))) & 15u;
+}
+PSTL_HD unsigned rec_win(const Rec& r, int t) {
+  const int wb = t >> 2;
+  const unsigned x = wb == 0 ? r.cl[0] : (wb == 1 ? r.cl[1] : (wb == 2 ? r.cl[2] : (wb == 3 ? r.cl[3] : r.cl[4])));
+  return (x >> (8 * (t & 3))) & 255u;
+}
+
 struct StlEnv {
   float tau;
   float dt;
@@ -147,28 +183,35 @@ PSTL_HD float lse2(float a, float b) {
 struct LaneHit {
   float d, th;
   float dd_dx, dd_dy, dth_dth;  // partials (only meaningful when requested)
+  int jb;                       // the winning waypoint pair
 };
 
+// seg >= 0: the winning pair is known (recorded by the forward sweep at this very state): no ranking
 template <bool GRAD>
-PSTL_HD void lane_eval(const f4* lane, float px, float py, float pth, LaneHit& h) {
-  f4 p = lane[0];
-  float ex = px - p.x, ey = py - p.y;
-  float prev = PSTL_SQRT_RANK(ex * ex + ey * ey);
-  float best = INFINITY;
+PSTL_HD void lane_eval(const f4* lane, float px, float py, float pth, LaneHit& h, int seg = -1) {
   int jb = 0;
-  PSTL_UNROLL
-  for (int j = 0; j < kNseg - 1; ++j) {
-    const f4 n = lane[j + 1];
-    ex = px - n.x;
-    ey = py - n.y;
-    const float cur = PSTL_SQRT_RANK(ex * ex + ey * ey);
-    const float s = prev + cur;
-    if (s < best) {  // strict: lowest index wins ties, like torch.argmin
-      best = s;
-      jb = j;
+  if (seg >= 0) {
+    jb = seg;
+  } else {
+    f4 p = lane[0];
+    float ex = px - p.x, ey = py - p.y;
+    float prev = PSTL_SQRT_RANK(ex * ex + ey * ey);
+    float best = INFINITY;
+    PSTL_UNROLL
+    for (int j = 0; j < kNseg - 1; ++j) {
+      const f4 n = lane[j + 1];
+      ex = px - n.x;
+      ey = py - n.y;
+      const float cur = PSTL_SQRT_RANK(ex * ex + ey * ey);
+      const float s = prev + cur;
+      if (s < best) {  // strict: lowest index wins ties, like torch.argmin
+        best = s;
+        jb = j;
+      }
+      prev = cur;
     }
-    prev = cur;
   }
+  h.jb = jb;
   const f4 p2 = lane[jb], p3 = lane[jb + 1];
   const float area = px * (p2.y - p3.y) + p2.x * (p3.y - py) + p3.x * (py - p2.y);
   const float sx = p2.x - p3.x, sy = p2.y - p3.y;
@@ -209,11 +252,13 @@ PSTL_HD void lane_eval(const f4* lane, float px, float py, float pth, LaneHit& h
 struct ClearHit {
   float dn;
   float d_dx, d_dy, d_dth;
+  unsigned win;   // REC: neighbour << 4 | circle pair of the minimum (neighbour 15: none, the constant 100)
 };
 
-template <bool GRAD>
+template <bool GRAD, bool REC = false>
 PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, float x, float y, float c, float s,
                             ClearHit& h) {
+  unsigned win = 0xF0u;
   float ex[4], ey[4];
   PSTL_UNROLL
   for (int i = 0; i < 4; ++i) {
@@ -239,6 +284,7 @@ PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, f
       if (100.0f < best) {
         best = 100.0f;
         if (GRAD) gx = gy = gth = 0.0f;
+        if (REC) win = 0xF0u;
       }
       continue;
     }
@@ -255,6 +301,7 @@ PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, f
     }
     float q = INFINITY;
     float bdx = 0.0f, bdy = 0.0f, boff = 0.0f;  // the closest circle pair (first one on ties)
+    unsigned pair = 15u;
     if (!GRAD) {
       // value only: a tree of plain minima over the 16 independent pair distances (the same number as the sequential
       // "if (qq < q)" scan for any non-NaN input, without its compare -> select -> compare chain and the wait states
@@ -270,6 +317,10 @@ PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, f
       }
       q = fminf(fminf(fminf(qs[0], qs[1]), fminf(qs[2], qs[3])), fminf(fminf(qs[4], qs[5]), fminf(qs[6], qs[7])));
       q = fminf(q, fminf(fminf(fminf(qs[8], qs[9]), fminf(qs[10], qs[11])), fminf(fminf(qs[12], qs[13]), fminf(qs[14], qs[15]))));
+      if (REC) {   // which pair it was: the first one equal to the minimum (what the sequential "<" scan of the adjoint keeps)
+        PSTL_UNROLL
+        for (int n = 14; n >= 0; --n) pair = (qs[n] == q) ? (unsigned)n : pair;
+      }
     } else {
       // with the gradient the winning pair has to be tracked (finding it afterwards by equality with the tree minimum
       // was measured slower: 16 compares and 48 selects)
@@ -294,6 +345,7 @@ PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, f
     const float val = clipped * valid + (1.0f - valid) * 100.0f;
     if (val < best) {  // lowest neighbour index wins ties (torch.min)
       best = val;
+      if (REC) win = ((unsigned)k << 4) | pair;
       if (GRAD) {
         const bool pass = (car >= -5.0f) && (car <= 20.0f) && (dist > 0.0f);
         const float g = pass ? valid / dist : 0.0f;
@@ -305,11 +357,42 @@ PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, f
     }
   }
   h.dn = best;
+  if (REC) h.win = win;
   if (GRAD) {
     h.d_dx = gx;
     h.d_dy = gy;
     h.d_dth = gth;
   }
+}
+
+// The same value and partials from the minimum's recorded position (neighbour, circle pair) -- one pair instead of 16 K:
+// the operations that produced the recorded minimum, repeated on the same operands (bit-identical).
+PSTL_HD void clearance_from_winner(const StlEnv& env, const float* nei, int t, float x, float y, float c, float s,
+                                   unsigned win, ClearHit& h) {
+  const unsigned k = win >> 4, pi = win & 15u;
+  h.dn = 100.0f;
+  h.d_dx = h.d_dy = h.d_dth = 0.0f;
+  if (k == 15u) return;
+  const f4* e = reinterpret_cast<const f4*>(nei + (size_t)(k * kT + t) * kNeiPrep);
+  const f4 a = e[0], b = e[1], cc = e[2];
+  const float valid = a.x, r = a.y;
+  const unsigned i = pi >> 2, j = pi & 3u;
+  const float off = i == 0 ? env.eoff[0] : (i == 1 ? env.eoff[1] : (i == 2 ? env.eoff[2] : env.eoff[3]));
+  const float nxj = j == 0 ? a.z : (j == 1 ? a.w : (j == 2 ? b.x : b.y));
+  const float nyj = j == 0 ? b.z : (j == 1 ? b.w : (j == 2 ? cc.x : cc.y));
+  const float exi = off * c + x, eyi = off * s + y;
+  const float dx = exi - nxj, dy = eyi - nyj;
+  const float q = dx * dx + dy * dy;
+  const float dist = sqrtf(q);
+  const float car = dist - env.er - r;
+  const float clipped = fminf(fmaxf(car, -5.0f), 20.0f);
+  h.dn = clipped * valid + (1.0f - valid) * 100.0f;
+  const bool pass = (car >= -5.0f) && (car <= 20.0f) && (dist > 0.0f);
+  const float g = pass ? valid / dist : 0.0f;
+  const float ddx = dx * g, ddy = dy * g;
+  h.d_dx = ddx;
+  h.d_dy = ddy;
+  h.d_dth = ddx * (-off * s) + ddy * (off * c);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -481,9 +564,12 @@ struct FwdOut {  // what the adjoint needs from the forward sweep
 //   ALL3 = true : all three formulas -> out3[0..2]; returns the mode-selected score   (scratch: kScratchFwd3)
 //   ALL3 = false: only the formula of r.mode                                           (scratch: kScratchFwd)
 //   XY != -1    : additionally parks the state of every 4th step at scratch[XY ...] (x, y, th, v; 5 each)  (adjoint)
-template <bool ALL3, int XY, class Src>
-PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Src src, Scratch st,
-                       int tab, float* out3, FwdOut* fo) {
+//   REC         : records the winners of the hard minima (lane segment, neighbour, circle pair) per step in `rec`
+//                 (for the adjoint; !ALL3)
+template <bool ALL3, int XY, bool REC, class Src>
+PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Src src, Scratch st,
+                           int tab, float* out3, FwdOut* fo, Rec& rec) {
+  static_assert(!(ALL3 && REC), "winners are recorded for the selected formula only");
   const float tau = env.tau;
   Lse gv1, gv2, gsafe, g1, g2, g3;
   gv1.init();
@@ -511,10 +597,11 @@ PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, cons
     gv1.add(-(v - r.vmin) * tau);
     gv2.add(-(-v + r.vmax) * tau);
     ClearHit ch;
-    clearance_eval<false>(env, nei, K, t, x, y, c, s, ch);
+    clearance_eval<false, REC>(env, nei, K, t, x, y, c, s, ch);
     gsafe.add(-(ch.dn - r.dsafe) * tau);
     LaneHit h;
     lane_eval<false>(ALL3 ? lanes : sel_lane, x, y, th, h);
+    if (REC) rec_put(rec, t, (unsigned)h.jb, ch.win);
     {
       const float s1 = h.d - r.dmin, s2 = -h.d + r.dmax, a3 = -((r.thmax - h.th) / r.thmax) * tau;
       g1.add(-s1 * tau);
@@ -570,6 +657,13 @@ PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, cons
   return score;
 }
 
+template <bool ALL3, int XY, class Src>
+PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Src src, Scratch st,
+                       int tab, float* out3, FwdOut* fo) {
+  Rec none;
+  return stl_eval_rec<ALL3, XY, false>(env, r, lanes, nei, K, src, st, tab, out3, fo, none);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Forward + adjoint of one row: returns the score and calls emit(t, gw, ga, w, a) once for every t in [0,T) with
 // (gw, ga) = dscore_fn(score) * d score / d (u[2t], u[2t+1]) and (w, a) = the stored values u[2t], u[2t+1] themselves
@@ -607,7 +701,11 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   const int CKP = 0, LB = 4 * kCk, LT = 4 * kCk + kFwin;
   // ---- forward sweep ------------------------------------------------------------------------------------------
   FwdOut fo;
-  const float score = stl_eval<false, 0>(env, r, lanes, nei, K, DynSrc(s0, u, wscale, ascale, env.dt, us), st, LB, nullptr, &fo);
+  Rec rec;
+  rec_clear(rec);
+  const bool use_rec = K <= kRecMaxK;   // uniform; with more neighbours the record is written but not trusted
+  const float score = stl_eval_rec<false, 0, true>(env, r, lanes, nei, K, DynSrc(s0, u, wscale, ascale, env.dt, us), st, LB,
+                                                   nullptr, &fo, rec);
   const float Lv1 = fo.Lv1, Lv2 = fo.Lv2, Ls = fo.Ls, L1 = fo.L1, L2 = fo.L2, L3 = fo.L3, Lfb = fo.Lfb, Lft = fo.Lft;
   float V[6];
   int n;
@@ -698,13 +796,14 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     float gx, gy, gth, gv;
     gv = o_v1 * PSTL_EXP(-(v - r.vmin) * tau - Lv1) - o_v2 * PSTL_EXP(-(-v + r.vmax) * tau - Lv2);
     ClearHit ch;
-    clearance_eval<true>(env, nei, K, t, x, y, c, s, ch);
+    if (use_rec) clearance_from_winner(env, nei, t, x, y, c, s, rec_win(rec, t), ch);
+    else clearance_eval<true>(env, nei, K, t, x, y, c, s, ch);
     const float gs = o_s * PSTL_EXP(-(ch.dn - r.dsafe) * tau - Ls);
     gx = gs * ch.d_dx;
     gy = gs * ch.d_dy;
     gth = gs * ch.d_dth;
     LaneHit h;
-    lane_eval<true>(lane, x, y, th, h);
+    lane_eval<true>(lane, x, y, th, h, use_rec ? (int)rec_seg(rec, t) : -1);
     const float s1 = h.d - r.dmin, s2 = -h.d + r.dmax, s3 = (r.thmax - h.th) / r.thmax;
     float gd, gsth;  // d score / d d_t , d score / d s3_t
     if (mode == 0) {

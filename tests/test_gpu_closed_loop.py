@@ -29,5 +29,7 @@ def test_reference_command_line_runs(capsys):
     recs = nusc_sim.main("-e e7_ours --diffusion --stl_weight 0.0 --rect_head --flex --diverse_loss --multi_cands 5 --test "
                          "-P e7_ours --filter_traj 0 --test_scenes --viz_last --guidance --guidance_before 10 "
                          "--guidance_niters 1 --guidance_lr 0.04 --suffix sim_guide --n_trials 3 --diffusion_steps 20 "
-                         "--n_neighbors 4".split())
+                         "--n_neighbors 4 --allow_random_init".split())
     assert len(recs) == 3 and "median latency" in capsys.readouterr().out
+    with pytest.raises(SystemExit):      # -P names no file: an error unless random init is asked for
+        nusc_sim.main("--diffusion --rect_head --diverse_loss --test -P e7_ours --n_trials 1".split())
