@@ -289,7 +289,7 @@ def main():
     # HBM bytes of that launch from the committed PMC passes (FETCH_SIZE/WRITE_SIZE cannot be read inside this process);
     # only quoted when this run is the configuration those passes were collected on
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")
+    pmc = os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")
     is_default = (a.workload == "e7_guid" and bs == 4096 and S == 64 and a.neighbors == 2 and steps == 50
                   and a.noise == "kernel" and not a.chain_waves)
     if is_default and os.path.exists(pmc):
@@ -319,7 +319,7 @@ def main():
                                        if (split_f16 or split_bf16) else "dense f32 MFMA peak"),
                          "matrix_pipe_frac_issued": (achieved * F_STEP_ISSUED_BF16 / F_STEP_MIN / PEAK_BF16_MATRIX_TFLOPS)
                                                     if (split_f16 or split_bf16) else achieved / peak,
-                         "traffic_source": "profiles/r1/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
+                         "traffic_source": "profiles/r2/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
                                            if traffic else None,
                          "kernel_ms": k_ms, "flop_per_launch": flop, "stl_kernels": stl_info,
                          "note": "algorithmic FLOP = rows x steps x 172032 (hoisted layer-1 columns not counted); achieved "

@@ -52,7 +52,7 @@ f = out["per_kernel"]["FETCH_SIZE"].get(dom, {})
 w = out["per_kernel"]["WRITE_SIZE"].get(dom, {})
 sq = out["per_kernel"]["SQ"].get(dom, {})
 summ = {"kernel": "k_chain<8,false,...> (multi-step denoiser launch of the default bench: 786432 rows, in-kernel noise, "
-                  "split-bf16 MFMA unless the bench was run with --chain_waves 8)",
+                  "split-f16 MFMA unless the bench was run with another --chain_waves)",
         "FETCH_SIZE_KB": f.get("FETCH_SIZE"), "WRITE_SIZE_KB": w.get("WRITE_SIZE"),
         "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); WRITE_SIZE as reported"}
 if f.get("FETCH_SIZE") is not None and w.get("WRITE_SIZE") is not None:
