@@ -395,10 +395,43 @@ def rect_forward(sd, feature, rows, init_controls, scores, n_shards, diverse=Tru
 # ------------------------------------------------------------------------------------------------
 # A12 the whole timed region (reference nusc_train.py:957-1105)
 # ------------------------------------------------------------------------------------------------
+REFINEMENT_LIST_IDX = (0, 50, 80, 85, 90, 95, 98)    # k_d_list[8] of the reference (nusc_train.py:1052-1055)
+
+
+def refinement(rows, controls, clist, iters=50, lr=0.3, thres=0.0005, record=None):
+    """--refinement (reference nusc_train.py:1034-1071): 50 Adam iterations (lr 0.3) over per-row mixing weights
+    softmax(lambda) of K = 8 control sequences -- the current controls and entries 0, 50, 80, 85, 90, 95, 98 of the
+    rollout's list -- under loss = mask_mean(relu(5e-4 - score), valid); only rows whose current score is <= 0 (and whose
+    lane is valid) are mixed.  Returns the controls of the LAST forward pass (the mixing weights after iters-1 steps)."""
+    with torch.no_grad():
+        _, score0, _ = rows.score(controls)
+    violated = ((score0 <= 0) & (rows.valid > 0)).float().reshape(rows.N, 1, 1)
+    lam = torch.ones(rows.N, 8, requires_grad=True)
+    opt = torch.optim.Adam([lam], lr=lr)
+    base = controls.detach()
+    others = [clist[i].detach() for i in REFINEMENT_LIST_IDX]
+    optim = base
+    for it in range(iters):
+        ratios = torch.softmax(lam, dim=-1)
+        comb = [others[i] * ratios[..., i + 1:i + 2, None] for i in range(7)]
+        optim = base * ratios[..., 0:1, None] + torch.sum(torch.stack(comb, dim=-1), dim=-1)
+        optim = base * (1 - violated) + violated * optim
+        _, sc, _ = rows.score(optim)
+        loss = mask_mean(torch.relu(thres - sc), rows.valid)
+        opt.zero_grad()
+        loss.backward()
+        if record is not None:
+            record.append(lam.grad.detach().clone())
+        opt.step()
+    return optim.detach()
+
+
 def sampling_region(sd, scene, S, steps, hp, x_T, z, rect_head=False, multi_cands=None, refinenet=True,
-                    guidance=None, n_rolls=None, diverse=True, n_shards=4, clip_rect=False, use_rect=True):
+                    guidance=None, n_rolls=None, diverse=True, n_shards=4, clip_rect=False, use_rect=True,
+                    refinement_iters=None):
     """use_rect=False is --not_use_rect: --rect_head's side effects (clip, full list) stay, the RefineNet block is skipped
-    (nusc_train.py:993 `if args.rect_head and not args.not_use_rect`)."""
+    (nusc_train.py:993 `if args.rect_head and not args.not_use_rect`).  refinement_iters: --refinement (50 in the
+    reference), inside the same block."""
     rows = Rows(scene, S, hp)
     out = {}
     with torch.no_grad():
@@ -425,6 +458,10 @@ def sampling_region(sd, scene, S, steps, hp, x_T, z, rect_head=False, multi_cand
                 controls = rect_forward(sd, feature, rows, controls, sc, n_shards, diverse, clip_rect)
                 out["roll%d_scores" % ri] = sc
                 out["roll%d_controls" % ri] = controls
+            if refinement_iters:
+                with torch.enable_grad():
+                    controls = refinement(rows, controls, clist, iters=refinement_iters)
+                out["refinement_controls"] = controls
         s3, score, sig = rows.score(controls)
         acc, scene_acc = stl_metrics(score, rows.valid, S)
         out.update(final_controls=controls, final_scores3=s3, final_scores=score, final_acc=acc,

@@ -380,6 +380,155 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) v
   if (a.scores) a.scores[row] = score;
 }
 
+// ---- --refinement (nusc_train.py:1034-1071): 50 Adam iterations over per-row mixing weights, in ONE launch -----------
+// For every row whose current controls score <= 0 (and whose lane is valid) the reference optimises lambda (8 values,
+// start 1, Adam lr 0.3) so that   optim = sum_k softmax(lambda)_k * base_k,   base_0 = the current controls, base_1..7 =
+// entries 0, 50, 80, 85, 90, 95, 98 of the rollout's list, minimises mask_mean(relu(5e-4 - score(optim)), valid); the
+// result is the optim of the LAST forward pass.  Rows are independent, so one launch runs all iterations of a row back
+// to back, exactly like k_trajopt: the bases, the iterate and its gradient live element-major in `work` (plane p of the
+// lane's slot at work[p * n_slots + slot]: 64 lanes touch 256 contiguous bytes), the scene tables stay in LDS.
+// Planes: [0,40) iterate | [40,80) d loss / d iterate | [80,400) the 8 bases | [400,424) lambda, Adam m, v.
+constexpr int kMixK = 8, kMixPlanes = 2 * (2 * kT) + kMixK * (2 * kT) + 3 * kMixK;
+
+struct MixArgs {
+  long N;
+  int rows_per_scene;
+  int K;
+  int by_mode;
+  StlEnv env;
+  float thres, grad_scale;
+  int iters;
+  const float* neg_step;     // [iters] device: -lr / (1 - 0.9^k)
+  const float* bc2_sqrt;     // [iters] device: sqrt(1 - 0.999^k)
+  const float* s0;
+  const float* nei_prep;
+  const float* lane_prep;
+  const float* stlp;
+  const float* hl;
+  const float* valid;
+  const float* base[kMixK];  // (N,40) each, physical units
+  float* work;               // kMixPlanes * n_slots floats
+  float* out;                // (N,40)
+  float* grad_trace;         // (iters,N,8) d loss / d lambda of every iteration, or null (tests)
+};
+
+template <bool STAGED>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_mixopt(MixArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const long row = map_row(a.by_mode, a.rows_per_scene);
+  const long slot = (long)blockIdx.x * kWave + threadIdx.x;
+  const long P = (long)gridDim.x * kWave;      // slots per plane
+  const f4* lanes;
+  const float* nei;
+  scene_tables<STAGED>(lds, kScratchGrad, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes,
+                       nei);
+  if (row >= a.N) return;
+  const Scratch st = {lds + threadIdx.x, kWave};
+  const long b = row / a.rows_per_scene;
+  const StlRow r = load_row(a.stlp, a.hl, row);
+  constexpr int E = 2 * kT;
+  float* U = a.work + slot;
+  float* G = a.work + (long)E * P + slot;
+  float* B = a.work + 2L * E * P + slot;              // base k, element e at B[(k*E + e) * P]
+  float* LM = a.work + (2L + kMixK) * E * P + slot;   // lambda k at LM[k*P], m at LM[(8+k)*P], v at LM[(16+k)*P]
+  PSTL_NOUNROLL
+  for (int k = 0; k < kMixK; ++k) {
+    const f4* src = reinterpret_cast<const f4*>(a.base[k] + row * E);
+    PSTL_NOUNROLL
+    for (int q = 0; q < E / 4; ++q) {
+      const f4 v = src[q];
+      float* d = B + ((long)k * E + 4 * q) * P;
+      d[0] = v.x, d[P] = v.y, d[2 * P] = v.z, d[3 * P] = v.w;
+    }
+  }
+  const float vr = a.valid[row];
+  // the rows to mix: score of the current controls <= 0 on a valid lane (nusc_train.py:1045-1046)
+  const float score0 = stl_eval<false, -1>(a.env, r, lanes, nei, a.K, DynSrc(a.s0 + b * 4, B, 1.0f, 1.0f, a.env.dt, P), st, 0,
+                                           nullptr, nullptr);
+  float* out = a.out + row * E;
+  if (!(score0 <= 0.0f && vr > 0.0f)) {
+    PSTL_NOUNROLL
+    for (int e = 0; e < E; ++e) out[e] = B[(long)e * P];
+    if (a.grad_trace) {
+      PSTL_NOUNROLL
+      for (int it = 0; it < a.iters; ++it)
+        PSTL_NOUNROLL
+        for (int k = 0; k < kMixK; ++k) a.grad_trace[((long)it * a.N + row) * kMixK + k] = 0.0f;
+    }
+    return;
+  }
+  PSTL_NOUNROLL
+  for (int k = 0; k < kMixK; ++k) LM[(long)k * P] = 1.0f, LM[(long)(kMixK + k) * P] = 0.0f, LM[(long)(2 * kMixK + k) * P] = 0.0f;
+  const float gs = a.grad_scale * vr;
+  const float thres = a.thres;
+  auto ratios = [&](float (&rt)[kMixK]) {          // torch.softmax over the 8 weights
+    float mx = -INFINITY;
+    PSTL_UNROLL
+    for (int k = 0; k < kMixK; ++k) {
+      rt[k] = LM[(long)k * P];
+      mx = fmaxf(mx, rt[k]);
+    }
+    float sum = 0.0f;
+    PSTL_UNROLL
+    for (int k = 0; k < kMixK; ++k) {
+      rt[k] = expf(rt[k] - mx);
+      sum += rt[k];
+    }
+    PSTL_UNROLL
+    for (int k = 0; k < kMixK; ++k) rt[k] = rt[k] / sum;
+  };
+  for (int it = 0; it < a.iters; ++it) {
+    {
+      float rt[kMixK];
+      ratios(rt);
+      PSTL_NOUNROLL
+      for (int e = 0; e < E; ++e) {     // base_0 * r_0 + sum_{k >= 1} base_k * r_k   (:1056-1057)
+        float acc = B[((long)E + e) * P] * rt[1];
+        PSTL_UNROLL
+        for (int k = 2; k < kMixK; ++k) acc += B[((long)k * E + e) * P] * rt[k];
+        U[(long)e * P] = B[(long)e * P] * rt[0] + acc;
+      }
+    }
+    stl_eval_grad(
+        a.env, r, lanes, nei, a.K, a.s0 + b * 4, U, st, 1.0f, 1.0f,
+        [=](float sc) { return (thres - sc > 0.0f) ? -gs : 0.0f; },
+        [=](int t, float gw, float ga, float, float) {
+          G[(long)(2 * t) * P] = gw;
+          G[(long)(2 * t + 1) * P] = ga;
+        },
+        P);
+    // d loss / d ratio_k = <G, base_k>; softmax backward; one Adam step on lambda
+    float rt[kMixK], gr[kMixK];
+    ratios(rt);
+    PSTL_UNROLL
+    for (int k = 0; k < kMixK; ++k) gr[k] = 0.0f;
+    PSTL_NOUNROLL
+    for (int e = 0; e < E; ++e) {
+      const float g = G[(long)e * P];
+      PSTL_UNROLL
+      for (int k = 0; k < kMixK; ++k) gr[k] += g * B[((long)k * E + e) * P];
+    }
+    float dot = 0.0f;
+    PSTL_UNROLL
+    for (int k = 0; k < kMixK; ++k) dot += rt[k] * gr[k];
+    const float neg_step = a.neg_step[it], bc2 = a.bc2_sqrt[it];
+    PSTL_UNROLL
+    for (int k = 0; k < kMixK; ++k) {
+      const float g = rt[k] * (gr[k] - dot);
+      if (a.grad_trace) a.grad_trace[((long)it * a.N + row) * kMixK + k] = g;
+      float m = LM[(long)(kMixK + k) * P], v = LM[(long)(2 * kMixK + k) * P];
+      m = m + 0.1f * (g - m);
+      v = v * 0.999f + (0.001f * g) * g;
+      const float denom = sqrtf(v) / bc2 + 1e-8f;
+      LM[(long)k * P] = LM[(long)k * P] + (neg_step * m) / denom;
+      LM[(long)(kMixK + k) * P] = m;
+      LM[(long)(2 * kMixK + k) * P] = v;
+    }
+  }
+  PSTL_NOUNROLL
+  for (int e = 0; e < E; ++e) out[e] = U[(long)e * P];   // the iterate of the last forward pass (:1071)
+}
+
 // prep_stl_cache (nusc_train.py:74-93): the seven signals the formulas read, per row and time step --
 // signed lateral distance and heading error to the current / left / right lane (compute_t2l_dist, nusc_api.py:685-739)
 // and the clearance to the closest neighbour (compute_shortest_dist_refined, nusc_train.py:142-148).
@@ -706,6 +855,55 @@ extern "C" int pstl_trajopt(const pstl_cfg* cfg, const float* s0, const float* n
   a.by_mode = rows_by_mode(cfg, staged) ? 1 : 0;
   const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged);
   void (*fn)(TrajoptArgs) = staged ? k_trajopt<true> : k_trajopt<false>;
+  if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
+  hipLaunchKernelGGL(fn, dim3((unsigned)((a.N + kWave - 1) / kWave)), dim3(kWave), lds, as_stream(stream), a);
+  return launch_status();
+}
+
+extern "C" size_t pstl_refinement_work_floats(const pstl_cfg* cfg) {
+  if (check_cfg(cfg)) return 0;
+  const long blocks = (n_rows(cfg) + kWave - 1) / kWave;
+  return (size_t)kMixPlanes * (size_t)blocks * kWave;
+}
+
+extern "C" int pstl_refinement(const pstl_cfg* cfg, const float* s0, const float* nei_prep, const float* lane_prep,
+                               const float* stlp, const float* hl, const float* valid, float thres, float grad_scale,
+                               int iters, const float* adam_neg_step, const float* adam_bc2_sqrt, const float* controls,
+                               const float* list, int n_list, const int32_t* list_idx, float* work, float* out_controls,
+                               float* grad_trace, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!s0 || !lane_prep || !stlp || !hl || !valid || !controls || !list || !list_idx || !work || !out_controls ||
+      !adam_neg_step || !adam_bc2_sqrt || iters < 1)
+    return PSTL_ERR_ARG;
+  if (cfg->K > 0 && !nei_prep) return PSTL_ERR_ARG;
+  MixArgs a;
+  a.N = n_rows(cfg);
+  a.rows_per_scene = cfg->rows_per_scene;
+  a.K = cfg->K;
+  a.env = make_env(cfg->tau, cfg->dt, cfg->ego_L, cfg->ego_W);
+  a.thres = thres;
+  a.grad_scale = grad_scale;
+  a.iters = iters;
+  a.neg_step = adam_neg_step;
+  a.bc2_sqrt = adam_bc2_sqrt;
+  a.s0 = s0;
+  a.nei_prep = nei_prep;
+  a.lane_prep = lane_prep;
+  a.stlp = stlp;
+  a.hl = hl;
+  a.valid = valid;
+  a.base[0] = controls;
+  for (int k = 1; k < kMixK; ++k) {
+    if (list_idx[k - 1] < 0 || list_idx[k - 1] >= n_list) return PSTL_ERR_ARG;   // the reference: IndexError
+    a.base[k] = list + (long)list_idx[k - 1] * a.N * (2 * kT);
+  }
+  a.work = work;
+  a.out = out_controls;
+  a.grad_trace = grad_trace;
+  const bool staged = scene_staged(cfg);
+  a.by_mode = rows_by_mode(cfg, staged) ? 1 : 0;
+  const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged);
+  void (*fn)(MixArgs) = staged ? k_mixopt<true> : k_mixopt<false>;
   if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
   hipLaunchKernelGGL(fn, dim3((unsigned)((a.N + kWave - 1) / kWave)), dim3(kWave), lds, as_stream(stream), a);
   return launch_status();

@@ -338,6 +338,34 @@ class Sampler:
                   "trajopt")
         return scores, work
 
+    # ---- --refinement: Adam over per-row mixing weights of eight control sequences ----
+    REFINEMENT_LIST_IDX = (0, 50, 80, 85, 90, 95, 98)     # k_d_list[8] of the reference (nusc_train.py:1052-1055)
+
+    def refinement(self, sb, controls, clist, iters=50, lr=0.3, thres=0.0005, trace=False):
+        """controls (N,40), clist (n_list,N,40): the rollout's normalised list (entry 0 = x_T).  Returns the refined controls
+        (N,40) [, d loss / d lambda per iteration (iters,N,8)]: the reference's --refinement block (nusc_train.py:1034-1071),
+        all iterations in one launch."""
+        dev = sb.device
+        n_list = int(clist.shape[0])
+        if max(self.REFINEMENT_LIST_IDX) >= n_list:
+            raise IndexError("--refinement reads entry %d of the rollout's list, which has %d entries "
+                             "(--diffusion_steps >= 99)" % (max(self.REFINEMENT_LIST_IDX), n_list))
+        ks = range(1, iters + 1)
+        neg_step = torch.tensor([-lr / (1 - 0.9 ** k) for k in ks], dtype=torch.float32, device=dev)
+        bc2 = torch.tensor([math.sqrt(1 - 0.999 ** k) for k in ks], dtype=torch.float32, device=dev)
+        cfg = sb.cfg(2)
+        work = torch.empty(self.L.pstl_refinement_work_floats(ctypes.byref(cfg)), dtype=torch.float32, device=dev)
+        out = torch.empty(sb.N, ffi.CTRL, dtype=torch.float32, device=dev)
+        tr = torch.empty(iters, sb.N, 8, dtype=torch.float32, device=dev) if trace else None
+        idx = (ctypes.c_int32 * 7)(*self.REFINEMENT_LIST_IDX)
+        clist = clist.reshape(n_list, sb.N, ffi.CTRL)
+        ffi.check(self.L.pstl_refinement(ctypes.byref(cfg), ffi.ptr(sb.s0), ffi.ptr(sb.nei_prep), ffi.ptr(sb.lane_prep),
+                                         ffi.ptr(sb.stlp), ffi.ptr(sb.hl), ffi.ptr(sb.valid), ctypes.c_float(thres),
+                                         ctypes.c_float(sb.grad_scale), int(iters), ffi.ptr(neg_step), ffi.ptr(bc2),
+                                         ffi.ptr(controls), ffi.ptr(clist), n_list, idx, ffi.ptr(work), ffi.ptr(out),
+                                         ffi.ptr(tr), ffi.stream()), "refinement")
+        return (out, tr) if trace else out
+
     # ---- N2: post-sampling diversity metrics ----
     def diversity(self, sb, controls, scores):
         """std / hull volume / entropies / occupancy area / ADE / FDE of the final controls (N,40) (physical units):
@@ -359,7 +387,7 @@ class Sampler:
     # ---- A12: the timed region ----
     def sampling_region(self, sb, steps, x_T, noise, rect_head=False, multi_cands=None, refinenet=True, guidance=None,
                         n_rolls=None, diverse=True, full_list=False, coeffs=None, want_scores3=True, seed=None,
-                        diversity=False, clip_rect=False, use_rect=True):
+                        diversity=False, clip_rect=False, use_rect=True, refinement_iters=None):
         """x_T (N,40) and noise (steps-1,N,40) supplied by the caller (parity), or seed != None: x_T and all noise are
         drawn by the kernels (x_T / noise arguments ignored)."""
         out = {}
@@ -370,6 +398,8 @@ class Sampler:
         else:
             x = x_T.clone()
         mc = multi_cands if (rect_head and multi_cands is not None) else 0
+        if refinement_iters and rect_head and use_rect:
+            full_list = True         # --refinement mixes entries 0..98 of the list
         n_emit = steps if full_list else max(mc, 1)
         emit = self.rollout(sb, base_p, x, noise, steps, n_emit=n_emit, clip=bool(rect_head), guidance=guidance,
                             coeffs=coeffs, seed=seed)
@@ -392,6 +422,9 @@ class Sampler:
                 controls = self.refine(sb, base_r, controls, sc, diverse=diverse, clip_rect=clip_rect)
                 out["roll%d_scores" % ri] = sc
                 out["roll%d_controls" % ri] = controls
+            if refinement_iters:
+                controls = self.refinement(sb, controls.contiguous(), emit, iters=int(refinement_iters))
+                out["refinement_controls"] = controls
         fin = self.score(sb, controls.reshape(1, sb.N, ffi.CTRL), all3=want_scores3)
         counts, _ = self.metrics(sb, fin["scores"][0])
         out.update(final_controls=controls, final_scores=fin["scores"][0], counts=counts)

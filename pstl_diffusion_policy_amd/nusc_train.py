@@ -535,6 +535,9 @@ def run_sampling_test(stls_cac, data_loader, net, coeffs, args, result_queue=Non
             for _ in range(args.n_rolls or 0):
                 sc = sm.score(sb, nn_controls.reshape(1, N, -1).contiguous())["scores"][0]
                 nn_controls = net.rect_forward(feature, highlevel_new, new_batch["stlp_dense"][:, 0], nn_controls, sc)
+            if args.refinement:      # "further gradient" (reference :1034-1071): K = 8, 50 iterations, lr 0.3, thres 5e-4
+                clist = torch.stack(nn_controls_list, dim=0).reshape(len(nn_controls_list), N, -1).contiguous()
+                nn_controls = sm.refinement(sb, nn_controls.reshape(N, -1).contiguous(), clist).reshape(N, args.nt, 2)
         nn_trajs = generate_trajs(states_flat_new, nn_controls, args.dt).reshape(N, args.nt + 1, 4)
         stl_input = pre_prepare_stl_cache(new_batch, dense_trajs=nn_trajs[:, :-1])
         scores_list, scores, acc, scene_acc = compute_stl_dense(stl_input, stls_cac, new_batch["highlevel_dense"],
@@ -840,7 +843,7 @@ def generate_parser(argv=None):
 def main(argv=None):
     args = generate_parser(argv)
     for flag, why in (("collect_data", "dataset extraction needs the nuScenes devkit"), ("bc", "the BC baseline"),
-                      ("vae", "the VAE baseline"), ("refinement", "the mixing-weight optimiser (nusc_train.py:1034-1071)"),
+                      ("vae", "the VAE baseline"),
                       ("gt_data_training", "the mono (GT-data) training mode"), ("check_stl_params", "a data-inspection tool")):
         if getattr(args, flag, False):
             raise SystemExit("--%s selects %s, which is outside the path this package implements" % (flag, why))

@@ -25,7 +25,11 @@ def golden_weights():
 def scene_from_golden(d):
     keys = ["ego_traj", "neighbors", "neighbors_traj", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
             "curr_id", "left_id", "right_id", "stlp_modes"]
-    return {k: d["in_" + k] for k in keys}
+    scene = {k: d["in_" + k] for k in keys}
+    if "in_stlp_rows" in d:      # fixtures recorded from the reference's own harness: the STL parameters it inferred
+        del scene["stlp_modes"]
+        scene["stlp_rows"] = d["in_stlp_rows"]
+    return scene
 
 
 def golden_meta(d):
@@ -38,6 +42,7 @@ def golden_meta(d):
     x = [int(v) for v in d["meta_x"]] if "meta_x" in d else [1, 0, 1, 1, 0, -1]
     m["diverse"], m["clip_rect"], m["refinenet"], m["use_rect"], m["guidance_reverse"], m["guidance_freq"] = x
     m["guidance_sets"] = [int(v) for v in d["guid_sets"]] if ("guid_sets" in d and len(d["guid_sets"])) else None
+    m["refinement"] = int(d["meta_refinement"][0]) if "meta_refinement" in d else 0
     return m
 
 
@@ -55,13 +60,39 @@ def region_kwargs(meta):
     return dict(rect_head=bool(meta["rect_head"]), multi_cands=None if meta["multi_cands"] < 0 else meta["multi_cands"],
                 guidance=guidance_cfg(meta), n_rolls=None if meta["n_rolls"] < 0 else meta["n_rolls"],
                 refinenet=bool(meta["refinenet"]), diverse=bool(meta["diverse"]), clip_rect=bool(meta["clip_rect"]),
-                use_rect=bool(meta["use_rect"]))
+                use_rect=bool(meta["use_rect"]), refinement_iters=meta.get("refinement") or None)
 
 
 SAMPLING_CASES = ["e5_steps10", "e5_steps100", "e7_steps12", "e7_steps50_k8", "e7_damped", "e7_wide", "e7_guid",
                   "e7_guid_n2_rolls", "e5_guid_all", "sim_maximize", "sim_maximize_b",
                   "fl_e8_clip_rect", "fl_no_arch", "fl_no_refinenet", "fl_not_use_rect", "fl_guid_sets", "fl_guid_freq_rev", "e7_s64_guid", "e7_guid_c4"]
 STL_CASES = ["stl_mixed", "stl_mixed_k8", "stl_wild"]
+REFINEMENT_CASES = ["e7_refinement", "e7_refinement_b"]
+
+
+def refinement_gate(mine, grads, d, tol=1e-4, min_frac=0.8):
+    """--refinement runs 50 Adam steps (lr 0.3) on eight mixing weights per row through a score with hard minima in it
+    (closest neighbour, closest circle pair, closest lane segment): a last-bit difference that flips one of those minima
+    changes the gradient's direction, and with steps of 0.3 the two runs part ways for good -- the CPU oracle, which agrees
+    with the reference BIT FOR BIT on most rows, is 0.2 away on a few.  So the gate is on the mechanism and on the
+    population:  (1) the first gradient (no history) matches everywhere; (2) the gradients of iterations 1..19 match on
+    >= 95 % of the rows (observed on the GPU: all rows through iteration 19, 76-98 % at iteration 49); (3) rows the
+    reference left untouched are untouched; (4) >= min_frac of the rows end within `tol` of the reference (the callers add:
+    the refined batch reaches the reference's loss).  mine (N,20,2); grads (>= 20, N, 8) = d loss / d lambda per iteration."""
+    want, g_ref = d["refinement_controls"], d["refinement_grads"]
+    N = want.shape[0]
+    g = np.asarray(grads)
+    np.testing.assert_allclose(g[0], g_ref[0], rtol=2e-3, atol=2e-6 * np.abs(g_ref[0]).max())
+    for it in range(1, 20):
+        sc = np.abs(g_ref[it]).max(axis=1, keepdims=True) + 1e-30
+        row_ok = (np.abs(g[it] - g_ref[it]) <= 5e-3 * sc + 1e-9).all(axis=1)
+        assert row_ok.mean() >= 0.95, "iteration %d: gradients agree on %.3f of the rows" % (it, row_ok.mean())
+    mine = np.asarray(mine)
+    untouched = np.abs(want - d["refinement_in_controls"]).reshape(N, -1).max(axis=1) == 0
+    np.testing.assert_array_equal(mine[untouched], want[untouched])
+    ok = np.abs(mine - want).reshape(N, -1).max(axis=1) <= tol
+    assert ok.mean() >= min_frac, "rows within %g of the reference: %.3f" % (tol, ok.mean())
+    return ok
 
 
 def guided_outlier_rows(err_all, d, meta, tol=1e-4, g_eps=1e-6, n_shards=4):

@@ -152,6 +152,7 @@ def sampling_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=
                               int(not args.not_use_rect), int(args.guidance_reverse),
                               -1 if args.guidance_freq is None else args.guidance_freq], dtype=np.int64)
     out["guid_sets"] = np.array(args.guidance_sets if args.guidance_sets is not None else [], dtype=np.int64)
+    out["meta_refinement"] = np.array([50 if args.refinement else 0], dtype=np.int64)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print("%-28s N=%d acc=%.4f scene_acc=%.4f sat=%d/%d -> %s (%.1f KB)" % (
@@ -235,7 +236,7 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided", "--refinement-case")):
     main()
 
 
@@ -600,6 +601,125 @@ def main_baseline_shape():
 
 if __name__ == "__main__" and "--baseline-shape" in sys.argv:
     main_baseline_shape()
+
+
+def harness_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=0.0, stlp_mode="loose"):
+    """A fixture recorded from the reference's OWN harness: nusc_train.run_sampling_test is called on a one-batch loader
+    and taps on the functions it calls record what passes through (the noise draws, the rollout's list, RefineNet's
+    output, every generate_trajs input, every gradient torch.optim.Adam consumes, the final scores).  Used for the parts of
+    the harness that are inline code there and cannot be called on their own: --refinement (nusc_train.py:1034-1071)."""
+    nt = ref.nusc_train
+    argv = list(argv) + ["--diffusion_steps", str(steps), "--sampling_size", str(S), "--n_randoms", str(S),
+                         "--n_neighbors", str(K), "--test", "--run_sampling_test", "--n_trials", "0"]
+    args = ref_harness.parse_reference_args(argv)
+    net = load_net(ref, args, sd)
+    coeffs = nt.get_diffusion_coeffs(args)
+    stls = nt.build_stl_cache(args)
+    batch = make_scene_batch(bs, K=K, S=S, seed=seed, invalid_lane_frac=invalid_lane_frac, stlp_mode=stlp_mode)
+    N = bs * S * 3
+    rec = {"trajs_in": [], "aug": [], "rollout": [], "rect": [], "stl": []}
+    orig = dict(gt=nt.generate_trajs, aug=nt.augment_batch_data, ro=nt.diffusion_rollout, stl=nt.compute_stl_dense,
+                rf=net.rect_forward)
+
+    def tap_gt(s, us, dt, *a, **k):
+        rec["trajs_in"].append(us.detach().clone())
+        return orig["gt"](s, us, dt, *a, **k)
+
+    def tap_aug(*a, **k):
+        o = orig["aug"](*a, **k)
+        rec["aug"].append({kk: v.detach().clone() for kk, v in o.items() if isinstance(v, torch.Tensor)})
+        return o
+
+    def tap_ro(*a, **k):
+        o = orig["ro"](*a, **k)
+        rec["rollout"].append(o)
+        return o
+
+    def tap_stl(*a, **k):
+        o = orig["stl"](*a, **k)
+        rec["stl"].append(o)
+        return o
+
+    def tap_rf(*a, **k):
+        o = orig["rf"](*a, **k)
+        rec["rect"].append(o.detach().clone())
+        return o
+
+    nt.generate_trajs, nt.augment_batch_data, nt.diffusion_rollout, nt.compute_stl_dense = tap_gt, tap_aug, tap_ro, tap_stl
+    net.rect_forward = tap_rf
+    draws, grads = [], []
+    torch.manual_seed(seed + 17)
+
+    class _BatchDone(Exception):
+        pass
+
+    class _NoDevkit:        # behind the timed region the harness waits for the nuScenes devkit to draw figures: stop there
+        def join(self):
+            raise _BatchDone()
+
+    try:
+        with ref_harness.record_randn_like(draws), ref_harness.record_adam_grads(grads):
+            try:
+                nt.run_sampling_test(stls, [dict(batch)], net, coeffs, args, None, _NoDevkit())
+            except _BatchDone:
+                pass
+    finally:
+        nt.generate_trajs, nt.augment_batch_data, nt.diffusion_rollout, nt.compute_stl_dense = (
+            orig["gt"], orig["aug"], orig["ro"], orig["stl"])
+        net.rect_forward = orig["rf"]
+    controls, feature, clist = rec["rollout"][0]
+    E = steps - 1
+    assert len(draws) == 1 + (E - 1) and len(rec["aug"]) == 2 and len(rec["rect"]) == 1 and len(grads) == 50
+    nb = rec["aug"][1]                                   # the harness's second augment call: sampling_size rows
+    out = {"x_T": np_(draws[0]), "z": np_(torch.stack(draws[1:] + [torch.zeros_like(draws[0])], dim=0)),
+           "controls_list": np_(torch.stack(clist, dim=0)), "feature_scene": np_(feature.reshape(bs, S * 3, -1)[:, 0]),
+           "rect_controls": np_(rec["rect"][0]),
+           # generate_trajs calls of the refinement block: its input, its 50 iterates, then the harness's final rollout
+           "refinement_in_controls": np_(rec["trajs_in"][-52]), "refinement_controls": np_(rec["trajs_in"][-1]),
+           "refinement_grads": np_(torch.stack(grads, dim=0))}
+    assert torch.equal(rec["trajs_in"][-1], rec["trajs_in"][-2]) and torch.equal(rec["trajs_in"][-52], rec["rect"][0])
+    scores_list, scores, acc, scene_acc = rec["stl"][-1]
+    out["final_controls"] = out["refinement_controls"]
+    out["final_scores"] = np_(scores)
+    out["final_scores3"] = np_(torch.stack(scores_list[:3], dim=0))
+    out["final_acc"], out["final_scene_acc"] = np.float32(acc.item()), np.float32(scene_acc.item())
+    out["refinement_in_scores"] = np_(rec["stl"][-52][1])
+    for k in ["ego_traj", "neighbors", "neighbors_traj", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
+              "curr_id", "left_id", "right_id", "stlp_modes"]:
+        out["in_" + k] = np_(batch[k])
+    out["in_stlp_rows"] = np_(nb["stlp_dense"]).reshape(N, 6)     # from the harness's own infer_gt_stlp, not stlp_modes
+    out["in_valids_dense"] = np_(nb["valids_dense"])
+    out["in_highlevel_dense"] = np_(nb["highlevel_dense"])
+    out["meta"] = np.array([bs, S, K, steps, seed, int(args.rect_head), int(args.guidance),
+                            -1 if args.multi_cands is None else args.multi_cands, int(args.diffusion_clip), 0,
+                            args.guidance_before, args.guidance_niters, -1 if args.n_rolls is None else args.n_rolls, 0, 0],
+                           dtype=np.int64)
+    out["meta_f"] = np.array([args.guidance_lr, args.stl_nn_thres, args.smoothing_factor], dtype=np.float64)
+    out["meta_x"] = np.array([int(args.diverse_loss and not args.no_arch), int(args.clip_rect), int(not args.no_refinenet),
+                              int(not args.not_use_rect), int(args.guidance_reverse),
+                              -1 if args.guidance_freq is None else args.guidance_freq], dtype=np.int64)
+    out["guid_sets"] = np.array([], dtype=np.int64)
+    out["meta_refinement"] = np.array([50], dtype=np.int64)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    moved = (rec["trajs_in"][-1] - rec["trajs_in"][-52]).abs().reshape(N, -1).max(dim=1)[0]
+    print("%-28s N=%d acc=%.4f (before refinement: %d rows with score <= 0; %d rows moved) -> %s (%.1f KB)" % (
+        name, N, acc.item(), int((rec["stl"][-52][1] <= 0).sum()), int((moved > 0).sum()), os.path.basename(path),
+        os.path.getsize(path) / 1024))
+
+
+def main_refinement():
+    """--refinement (nusc_train.py:1034-1071): needs the 100-entry list of the default --diffusion_steps (its k_d_list reads
+    entry 98)."""
+    ref = ref_harness.load_reference()
+    sd = dict(np.load(WEIGHTS_FILE))
+    e7 = ["--diffusion", "--load_stlp", "--rect_head", "--flex", "--diverse_loss", "--multi_cands", "5", "--refinement"]
+    harness_case(ref, sd, "e7_refinement", e7, bs=2, S=16, K=3, steps=100, seed=91, stlp_mode="wide", invalid_lane_frac=0.25)
+    harness_case(ref, sd, "e7_refinement_b", e7, bs=3, S=8, K=2, steps=100, seed=92)
+
+
+if __name__ == "__main__" and "--refinement-case" in sys.argv:
+    main_refinement()
 
 
 def main_regen_guided():

@@ -3,8 +3,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (SAMPLING_CASES, STL_CASES, golden_meta, golden_weights, guided_outlier_rows, load_golden,
-                      region_kwargs, scene_from_golden)
+from conftest import (REFINEMENT_CASES, SAMPLING_CASES, STL_CASES, golden_meta, golden_weights, guided_outlier_rows,
+                      load_golden, refinement_gate, region_kwargs, scene_from_golden)
 from oracle import pstl_oracle as orc
 from pstl_diffusion_policy_amd.synthetic import default_hparams
 
@@ -94,3 +94,26 @@ def test_stl_scores_and_gradients_match_reference(name):
     for mine, ref in [(g_loss, d["grad_loss"]), (g_sum, d["grad_sum"])]:
         scale = np.abs(ref).max() + 1e-30
         np.testing.assert_allclose(mine.numpy() / scale, ref / scale, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", REFINEMENT_CASES)
+def test_refinement_matches_the_reference_harness(name):
+    """--refinement (nusc_train.py:1034-1071) against fixtures recorded from the reference's own run_sampling_test: first
+    the block alone, fed with the reference's own input controls and list; then the whole region."""
+    d = load_golden(name)
+    meta = golden_meta(d)
+    hp = default_hparams()
+    rows = orc.Rows(scene_from_golden(d), meta["S"], hp)
+    np.testing.assert_array_equal(rows.valid.numpy(), d["in_valids_dense"].reshape(-1))
+    clist = [torch.from_numpy(c) for c in d["controls_list"]]
+    rec = []
+    got = orc.refinement(rows, torch.from_numpy(d["refinement_in_controls"]), clist, iters=meta["refinement"], record=rec)
+    refinement_gate(got.numpy(), [r.numpy() for r in rec], d, tol=2e-5, min_frac=0.85)   # (same torch ops as the reference)
+    out = orc.sampling_region(_weights_for(meta), scene_from_golden(d), meta["S"], meta["steps"], hp, d["x_T"], d["z"],
+                              **region_kwargs(meta))
+    np.testing.assert_allclose(out["controls_list"].numpy(), d["controls_list"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(out["rect_controls"].numpy(), d["rect_controls"], rtol=0, atol=2e-5)
+    ok = np.abs(out["refinement_controls"].numpy() - d["refinement_controls"]).reshape(rows.N, -1).max(axis=1) <= 1e-4
+    assert ok.mean() >= 0.8, ok.mean()
+    np.testing.assert_allclose(out["final_scores"].numpy()[ok], d["final_scores"][ok], rtol=1e-4, atol=2e-3)
+    assert abs(float(out["final_acc"]) - float(d["final_acc"])) <= 0.03
