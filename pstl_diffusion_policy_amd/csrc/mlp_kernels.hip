@@ -458,41 +458,12 @@ __device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, PV& hi, P
   }
 }
 
-// PSTL_MIXSPLIT: the half pieces of the split-f16 form come from v_fma_mixlo/hi_f16 (an fp32 fma whose result is rounded to
-// half and written to one half of a register): hi = f16(a * k), lo = f16(a * k - hi) -- three instructions per value
-// with the ReLU, no packed-fp32 operation (expensive beside MFMAs, MI355X_MICROARCH.md) and no separate rescaling.
-// Same bits as the conversion form: a * k is exact (k a power of two), the fma rounds once.
-#ifndef PSTL_MIXSPLIT
-#define PSTL_MIXSPLIT 1
-#endif
 // PSTL_XSPLIT_ONCE: the pieces of a tile's layer-1 input are made once per tile-step by two waves with slack (3 and 7)
 // and handed over through LDS, instead of by all eight waves (44 of a wave's ~135 vector instructions per tile-step).
 #ifndef PSTL_XSPLIT_ONCE
 #define PSTL_XSPLIT_ONCE 1
 #endif
 
-
-__device__ __forceinline__ void mix_split2(float a0, float a1, float k, unsigned& hi, unsigned& lo) {
-  unsigned h, l;   // (the first instruction of each pair leaves the upper half as it finds it; the second one writes it)
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(a0), "s"(k));
-  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(a1), "s"(k));
-  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a0), "s"(k), "v"(h));
-  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(a1), "s"(k), "v"(h));
-  hi = h;
-  lo = l;
-}
-
-// eight fp32 values times k -> half pieces (hi[0..3] from u, hi[4..7] from v)
-__device__ __forceinline__ void split8_mix(const f32x4& u, const f32x4& v, float k, f16x8& hi, f16x8& lo) {
-  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-  mix_split2(u[0], u[1], k, h0, l0);
-  mix_split2(u[2], u[3], k, h1, l1);
-  mix_split2(v[0], v[1], k, h2, l2);
-  mix_split2(v[2], v[3], k, h3, l3);
-  hi = __builtin_bit_cast(f16x8, u32x4{h0, h1, h2, h3});
-  lo = __builtin_bit_cast(f16x8, u32x4{l0, l1, l2, l3});
-}
-__device__ __forceinline__ void split8_mix(const f32x4&, const f32x4&, float, bf16x8&, bf16x8&) {}   // never called
 
 // A value the optimiser must take as it comes at this point of the loop: stops it from hoisting `uniform pointer +
 // lane offset` out of the tile-step loop as a per-lane 64-bit pointer (five of those were live across the loop, spilled,
@@ -627,14 +598,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
   }
 
+  // CONT (single-step launches of the split kernels, PERSIST): the workgroup's groups blockIdx.x, blockIdx.x + gridDim.x,
+  // ... are ONE stream of tile-steps through the software pipeline -- no drain, prologue and refill between groups (7 of
+  // the 31 us a group took).  A position's `n` then counts the rounds (groups), not reverse steps; the image slot of a
+  // finished tile is refilled with the same tile of the next round by LDS-DMA (stage_x) two iterations after its
+  // epilogue, >= 3 iterations before the splitter waves read it (tiles_per_group >= 8).
+  const bool cont = PERSIST && XONCE && !REFINE && a.tiles_per_group >= 8 &&
+                    !(a.n_emit >= a.steps && a.step_hi == a.steps - 1);
   for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {   // one pass unless PERSIST (gridDim.x == n_groups)
   if (PERSIST && grp != blockIdx.x) __syncthreads();   // the previous group's last epilogue has left xs / part
   const long tile0 = grp * a.tiles_per_group;
+  auto t0 = [&](int n) { return cont ? ((long)blockIdx.x + (long)n * gridDim.x) * a.tiles_per_group : tile0; };
   int G = (int)((n_tiles - tile0) < a.tiles_per_group ? (n_tiles - tile0) : a.tiles_per_group);
   // Layer 1 runs two tile-steps ahead and the epilogue one behind, so >= 4 tiles must be in flight (see the hazard
   // notes below); short tail blocks process phantom tiles whose rows are clamped on load and masked on store.
   // (XONCE: the pieces of a tile's image are made one more iteration ahead: >= 5.)
   if (G < (XONCE ? 5 : 4)) G = XONCE ? 5 : 4;
+  if (cont) G = a.tiles_per_group;   // every round walks all slots; tiles past the end are phantoms
   // ---- per-row constants and the initial state into the B-operand image ----
   // Four consecutive input columns k = 4j .. 4j+3 of one tile column sit in one 16-byte LDS slot of the B-operand image,
   // so a row is moved as 12 quads: 10 straight from the 160-byte state row (16-byte global loads), 2 assembled from
@@ -664,7 +644,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       const float* sp = a.stlp + row * 6;
       v = f32x4{sp[3], sp[4], sp[5], 0.0f};
     }
-    *reinterpret_cast<f32x4*>(xs + tl * 768 + xs_addr(4 * j, c)) = v * kSX;
+    *reinterpret_cast<f32x4*>(xs + tl * 768 + xs_addr(4 * j, c)) = v;   // (unscaled: the split-f16 factor kSX is applied where the pieces are made)
   }
   if (!REFINE && a.n_emit >= a.steps && a.step_hi == a.steps - 1) {  // x_T itself is entry 0 of the full list
     for (int e = tid; e < G * kTileRows * kCtrl; e += NT) {
@@ -679,7 +659,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
   }
   const int s_hi = REFINE ? 1 : a.step_hi, s_lo = REFINE ? 1 : a.step_lo;
-  const int total = (s_hi - s_lo + 1) * G;  // tile-steps of this workgroup; tile-step `it` = (step s_hi - it/G, tile it%G)
+  // tile-steps of this workgroup; tile-step `it` = (step s_hi - it/G, tile it%G); CONT: (round it/G, tile it%G) of step s_hi
+  const int rounds = (int)((n_groups - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  const int total = cont ? rounds * G : (s_hi - s_lo + 1) * G;
+  auto step_of = [&](int n) { return cont ? s_hi : s_hi - n; };
+  auto coef_of = [&](int n) { return cont ? 0 : n; };
 
   // ---- layer 1 of tile-step `it`: 48 -> 256, result (after ReLU) into h1[it % 3] --------------------------------
   // It is issued two iterations before layer 2 consumes it, at the START of an iteration: its LDS write has long
@@ -706,8 +690,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     return p;
   };
   auto stage_cst = [&](Pos p, int slot3) {
-    const int tl = p.tl, i = s_hi - p.n;
-    long row = (tile0 + tl) * kTileRows;
+    const int tl = p.tl, i = step_of(p.n);
+    long row = (t0(p.n) + tl) * kTileRows;
     if (row >= a.N) row = a.N - 1;
     float* dst = crow + slot3 * 512;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -720,10 +704,36 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       __builtin_amdgcn_global_load_lds((glb_ptr)((a.tbias + (long)i * kHid) + lo4), (lds_ptr)(dst + 256), 16, 0, 0);
   };
 
+  // CONT: the input image of the tile at position p (its 16 rows of x, hl | stlp) straight from global memory into its
+  // LDS slot by direct-to-LDS loads (no registers), issued by the stager wave.  The image is three 1 KB blocks
+  // [q][lane = g*16 + c][4 floats] holding columns 4 (4q + g) .. +3 of row c: blocks 0, 1 and the lower half of block 2
+  // are 16-byte pieces of the state rows; columns 40..43 = hl | stlp[0..2] and 44..46 = stlp[3..5] are gathered word by
+  // word (the last word of the image, column 47, stays the zero the prologue wrote).
+  auto stage_x = [&](Pos p) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const long row0 = (t0(p.n) + p.tl) * kTileRows;
+    float* dst = xs + p.tl * 768;
+    const unsigned ln = here((unsigned)lane);
+    const unsigned gq = ln >> 4, c16 = ln & 15;
+    long r = row0 + c16;
+    if (r >= a.N) r = a.N - 1;
+    const float* xrow = a.x_inout + r * kCtrl + 4 * gq;
+    __builtin_amdgcn_global_load_lds((glb_ptr)xrow, (lds_ptr)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(xrow + 16), (lds_ptr)(dst + 256), 16, 0, 0);
+    if (gq < 2) __builtin_amdgcn_global_load_lds((glb_ptr)(xrow + 32), (lds_ptr)(dst + 512), 16, 0, 0);
+    const unsigned c4 = ln >> 2, e4 = ln & 3;
+    long r4 = row0 + c4;
+    if (r4 >= a.N) r4 = a.N - 1;
+    const float* w0 = e4 == 0 ? a.hl + r4 : a.stlp + r4 * 6 + (e4 - 1);
+    __builtin_amdgcn_global_load_lds((glb_ptr)w0, (lds_ptr)(dst + 512 + 128), 4, 0, 0);
+    if (e4 < 3) __builtin_amdgcn_global_load_lds((glb_ptr)(a.stlp + r4 * 6 + 3 + e4), (lds_ptr)(dst + 512 + 192), 4, 0, 0);
+  };
+
   // the scene/timestep constant part of layer 1's pre-activation for this lane's 4*OT outputs
   auto l1_const = [&](Pos p, int buf, f32x4 (&cst)[OT]) {
     const int tl = p.tl;
-    int i = s_hi - p.n;
+    int i = step_of(p.n);
     if (i < 0) i = 0;   // a tile-step past the end of the launch (computed and discarded by the fused split-bf16 loop)
     if (UT) {
       const f32x4* cb = reinterpret_cast<const f32x4*>(crow + buf * 512);
@@ -734,7 +744,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         if (F16) cst[ot] *= kAcc;
       }
     } else {
-      long rowc = (tile0 + tl) * kTileRows + col;
+      long rowc = (t0(p.n) + tl) * kTileRows + col;
       if (rowc >= a.N) rowc = a.N - 1;
       const float* bp = a.base + (rowc / a.rows_per_scene) * kHid;
 #pragma unroll
@@ -749,13 +759,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 
   // a hidden layer's output as the next layer's input: relu, (F16) the accumulator's weight factor divided out, pieces
   auto split_hidden = [&](const f32x4& a0, const f32x4& a1, pv8& hi, pv8& lo) {
-    if constexpr (F16 && PSTL_MIXSPLIT) {
-      split8_mix(relu4(a0), relu4(a1), kInvSW, hi, lo);
-    } else {
-      f32x4 h0 = relu4(a0), h1v = relu4(a1);
-      if (F16) h0 *= kInvSW, h1v *= kInvSW;
-      split8(h0, h1v, hi, lo);
-    }
+    f32x4 h0 = relu4(a0), h1v = relu4(a1);
+    if (F16) h0 *= kInvSW, h1v *= kInvSW;
+    split8(h0, h1v, hi, lo);
   };
   auto layer1 = [&](Pos p, int buf) {   // buf = tile-step index mod 3: the h1 buffer written and the crow slot read
     const int tl = p.tl;
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         const f32x4 x0 = xb[2 * kb * 64];
         const f32x4 x1 = kb == 0 ? xb[64] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         pv8 bh, bl;
-        split8(x0, x1, bh, bl);
+        split8(x0 * kSX, x1 * kSX, bh, bl);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w1h[ot][kb], bh, acc[ot]);
 #pragma unroll
@@ -805,7 +811,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       const f32x4 hv = relu4(acc[ot] + cst[ot]);
       hw[(w * OT + ot) * 64 + lane] = hv;
       if (REFINE && a.h1_save) {
-        const long row = (tile0 + tl) * kTileRows + col;
+        const long row = (t0(p.n) + tl) * kTileRows + col;
         if (row < a.N) *reinterpret_cast<f32x4*>(a.h1_save + row * kHid + 16 * (w * OT + ot) + 4 * g) = hv;
       }
     }
@@ -816,11 +822,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // it + 2, after another barrier) and rewrites xs[tile], which layer1 reads again G - 3 iterations later -- at least
   // one barrier later as long as G >= 4.
   auto epilogue = [&](Pos p, int par, const f32x4& z4) {   // par = tile-step index & 1
-    const int tl = p.tl, i = s_hi - p.n;
-    const long row0 = (tile0 + tl) * kTileRows;
+    const int tl = p.tl, i = step_of(p.n);
+    const long row0 = (t0(p.n) + tl) * kTileRows;
     float c1 = 0.0f, inv_sa = 0.0f, sbeta = 0.0f;
     if (!REFINE) {
-      const f32x4 cf = reinterpret_cast<const f32x4*>(coef)[p.n];
+      const f32x4 cf = reinterpret_cast<const f32x4*>(coef)[coef_of(p.n)];
       c1 = cf.x;
       inv_sa = cf.y;
       sbeta = cf.z;
@@ -851,11 +857,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       const f32x4 sc = f32x4{a.w_max, a.a_max, a.w_max, a.a_max};
       if (!REFINE) {
         f32x4* xp = reinterpret_cast<f32x4*>(xs + tl * 768) + j * 64 + slot;
-        const f32x4 x = F16 ? *xp * kInvSX : *xp;
+        const f32x4 x = *xp;
         const f32x4 eps = o + x;
         const f32x4 mu = inv_sa * (x - c1 * eps);
         const f32x4 xn = a.mu_only == 2 ? eps : a.mu_only ? mu : mu + sbeta * z4;
-        *xp = F16 ? xn * kSX : xn;
+        if (!cont) *xp = xn;   // (CONT: one reverse step per launch, the slot is refilled from the next round's rows)
         if (row < a.N) {
           if (i == s_lo) *reinterpret_cast<f32x4*>((a.x_inout + row0 * kCtrl) + loff) = xn;
           if (i <= a.n_emit && !a.mu_only) {
@@ -893,10 +899,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     const int et = (int)here((unsigned)et_);
     z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (REFINE || (!a.noise && !a.rng) || a.mu_only) return;
-    const int tl = p.tl, i = s_hi - p.n;
+    const int tl = p.tl, i = step_of(p.n);
     if (i <= 1) return;  // the reference adds zeros at the last step
     if (et < 160) {
-      const long row0 = (tile0 + tl) * kTileRows;
+      const long row0 = (t0(p.n) + tl) * kTileRows;
       const long row = row0 + (et & 15);
       if (row < a.N) {
         if (a.rng) {
@@ -925,20 +931,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       pv8 ph, pl;
       if (w == 7) {
         const f32x4 q0 = xb[0], q1 = xb[64];
-        if constexpr (F16 && PSTL_MIXSPLIT) split8_mix(q0, q1, 1.0f, ph, pl);
-        else split8(q0, q1, ph, pl);
+        split8(q0 * kSX, q1 * kSX, ph, pl);
         dst[0] = __builtin_bit_cast(u32x4, ph);
         dst[64] = __builtin_bit_cast(u32x4, pl);
       } else {
         const f32x4 q2 = xb[128], zero = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if constexpr (F16 && PSTL_MIXSPLIT) split8_mix(q2, zero, 1.0f, ph, pl);
-        else split8(q2, zero, ph, pl);
+        split8(q2 * kSX, zero, ph, pl);
         dst[128] = __builtin_bit_cast(u32x4, ph);
         dst[192] = __builtin_bit_cast(u32x4, pl);
       }
     }
   };
 
+  Pos pm2{0, 0};                             // tile-step it - 2 (CONT: its slot is refilled now)
   Pos pm1{0, 0}, p0{0, 0};                   // tile-steps it - 1, it, it + 1, it + 2, it + 3
   Pos p1 = next_pos(p0), p2 = next_pos(p1), p3 = next_pos(p2);
   if (UT && w == kStager) {
@@ -985,6 +990,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   for (int it = 0; it < total; ++it) {
     PSTL_STAMP(0)
     if (UT && w == kStager && it + 3 < total) stage_cst(p3, hbuf);
+    if (cont && w == kStager && it >= 2 && it - 2 + G < total) stage_x(Pos{pm2.tl, pm2.n + 1});
     split_x(p3, (it + 1) & 1);      // pieces for the layer 1 woven into iteration it + 1
     if (NOISE_SPLIT && (ABL == 0 || ABL == 7)) {
       if (w >= NW / 2 && w < NW / 2 + NCW && !woven_noise) {
@@ -1008,7 +1014,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     if (ABL == 5 && w >= NW / 2) {  // solo-rate probe: one wave per SIMD issues MFMAs, its partner only joins barriers
       __syncthreads();
       hbuf = hbuf == 2 ? 0 : hbuf + 1;
-      pm1 = p0, p0 = p1, p1 = p2, p2 = p3, p3 = next_pos(p3);
+      pm2 = pm1, pm1 = p0, p0 = p1, p1 = p2, p2 = p3, p3 = next_pos(p3);
       continue;
     }
     PSTL_STAMP(1)
@@ -1067,8 +1073,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           if (kb == 0) x0h = __builtin_bit_cast(pv8, xq0h), x0l = __builtin_bit_cast(pv8, xq0l);
           if (kb == 1) x1h = __builtin_bit_cast(pv8, xq1h), x1l = __builtin_bit_cast(pv8, xq1l);
         } else {
-          if (kb == 0) split8(xa, xc, x0h, x0l);
-          if (kb == 1) split8(xe, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, x1h, x1l);
+          if (kb == 0) split8(xa * kSX, xc * kSX, x0h, x0l);
+          if (kb == 1) split8(xe * kSX, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, x1h, x1l);
         }
         if (kb == 2 || kb == 3) {
           const pv8 vh = kb == 2 ? x0h : x1h, vl = kb == 2 ? x0l : x1l;
@@ -1083,9 +1089,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         if (kb == 5) split_hidden(a1[0], a1[OT - 1], hh, hl2);   // layer 1's output, in the shadow of layer 2's MFMAs
         if (NOISE && kb == 6) {   // this wave's share of the noise of tile-step it (rows past N and the quads 10, 11 are never read)
           const int nt = tid - NT / 2;
-          const int i = s_hi - p0.n;
+          const int i = step_of(p0.n);
           float z[4];
-          normal4(a.seed, a.row_offset + (tile0 + p0.tl) * kTileRows + (nt & 15), nt >> 4, i, z);
+          normal4(a.seed, a.row_offset + (t0(p0.n) + p0.tl) * kTileRows + (nt & 15), nt >> 4, i, z);
           zv = i > 1 ? f32x4{z[0], z[1], z[2], z[3]} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
         ch = nh;
@@ -1190,12 +1196,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     PSTL_STAMP(5)
     PSTL_STAMP_FLUSH()
     hbuf = hbuf == 2 ? 0 : hbuf + 1;
-    pm1 = p0, p0 = p1, p1 = p2, p2 = p3, p3 = next_pos(p3);
+    pm2 = pm1, pm1 = p0, p0 = p1, p1 = p2, p2 = p3, p3 = next_pos(p3);
   }
   if (NOISE_SPLIT && epi_wave && tid < 160) zreg = zbuf[((total - 1) & 1) * 192 + tid];
   if (epi_wave && (ABL == 0 || ABL == 7)) epilogue(pm1, (total - 1) & 1, zreg);
   if (ABL != 0 && a.N < 0) epilogue(p0, 0, zreg);  // keep the code reachable for the compiler, never executed
-  if (!PERSIST) break;
+  if (!PERSIST || cont) break;
   }
 }
 

@@ -331,6 +331,14 @@ def test_full_size_properties(dev):
         assert torch.equal(part["final_scores"], full["final_scores"][r0:r1])
         total += part["counts"]
     assert torch.equal(total, full["counts"])
+    # a shard small enough for 5-tile workgroups: its single-step (guided) denoiser launches walk their groups one by one,
+    # while the full batch streams them through the pipeline without draining (CONT, mlp_kernels.hip) -- same bits
+    lo, hi = 1000, 1064
+    sub = {k: v[lo:hi].contiguous() for k, v in scene.items()}
+    part = sm.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=lo * S * 3, global_valid_sum=vsum, global_rows=N),
+                              steps, None, None, rect_head=True, multi_cands=5, guidance=guid, seed=seed, want_scores3=False)
+    assert torch.equal(part["final_controls"], full["final_controls"][lo * S * 3:hi * S * 3])
+    assert torch.equal(part["final_scores"], full["final_scores"][lo * S * 3:hi * S * 3])
     acc, sacc = acc_from_counts(full["counts"])
     assert 0.0 < acc < 1.0 and 0.0 < sacc <= 1.0
 
