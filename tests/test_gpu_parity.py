@@ -343,6 +343,41 @@ def test_full_size_properties(dev):
     assert 0.0 < acc < 1.0 and 0.0 < sacc <= 1.0
 
 
+@pytest.mark.parametrize("noise", ["kernel", "tensor"])
+def test_streamed_single_step_launches_equal_the_grouped_ones(dev, noise):
+    """Single-step denoiser launches of a large batch stream their 12-tile groups through the pipeline without draining
+    (CONT, mlp_kernels.hip); a small batch walks 5-tile groups one by one.  With guidance on every other step all launches
+    are single steps -- guided ones (mu only) and plain ones (noise drawn in the kernel or read from the caller's tensor,
+    candidates emitted by the chain's epilogue): every shard evaluated alone must reproduce the rows of the whole batch
+    bit for bit."""
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    bs, S, K, steps, seed = 256, 64, 3, 14, 11
+    scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=K, S=S, seed=9, invalid_lane_frac=0.2, stlp_mode="wide").items()
+             if k not in ("params", "pre_stlp", "tj_scores_prior")}
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    guid = dict(enabled=True, freq=2, niters=1, lr=0.01)
+    sb = SceneBatch(scene, S, hp, dev)
+    N = sb.N
+    g = torch.Generator(device=dev).manual_seed(3)
+    x_T = torch.randn(N, 40, device=dev, generator=g) if noise == "tensor" else None
+    z = torch.randn(steps - 1, N, 40, device=dev, generator=g) if noise == "tensor" else None
+    kw = dict(rect_head=True, multi_cands=5, guidance=guid, want_scores3=False, seed=seed if noise == "kernel" else None)
+    full = sm.sampling_region(sb, steps, x_T, z, **kw)
+    vsum = float(sb.valid.sum())
+    for lo in (0, 96, 224):
+        hi = lo + 32
+        sub = {k: v[lo:hi].contiguous() for k, v in scene.items()}
+        r0, r1 = lo * S * 3, hi * S * 3
+        part = sm.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=r0, global_valid_sum=vsum, global_rows=N), steps,
+                                  None if x_T is None else x_T[r0:r1].contiguous(),
+                                  None if z is None else z[:, r0:r1].contiguous(), **kw)
+        for k in ("final_controls", "final_scores", "sel_controls", "cand_scores"):
+            a, b = part[k], (full[k][:, r0:r1] if k == "cand_scores" else full[k][r0:r1])
+            assert torch.equal(a, b), k
+
+
 def test_stl_masks_at_scale_match_reference(dev):
     """6144 rows (32 scenes x the reference's sampling_size 64 x 3 modes; LDS-staged scene tables): the three formula
     scores and the satisfaction mask against the reference's own compute_stl_dense, plus the loss gradient."""
