@@ -25,11 +25,6 @@
 #include "pstl_common.hpp"
 #include "rng.hpp"
 
-// PSTL_EXP != 0: timing-only builds of the split-bf16 loop (wrong results; tools/dbg/build_variants.sh): 1 = layer 2
-// issues its MFMAs for the first k-block only, 2 = no barrier, 3 = no LDS reads inside layer 2's loop
-#ifndef PSTL_EXP
-#define PSTL_EXP 0
-#endif
 
 namespace pstl {
 namespace {
@@ -458,11 +453,6 @@ __device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, PV& hi, P
   }
 }
 
-// PSTL_XSPLIT_ONCE: the pieces of a tile's layer-1 input are made once per tile-step by two waves with slack (3 and 7)
-// and handed over through LDS, instead of by all eight waves (44 of a wave's ~135 vector instructions per tile-step).
-#ifndef PSTL_XSPLIT_ONCE
-#define PSTL_XSPLIT_ONCE 1
-#endif
 
 
 // A value the optimiser must take as it comes at this point of the loop: stops it from hoisting `uniform pointer +
@@ -486,19 +476,17 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // LDS address (in floats) of activation element k (0..47) of tile column c in the B-operand image [q][lane][r]
 __device__ __forceinline__ int xs_addr(int k, int c) { return (((k >> 4) * 64) + (((k >> 2) & 3) * 16 + c)) * 4 + (k & 3); }
 
-// ABL != 0 are timing-only ablation builds (wrong results by construction; selected with cfg->chain_waves = 8 + 100*ABL
-// and used only to attribute the kernel's time): 1 = no epilogue, 2 = also no layer 1, 3 = also no barrier,
-// 5 = no epilogue and only waves 0..NW/2-1 issue MFMAs (what one wave per SIMD sustains alone),
-// 7 = full kernel with s_memtime stamps of workgroup 7, iterations 64..95, every wave, written as 64-bit ticks to the
-//     buffer passed as emit_out (n_emit must be 0): [it-64][wave][slot], slots 0 start, 1 after epilogue, 2 after
-//     layer 1, 3 after layer 2, 4 after layer 3 + partial-sum write, 5 after the barrier.
+// ABL != 0 are timing-only diagnostic builds (selected with cfg->chain_waves = 8 | 16 + 100*ABL, used only to attribute
+// the kernel's time): 1 = no epilogue and no noise (wrong results by construction), 7 = the full kernel with s_memtime
+// stamps of workgroup 7, iterations 64..95, every wave, written as 64-bit cycle counts to the buffer passed as emit_out
+// (n_emit must be 0): [it-64][wave][slot] (tools/dbg/chain_stamps.py names the slots).
 //
-// BF: the three layers run on v_mfma_f32_16x16x32_bf16 with every fp32 operand split into two bf16 pieces
-// (x = hi + lo): W.X ~ Whi.Xhi + Wlo.Xhi + Whi.Xlo, three products accumulated in fp32 (the dropped Wlo.Xlo term is
-// ~2^-16 relative).  One k-block of 32 = the 2 x 16 features one wave produces, so the register-to-register hand-over
-// between layers of the fp32 kernel carries over: lane (g, c) holds features 16 ot + 4 g + r of row c in acc[ot][r],
-// which is slot s = 4 ot + r of its B operand.  Measured on the reference's 100-step fixture the split costs 8e-6 in
-// the final controls (tools/dbg/bf16_split_study.py), against the 1e-4 gate.
+// PT: 0 = fp32 MFMA; 1, 2 = the three layers on v_mfma_f32_16x16x32_{bf16,f16} with every fp32 operand split into two
+// 16-bit pieces (x = hi + lo): W.X ~ Whi.Xhi + Wlo.Xhi + Whi.Xlo, three products accumulated in fp32.  One k-block of 32
+// = the 2 x 16 features one wave produces, so the register-to-register hand-over between layers of the fp32 kernel
+// carries over: lane (g, c) holds features 16 ot + 4 g + r of row c in acc[ot][r], which is slot s = 4 ot + r of its B
+// operand.  PT = 2 (half pieces of 2^10 w and 2^4 x, see k_pack_a_split): an operand to 2^-23, 1.9e-6 from the reference
+// after 99 chained steps like the fp32 kernel; PT = 1 (bfloat16 pieces): 2^-17, 8e-6.
 // PERSIST: one workgroup per CU walks the 12-tile groups blockIdx.x, blockIdx.x + gridDim.x, ... with the weights loaded
 // into registers once (used for the single-step launches of the guided phase, where the 344 KB weight fetch and the
 // workgroup turnover are ~10 % of a 12-iteration workgroup).
@@ -537,9 +525,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   constexpr bool NOISE_SPLIT = BF;
   f32x4* zbuf = reinterpret_cast<f32x4*>(crow + 3 * 512);   // [2][192] noise quads of a tile-step (160 used)
   // split forms: [2][kb 2][hi | lo][64 lanes] B operands of layer 1 (pieces of a tile's input image), made by waves 7 / 3
-  // one iteration before layer 1 of that tile-step reads them (PSTL_XSPLIT_ONCE)
+  // one iteration before layer 1 of that tile-step reads them (XONCE: all eight waves used to split the same 48 x 16 values)
   u32x4* xpb = reinterpret_cast<u32x4*>(zbuf + 2 * 192);
-  constexpr bool XONCE = BF && PSTL_XSPLIT_ONCE && (ABL == 0 || ABL == 7);
+  constexpr bool XONCE = BF;
   // (declaring the wave index uniform -- readfirstlane -- turns the role branches into scalar branches and was measured
   // 30 % slower: that form of the loop spills inside it)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1011,16 +999,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       fetch_noise(p0, et, zreg);             // HBM read of this tile-step's noise first: a full iteration to land
       if (it > 0) epilogue(pm1, (it - 1) & 1, zprev);
     }
-    if (ABL == 5 && w >= NW / 2) {  // solo-rate probe: one wave per SIMD issues MFMAs, its partner only joins barriers
-      __syncthreads();
-      hbuf = hbuf == 2 ? 0 : hbuf + 1;
-      pm2 = pm1, pm1 = p0, p0 = p1, p1 = p2, p2 = p3, p3 = next_pos(p3);
-      continue;
-    }
     PSTL_STAMP(1)
     // ---------------- layer 1 of tile-step it + 2 (two ahead) ------------------------------------------------------
     // (BF: woven into layers 2 + 3 below)
-    if (!BF && it + 2 < total && (ABL < 2 || ABL == 5 || ABL == 7)) layer1(p2, hbuf == 0 ? 2 : hbuf - 1);
+    if (!BF && it + 2 < total) layer1(p2, hbuf == 0 ? 2 : hbuf - 1);
     PSTL_STAMP(2)
     // ---------------- layer 2: 256 -> 256 (B from LDS), layer 3: this wave's 16*OT features -> 48 ----------------
     f32x4 acc[OT];
@@ -1038,17 +1020,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       // (independent work) go into the 8 issue cycles each 16-cycle MFMA leaves free.  Layer 1 is computed for the
       // two tile-steps past the end as well (results never read) to keep the loop body one basic block.
       const int b1 = hbuf == 0 ? 2 : hbuf - 1;
-      const f32x4* xb = reinterpret_cast<const f32x4*>(xs + p2.tl * 768) + lane;
       const u32x4* hbb = reinterpret_cast<const u32x4*>(h1 + hbuf * 4096) + lane;
       u32x4 ch = hbb[0], cl = hbb[64];
-      f32x4 xa, xc, xe;
-      u32x4 xq0h, xq0l, xq1h, xq1l;
-      if constexpr (XONCE) {
-        const u32x4* xr = xpb + (it & 1) * 256 + lane;
-        xq0h = xr[0], xq0l = xr[64], xq1h = xr[128], xq1l = xr[192];
-      } else {
-        xa = xb[0], xc = xb[64], xe = xb[128];
-      }
+      const u32x4* xr = xpb + (it & 1) * 256 + lane;
+      const u32x4 xq0h = xr[0], xq0l = xr[64], xq1h = xr[128], xq1l = xr[192];
       f32x4 a1[OT];   // starts from the scene/timestep constant part (fetched at k-block 1, used from k-block 2 on)
       pv8 x0h, x0l, x1h, x1l, hh, hl2;
       f32x4 zv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -1056,26 +1031,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
         u32x4 nh = ch, nl = cl;
-        if (kb < 7 && PSTL_EXP != 3) {
+        if (kb < 7) {
           nh = hbb[(2 * kb + 2) * 64];
           nl = hbb[(2 * kb + 3) * 64];
         }
         const pv8 bh = __builtin_bit_cast(pv8, ch), bl = __builtin_bit_cast(pv8, cl);
-        if (PSTL_EXP != 1 || kb == 0) {
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2h[ot][kb], bh, acc[ot]);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2l[ot][kb], bh, acc[ot]);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2h[ot][kb], bl, acc[ot]);
-        }
-        if constexpr (XONCE) {
-          if (kb == 0) x0h = __builtin_bit_cast(pv8, xq0h), x0l = __builtin_bit_cast(pv8, xq0l);
-          if (kb == 1) x1h = __builtin_bit_cast(pv8, xq1h), x1l = __builtin_bit_cast(pv8, xq1l);
-        } else {
-          if (kb == 0) split8(xa * kSX, xc * kSX, x0h, x0l);
-          if (kb == 1) split8(xe * kSX, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, x1h, x1l);
-        }
+        if (kb == 0) x0h = __builtin_bit_cast(pv8, xq0h), x0l = __builtin_bit_cast(pv8, xq0l);
+        if (kb == 1) x1h = __builtin_bit_cast(pv8, xq1h), x1l = __builtin_bit_cast(pv8, xq1l);
         if (kb == 2 || kb == 3) {
           const pv8 vh = kb == 2 ? x0h : x1h, vl = kb == 2 ? x0l : x1l;
 #pragma unroll
@@ -1192,7 +1160,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     for (int j = 0; j < 3; ++j) pw[(w * 3 + j) * 64 + lane] = acc3[j];
     PSTL_STAMP(4)
     if (UT && w == kStager) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged rows have landed
-    if ((ABL < 3 || ABL == 5 || ABL == 7) && PSTL_EXP != 2) __syncthreads();
+    __syncthreads();
     PSTL_STAMP(5)
     PSTL_STAMP_FLUSH()
     hbuf = hbuf == 2 ? 0 : hbuf + 1;
@@ -1363,9 +1331,6 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   // diagnostic builds of the rollout kernel (see the comment above k_chain); results are not meaningful
   switch (chain_waves) {
     case 108: return launch_chain<8, false, 1>(a, st);
-    case 208: return launch_chain<8, false, 2>(a, st);
-    case 308: return launch_chain<8, false, 3>(a, st);
-    case 508: return launch_chain<8, false, 5>(a, st);
     case 708: return ut ? launch_chain<8, false, 7, true>(a, st) : launch_chain<8, false, 7>(a, st);
     case 1008: return launch_chain<8, false>(a, st);   // force the general (non-uniform-tile) path
     case 116: return launch_chain<8, false, 1, true, 2>(a, st);
