@@ -493,19 +493,28 @@ def dpp_diversity(rect, scores, bs, S, n_shards, hp, scale=1.0, detach=False):
     return torch.mean(-div), div
 
 
+JOINT_PREFIXES = ("rect_net.", "ego_encoder.", "neighbor_encoder.", "lane_encoder.", "merge_net.")
+
+
 def rect_train_step(sd, scene, S, hp, init_controls, prev_scores, lr, diverse=False, n_shards=4, e7=None, merge=None,
-                    clip_rect=False):
+                    clip_rect=False, joint=False):
     """e7 is None: loss = mask_mean(relu(thres - score(rect_controls)), valid) (config 5; zero-weight regularisers).
     e7 = dict(stl_weight, diversity_weight, diversity_scale, rect_reg_loss, detach): the --diverse_loss objective
     loss_stl*stl_weight + loss_reg*rect_reg_loss + loss_diversity*diversity_weight (reference nusc_train.py:442-467),
     with the merge_net architecture unless merge=False (--no_arch, nusc_model.py:185).  Returns the loss, the gradients of the six rect_net tensors (the only parameters
-    in the reference's optimiser without --joint, :1230-1233) and the tensors after one Adam step."""
+    in the reference's optimiser without --joint, :1230-1233) and the tensors after one Adam step.
+    joint=True (--joint, :1230-1231: Adam over net.parameters()): the scene feature keeps its graph, so the three scene
+    encoders and merge_net (when the architecture uses it) receive gradients too; policy_net gets none -- the rollout
+    runs under no_grad and the --rect_head losses (:455-467) leave loss_diffusion out -- and Adam skips it."""
     rows = Rows(scene, S, hp)
-    params = {k: _t(v).clone().requires_grad_() for k, v in sd.items() if k.startswith("rect_net.")}
-    sd_live = {k: (params[k] if k in params else _t(v)) for k, v in sd.items()}
-    feature = encode_feat(sd_live, scene).detach()
-    init = _t(init_controls)
     use_merge = (diverse or e7 is not None) if merge is None else bool(merge)
+    prefixes = tuple(p for p in JOINT_PREFIXES if use_merge or p != "merge_net.") if joint else ("rect_net.",)
+    params = {k: _t(v).clone().requires_grad_() for k, v in sd.items() if k.startswith(prefixes)}
+    sd_live = {k: (params[k] if k in params else _t(v)) for k, v in sd.items()}
+    feature = encode_feat(sd_live, scene)
+    if not joint:
+        feature = feature.detach()
+    init = _t(init_controls)
     rect = rect_forward(sd_live, feature, rows, init, _t(prev_scores), n_shards, use_merge, clip_rect=clip_rect)
     _, score, _ = rows.score(rect)
     loss_stl = mask_mean(torch.relu(hp["stl_nn_thres"] - score), rows.valid)

@@ -236,11 +236,11 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided", "--refinement-case")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided", "--refinement-case", "--train-joint")):
     main()
 
 
-def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None):
+def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None, joint=False):
     """One training step of config 5 (e8_ours_ablation: --rect_head, STL loss through RefineNet; reference
     nusc_train.py:1365-1427 + compute_policy_loss :370-478 + optimizer :1522-1525), driven through the reference's own
     functions.  Stored: inputs, every noise draw, the loss, d loss / d rect_net parameters and the parameters after
@@ -257,12 +257,13 @@ def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None):
                 "--diffusion_steps", str(steps), "--n_randoms", str(S), "--sampling_size", str(S), "--n_neighbors", str(K),
                 "--lr", str(lr)] + (["--diverse_detach"] if e7.get("detach") else []) + (
                     ["--no_arch"] if e7.get("no_arch") else []) + (["--clip_rect"] if e7.get("clip_rect") else [])
-    args = ref_harness.parse_reference_args(argv)
+    args = ref_harness.parse_reference_args(argv + (["--joint"] if joint else []))
     args.measure_diversity = False        # CPU-side metric (scipy hull), not part of the loss
     net = ref.nusc_model.Net(args)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()
                          if e7 is not None or not k.startswith("merge_net")}, strict=True)
-    optimizer = torch.optim.Adam(net.rect_net.parameters(), lr=args.lr)   # reference :1233 (no --joint)
+    # reference :1230-1233: Adam over the whole net with --joint, over rect_net without
+    optimizer = torch.optim.Adam(net.parameters() if args.joint else net.rect_net.parameters(), lr=args.lr)
     coeffs = nt.get_diffusion_coeffs(args)
     stls = nt.build_stl_cache(args)
     batch = make_scene_batch(bs, K=K, S=S, seed=seed, invalid_lane_frac=0.25, stlp_mode="wide")
@@ -304,12 +305,16 @@ def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None):
     rd, _ = nt.compute_policy_loss(batch_cuda, None, stls, nn_trajs, rect_trajs, dense_trajs, args, diffusion_extras=extras,
                                    opt_controls=dense_controls)
     before = {k: v.detach().clone() for k, v in net.rect_net.state_dict().items()}
+    before_all = {k: v.detach().clone() for k, v in net.state_dict().items()}
     optimizer.zero_grad()
     rd["loss"].backward()
     grads = {k: p.grad.detach().clone() for k, p in net.rect_net.named_parameters()}
     feat_grad_norm = float(sum((p.grad ** 2).sum() for nme, p in net.named_parameters() if "encoder" in nme and p.grad is not None))
+    joint_grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()
+                   if p.grad is not None and not k.startswith("rect_net.")} if joint else {}
     optimizer.step()
     after = {k: v.detach().clone() for k, v in net.rect_net.state_dict().items()}
+    after_all = {k: v.detach().clone() for k, v in net.state_dict().items()}
     out = {"x_T": np_(draws[0]), "z": np_(torch.stack(draws[1:] + [torch.zeros_like(draws[0])], dim=0)),
            "sel_controls": np_(c_max), "sel_scores": np_(sc_max), "rect_controls": np_(rect_controls),
            "scores": np_(rd["scores"]), "loss": np.float32(rd["loss"].item()), "loss_stl": np.float32(rd["loss_stl"].item()),
@@ -322,6 +327,15 @@ def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None):
                                    e7.get("rect_reg_loss", 0.0), 1.0 if e7.get("detach") else 0.0, args.n_shards,
                                    1.0 if e7.get("no_arch") else 0.0, 1.0 if e7.get("clip_rect") else 0.0],
                                   dtype=np.float64)
+    if joint:   # everything that received a gradient besides rect_net; the rest of the net must come out of Adam untouched
+        assert not any(k.startswith("policy_net.") for k in joint_grads)
+        for k in joint_grads:
+            out["grad_" + k] = np_(joint_grads[k])
+            out["after_" + k] = np_(after_all[k])
+        for k in after_all:
+            if k not in joint_grads and not k.startswith("rect_net."):
+                assert torch.equal(after_all[k], before_all[k]), k
+        out["joint_names"] = np.array(sorted(joint_grads))
     for k in grads:
         out["grad_rect_net." + k] = np_(grads[k])
         out["after_rect_net." + k] = np_(after[k])
@@ -372,6 +386,20 @@ def main_train_e7(ref=None, sd=None):
                e7=dict(stl_weight=1.0, diversity_weight=0.5, no_arch=True, clip_rect=True))
 
 
+def main_train_joint():
+    """--joint (reference nusc_train.py:1230-1231): the same training steps with Adam over the whole net -- gradients into
+    the three scene encoders and, with the merge_net architecture, into merge_net."""
+    ref = ref_harness.load_reference()
+    sd = dict(np.load(WEIGHTS_FILE))
+    train_case(ref, sd, "train_e8_joint", bs=4, S=8, K=3, steps=8, seed=51, joint=True)
+    train_case(ref, sd, "train_e7_joint", bs=3, S=16, K=4, steps=8, seed=52, joint=True,
+               e7=dict(stl_weight=1.0, diversity_weight=0.5, diversity_scale=1.0))
+    train_case(ref, sd, "train_e7_joint_b", bs=2, S=64, K=2, steps=8, seed=53, joint=True,
+               e7=dict(stl_weight=0.0, diversity_weight=1.0))
+
+
+if __name__ == "__main__" and "--train-joint" in sys.argv:
+    main_train_joint()
 if __name__ == "__main__" and "--train-e7" in sys.argv:
     main_train_e7()
 if __name__ == "__main__" and "--train" in sys.argv:

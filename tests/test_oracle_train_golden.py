@@ -43,3 +43,31 @@ def test_e7_diversity_train_step_matches_reference(name):
         ref = d["grad_" + k]
         np.testing.assert_allclose(g.numpy(), ref, rtol=2e-3, atol=2e-5 * np.abs(ref).max(), err_msg=k)
         np.testing.assert_allclose(out["after"][k].numpy(), d["after_" + k], rtol=0, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["train_e8_joint", "train_e7_joint", "train_e7_joint_b"])
+def test_joint_train_step_matches_reference(name):
+    """--joint (reference nusc_train.py:1230-1231): Adam over the whole net; the gradients of the three scene encoders and
+    of merge_net (e7 architecture) against the reference's autograd, and every touched tensor after the Adam step."""
+    d = load_golden(name)
+    bs, S, K, steps, seed, mc = [int(v) for v in d["meta"]]
+    lr = float(d["meta_f"][0])
+    kw = {}
+    if "meta_e7" in d:
+        stl_w, div_w, scale, reg_w, detach, n_shards, no_arch, clip_rect = [float(v) for v in d["meta_e7"]]
+        kw = dict(n_shards=int(n_shards), merge=not no_arch, clip_rect=bool(clip_rect),
+                  e7=dict(stl_weight=stl_w, diversity_weight=div_w, diversity_scale=scale, rect_reg_loss=reg_w, detach=bool(detach)))
+    sd = {k: v for k, v in golden_weights().items()}
+    out = orc.rect_train_step(sd, scene_from_golden(d), S, default_hparams(), d["sel_controls"], d["sel_scores"], lr,
+                              joint=True, **kw)
+    names = set(str(k) for k in d["joint_names"])
+    assert names == set(k for k in out["grads"] if not k.startswith("rect_net."))
+    assert ("merge_net.0.weight" in names) == ("meta_e7" in d)
+    np.testing.assert_allclose(float(out["loss"]), float(d["loss"]), rtol=2e-5)
+    for k, g in out["grads"].items():
+        ref = d["grad_" + k]
+        np.testing.assert_allclose(g.numpy(), ref, rtol=2e-3, atol=2e-5 * np.abs(ref).max(), err_msg=k)
+        # Adam's first step is lr * sign(g) wherever |g| >> 1e-8: entries whose reference gradient is at rounding level
+        # (a different summation order flips the sign) are left out
+        solid = np.abs(ref) > 1e-4 * np.abs(ref).max()
+        np.testing.assert_allclose(out["after"][k].numpy()[solid], d["after_" + k][solid], rtol=0, atol=2e-5, err_msg=k)
