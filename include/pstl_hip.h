@@ -204,21 +204,55 @@ int pstl_refine_train_forward(const pstl_cfg* cfg, const float* packed, const fl
  * divides by N * clip(mean(valid), 1e-2)). */
 int pstl_loss_grad(const pstl_cfg* cfg, const float* scores, const float* valid, float grad_scale, float* dscore,
                    float* loss_parts, void* stream);
-/* Context of the backward pass (a rocBLAS handle for its five plain fp32 GEMMs). */
+/* Context of the backward pass (it once held a vendor-BLAS handle; now empty, kept for the signatures). */
 int pstl_train_create(void** ctx);
 int pstl_train_destroy(void* ctx);
 size_t pstl_train_work_floats(const pstl_cfg* cfg);
 /* d loss / d rect_net parameters given dcontrols = d loss / d out_controls (from pstl_stl_backward).  w2, w3: the
  * reference-layout weights rect_net.2.weight (256,256), rect_net.4.weight (40,256).  Gradients in the reference layout:
- * dw1 (256,271), db1 (256), dw2 (256,256), db2 (256), dw3 (40,256), db3 (40).  Gradients w.r.t. the scene feature and
- * merge_net (both needed only with --joint: the reference's optimiser holds rect_net.parameters() otherwise,
- * nusc_train.py:1230-1233) are not produced.  work: pstl_train_work_floats(cfg) floats. */
+ * dw1 (256,271), db1 (256), dw2 (256,256), db2 (256), dw3 (40,256), db3 (40).  Gradients w.r.t. the scene encoders and
+ * merge_net (needed only with --joint: the reference's optimiser holds rect_net.parameters() otherwise,
+ * nusc_train.py:1230-1233) come from pstl_encoder_backward / pstl_merge_backward below, which continue from what this
+ * call leaves in `work`.  work: pstl_train_work_floats(cfg) floats. */
 int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float* w2, const float* w3, const float* feature,
                          const float* stlp, const float* hl, const float* init_controls,
                          const float* pooled /* (bs,3,n_shards,40) from the forward call; null with PSTL_FLAG_NO_MERGE */,
                          const float* prev_scores, const float* h1, const float* h2, const float* pre,
                          const float* dcontrols, float* work, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
                          float* db3, void* stream);
+/* ---- --joint (reference nusc_train.py:1230-1231: Adam over net.parameters()) ------------------------------------
+ * With --rect_head the loss reaches the scene encoders through `feature` (Net.forward(get_feature=True), nusc_model.py:
+ * 55-95 -> Net.rect_forward :182-209) and merge_net through the pooled columns (:186-200); policy_net receives no
+ * gradient (the rollout runs under no_grad and loss_diffusion is not in the --rect_head losses, :455-467).
+ *
+ * pstl_encode_scene_saved: pstl_encode_scene that also keeps, per token, what the encoders' backward needs.  Tokens are
+ * ordered [bs ego | bs*K neighbours (scene-major) | 3*bs lanes (scene-major)], T = bs*(K+4):
+ * tok_in (T,48) inputs (6 / 7 / 45 valid columns), tok_h1, tok_h2 (T,256) the two hidden layers after ReLU, tok_out (T,32). */
+int pstl_encode_scene_saved(const pstl_cfg* cfg, const float* packed, const float* ego0, const float* neighbors,
+                            const float* currlane, const float* leftlane, const float* rightlane, const float* curr_id,
+                            const float* left_id, const float* right_id, float* feature, float* base_policy,
+                            float* base_rect, float* tok_in, float* tok_h1, float* tok_h2, float* tok_out, void* stream);
+/* Gradients of {ego,neighbor,lane}_encoder (arrays of 3 device pointers, in that order; reference layouts:
+ * d_w0 (256,6|7|45), d_b0 (256), d_w1 (256,256), d_b1 (256), d_w2 (32,256), d_b2 (32)).  Call right after
+ * pstl_refine_backward on the same stream with the SAME cfg and its work buffer `refine_work` untouched (d loss / d
+ * hidden-1 and its per-scene sums are read from it; its scratch regions are reused).  rect_w1 = rect_net.0.weight
+ * (256,271); enc_w1[e] = <encoder>.2.weight (256,256), enc_w2[e] = <encoder>.4.weight (32,256), live reference-layout
+ * tensors.  work: pstl_encoder_backward_work_floats(cfg).  dfused (N,40) or null: WRITTEN with d loss / d (rect_net
+ * input columns 231..270), the input of pstl_merge_backward. */
+size_t pstl_encoder_backward_work_floats(const pstl_cfg* cfg);
+int pstl_encoder_backward(const pstl_cfg* cfg, float* refine_work, const float* rect_w1, const float* const* enc_w1,
+                          const float* const* enc_w2, const float* tok_in, const float* tok_h1, const float* tok_h2,
+                          const float* tok_out, float* work, float* const* d_w0, float* const* d_b0, float* const* d_w1,
+                          float* const* d_b1, float* const* d_w2, float* const* d_b2, float* dfused, void* stream);
+/* Gradients of merge_net (40 -> 32 -> 32 -> 40; reference layouts dw0 (32,40), db0 (32), dw1 (32,32), db1 (32),
+ * dw2 (40,32), db2 (40)) through the shard max-pool: the gradient of a pooled column goes to the first sample of the
+ * shard holding the maximum.  packed: the weights the forward ran with.  dfused (N,ldf), first 40 columns used.
+ * Requires rows_per_scene == 3*S, S <= 64, n_shards*40 <= 256 (as the forward and the DPP loss do).
+ * work: pstl_merge_backward_work_floats(cfg). */
+size_t pstl_merge_backward_work_floats(const pstl_cfg* cfg);
+int pstl_merge_backward(const pstl_cfg* cfg, const float* packed, const float* init_controls, const float* dfused, int ldf,
+                        float* work, float* dw0, float* db0, float* dw1, float* db1, float* dw2, float* db2, void* stream);
+
 /* e7 training objective (--diverse_loss, reference nusc_train.py:442-467).  For every (scene, mode, shard) group of
  * S/n_shards samples the DPP diversity tr(I - (L+I)^-1), L = diag(q) exp(-diversity_scale |x_i - x_j|) diag(q),
  * x = rect_controls/(w_max,a_max), q = exp(score)[score>0] (detach != 0: q = [score>0], no gradient into the scores).

@@ -220,6 +220,12 @@ struct EncArgs {
   float* feature;          // (bs,224)
   float* base_policy;      // (bs,256)
   float* base_rect;        // (bs,256) or null
+  // training with --joint (pstl_encode_scene_saved): what the encoders' backward pass needs, per token, tokens ordered
+  // [bs ego | bs*K neighbours (scene-major) | 3*bs lanes (scene-major)]; all four null otherwise
+  float* sv_in;            // (T,48)  token inputs (first enc_in(e) columns valid)
+  float* sv_h1;            // (T,256) relu(layer 0)
+  float* sv_h2;            // (T,256) relu(layer 1)
+  float* sv_out;           // (T,32)  layer 2 output
 };
 
 constexpr int kMaxTok = 48;   // tokens (1 ego + K neighbours + 3 lanes per scene) of the scenes one workgroup encodes
@@ -285,6 +291,18 @@ __global__ __launch_bounds__(256) void k_encode(EncArgs a, int SCN) {
     in_s[t_lane + sm][e] = j == 0 ? l[c] : l[j * 3 + c] - l[(j - 1) * 3 + c];
   }
   __syncthreads();
+  // global index of local token tk (tokens of one encoder are contiguous over the whole batch)
+  auto tok_global = [&](int tk) -> long {
+    if (tk < t_nei) return (long)b0 + tk;
+    if (tk < t_lane) return (long)a.bs + (long)b0 * K + (tk - t_nei);
+    return (long)a.bs * (K + 1) + (long)b0 * 3 + (tk - t_lane);
+  };
+  if (a.sv_in)
+    for (int i = tid; i < ntok * 48; i += 256) {
+      const int tk = i / 48, c = i % 48;
+      const int nin = tk < t_nei ? enc_in(0) : tk < t_lane ? enc_in(1) : enc_in(2);
+      a.sv_in[tok_global(tk) * 48 + c] = c < nin ? in_s[tk][c] : 0.0f;
+    }
   for (int e = 0; e < 3; ++e) {
     const int t0 = e == 0 ? 0 : e == 1 ? t_nei : t_lane;
     const int t1 = e == 0 ? t_nei : e == 1 ? t_lane : ntok;
@@ -341,6 +359,13 @@ __global__ __launch_bounds__(256) void k_encode(EncArgs a, int SCN) {
       out_s[tk][o] = acc;
     }
     __syncthreads();
+    if (a.sv_h1)
+      for (int tk = t0; tk < t1; ++tk) {
+        const long gt = tok_global(tk);
+        a.sv_h1[gt * kHid + tid] = h_a[tk][tid];
+        a.sv_h2[gt * kHid + tid] = h_b[tk][tid];
+        if (tid < 32) a.sv_out[gt * 32 + tid] = out_s[tk][tid];
+      }
   }
   // feature = [ego 32 | nei min 32 | nei mean 32 | nei max 32 | lanes 3x32]  (nusc_model.py:82-93)
   for (int i = tid; i < ns * 32; i += 256) {
@@ -1182,17 +1207,48 @@ struct MergeArgs {
   float* pooled;       // (bs,3,n_shards,40)
 };
 
+// LDS copy of the packed merge_net block: w0t [40][32] | b0 [32] | w1t [32][32] | b1 [32] | w2t [32][40] | b2 [40]
+constexpr int kMrgW0 = 0, kMrgB0 = 40 * 32, kMrgW1 = kMrgB0 + 32, kMrgB1 = kMrgW1 + 32 * 32, kMrgW2 = kMrgB1 + 32,
+              kMrgB2 = kMrgW2 + 32 * 40, kMrgFloats = kMrgB2 + 40;   // 3688
+
+// merge_net on one row, lane-private: h0 / h1v = the two hidden layers BEFORE their ReLU, out[0..40) the output (LDS).
+// One k-ordered fma chain per output: the forward (k_merge_pool) and the backward's recomputation (k_merge_bwd) see the
+// same bits, so the backward finds the maximum the forward pooled.
+__device__ __forceinline__ void merge_row(const float* x, const float* wt, float (&h0)[32], float (&h1v)[32], float* out) {
+  const float* w0t = wt + kMrgW0;
+  const float* b0 = wt + kMrgB0;
+  const float* w1t = wt + kMrgW1;
+  const float* b1 = wt + kMrgB1;
+  const float* w2t = wt + kMrgW2;
+  const float* b2 = wt + kMrgB2;
+#pragma unroll
+  for (int o = 0; o < 32; ++o) h0[o] = b0[o];
+  for (int k = 0; k < 40; ++k) {
+    const float xv = x[k];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) h0[o] += w0t[k * 32 + o] * xv;
+  }
+#pragma unroll
+  for (int o = 0; o < 32; ++o) h1v[o] = b1[o];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const float hv = fmaxf(h0[k], 0.0f);
+#pragma unroll
+    for (int o = 0; o < 32; ++o) h1v[o] += w1t[k * 32 + o] * hv;
+  }
+  for (int o = 0; o < 40; ++o) {
+    float acc = b2[o];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc += w2t[k * 40 + o] * fmaxf(h1v[k], 0.0f);
+    out[o] = acc;
+  }
+}
+
 __global__ __launch_bounds__(64) void k_merge_pool(MergeArgs a) {
-  __shared__ float wt[40 * 32 + 32 + 32 * 32 + 32 + 32 * 40 + 40];
+  __shared__ float wt[kMrgFloats];
   __shared__ float outs[64][41];
   const int tid = threadIdx.x;
-  for (int i = tid; i < 40 * 32 + 32 + 32 * 32 + 32 + 32 * 40 + 40; i += 64) wt[i] = a.packed[a.off.w0t + i];
-  const float* w0t = wt;
-  const float* b0 = w0t + 40 * 32;
-  const float* w1t = b0 + 32;
-  const float* b1 = w1t + 32 * 32;
-  const float* w2t = b1 + 32;
-  const float* b2 = w2t + 32 * 40;
+  for (int i = tid; i < kMrgFloats; i += 64) wt[i] = a.packed[a.off.w0t + i];
   // one workgroup per (scene, mode); the S samples are walked 64 at a time (all lanes busy when S >= 64); the running
   // maximum of every shard is kept by the 40 x n_shards threads that own one (shard, output) pair each
   const long bm = blockIdx.x;
@@ -1205,29 +1261,8 @@ __global__ __launch_bounds__(64) void k_merge_pool(MergeArgs a) {
     const int s = s0 + tid;
     if (s < a.S) {
       const long row = (b * a.S + s) * 3 + m;
-      const float* x = a.init + row * kCtrl;
       float h0[32], h1v[32];
-#pragma unroll
-      for (int o = 0; o < 32; ++o) h0[o] = b0[o];
-      for (int k = 0; k < 40; ++k) {
-        const float xv = x[k];
-#pragma unroll
-        for (int o = 0; o < 32; ++o) h0[o] += w0t[k * 32 + o] * xv;
-      }
-#pragma unroll
-      for (int o = 0; o < 32; ++o) h1v[o] = b1[o];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        const float hv = fmaxf(h0[k], 0.0f);
-#pragma unroll
-        for (int o = 0; o < 32; ++o) h1v[o] += w1t[k * 32 + o] * hv;
-      }
-      for (int o = 0; o < 40; ++o) {
-        float acc = b2[o];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) acc += w2t[k * 40 + o] * fmaxf(h1v[k], 0.0f);
-        outs[tid][o] = acc;
-      }
+      merge_row(a.init + row * kCtrl, wt, h0, h1v, outs[tid]);
     }
     __syncthreads();
     const int n = (a.S - s0) < 64 ? (a.S - s0) : 64;
@@ -1247,6 +1282,179 @@ __global__ __launch_bounds__(64) void k_merge_pool(MergeArgs a) {
     const int p = tid + 64 * u;
     if (p < a.n_shards * 40) a.pooled[bm * a.n_shards * kCtrl + p] = best[u];
   }
+}
+
+// ---- merge_net backward (training with --joint) ------------------------------------------------------------------
+// fused = init + pooled[scene, mode, shard] feeds rect_net's last 40 input columns, so d pooled[shard][c] is the sum of
+// d fused[row][c] over the shard's rows and goes to the ONE row whose merge_net output c was the shard's maximum
+// (torch.max(dim): the first such row).  One wave per (scene, mode), lane = sample s (S <= 64, as the DPP loss kernel
+// requires): recompute the row's merge_net forward (merge_row), find the winners, back-propagate the sparse d out through
+// the two hidden layers lane-privately, and accumulate the weight gradients -- 58 entries per lane, held in registers
+// over all the (scene, mode) pairs this workgroup walks -- from per-layer (d output | layer input) row vectors staged in
+// LDS; rows without a winner are skipped.  Every workgroup writes one slab; k_merge_reduce adds the slabs in order.
+struct MergeBwdArgs {
+  int bs, S, n_shards;
+  MergeOff off;
+  const float* packed;
+  const float* init;     // (N,40)
+  const float* dfused;   // (N,ldf): d loss / d rect_net input columns 231..270
+  int ldf;
+  float* slabs;          // (gridDim.x, kMrgFloats): dW0 (32,40) | db0 | dW1 (32,32) | db1 | dW2 (40,32) | db2, reference layout
+};
+
+__global__ __launch_bounds__(64) void k_merge_bwd(MergeBwdArgs a) {
+  __shared__ float wt[kMrgFloats];
+  __shared__ float outs[64][41];
+  __shared__ float rowv[64][73];          // per layer: d output (<= 40) | layer input (<= 40)
+  __shared__ float dpl[256];              // d pooled[(shard, output)]
+  __shared__ int win[256];                // winning sample of (shard, output)
+  __shared__ int live[64];                // row holds a winner
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kMrgFloats; i += 64) wt[i] = a.packed[a.off.w0t + i];
+  const int sps = a.S / a.n_shards;
+  float g2[20], g1[16], g0[20], gb[2];    // dW2[c = 2j + (tid>>5)][k = tid&31], dW1[o = 2j + (tid>>5)][k], dW0[o = e/40][k = e%40], biases
+#pragma unroll
+  for (int j = 0; j < 20; ++j) g2[j] = g0[j] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) g1[j] = 0.0f;
+  gb[0] = gb[1] = 0.0f;
+  __syncthreads();
+  for (long bm = blockIdx.x; bm < (long)a.bs * 3; bm += gridDim.x) {
+    const int m = (int)(bm % 3);
+    const long b = bm / 3;
+    const int s = tid;
+    const bool has = s < a.S;
+    const long row = (b * a.S + (has ? s : 0)) * 3 + m;
+    float h0[32], h1v[32], xin[40];
+    if (has) {
+#pragma unroll
+      for (int k = 0; k < 40; ++k) xin[k] = a.init[row * kCtrl + k];
+      merge_row(a.init + row * kCtrl, wt, h0, h1v, outs[tid]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = tid + 64 * u;
+      if (p < a.n_shards * 40) {
+        const int sh = p / 40, o = p % 40;
+        float best = -INFINITY, dsum = 0.0f;
+        int bi = sh * sps;
+        for (int s2 = sh * sps; s2 < (sh + 1) * sps; ++s2) {
+          const float v = outs[s2][o];
+          if (v > best) best = v, bi = s2;
+          dsum += a.dfused[((b * a.S + s2) * 3 + m) * a.ldf + o];
+        }
+        win[p] = bi;
+        dpl[p] = dsum;
+      }
+    }
+    __syncthreads();
+    // d out of this row, then the two hidden layers (lane-private)
+    float dout[40], dh1[32], dh0[32];
+    bool any = false;
+    const int sh = has ? s / sps : 0;
+#pragma unroll
+    for (int o = 0; o < 40; ++o) {
+      const bool mine = has && win[sh * 40 + o] == s;
+      dout[o] = mine ? dpl[sh * 40 + o] : 0.0f;
+      any |= mine;
+    }
+    live[tid] = any ? 1 : 0;
+    if (any) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 40; ++o) acc += wt[kMrgW2 + k * 40 + o] * dout[o];
+        dh1[k] = h1v[k] > 0.0f ? acc : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc += wt[kMrgW1 + k * 32 + o] * dh1[o];
+        dh0[k] = h0[k] > 0.0f ? acc : 0.0f;
+      }
+    }
+    // layer 2: dW2[c][k] += dout[c] * relu(h1v[k]);  db2[c] += dout[c]
+    if (any) {
+#pragma unroll
+      for (int o = 0; o < 40; ++o) rowv[tid][o] = dout[o];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) rowv[tid][40 + k] = fmaxf(h1v[k], 0.0f);
+    }
+    __syncthreads();
+    for (int r = 0; r < a.S; ++r) {
+      if (!live[r]) continue;
+      const float hv = rowv[r][40 + (tid & 31)];
+#pragma unroll
+      for (int j = 0; j < 20; ++j) g2[j] += rowv[r][2 * j + (tid >> 5)] * hv;
+      if (tid < 40) gb[0] += rowv[r][tid];
+    }
+    __syncthreads();
+    // layer 1: dW1[o][k] += dh1[o] * relu(h0[k]);  db1[o] += dh1[o]
+    if (any) {
+#pragma unroll
+      for (int o = 0; o < 32; ++o) rowv[tid][o] = dh1[o];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) rowv[tid][40 + k] = fmaxf(h0[k], 0.0f);
+    }
+    __syncthreads();
+    for (int r = 0; r < a.S; ++r) {
+      if (!live[r]) continue;
+      const float hv = rowv[r][40 + (tid & 31)];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) g1[j] += rowv[r][2 * j + (tid >> 5)] * hv;
+      if (tid >= 40) gb[0] += rowv[r][tid - 40];   // lanes 40..63 hold db1[0..23] in gb[0], lanes 0..7 db1[24..31] in gb[1]
+      if (tid < 8) gb[1] += rowv[r][24 + tid];
+    }
+    __syncthreads();
+    // layer 0: dW0[o][k] += dh0[o] * x[k];  db0[o] += dh0[o]   (entry e = tid + 64 j of the 32 x 40 matrix)
+    if (any) {
+#pragma unroll
+      for (int o = 0; o < 32; ++o) rowv[tid][o] = dh0[o];
+#pragma unroll
+      for (int k = 0; k < 40; ++k) rowv[tid][32 + k] = xin[k];
+    }
+    __syncthreads();
+    for (int r = 0; r < a.S; ++r) {
+      if (!live[r]) continue;
+#pragma unroll
+      for (int j = 0; j < 20; ++j) {
+        const int e = tid + 64 * j;
+        g0[j] += rowv[r][e / 40] * rowv[r][32 + e % 40];
+      }
+      if (tid >= 8 && tid < 40) gb[1] += rowv[r][tid - 8];   // lanes 8..39: db0[0..31]
+    }
+    __syncthreads();
+  }
+  float* out = a.slabs + (long)blockIdx.x * kMrgFloats;
+  // slab layout: dW0 (32,40) at 0 | db0 at 1280 | dW1 (32,32) at 1312 | db1 at 2336 | dW2 (40,32) at 2368 | db2 at 3648
+#pragma unroll
+  for (int j = 0; j < 20; ++j) out[tid + 64 * j] = g0[j];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) out[1312 + (2 * j + (tid >> 5)) * 32 + (tid & 31)] = g1[j];
+#pragma unroll
+  for (int j = 0; j < 20; ++j) out[2368 + (2 * j + (tid >> 5)) * 32 + (tid & 31)] = g2[j];
+  if (tid < 40) out[3648 + tid] = gb[0];            // db2
+  if (tid >= 40) out[2336 + tid - 40] = gb[0];      // db1[0..23]
+  if (tid < 8) out[2336 + 24 + tid] = gb[1];        // db1[24..31]
+  if (tid >= 8 && tid < 40) out[1280 + tid - 8] = gb[1];   // db0
+}
+
+// gradient tensors (reference layout) = sum of the slabs, in slab order
+__global__ void k_merge_reduce(int nslabs, const float* slabs, float* dw0, float* db0, float* dw1, float* db1, float* dw2,
+                               float* db2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kMrgFloats) return;
+  float acc = 0.0f;
+  for (int sl = 0; sl < nslabs; ++sl) acc += slabs[(long)sl * kMrgFloats + i];
+  if (i < 1280) dw0[i] = acc;
+  else if (i < 1312) db0[i - 1280] = acc;
+  else if (i < 2336) dw1[i - 1312] = acc;
+  else if (i < 2368) db1[i - 2336] = acc;
+  else if (i < 3648) dw2[i - 2368] = acc;
+  else db2[i - 3648] = acc;
 }
 
 __global__ void k_fill_normal(long N, unsigned long long seed, long row_offset, int step, float* out) {
@@ -1442,10 +1650,10 @@ extern "C" int pstl_time_bias(const float* packed, int steps, float* tbias, void
   return launch_status();
 }
 
-extern "C" int pstl_encode_scene(const pstl_cfg* cfg, const float* packed, const float* ego0, const float* neighbors,
-                                 const float* currlane, const float* leftlane, const float* rightlane,
-                                 const float* curr_id, const float* left_id, const float* right_id, float* feature,
-                                 float* base_policy, float* base_rect, void* stream) {
+static int encode_scene(const pstl_cfg* cfg, const float* packed, const float* ego0, const float* neighbors,
+                        const float* currlane, const float* leftlane, const float* rightlane, const float* curr_id,
+                        const float* left_id, const float* right_id, float* feature, float* base_policy, float* base_rect,
+                        float* sv_in, float* sv_h1, float* sv_h2, float* sv_out, void* stream) {
   if (int e = check_cfg(cfg)) return e;
   if (!packed || !ego0 || !currlane || !leftlane || !rightlane || !curr_id || !left_id || !right_id || !feature ||
       !base_policy)
@@ -1474,12 +1682,31 @@ extern "C" int pstl_encode_scene(const pstl_cfg* cfg, const float* packed, const
   a.feature = feature;
   a.base_policy = base_policy;
   a.base_rect = base_rect;
+  a.sv_in = sv_in, a.sv_h1 = sv_h1, a.sv_h2 = sv_h2, a.sv_out = sv_out;
   const size_t lds = enc_lds_floats(scn, cfg->K) * sizeof(float);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_encode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return PSTL_ERR_LAUNCH;
   hipLaunchKernelGGL(k_encode, dim3((cfg->bs + scn - 1) / scn), dim3(256), lds, as_stream(stream), a, scn);
   return launch_status();
+}
+
+extern "C" int pstl_encode_scene(const pstl_cfg* cfg, const float* packed, const float* ego0, const float* neighbors,
+                                 const float* currlane, const float* leftlane, const float* rightlane,
+                                 const float* curr_id, const float* left_id, const float* right_id, float* feature,
+                                 float* base_policy, float* base_rect, void* stream) {
+  return encode_scene(cfg, packed, ego0, neighbors, currlane, leftlane, rightlane, curr_id, left_id, right_id, feature,
+                      base_policy, base_rect, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int pstl_encode_scene_saved(const pstl_cfg* cfg, const float* packed, const float* ego0, const float* neighbors,
+                                       const float* currlane, const float* leftlane, const float* rightlane,
+                                       const float* curr_id, const float* left_id, const float* right_id, float* feature,
+                                       float* base_policy, float* base_rect, float* tok_in, float* tok_h1, float* tok_h2,
+                                       float* tok_out, void* stream) {
+  if (!tok_in || !tok_h1 || !tok_h2 || !tok_out) return PSTL_ERR_ARG;
+  return encode_scene(cfg, packed, ego0, neighbors, currlane, leftlane, rightlane, curr_id, left_id, right_id, feature,
+                      base_policy, base_rect, tok_in, tok_h1, tok_h2, tok_out, stream);
 }
 
 extern "C" int pstl_rollout(const pstl_cfg* cfg, const float* packed, const float* base_policy, const float* tbias,
@@ -1597,4 +1824,40 @@ static int refine_impl(const pstl_cfg* cfg, const float* packed, const float* ba
   a.h2_save = h2_save;
   a.pre_save = pre_save;
   return launch_chain_nw<true>(cfg->chain_waves, a, st);
+}
+
+// ---- merge_net backward (training with --joint) ------------------------------------------------------------------
+constexpr int kMergeBwdBlocks = 1024;
+
+extern "C" size_t pstl_merge_backward_work_floats(const pstl_cfg* cfg) {
+  if (check_cfg(cfg)) return 0;
+  return (size_t)kMergeBwdBlocks * kMrgFloats;
+}
+
+extern "C" int pstl_merge_backward(const pstl_cfg* cfg, const float* packed, const float* init_controls,
+                                   const float* dfused, int ldf, float* work, float* dw0, float* db0, float* dw1,
+                                   float* db1, float* dw2, float* db2, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!packed || !init_controls || !dfused || !work || !dw0 || !db0 || !dw1 || !db1 || !dw2 || !db2) return PSTL_ERR_ARG;
+  if ((cfg->flags & PSTL_FLAG_NO_MERGE) || ldf < kCtrl) return PSTL_ERR_ARG;
+  if (cfg->rows_per_scene != 3 * cfg->S || cfg->n_shards < 1 || cfg->S % cfg->n_shards != 0 || cfg->n_shards * 40 > 256 ||
+      cfg->S > 64)
+    return PSTL_ERR_SHAPE;
+  hipStream_t st = as_stream(stream);
+  MergeBwdArgs m;
+  m.bs = cfg->bs;
+  m.S = cfg->S;
+  m.n_shards = cfg->n_shards;
+  m.off = make_layout().mrg;
+  m.packed = packed;
+  m.init = init_controls;
+  m.dfused = dfused;
+  m.ldf = ldf;
+  m.slabs = work;
+  const long pairs = (long)cfg->bs * 3;
+  const int nb = (int)(pairs < kMergeBwdBlocks ? pairs : kMergeBwdBlocks);
+  hipLaunchKernelGGL(k_merge_bwd, dim3(nb), dim3(64), 0, st, m);
+  hipLaunchKernelGGL(k_merge_reduce, dim3((kMrgFloats + 255) / 256), dim3(256), 0, st, nb, (const float*)work, dw0, db0, dw1,
+                     db1, dw2, db2);
+  return launch_status();
 }

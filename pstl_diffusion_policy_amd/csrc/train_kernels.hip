@@ -457,8 +457,8 @@ __device__ __forceinline__ unsigned bf16_pair(float a, float b) {
 
 // A operands of W^T: word m of lane l for block (T, kb) at dst[(((T*nkb + kb)*2 + (m>>2))*64 + l)*4 + (m&3)], m < 4 the hi
 // pieces of slots 2m, 2m+1, m >= 4 the lo pieces; slot s of lane group g = l>>4 is k = 32 kb + 16 (s>>2) + 4 g + (s&3),
-// the lane's feature is f = 16 T + (l&15); element = W[k][f] (k < kvalid, else 0)
-__global__ void k_pack_wt_bf(const float* W, int ld, int kvalid, int nkb, unsigned* dst) {
+// the lane's feature is f = 16 T + (l&15); element = W[k*ld + f] (k < kvalid and f < fvalid, else 0)
+__global__ void k_pack_wt_bf(const float* W, int ld, int kvalid, int fvalid, int nkb, unsigned* dst) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 16L * nkb * 512) return;
   const int lane = (int)((i >> 2) & 63), m = (int)((i & 3) | (((i >> 8) & 1) << 2));
@@ -469,7 +469,7 @@ __global__ void k_pack_wt_bf(const float* W, int ld, int kvalid, int nkb, unsign
   for (int e = 0; e < 2; ++e) {
     const int sl = 2 * (m & 3) + e;
     const int k = 32 * kb + 16 * (sl >> 2) + 4 * g + (sl & 3);
-    const float wv = k < kvalid ? W[(long)k * ld + f] : 0.0f;
+    const float wv = (k < kvalid && f < fvalid) ? W[(long)k * ld + f] : 0.0f;
     const float hi = (float)(__bf16)wv;
     v[e] = m < 4 ? hi : wv - hi;
   }
@@ -478,7 +478,7 @@ __global__ void k_pack_wt_bf(const float* W, int ld, int kvalid, int nkb, unsign
 
 template <int NKB>
 __global__ __launch_bounds__(512, 2) void k_dgrad(long N, const float* G, int ldg, int kvalid, const unsigned* Wp,
-                                                  const float* H, float* out, float* partial) {
+                                                  const float* H, float* out, int ldo, int fvalid, float* partial) {
   static_assert(NKB <= 8, "one staging wave per k-block");
   __shared__ __attribute__((aligned(16))) u32x4 pieces[2][NKB * 2 * 64];   // [buffer][kb][hi | lo][lane]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -539,7 +539,9 @@ __global__ __launch_bounds__(512, 2) void k_dgrad(long N, const float* G, int ld
     f32x4 hm[2];
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
-      hm[ot] = row < N ? *reinterpret_cast<const f32x4*>(H + row * kHid + 16 * (2 * w + ot) + 4 * g) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      hm[ot] = !H ? f32x4{1.0f, 1.0f, 1.0f, 1.0f}     // no mask (the product feeds a linear input, not a ReLU)
+               : row < N ? *reinterpret_cast<const f32x4*>(H + row * kHid + 16 * (2 * w + ot) + 4 * g)
+                         : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
     const u32x4* pb = &pieces[buf][lane];
 #pragma unroll
@@ -557,8 +559,8 @@ __global__ __launch_bounds__(512, 2) void k_dgrad(long N, const float* G, int ld
       f32x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = hm[ot][r] > 0.0f ? acc[ot][r] : 0.0f;
-      if (row < N) {
-        *reinterpret_cast<f32x4*>(out + row * kHid + 16 * (2 * w + ot) + 4 * g) = o;
+      if (row < N && 16 * (2 * w + ot) + 4 * g < fvalid) {   // fvalid is a multiple of 4: whole quads
+        *reinterpret_cast<f32x4*>(out + row * ldo + 16 * (2 * w + ot) + 4 * g) = o;
         cs[ot] += o;
       }
     }
@@ -580,16 +582,81 @@ __global__ __launch_bounds__(512, 2) void k_dgrad(long N, const float* G, int ld
   }
 }
 
+// out (N, ldo)[:, :fvalid] = (G[:, :kvalid] W[:kvalid, :fvalid]) * [H > 0] (H null: no mask); colsum (null: skipped) = its
+// column sums.  W[k][f] = W[k*ldw + f].  fvalid is a multiple of 4, ldo too (16-byte stores).
+template <int NKB>
+int dgrad(long N, const float* G, int ldg, int kvalid, const float* W, int ldw, int fvalid, unsigned* wpack, const float* H,
+          float* out, int ldo, float* partial, float* colsum, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_wt_bf, dim3(16 * NKB * 2), dim3(256), 0, st, W, ldw, kvalid, fvalid, NKB, wpack);
+  const long n_tiles = (N + 15) / 16;
+  const int nb = (int)(n_tiles < 256 ? n_tiles : 256);
+  hipLaunchKernelGGL(k_dgrad<NKB>, dim3(nb), dim3(512), 0, st, N, G, ldg, kvalid, (const unsigned*)wpack, H, out, ldo, fvalid,
+                     partial);
+  if (colsum) hipLaunchKernelGGL(k_colsum_final, dim3(fvalid), dim3(64), 0, st, nb, kHid, partial, colsum);
+  return launch_status();
+}
+
 template <int NKB>
 int dgrad(long N, const float* G, int ldg, int kvalid, const float* W, unsigned* wpack, const float* H, float* out,
           float* partial, float* colsum, hipStream_t st) {
-  hipLaunchKernelGGL(k_pack_wt_bf, dim3(16 * NKB * 2), dim3(256), 0, st, W, kHid, kvalid, NKB, wpack);
-  const long n_tiles = (N + 15) / 16;
-  const int nb = (int)(n_tiles < 256 ? n_tiles : 256);
-  hipLaunchKernelGGL(k_dgrad<NKB>, dim3(nb), dim3(512), 0, st, N, G, ldg, kvalid, (const unsigned*)wpack, H, out, partial);
-  hipLaunchKernelGGL(k_colsum_final, dim3(kHid), dim3(64), 0, st, nb, kHid, partial, colsum);
-  return launch_status();
+  return dgrad<NKB>(N, G, ldg, kvalid, W, kHid, kHid, wpack, H, out, kHid, partial, colsum, st);
 }
+
+// ---- scene-encoder backward (training with --joint) -----------------------------------------------------------------
+// feature (bs,224) = [ego 32 | neighbour min 32 | mean 32 | max 32 | 3 lanes x 32] (nusc_model.py:82-93): route d feature
+// to the encoder outputs, tokens ordered [bs ego | bs*K neighbours | 3*bs lanes].  min / max send their gradient to the
+// first neighbour holding the extreme (torch.min/max(dim)); the mean to all K.
+__global__ void k_pool_bwd(int bs, int K, const float* dfeat, const float* tok_out, float* dtok) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)bs * 32) return;
+  const long b = i >> 5;
+  const int o = (int)(i & 31);
+  const float* df = dfeat + b * kFeat;
+  dtok[b * 32 + o] = df[o];
+  const float* no = tok_out + ((long)bs + b * K) * 32 + o;
+  int imin = 0, imax = 0;
+  float vmin = no[0], vmax = no[0];
+  for (int k = 1; k < K; ++k) {
+    const float v = no[(long)k * 32];
+    if (v < vmin) vmin = v, imin = k;
+    if (v > vmax) vmax = v, imax = k;
+  }
+  const float gmin = df[32 + o], gmean = df[64 + o] / (float)K, gmax = df[96 + o];
+  for (int k = 0; k < K; ++k)
+    dtok[((long)bs + b * K + k) * 32 + o] = gmean + (k == imin ? gmin : 0.0f) + (k == imax ? gmax : 0.0f);
+  for (int m = 0; m < 3; ++m) dtok[((long)bs * (K + 1) + b * 3 + m) * 32 + o] = df[128 + 32 * m + o];
+}
+
+// partial[block][c] = sum over the block's rows of G[row][c], c < ncol <= 64 (one column per thread, 4 row-lanes)
+__global__ __launch_bounds__(256) void k_colsum_narrow(long N, const float* G, int ld, int ncol, float* partial) {
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long per = (N + gridDim.x - 1) / gridDim.x;
+  const long r0 = blockIdx.x * per, r1 = (r0 + per < N) ? r0 + per : N;
+  float acc = 0.0f;
+  if (c < ncol)
+    for (long r = r0 + rl; r < r1; r += 4) acc += G[r * ld + c];
+  __shared__ float red[4][64];
+  red[rl][c] = acc;
+  __syncthreads();
+  if (rl == 0 && c < ncol) partial[(long)blockIdx.x * ncol + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// the work buffer of pstl_refine_backward (pstl_train_work_floats); pstl_encoder_backward reads dH1 and S from it
+struct RefineWork {
+  float *dO, *x47, *dH2, *dH1, *S, *part, *slabs;
+  unsigned* wpack;
+  RefineWork(const pstl_cfg* cfg, float* work) {
+    const long N = n_rows(cfg);
+    dO = work;                                // (N,40)
+    x47 = dO + N * kCtrl;                     // (N,47)
+    dH2 = x47 + N * kX47;                     // (N,256)
+    dH1 = dH2 + N * kHid;                     // (N,256)
+    S = dH1 + N * kHid;                       // (bs,256)
+    part = S + (long)cfg->bs * kHid;          // (kRedBlocks,256)
+    slabs = part + (long)kRedBlocks * kHid;   // (kRedBlocks,256,256) split-K partials of k_wgrad
+    wpack = reinterpret_cast<unsigned*>(slabs + (long)kRedBlocks * kHid * kHid);   // kWtPackWords
+  }
+};
 
 }  // namespace
 }  // namespace pstl
@@ -641,14 +708,9 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
     return PSTL_ERR_ARG;
   hipStream_t st = as_stream(stream);
   const long N = n_rows(cfg);
-  float* dO = work;                       // (N,40)
-  float* x47 = dO + N * kCtrl;            // (N,47)
-  float* dH2 = x47 + N * kX47;            // (N,256)
-  float* dH1 = dH2 + N * kHid;            // (N,256)
-  float* S = dH1 + N * kHid;              // (bs,256)
-  float* part = S + (long)cfg->bs * kHid; // (kRedBlocks,256)
-  float* slabs = part + (long)kRedBlocks * kHid;  // (kRedBlocks,256,256) split-K partials of k_wgrad
-  unsigned* wpack = reinterpret_cast<unsigned*>(slabs + (long)kRedBlocks * kHid * kHid);   // kWtPackWords
+  const RefineWork rw(cfg, work);
+  float *dO = rw.dO, *x47 = rw.x47, *dH2 = rw.dH2, *dH1 = rw.dH1, *S = rw.S, *part = rw.part, *slabs = rw.slabs;
+  unsigned* wpack = rw.wpack;
   const int nb = (int)(N < kRedBlocks ? N : kRedBlocks);
 
   hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)((N * kCtrl + 255) / 256)), dim3(256), 0, st, N, cfg->w_max, cfg->a_max,
@@ -712,6 +774,65 @@ extern "C" int pstl_diversity_loss(const pstl_cfg* cfg, const float* rect_contro
     if (rect_reg_weight != 0.0f)
       hipLaunchKernelGGL(k_reg_grad, dim3((unsigned)((N * kCtrl + 255) / 256)), dim3(256), 0, st, N, rect_reg_weight,
                          rect_controls, init_controls, scores, reg_out, dcontrols);
+  }
+  return launch_status();
+}
+
+
+// ---- --joint: gradients of the three scene encoders (and d fused for merge_net) -------------------------------------
+extern "C" size_t pstl_encoder_backward_work_floats(const pstl_cfg* cfg) {
+  if (check_cfg(cfg)) return 0;
+  const long bs = cfg->bs, K = cfg->K;
+  const long tmax = bs * (K > 3 ? K : 3);
+  return (size_t)(bs * kFeat + bs * (K + 4) * 32 + 2 * tmax * kHid + 64);
+}
+
+extern "C" int pstl_encoder_backward(const pstl_cfg* cfg, float* refine_work, const float* rect_w1, const float* const* enc_w1,
+                                     const float* const* enc_w2, const float* tok_in, const float* tok_h1, const float* tok_h2,
+                                     const float* tok_out, float* work, float* const* d_w0, float* const* d_b0,
+                                     float* const* d_w1, float* const* d_b1, float* const* d_w2, float* const* d_b2,
+                                     float* dfused, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!refine_work || !rect_w1 || !enc_w1 || !enc_w2 || !tok_in || !tok_h1 || !tok_h2 || !tok_out || !work || !d_w0 ||
+      !d_b0 || !d_w1 || !d_b1 || !d_w2 || !d_b2)
+    return PSTL_ERR_ARG;
+  for (int e = 0; e < 3; ++e)
+    if (!enc_w1[e] || !enc_w2[e] || !d_w0[e] || !d_b0[e] || !d_w1[e] || !d_b1[e] || !d_w2[e] || !d_b2[e]) return PSTL_ERR_ARG;
+  hipStream_t st = as_stream(stream);
+  const long N = n_rows(cfg), bs = cfg->bs, K = cfg->K;
+  const RefineWork rw(cfg, refine_work);
+  const long tmax = bs * (K > 3 ? K : 3);
+  float* dfeat = work;                  // (bs,224)
+  float* dtok = dfeat + bs * kFeat;     // (T,32)
+  float* dh2 = dtok + bs * (K + 4) * 32;  // (tmax,256)
+  float* dh1 = dh2 + tmax * kHid;       // (tmax,256)
+  // d fused = dH1 W1[:, 231:271] (the rect_net input columns merge_net feeds); no mask: a linear input
+  if (dfused)
+    if (int e = dgrad<8>(N, rw.dH1, kHid, kHid, rect_w1 + kFeat + 7, kIn, kCtrl, rw.wpack, nullptr, dfused, kCtrl, rw.part,
+                         nullptr, st))
+      return e;
+  // d feature = S W1[:, :224], S = per-scene sums of dH1 (left in the work buffer by pstl_refine_backward)
+  if (int e = dgrad<8>(bs, rw.S, kHid, kHid, rect_w1, kIn, kFeat, rw.wpack, nullptr, dfeat, kFeat, rw.part, nullptr, st)) return e;
+  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)((bs * 32 + 255) / 256)), dim3(256), 0, st, (int)bs, (int)K, dfeat, tok_out, dtok);
+  const long t0[3] = {0, bs, bs * (K + 1)}, tn[3] = {bs, bs * K, 3 * bs};
+  const int nin[3] = {6, 7, 45};
+  for (int e = 0; e < 3; ++e) {
+    const long T = tn[e];
+    const float* g_out = dtok + t0[e] * 32;
+    const float* h1 = tok_h1 + t0[e] * kHid;
+    const float* h2 = tok_h2 + t0[e] * kHid;
+    const float* xin = tok_in + t0[e] * 48;
+    // layer 2 (256 -> 32): db2, dW2 = d out^T h2, dh2 = (d out W2) * [h2 > 0] with db1 = its column sums
+    const int nb = (int)(T < 256 ? T : 256);
+    hipLaunchKernelGGL(k_colsum_narrow, dim3(nb), dim3(256), 0, st, T, g_out, 32, 32, rw.part);
+    hipLaunchKernelGGL(k_colsum_final, dim3(32), dim3(64), 0, st, nb, 32, rw.part, d_b2[e]);
+    if (int er = wgrad<2, 16, 1, 8>(T, g_out, 32, 32, h2, kHid, kHid, rw.slabs, d_w2[e], kHid, st)) return er;
+    if (int er = dgrad<1>(T, g_out, 32, 32, enc_w2[e], rw.wpack, h2, dh2, rw.part, d_b1[e], st)) return er;
+    // layer 1 (256 -> 256)
+    if (int er = wgrad<16, 16, 4, 2>(T, dh2, kHid, kHid, h1, kHid, kHid, rw.slabs, d_w1[e], kHid, st)) return er;
+    if (int er = dgrad<8>(T, dh2, kHid, kHid, enc_w1[e], rw.wpack, h1, dh1, rw.part, d_b0[e], st)) return er;
+    // layer 0 (nin -> 256): dW0 = dh1^T token inputs
+    if (int er = wgrad<16, 3, 8, 1>(T, dh1, kHid, kHid, xin, 48, nin[e], rw.slabs, d_w0[e], nin[e], st)) return er;
   }
   return launch_status();
 }

@@ -151,12 +151,27 @@ class Sampler:
         return ev
 
     # ---- A1 ----
-    def encode(self, sb, need_rect=True):
+    def encode(self, sb, need_rect=True, save=False):
+        """save=True (training with --joint): a fourth return value, the per-token activations the encoders' backward pass
+        needs (dict tok_in (T,48), tok_h1, tok_h2 (T,256), tok_out (T,32); T = bs*(K+4), see pstl_encode_scene_saved)."""
         dev = sb.device
         feature = torch.empty(sb.bs, ffi.FEAT, dtype=torch.float32, device=dev)
         base_p = torch.empty(sb.bs, ffi.HID, dtype=torch.float32, device=dev)
         base_r = torch.empty(sb.bs, ffi.HID, dtype=torch.float32, device=dev) if (need_rect and self.w.has_rect) else None
         cfg = sb.cfg(2)
+        if save:
+            T = sb.bs * (sb.K + 4)
+            sv = dict(tok_in=torch.empty(T, 48, dtype=torch.float32, device=dev),
+                      tok_h1=torch.empty(T, ffi.HID, dtype=torch.float32, device=dev),
+                      tok_h2=torch.empty(T, ffi.HID, dtype=torch.float32, device=dev),
+                      tok_out=torch.empty(T, 32, dtype=torch.float32, device=dev))
+            ffi.check(self.L.pstl_encode_scene_saved(ctypes.byref(cfg), ffi.ptr(self.w.packed), ffi.ptr(sb.ego0),
+                                                     ffi.ptr(sb.neighbors), ffi.ptr(sb.lanes[0]), ffi.ptr(sb.lanes[1]),
+                                                     ffi.ptr(sb.lanes[2]), ffi.ptr(sb.ids[0]), ffi.ptr(sb.ids[1]),
+                                                     ffi.ptr(sb.ids[2]), ffi.ptr(feature), ffi.ptr(base_p), ffi.ptr(base_r),
+                                                     ffi.ptr(sv["tok_in"]), ffi.ptr(sv["tok_h1"]), ffi.ptr(sv["tok_h2"]),
+                                                     ffi.ptr(sv["tok_out"]), ffi.stream()), "encode_scene_saved")
+            return feature, base_p, base_r, sv
         ffi.check(self.L.pstl_encode_scene(ctypes.byref(cfg), ffi.ptr(self.w.packed), ffi.ptr(sb.ego0),
                                            ffi.ptr(sb.neighbors), ffi.ptr(sb.lanes[0]), ffi.ptr(sb.lanes[1]),
                                            ffi.ptr(sb.lanes[2]), ffi.ptr(sb.ids[0]), ffi.ptr(sb.ids[1]),
@@ -465,6 +480,19 @@ class RectTrainer:
 
     NAMES = ("rect_net.0.weight", "rect_net.0.bias", "rect_net.2.weight", "rect_net.2.bias", "rect_net.4.weight",
              "rect_net.4.bias")
+    ENCODERS = ("ego_encoder", "neighbor_encoder", "lane_encoder")
+    ENCODER_IN = (6, 7, 45)
+
+    @classmethod
+    def joint_names(cls, merge):
+        """Every tensor that receives a gradient under --joint (reference nusc_train.py:1230-1231: Adam over
+        net.parameters(); policy_net gets none and Adam skips it)."""
+        names = list(cls.NAMES)
+        for e in cls.ENCODERS:
+            names += ["%s.%d.%s" % (e, i, t) for i in (0, 2, 4) for t in ("weight", "bias")]
+        if merge:
+            names += ["merge_net.%d.%s" % (i, t) for i in (0, 2, 4) for t in ("weight", "bias")]
+        return tuple(names)
 
     def __init__(self, sampler):
         self.sm = sampler
@@ -480,7 +508,7 @@ class RectTrainer:
             pass
 
     def loss_and_grads(self, sb, feature, base_rect, w2, w3, init_controls, prev_scores, e7=None, stl_weight=1.0, merge=None,
-                       clip_rect=False):
+                       clip_rect=False, joint=None):
         """init_controls (N,40) physical units, prev_scores (N,) (both detached in the reference).  w2, w3: the live
         rect_net.2.weight / rect_net.4.weight tensors.  Returns (loss tensor, rect_controls, scores, {name: grad}).
         e7 = None: config 5, loss = mask_mean(relu(thres - score), valid), plain rect_net input.
@@ -489,7 +517,10 @@ class RectTrainer:
         merge_net architecture; self.last holds the individual terms.
         merge: rect_net sees init + merge_net max-pool (the reference: --diverse_loss without --no_arch, nusc_model.py:185);
         default = (e7 is not None).  clip_rect: --clip_rect (nusc_model.py:230-233); the interval head already keeps a
-        refined control inside its bounds, so the clip is the identity up to rounding and passes the gradient through."""
+        refined control inside its bounds, so the clip is the identity up to rounding and passes the gradient through.
+        joint: None, or dict(params={name: live tensor} for rect_net.0.weight and the .2/.4 weights of the three encoders,
+        saved=the fourth return value of Sampler.encode(save=True)): --joint, the gradient dict also holds the encoders'
+        tensors and, with merge, merge_net's (RectTrainer.joint_names)."""
         dev = sb.device
         N = sb.N
         objective_e7 = e7 is not None
@@ -550,18 +581,74 @@ class RectTrainer:
                                               ffi.ptr(g["rect_net.2.weight"]), ffi.ptr(g["rect_net.2.bias"]),
                                               ffi.ptr(g["rect_net.4.weight"]), ffi.ptr(g["rect_net.4.bias"]),
                                               ffi.stream()), "refine_backward")
+        if joint is not None:
+            g.update(self._joint_grads(sb, cfg, work, joint["params"], joint["saved"], init_controls, merge))
         return loss, rect, scores, g
 
+    def _joint_grads(self, sb, cfg, refine_work, params, sv, init_controls, merge):
+        """pstl_encoder_backward (+ pstl_merge_backward): continues from the work buffer pstl_refine_backward just filled."""
+        dev = sb.device
+        g = {}
+        arr = {}
+        keep = []   # converted copies must outlive the launches
+        PtrArr = ctypes.c_void_p * 3
+
+        def grads_of(idx, shape_of):
+            ts = []
+            for e, nin in zip(self.ENCODERS, self.ENCODER_IN):
+                w = torch.empty(shape_of(nin), dtype=torch.float32, device=dev)
+                b = torch.empty(shape_of(nin)[0], dtype=torch.float32, device=dev)
+                g["%s.%d.weight" % (e, idx)] = w
+                g["%s.%d.bias" % (e, idx)] = b
+                ts.append((w, b))
+            return PtrArr(*[t[0].data_ptr() for t in ts]), PtrArr(*[t[1].data_ptr() for t in ts])
+
+        dw0, db0 = grads_of(0, lambda nin: (ffi.HID, nin))
+        dw1, db1 = grads_of(2, lambda nin: (ffi.HID, ffi.HID))
+        dw2, db2 = grads_of(4, lambda nin: (32, ffi.HID))
+        for idx in (2, 4):
+            ws = [ffi.f32(params["%s.%d.weight" % (e, idx)].detach(), dev) for e in self.ENCODERS]
+            keep += ws
+            arr[idx] = PtrArr(*[w.data_ptr() for w in ws])
+        w1r = ffi.f32(params["rect_net.0.weight"].detach(), dev)
+        work = torch.empty(self.L.pstl_encoder_backward_work_floats(ctypes.byref(cfg)), dtype=torch.float32, device=dev)
+        dfused = torch.empty(sb.N, ffi.CTRL, dtype=torch.float32, device=dev) if merge else None
+        ffi.check(self.L.pstl_encoder_backward(ctypes.byref(cfg), ffi.ptr(refine_work), ffi.ptr(w1r), arr[2], arr[4],
+                                               ffi.ptr(sv["tok_in"]), ffi.ptr(sv["tok_h1"]), ffi.ptr(sv["tok_h2"]),
+                                               ffi.ptr(sv["tok_out"]), ffi.ptr(work), dw0, db0, dw1, db1, dw2, db2,
+                                               ffi.ptr(dfused), ffi.stream()), "encoder_backward")
+        if merge:
+            mw = torch.empty(self.L.pstl_merge_backward_work_floats(ctypes.byref(cfg)), dtype=torch.float32, device=dev)
+            shapes = {0: (32, ffi.CTRL), 2: (32, 32), 4: (ffi.CTRL, 32)}
+            for idx in (0, 2, 4):
+                g["merge_net.%d.weight" % idx] = torch.empty(shapes[idx], dtype=torch.float32, device=dev)
+                g["merge_net.%d.bias" % idx] = torch.empty(shapes[idx][0], dtype=torch.float32, device=dev)
+            ffi.check(self.L.pstl_merge_backward(ctypes.byref(cfg), ffi.ptr(self.sm.w.packed), ffi.ptr(init_controls),
+                                                 ffi.ptr(dfused), ffi.CTRL, ffi.ptr(mw),
+                                                 ffi.ptr(g["merge_net.0.weight"]), ffi.ptr(g["merge_net.0.bias"]),
+                                                 ffi.ptr(g["merge_net.2.weight"]), ffi.ptr(g["merge_net.2.bias"]),
+                                                 ffi.ptr(g["merge_net.4.weight"]), ffi.ptr(g["merge_net.4.bias"]),
+                                                 ffi.stream()), "merge_backward")
+        del keep   # (same-stream caching allocator: releasing the converted copies after the launches is ordered)
+        return g
+
     def train_step(self, sb, params, optimizer, steps, x_T=None, noise=None, seed=None, multi_cands=5, coeffs=None,
-                   group=None, e7=None, stl_weight=1.0, merge=None, clip_rect=False):
+                   group=None, e7=None, stl_weight=1.0, merge=None, clip_rect=False, joint=False):
         """One optimisation step of config 5 on one batch shard: sampling under no-grad (rollout, candidate scoring and
         selection), RefineNet forward/backward under the STL loss, gradient all-reduce over the ranks (the loss is a
         mean over the GLOBAL batch, so per-rank gradients simply add), optimizer.step() on the caller's parameters.
         `params`: dict name -> live torch Parameter/Tensor for RectTrainer.NAMES (the weights used by the kernels are
-        re-packed from them by the caller after the step)."""
+        re-packed from them by the caller after the step).
+        joint (--joint): `params` holds RectTrainer.joint_names(merge) -- the encoders and merge_net are trained too."""
         import torch.distributed as dist
         sm = self.sm
-        feature, base_p, base_r = sm.encode(sb, need_rect=True)
+        use_merge = (e7 is not None) if merge is None else bool(merge)
+        names = self.joint_names(use_merge) if joint else self.NAMES
+        saved = None
+        if joint:
+            feature, base_p, base_r, saved = sm.encode(sb, need_rect=True, save=True)
+        else:
+            feature, base_p, base_r = sm.encode(sb, need_rect=True)
         x = sm.fill_normal(sb, steps, steps, seed) if seed is not None else x_T.clone()
         emit = sm.rollout(sb, base_p, x, noise, steps, n_emit=max(multi_cands, 1), clip=True, coeffs=coeffs, seed=seed)
         r = sm.score(sb, emit[-multi_cands:].contiguous(), select=True)
@@ -573,18 +660,19 @@ class RectTrainer:
                       rect_reg_loss=float(e7.get("rect_reg_loss", 0.0)) / world)
         loss, rect, scores, g = self.loss_and_grads(sb, feature, base_r, params["rect_net.2.weight"],
                                                     params["rect_net.4.weight"], r["sel_controls"], r["sel_scores"], e7=e7,
-                                                    stl_weight=stl_weight, merge=merge, clip_rect=clip_rect)
+                                                    stl_weight=stl_weight, merge=merge, clip_rect=clip_rect,
+                                                    joint=dict(params=params, saved=saved) if joint else None)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            flat = torch.cat([g[k].reshape(-1) for k in self.NAMES] + [loss.reshape(1)])
-            dist.all_reduce(flat, group=group)          # 145 704 gradients + the loss: one 583 KB all-reduce
+            flat = torch.cat([g[k].reshape(-1) for k in names] + [loss.reshape(1)])
+            dist.all_reduce(flat, group=group)          # 145 704 gradients (--joint: up to 387 056) + the loss: one all-reduce
             o = 0
-            for k in self.NAMES:
+            for k in names:
                 n = g[k].numel()
                 g[k] = flat[o:o + n].reshape(g[k].shape)
                 o += n
             loss = flat[o]
         optimizer.zero_grad(set_to_none=True)
-        for k in self.NAMES:
+        for k in names:
             params[k].grad = g[k]
         optimizer.step()
         return loss, scores

@@ -31,7 +31,9 @@ EXPORTS = ["pstl_version", "pstl_error_string", "pstl_packed_weight_floats", "ps
            "pstl_refine_train_forward", "pstl_loss_grad", "pstl_train_create", "pstl_train_destroy",
            "pstl_train_work_floats", "pstl_refine_backward", "pstl_diversity",
            "pstl_stl_program_forward", "pstl_stl_program_backward", "pstl_trajopt",
-           "pstl_diversity_loss", "pstl_stl_signals", "pstl_refinement", "pstl_refinement_work_floats"]
+           "pstl_diversity_loss", "pstl_stl_signals", "pstl_refinement", "pstl_refinement_work_floats",
+           "pstl_encode_scene_saved", "pstl_encoder_backward", "pstl_encoder_backward_work_floats", "pstl_merge_backward",
+           "pstl_merge_backward_work_floats"]
 
 
 class PstlCfg(ctypes.Structure):
@@ -73,6 +75,8 @@ def lib():
             getattr(L, name).restype = ctypes.c_int
         L.pstl_train_work_floats.restype = ctypes.c_size_t
         L.pstl_refinement_work_floats.restype = ctypes.c_size_t
+        L.pstl_encoder_backward_work_floats.restype = ctypes.c_size_t
+        L.pstl_merge_backward_work_floats.restype = ctypes.c_size_t
         _lib = L
     return _lib
 

@@ -635,7 +635,8 @@ def run_trajopt(data_loader, args):
 # RefineNet training (reference main loop nusc_train.py:1237-1632 for --rect_head: configs e7_ours / e8_ours_ablation)
 # ---------------------------------------------------------------------------------------------------------------
 def run_training(data_loader, net, coeffs, args):
-    """Optimises rect_net (the only parameters in the reference's optimiser without --joint, nusc_train.py:1230-1233):
+    """Optimises rect_net (the only parameters in the reference's optimiser without --joint, nusc_train.py:1230-1233;
+    with --joint the whole net: the three scene encoders and merge_net receive gradients too, policy_net none):
     per batch, sampling under no-grad, candidate selection, RefineNet forward/backward under
       --diverse_loss:  loss_stl*stl_weight + loss_reg*rect_reg_loss + loss_diversity      (e7_ours,  :442-467)
       otherwise:       loss_stl*stl_weight                                                 (e8_ours_ablation, :468-478)
@@ -643,10 +644,12 @@ def run_training(data_loader, net, coeffs, args):
     from .engine import RectTrainer
     if not args.rect_head:
         raise SystemExit("training of the denoiser itself (e5_ddpm) is outside this path; --rect_head trains RefineNet")
-    if args.joint:
-        raise SystemExit("--joint (gradients into the scene encoders / merge_net) is not implemented")
-    optimizer = torch.optim.Adam(net.rect_net.parameters(), lr=args.lr)
-    params = {"rect_net." + k: p for k, p in net.rect_net.named_parameters()}
+    if args.joint:      # reference :1230-1231
+        optimizer = torch.optim.Adam(net.parameters(), lr=args.lr)
+        params = dict(net.named_parameters())
+    else:
+        optimizer = torch.optim.Adam(net.rect_net.parameters(), lr=args.lr)
+        params = {"rect_net." + k: p for k, p in net.rect_net.named_parameters()}
     e7 = None
     if args.diverse_loss:
         e7 = dict(stl_weight=args.stl_weight, diversity_weight=args.diversity_weight, diversity_scale=args.diversity_scale,
@@ -669,7 +672,8 @@ def run_training(data_loader, net, coeffs, args):
             step += 1
             loss, scores = tr.train_step(sb, params, optimizer, args.diffusion_steps, seed=args.seed * 100003 + step,
                                          multi_cands=args.multi_cands or 1, coeffs=coeffs, e7=e7, stl_weight=args.stl_weight,
-                                         merge=bool(args.diverse_loss and not args.no_arch), clip_rect=bool(args.clip_rect))
+                                         merge=bool(args.diverse_loss and not args.no_arch), clip_rect=bool(args.clip_rect),
+                                         joint=bool(args.joint))
             counts, _ = tr.sm.metrics(sb, scores)
             acc, _ = acc_from_counts(counts)
             md.update("loss", float(loss))

@@ -170,3 +170,103 @@ def test_dpp_kernel_matches_oracle(S, n_shards, detach):
     np.testing.assert_allclose(out["dc"].cpu().numpy(), gd, rtol=2e-3, atol=2e-5 * np.abs(gd).max())
     gs = scores.grad.numpy() if scores.grad is not None else np.zeros(N, dtype=np.float32)
     np.testing.assert_allclose(out["ds"].cpu().numpy(), gs, rtol=2e-3, atol=2e-5 * max(np.abs(gs).max(), 1e-6))
+
+
+# ---- --joint: gradients into the scene encoders and merge_net -----------------------------------------------------------
+def _joint_setup(d, dev):
+    sm, sb, sd, tr = _setup(d, dev)
+    kw = dict(e7=None, merge=False, clip_rect=False)
+    if "meta_e7" in d:
+        stl_w, div_w, scale, reg_w, detach, n_shards, no_arch, clip_rect = [float(v) for v in d["meta_e7"]]
+        kw = dict(e7=dict(stl_weight=stl_w, diversity_weight=div_w, diversity_scale=scale, rect_reg_loss=reg_w,
+                          detach=bool(detach)), merge=not no_arch, clip_rect=bool(clip_rect))
+    return sm, sb, sd, tr, kw
+
+
+@pytest.mark.parametrize("name", ["train_e8_joint", "train_e7_joint", "train_e7_joint_b"])
+def test_joint_gradients_match_reference(name):
+    """--joint (reference nusc_train.py:1230-1231): d loss / d (three encoders, merge_net, rect_net) against the reference's
+    autograd; the saved-token encoder is the plain encoder bit for bit."""
+    dev = torch.device("cuda:0")
+    d = load_golden(name)
+    sm, sb, sd, tr, kw = _joint_setup(d, dev)
+    feature, base_p, base_r, saved = sm.encode(sb, save=True)
+    f0, p0, r0 = sm.encode(sb)
+    assert torch.equal(feature, f0) and torch.equal(base_p, p0) and torch.equal(base_r, r0)
+    T = sb.bs * (sb.K + 4)
+    assert saved["tok_in"].shape == (T, 48) and saved["tok_out"].shape == (T, 32)
+    # the ego token's output is the first 32 feature columns, the lanes' the last 96
+    assert torch.equal(saved["tok_out"][:sb.bs], feature[:, :32])
+    assert torch.equal(saved["tok_out"][sb.bs * (sb.K + 1):].reshape(sb.bs, 96), feature[:, 128:])
+    init = torch.from_numpy(d["sel_controls"]).reshape(sb.N, 40).to(dev)
+    prev = torch.from_numpy(d["sel_scores"]).to(dev)
+    names = tr.joint_names(kw["merge"])
+    assert set(names) == set(str(k) for k in d["joint_names"]) | set(tr.NAMES)
+    loss, rect, scores, g = tr.loss_and_grads(sb, feature, base_r, sd["rect_net.2.weight"], sd["rect_net.4.weight"], init,
+                                              prev, joint=dict(params=sd, saved=saved), **kw)
+    np.testing.assert_allclose(float(loss), float(d["loss"]), rtol=3e-4, atol=1e-5)
+    assert set(g) == set(names)
+    for k in names:
+        ref = d["grad_" + k]
+        assert g[k].shape == ref.shape, k
+        np.testing.assert_allclose(g[k].cpu().numpy(), ref, rtol=5e-3, atol=3e-4 * np.abs(ref).max(), err_msg=k)
+
+
+def test_joint_gradients_against_oracle_on_fresh_scenes():
+    """Bigger than the fixtures (several workgroups per kernel, invalid lanes, K = 6), e7 architecture."""
+    from oracle import pstl_oracle as orc
+    from pstl_diffusion_policy_amd.engine import PackedWeights, RectTrainer, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    dev = torch.device("cuda:0")
+    hp = default_hparams()
+    bs, S, K = 37, 32, 6
+    scene = make_scene_batch(bs, K=K, S=S, seed=91, invalid_lane_frac=0.3, stlp_mode="wide")
+    sdn = golden_weights()
+    gen = torch.Generator().manual_seed(4)
+    N = bs * S * 3
+    init = (torch.randn(N, 20, 2, generator=gen) * torch.tensor([0.1, 1.0])).clamp(-0.5, 0.5)
+    prev = torch.randn(N, generator=gen)
+    e7 = dict(stl_weight=1.0, diversity_weight=0.5, diversity_scale=1.0, rect_reg_loss=0.0, detach=False)
+    ref = orc.rect_train_step(sdn, {k: v.numpy() for k, v in scene.items()}, S, hp, init, prev, 3e-4, e7=e7, joint=True)
+    sd = {k: torch.from_numpy(v).to(dev) for k, v in sdn.items()}
+    sm = Sampler(PackedWeights(sd, dev), hp)
+    sb = SceneBatch(scene, S, hp, dev)
+    tr = RectTrainer(sm)
+    feature, _, base_r, saved = sm.encode(sb, save=True)
+    loss, rect, scores, g = tr.loss_and_grads(sb, feature, base_r, sd["rect_net.2.weight"], sd["rect_net.4.weight"],
+                                              init.reshape(N, 40).to(dev), prev.to(dev), e7=e7,
+                                              joint=dict(params=sd, saved=saved))
+    np.testing.assert_allclose(float(loss), float(ref["loss"]), rtol=3e-4, atol=1e-5)
+    for k in tr.joint_names(True):
+        r = ref["grads"][k].numpy()
+        np.testing.assert_allclose(g[k].cpu().numpy(), r, rtol=5e-3, atol=3e-4 * np.abs(r).max(), err_msg=k)
+
+
+def test_joint_train_steps_move_every_trained_tensor_and_nothing_else():
+    """The CLI's --joint path: Adam over net.parameters(); encoders, merge_net and rect_net move, policy_net does not, the
+    loss goes down on a frozen batch."""
+    from pstl_diffusion_policy_amd import nusc_train as nt
+    from pstl_diffusion_policy_amd.engine import RectTrainer, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    dev = torch.device("cuda:0")
+    args = nt.generate_parser(["--diffusion", "--stl_weight", "1.0", "--load_stlp", "--rect_head", "--flex", "--diverse_loss",
+                               "--diversity_weight", "0.1", "--multi_cands", "5", "--diffusion_steps", "12", "--n_randoms",
+                               "64", "--sampling_size", "64", "--n_neighbors", "3", "--lr", "3e-4", "--joint"])
+    net = nt.Net(args).cuda()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in golden_weights().items()})
+    opt = torch.optim.Adam(net.parameters(), lr=args.lr)
+    hp = net.hparams()
+    scene = make_scene_batch(6, K=3, S=64, seed=5, invalid_lane_frac=0.2, stlp_mode="wide")
+    sb = SceneBatch(scene, 64, hp, dev)
+    params = dict(net.named_parameters())
+    before = {k: v.detach().clone() for k, v in params.items()}
+    e7 = dict(stl_weight=1.0, diversity_weight=0.1, diversity_scale=1.0, rect_reg_loss=0.0, detach=False)
+    losses = []
+    for it in range(5):
+        tr = RectTrainer(Sampler(net.packed(), hp))
+        loss, _ = tr.train_step(sb, params, opt, args.diffusion_steps, seed=11, multi_cands=5, e7=e7, joint=True)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    for k, v in params.items():
+        moved = not torch.equal(v.detach(), before[k])
+        assert moved == (not k.startswith("policy_net.")), k
