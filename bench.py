@@ -36,6 +36,7 @@ def parse():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--workload", default="e7_guid", choices=["e5", "e7", "e7_guid", "e8_train", "e7_train", "trajopt"])
+    p.add_argument("--joint", action="store_true", help="train workloads: Adam over the whole net (reference --joint)")
     p.add_argument("--scenes", type=int, default=4096, help="scenes per GPU (weak scaling)")
     p.add_argument("--sampling_size", type=int, default=64)
     p.add_argument("--neighbors", type=int, default=2)
@@ -180,8 +181,9 @@ def main():
     sampler = Sampler(PackedWeights(sd, dev), hp, chain_waves=a.chain_waves)
     if train:
         from pstl_diffusion_policy_amd.engine import RectTrainer
-        tparams = {k: sd[k].to(dev).clone().requires_grad_() for k in RectTrainer.NAMES}
-        topt = torch.optim.Adam([tparams[k] for k in RectTrainer.NAMES], lr=3e-4)
+        tnames = RectTrainer.joint_names(e7 is not None) if a.joint else RectTrainer.NAMES   # --joint: encoders (+ merge_net) too
+        tparams = {k: sd[k].to(dev).clone().requires_grad_() for k in tnames}
+        topt = torch.optim.Adam([tparams[k] for k in tnames], lr=3e-4)
         sd_live = {k: (tparams[k] if k in tparams else v) for k, v in sd.items()}
     coeffs = diffusion_coeffs(steps, dev)
     N = bs * S * 3
@@ -211,7 +213,7 @@ def main():
             sm_t = Sampler(PackedWeights(sd_live, dev), hp, chain_waves=a.chain_waves)   # weights changed: re-pack
             sm_t.trace = sampler.trace
             loss, scores = RectTrainer(sm_t).train_step(sb, tparams, topt, steps, x_T=x_T, noise=z, seed=seed,
-                                                        multi_cands=a.multi_cands, coeffs=coeffs, e7=e7)
+                                                        multi_cands=a.multi_cands, coeffs=coeffs, e7=e7, joint=a.joint)
             counts, _ = sm_t.metrics(sb, scores)
             return gather_final(counts, torch.zeros(12, dtype=torch.float64, device=dev))
         out = sampler.sampling_region(sb, steps, x_T, z, rect_head=rect_head,
@@ -304,7 +306,7 @@ def main():
             "config": {"workload": "%s: %d scenes/GPU x sampling_size %d x 3 modes = %d rows/GPU, T=20, K=%d neighbours, "
                                    "diffusion_steps=%d (%d denoiser evals), multi_cands=%s, guidance=%s, RefineNet=%s, "
                                    "random-init weights (seed 1007)"
-                                   % (a.workload, bs, S, N, a.neighbors, steps, steps - 1,
+                                   % (a.workload + (" --joint" if (train and a.joint) else ""), bs, S, N, a.neighbors, steps, steps - 1,
                                       a.multi_cands if rect_head else None,
                                       "before=10,niters=1,lr=0.01" if guidance else None, rect_head),
                        "rows_per_gpu": N, "parallelism": "scene shards x%d, no data-path collective" % world,

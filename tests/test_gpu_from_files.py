@@ -58,6 +58,15 @@ def test_refinenet_training_from_files_updates_the_checkpoint(tmp_path, capsys):
         moved = {k for k in sd1 if k in sd0 and not torch.equal(sd1[k], sd0[k].cpu())}
         assert moved and all(k.startswith("rect_net.") for k in moved), moved
     assert "epoch 001" in capsys.readouterr().out
+    # --joint (reference nusc_train.py:1230-1231): the encoders and merge_net move too, the denoiser never does
+    for extra in (["--diverse_loss", "--stl_weight", "1.0", "--joint"], ["--stl_weight", "1.0", "--diversity_weight", "0.0", "--joint"]):
+        nd.save_checkpoint(sd0, os.path.join(root, "models"))
+        md = nt.main(base + extra + ["-P", nd.smart_path(root)])
+        assert np.isfinite(md("loss"))
+        sd1 = torch.load(nd.smart_path(root), map_location="cpu")
+        moved = {k.split(".")[0] for k in sd1 if k in sd0 and not torch.equal(sd1[k], sd0[k].cpu())}
+        want = {"rect_net", "ego_encoder", "neighbor_encoder", "lane_encoder"} | ({"merge_net"} if "--diverse_loss" in extra else set())
+        assert moved == want, moved
     # a -P that names no file is an error (the reference fails in torch.load), unless random init is asked for
     with pytest.raises(SystemExit):
         nt.main(base + ["--stl_weight", "1.0", "-P", str(tmp_path / "no_such.ckpt")])
