@@ -1,5 +1,5 @@
-// mlp_kernels.hip -- the denoiser / RefineNet MLP chain on gfx950 MFMA (split-bf16 by default, exact fp32 on request),
-// the scene encoder and weight packing.
+// mlp_kernels.hip -- the denoiser / RefineNet MLP chain on gfx950 MFMA (split-f16 by default: fp32-faithful; split-bf16
+// or exact fp32 MFMA on request), the scene encoder, merge_net (forward + backward) and weight packing.
 //
 // Design:
 //  * Both 3-layer MLPs of the hot path (policy_net 303->256->256->40, rect_net 271->256->256->40) see only 47
@@ -15,9 +15,10 @@
 //  * A workgroup owns G tiles (192 rows = one scene at S = 64) for ALL reverse steps of a launch: x never leaves
 //    LDS between steps; HBM traffic is the noise read (parity mode) and the emitted candidates.
 //  * f32 MFMA is bit-for-bit a k-ordered fmaf chain, so results match an fp32 torch path to rounding (1e-4 gate).
-//  * Default arithmetic (template parameter BF): every fp32 operand is two bf16 pieces, every product three
-//    v_mfma_f32_16x16x32_bf16 products accumulated in fp32 -- 8e-6 from the reference after 99 chained steps, 2.7x the
-//    speed of the fp32 form.  See the comment above k_chain.
+//  * Default arithmetic (template parameter PT = 2): every fp32 operand is two IEEE-half pieces of a power-of-two
+//    multiple of the value (2^-23 per operand), every product three v_mfma_f32_16x16x32_f16 products accumulated in fp32
+//    -- 1.9e-6 from the reference after 99 chained steps, the same as the fp32 MFMA form, at 2.8x its speed.  PT = 1:
+//    bf16 pieces (2^-17 per operand, 8e-6).  See the comment above k_chain.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -999,6 +1000,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   bool woven_noise = BF && !REFINE && (ABL == 0 || ABL == 7) && a.rng && !a.mu_only && w >= NW / 2 && w < NW / 2 + 3;
   // (stamp build: its scalar stamps must not cross a branch the compiler takes for divergent)
   if (ABL == 7) woven_noise = __builtin_amdgcn_readfirstlane((int)woven_noise) != 0;
+  // (Tried in round 2: deferring layer 3 of every tile-step to the head of the next iteration -- accumulators kept across
+  // the barrier, epilogue two iterations behind -- so that an iteration ends with layer 2's MFMAs instead of the serial
+  // tail split -> layer 3 -> partial sums -> barrier.  Bit-identical, 5.8 % SLOWER (15.42 vs 14.57 ms): behind the barrier
+  // the split has no MFMAs of its own wave to hide under.)
   int hbuf = 0;  // it % 3
   for (int it = 0; it < total; ++it) {
     PSTL_STAMP(0)
