@@ -664,7 +664,12 @@ class RectTrainer:
                                                     joint=dict(params=params, saved=saved) if joint else None)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             flat = torch.cat([g[k].reshape(-1) for k in names] + [loss.reshape(1)])
-            dist.all_reduce(flat, group=group)          # 145 704 gradients (--joint: up to 387 056) + the loss: one all-reduce
+            if dist.get_backend(group) == "gloo":       # host tensors (ranks sharing a device in the tests); RCCL: in place
+                host = flat.cpu()
+                dist.all_reduce(host, group=group)
+                flat = host.to(flat.device)
+            else:
+                dist.all_reduce(flat, group=group)      # 145 704 gradients (--joint: up to 387 056) + the loss: one all-reduce
             o = 0
             for k in names:
                 n = g[k].numel()

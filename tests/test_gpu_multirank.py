@@ -129,3 +129,66 @@ def test_bench_starts_its_own_ranks():
     if ndev < 2:
         refused = _bench(["--gpus", "2"] + small)
         assert refused.returncode != 0 and "refusing" in refused.stderr
+
+
+# ---- N > 1 training: RectTrainer.train_step all-reduces the gradients (the loss is a mean over the GLOBAL batch) ---------
+T_BS, T_S, T_K, T_STEPS = 6, 16, 3, 10
+T_E7 = dict(stl_weight=1.0, diversity_weight=0.5, diversity_scale=1.0, rect_reg_loss=0.0, detach=False)
+
+
+def _train_grads(scene, lo, hi, vsum, vrows, dev, joint, group_ready):
+    from pstl_diffusion_policy_amd.engine import PackedWeights, RectTrainer, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.nusc_model import init_state_dict
+    from pstl_diffusion_policy_amd.synthetic import default_hparams
+    hp = default_hparams()
+    sd = {k: v.to(dev) for k, v in init_state_dict(1007).items()}
+    sub = {k: v[lo:hi].to(dev) for k, v in scene.items() if k not in ("pre_stlp", "tj_scores_prior")}
+    sb = SceneBatch(sub, T_S, hp, dev, global_valid_sum=vsum, global_rows=vrows, row_offset=lo * T_S * 3)
+    names = RectTrainer.joint_names(True) if joint else RectTrainer.NAMES
+    params = {k: sd[k].clone().requires_grad_() for k in names}
+    opt = torch.optim.Adam([params[k] for k in names], lr=3e-4)
+    tr = RectTrainer(Sampler(PackedWeights(sd, dev), hp))
+    loss, _ = tr.train_step(sb, params, opt, T_STEPS, seed=SEED, multi_cands=3, e7=T_E7, joint=joint)
+    return float(loss), {k: params[k].grad.detach().cpu() for k in names}
+
+
+def _train_worker(rank, world, port, out_path, joint):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pstl_diffusion_policy_amd.shard import global_valid_stats, shard_range
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = make_scene_batch(T_BS, K=T_K, S=T_S, seed=78, invalid_lane_frac=0.3, stlp_mode="wide")
+    lo, hi = shard_range(T_BS, rank, world)
+    ids = float(sum(scene[k][lo:hi].sum().item() for k in ("curr_id", "left_id", "right_id")))
+    vsum, vrows = global_valid_stats(ids * T_S, (hi - lo) * T_S * 3, torch.device("cpu"))
+    loss, grads = _train_grads(scene, lo, hi, vsum, vrows, dev, joint, True)
+    torch.save({"loss": loss, "grads": grads}, out_path + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("joint", [False, True])
+def test_two_rank_training_step_equals_the_single_process_step(tmp_path, joint):
+    """Two gloo ranks sharing GPU 0, three scenes each (e7 objective; joint: the encoders and merge_net too): after the
+    all-reduce every rank holds the loss and the gradients of the one-process step over all six scenes."""
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    out_path = str(tmp_path / "train")
+    port = 27000 + (os.getpid() % 4000)
+    mp.spawn(_train_worker, args=(2, port, out_path, joint), nprocs=2, join=True)
+    parts = [torch.load(out_path + ".%d" % r) for r in range(2)]
+    scene = make_scene_batch(T_BS, K=T_K, S=T_S, seed=78, invalid_lane_frac=0.3, stlp_mode="wide")
+    ids = float(sum(scene[k].sum().item() for k in ("curr_id", "left_id", "right_id")))
+    loss, grads = _train_grads(scene, 0, T_BS, ids * T_S, T_BS * T_S * 3, torch.device("cuda:0"), joint, False)
+    for p in parts:
+        assert p["loss"] == parts[0]["loss"]
+        np.testing.assert_allclose(p["loss"], loss, rtol=1e-5, atol=1e-6)
+        assert set(p["grads"]) == set(grads)
+        for k, g in grads.items():
+            assert torch.equal(p["grads"][k], parts[0]["grads"][k]), k
+            np.testing.assert_allclose(p["grads"][k].numpy(), g.numpy(), rtol=1e-3, atol=1e-5 * float(g.abs().max()), err_msg=k)
