@@ -115,10 +115,12 @@ int pstl_prepare_scene(const pstl_cfg* cfg, const float* neighbors_traj, const f
 
 /* Scene encoder.  Replaces Net.encode_feat (nusc_model.py:55-95) and the scene-constant 224 columns of layer 1 of
  * policy_net / rect_net: base_x[b][h] = bias1[h] + sum_k W1[h][k] * feature[b][k].
- * ego0 (bs,6) = ego_traj[:,0]; neighbors (bs,K,7); lanes (bs,15,3); ids (bs,) each. base_rect may be null. */
+ * ego0 (bs,6) = ego_traj[:,0]; neighbors (bs,K,7); lanes (bs,15,3); ids (bs,) each. base_rect may be null.
+ * work: pstl_encode_scene_work_floats(cfg) floats (token inputs and the activations between the three GEMM layers). */
+size_t pstl_encode_scene_work_floats(const pstl_cfg* cfg);
 int pstl_encode_scene(const pstl_cfg* cfg, const float* packed, const float* ego0, const float* neighbors,
                       const float* currlane, const float* leftlane, const float* rightlane, const float* curr_id,
-                      const float* left_id, const float* right_id, float* feature /* (bs,224) */,
+                      const float* left_id, const float* right_id, float* work, float* feature /* (bs,224) */,
                       float* base_policy /* (bs,256) */, float* base_rect /* (bs,256) or null */, void* stream);
 
 /* ---- reverse diffusion --------------------------------------------------------------------------------------- */
@@ -225,7 +227,8 @@ int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float* w2, const 
  * 55-95 -> Net.rect_forward :182-209) and merge_net through the pooled columns (:186-200); policy_net receives no
  * gradient (the rollout runs under no_grad and loss_diffusion is not in the --rect_head losses, :455-467).
  *
- * pstl_encode_scene_saved: pstl_encode_scene that also keeps, per token, what the encoders' backward needs.  Tokens are
+ * pstl_encode_scene_saved: pstl_encode_scene with its work buffer laid out by the caller -- per token, what the encoders'
+ * backward needs.  Tokens are
  * ordered [bs ego | bs*K neighbours (scene-major) | 3*bs lanes (scene-major)], T = bs*(K+4):
  * tok_in (T,48) inputs (6 / 7 / 45 valid columns), tok_h1, tok_h2 (T,256) the two hidden layers after ReLU, tok_out (T,32). */
 int pstl_encode_scene_saved(const pstl_cfg* cfg, const float* packed, const float* ego0, const float* neighbors,

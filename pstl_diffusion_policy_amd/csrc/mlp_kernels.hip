@@ -44,8 +44,13 @@ constexpr int kG = 12;             // tiles per workgroup (upper bound; small ba
 constexpr int kMaxLaunchSteps = 128;  // reverse steps per launch (longer segments are split by pstl_rollout)
 
 // ---- packed weight buffer (float offsets) -----------------------------------------------------------------------
-struct EncOff {
-  long w0t, b0, w1t, b1, w2t, b2;
+struct EncOff {        // one scene encoder (in -> 256 -> 256 -> 32), weights as fp32 MFMA A operands (k_pack_a layout)
+  long a0;             // [16 T][enc_k16(e) q][4 r][64 lanes]   layer 0, input columns padded to 16 / 16 / 48
+  long b0;             // [256]
+  long a1;             // [16 T][16 q][4 r][64]
+  long b1;             // [256]
+  long a2;             // [2 T][16 q][4 r][64]
+  long b2;             // [32]
 };
 struct ChainOff {       // one of policy_net / rect_net
   long w1f;             // [224][256]  scene columns, transposed
@@ -74,17 +79,18 @@ struct PackLayout {
 };
 
 __host__ __device__ constexpr int enc_in(int e) { return e == 0 ? 6 : e == 1 ? 7 : 45; }
+__host__ __device__ constexpr int enc_k16(int e) { return e == 2 ? 3 : 1; }   // 16-column blocks of the padded token input
 
 __host__ __device__ inline PackLayout make_layout() {
   PackLayout L;
   long o = 0;
   for (int e = 0; e < 3; ++e) {
-    L.enc[e].w0t = o; o += (long)enc_in(e) * kHid;
-    L.enc[e].b0 = o;  o += kHid;
-    L.enc[e].w1t = o; o += (long)kHid * kHid;
-    L.enc[e].b1 = o;  o += kHid;
-    L.enc[e].w2t = o; o += (long)kHid * 32;
-    L.enc[e].b2 = o;  o += 32;
+    L.enc[e].a0 = o; o += 16L * enc_k16(e) * 4 * 64;
+    L.enc[e].b0 = o; o += kHid;
+    L.enc[e].a1 = o; o += 16L * 16 * 4 * 64;
+    L.enc[e].b1 = o; o += kHid;
+    L.enc[e].a2 = o; o += 2L * 16 * 4 * 64;
+    L.enc[e].b2 = o; o += 32;
   }
   ChainOff* cs[2] = {&L.pol, &L.rect};
   for (int c = 0; c < 2; ++c) {
@@ -130,7 +136,8 @@ __global__ void k_copy(const float* src, int n, int npad, float* dst) {
 // A-operand layout: dst[((Tt*nq + q)*4 + r)*64 + lane] = W[16*Tt + (lane&15)][colmap(16q + 4(lane>>4) + r)]
 // mode 0: identity columns; mode 1: policy K-ext (x 224.., hl 296, stlp 297..302); mode 2: rect K-ext
 // (fused 231.., hl 224, stlp 225..230)
-__global__ void k_pack_a(const float* W, int ld, int rows_valid, int n_tiles, int nq, int mode, float* dst) {
+__global__ void k_pack_a(const float* W, int ld, int rows_valid, int n_tiles, int nq, int mode, float* dst,
+                         int cols_valid = 1 << 30) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)n_tiles * nq * 256) return;
   const int lane = (int)(i & 63), r = (int)((i >> 6) & 3);
@@ -141,7 +148,7 @@ __global__ void k_pack_a(const float* W, int ld, int rows_valid, int n_tiles, in
   int col = k;
   if (mode == 1) col = k < 40 ? 224 + k : k == 40 ? 296 : k < 47 ? 297 + (k - 41) : -1;
   if (mode == 2) col = k < 40 ? 231 + k : k == 40 ? 224 : k < 47 ? 225 + (k - 41) : -1;
-  dst[i] = (row < rows_valid && col >= 0) ? W[(long)row * ld + col] : 0.0f;
+  dst[i] = (row < rows_valid && col >= 0 && col < cols_valid) ? W[(long)row * ld + col] : 0.0f;
 }
 
 // Split A-operand layout (two 16-bit pieces per fp32 weight).  F16 = false: hi = bf16(w), lo = bf16(w - hi) (w = hi + lo to
@@ -207,210 +214,6 @@ __global__ void k_time_bias(const float* w1t /* [32][256] */, int steps, float* 
 #pragma unroll
   for (int k = 0; k < 32; ++k) acc += w1t[k * kHid + h] * pe[k];
   tbias[(long)t * kHid + h] = acc;
-}
-
-// ---- scene encoder (A1) -----------------------------------------------------------------------------------------
-struct EncArgs {
-  int bs, K;
-  PackLayout L;
-  const float* packed;
-  const float* ego0;       // (bs,6)
-  const float* neighbors;  // (bs,K,7)
-  const float* lanes[3];   // (bs,15,3)
-  const float* ids[3];     // (bs,)
-  float* feature;          // (bs,224)
-  float* base_policy;      // (bs,256)
-  float* base_rect;        // (bs,256) or null
-  // training with --joint (pstl_encode_scene_saved): what the encoders' backward pass needs, per token, tokens ordered
-  // [bs ego | bs*K neighbours (scene-major) | 3*bs lanes (scene-major)]; all four null otherwise
-  float* sv_in;            // (T,48)  token inputs (first enc_in(e) columns valid)
-  float* sv_h1;            // (T,256) relu(layer 0)
-  float* sv_h2;            // (T,256) relu(layer 1)
-  float* sv_out;           // (T,32)  layer 2 output
-};
-
-constexpr int kMaxTok = 48;   // tokens (1 ego + K neighbours + 3 lanes per scene) of the scenes one workgroup encodes
-constexpr int kMaxScn = 8;
-
-// One workgroup encodes SCN scenes (chosen by the host, see pstl_encode_scene), so that every weight it streams from L2
-// (3 x 256 KB for the hidden layers) is shared by the tokens of several scenes.
-// Dynamic LDS, MT = SCN*(K+4) tokens: in_s[MT][48] | h_a[MT][256] | h_b[MT][256] | out_s[MT][32] | feat_s[SCN][224] |
-// lane_n[SCN][3][15][3]
-__global__ __launch_bounds__(256) void k_encode(EncArgs a, int SCN) {
-  extern __shared__ __attribute__((aligned(16))) float enc_lds[];
-  const int MT = SCN * (a.K + 4);   // token capacity of this launch (the LDS allocation is sized for it)
-  float(*in_s)[48] = reinterpret_cast<float(*)[48]>(enc_lds);
-  float(*h_a)[kHid] = reinterpret_cast<float(*)[kHid]>(enc_lds + MT * 48);
-  float(*h_b)[kHid] = reinterpret_cast<float(*)[kHid]>(enc_lds + MT * 48 + MT * kHid);
-  float(*out_s)[32] = reinterpret_cast<float(*)[32]>(enc_lds + MT * 48 + 2 * MT * kHid);
-  float(*feat_s)[kFeat] = reinterpret_cast<float(*)[kFeat]>(enc_lds + MT * 48 + 2 * MT * kHid + MT * 32);
-  float* lane_n = enc_lds + MT * 48 + 2 * MT * kHid + MT * 32 + SCN * kFeat;  // [SCN][3][15][3]
-  const int tid = threadIdx.x, K = a.K;
-  const int b0 = blockIdx.x * SCN;
-  const int ns = (a.bs - b0) < SCN ? (a.bs - b0) : SCN;   // scenes of this workgroup
-  // token layout: [0, ns) ego | [ns, ns + ns*K) neighbours (scene-major) | [ns + ns*K, ns + ns*K + 3 ns) lanes
-  const int t_nei = ns, t_lane = ns + ns * K, ntok = ns + ns * K + 3 * ns;
-  // token inputs (normalize_xyth, nusc_model.py:238-263)
-  for (int i = tid; i < ns * 6; i += 256) {
-    const int sc = i / 6, c = i % 6;
-    in_s[sc][c] = c < 3 ? 0.0f : a.ego0[(long)(b0 + sc) * 6 + c];
-  }
-  for (int i = tid; i < ns * K; i += 256) {
-    const int sc = i / K;
-    const float* ego = a.ego0 + (long)(b0 + sc) * 6;
-    const float bx = ego[0], by = ego[1], bth = ego[2];
-    const float cb = cosf(bth), sb = sinf(bth);
-    const float* n = a.neighbors + ((long)b0 * K + i) * 7;
-    const float v = n[0];
-    const float xt = n[1] - bx * v, yt = n[2] - by * v;
-    float* o = in_s[t_nei + i];
-    o[0] = v;
-    o[1] = xt * cb + yt * sb;
-    o[2] = -xt * sb + yt * cb;
-    o[3] = n[3] - bth * v;
-    o[4] = n[4];
-    o[5] = n[5];
-    o[6] = n[6];
-  }
-  for (int i = tid; i < ns * 45; i += 256) {
-    const int sc = i / 45, m = (i % 45) / 15, j = i % 15;
-    const float* ego = a.ego0 + (long)(b0 + sc) * 6;
-    const float bx = ego[0], by = ego[1], bth = ego[2];
-    const float cb = cosf(bth), sb = sinf(bth);
-    const float* p = a.lanes[m] + ((long)(b0 + sc) * 15 + j) * 3;
-    const float v = a.ids[m][b0 + sc];
-    const float xt = p[0] - bx * v, yt = p[1] - by * v;
-    float* o = lane_n + ((sc * 3 + m) * 15 + j) * 3;
-    o[0] = xt * cb + yt * sb;
-    o[1] = -xt * sb + yt * cb;
-    o[2] = p[2] - bth * v;
-  }
-  __syncthreads();
-  for (int i = tid; i < ns * 135; i += 256) {  // difference encoding: first waypoint, then differences (nusc_model.py:73-76)
-    const int sm = i / 45, e = i % 45, j = e / 3, c = e % 3;   // sm = scene*3 + lane
-    const float* l = lane_n + sm * 45;
-    in_s[t_lane + sm][e] = j == 0 ? l[c] : l[j * 3 + c] - l[(j - 1) * 3 + c];
-  }
-  __syncthreads();
-  // global index of local token tk (tokens of one encoder are contiguous over the whole batch)
-  auto tok_global = [&](int tk) -> long {
-    if (tk < t_nei) return (long)b0 + tk;
-    if (tk < t_lane) return (long)a.bs + (long)b0 * K + (tk - t_nei);
-    return (long)a.bs * (K + 1) + (long)b0 * 3 + (tk - t_lane);
-  };
-  if (a.sv_in)
-    for (int i = tid; i < ntok * 48; i += 256) {
-      const int tk = i / 48, c = i % 48;
-      const int nin = tk < t_nei ? enc_in(0) : tk < t_lane ? enc_in(1) : enc_in(2);
-      a.sv_in[tok_global(tk) * 48 + c] = c < nin ? in_s[tk][c] : 0.0f;
-    }
-  for (int e = 0; e < 3; ++e) {
-    const int t0 = e == 0 ? 0 : e == 1 ? t_nei : t_lane;
-    const int t1 = e == 0 ? t_nei : e == 1 ? t_lane : ntok;
-    const int nin = enc_in(e);
-    const float* w0t = a.packed + a.L.enc[e].w0t;
-    const float* w1t = a.packed + a.L.enc[e].w1t;
-    const float b0v = a.packed[a.L.enc[e].b0 + tid];
-    const float b1v = a.packed[a.L.enc[e].b1 + tid];
-    for (int tk0 = t0; tk0 < t1; tk0 += 8) {
-      float acc[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] = b0v;
-#pragma unroll 4
-      for (int k = 0; k < nin; ++k) {
-        const float w = w0t[k * kHid + tid];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (tk0 + u < t1) acc[u] += w * in_s[tk0 + u][k];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (tk0 + u < t1) h_a[tk0 + u][tid] = fmaxf(acc[u], 0.0f);
-    }
-    __syncthreads();
-    for (int tk0 = t0; tk0 < t1; tk0 += 8) {  // 8 tokens share each weight load
-      float acc[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] = b1v;
-#pragma unroll 4   // 16 weight loads in flight: with one workgroup (4 waves) per CU nothing else hides their latency
-      for (int k = 0; k < kHid; k += 4) {   // 4 weights per step, activations as one 16-byte LDS broadcast per token
-        const float w0 = w1t[k * kHid + tid], w1 = w1t[(k + 1) * kHid + tid], w2 = w1t[(k + 2) * kHid + tid],
-                    w3 = w1t[(k + 3) * kHid + tid];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (tk0 + u < t1) {
-            const f32x4 h = *reinterpret_cast<const f32x4*>(&h_a[tk0 + u][k]);
-            acc[u] += w0 * h.x + w1 * h.y + w2 * h.z + w3 * h.w;
-          }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (tk0 + u < t1) h_b[tk0 + u][tid] = fmaxf(acc[u], 0.0f);
-    }
-    __syncthreads();
-    const float* w2t = a.packed + a.L.enc[e].w2t;
-    const int o = tid & 31;
-    for (int tk = t0 + (tid >> 5); tk < t1; tk += 8) {
-      float acc = a.packed[a.L.enc[e].b2 + o];
-#pragma unroll 4
-      for (int k = 0; k < kHid; k += 4) {
-        const f32x4 h = *reinterpret_cast<const f32x4*>(&h_b[tk][k]);
-        acc += w2t[k * 32 + o] * h.x + w2t[(k + 1) * 32 + o] * h.y + w2t[(k + 2) * 32 + o] * h.z + w2t[(k + 3) * 32 + o] * h.w;
-      }
-      out_s[tk][o] = acc;
-    }
-    __syncthreads();
-    if (a.sv_h1)
-      for (int tk = t0; tk < t1; ++tk) {
-        const long gt = tok_global(tk);
-        a.sv_h1[gt * kHid + tid] = h_a[tk][tid];
-        a.sv_h2[gt * kHid + tid] = h_b[tk][tid];
-        if (tid < 32) a.sv_out[gt * 32 + tid] = out_s[tk][tid];
-      }
-  }
-  // feature = [ego 32 | nei min 32 | nei mean 32 | nei max 32 | lanes 3x32]  (nusc_model.py:82-93)
-  for (int i = tid; i < ns * 32; i += 256) {
-    const int sc = i >> 5, o = i & 31;
-    feat_s[sc][o] = out_s[sc][o];
-    float mn = INFINITY, mx = -INFINITY, sm = 0.0f;
-    for (int k = 0; k < K; ++k) {
-      const float v = out_s[t_nei + sc * K + k][o];
-      mn = fminf(mn, v);
-      mx = fmaxf(mx, v);
-      sm += v;
-    }
-    feat_s[sc][32 + o] = mn;
-    feat_s[sc][64 + o] = sm / (float)K;
-    feat_s[sc][96 + o] = mx;
-    for (int m = 0; m < 3; ++m) feat_s[sc][128 + 32 * m + o] = out_s[t_lane + sc * 3 + m][o];
-  }
-  __syncthreads();
-  for (int i = tid; i < ns * kFeat; i += 256) a.feature[(long)b0 * kFeat + i] = feat_s[i / kFeat][i % kFeat];
-  for (int which = 0; which < 2; ++which) {
-    float* dst = which == 0 ? a.base_policy : a.base_rect;
-    if (!dst) continue;
-    const ChainOff& co = which == 0 ? a.L.pol : a.L.rect;
-    const float bias = a.packed[co.b1 + tid];
-    const float* w = a.packed + co.w1f;
-    float acc[kMaxScn];
-#pragma unroll
-    for (int u = 0; u < kMaxScn; ++u) acc[u] = bias;
-#pragma unroll 8
-    for (int k = 0; k < kFeat; ++k) {
-      const float wv = w[k * kHid + tid];
-#pragma unroll
-      for (int u = 0; u < kMaxScn; ++u)
-        if (u < ns) acc[u] += wv * feat_s[u][k];
-    }
-#pragma unroll
-    for (int u = 0; u < kMaxScn; ++u)
-      if (u < ns) dst[(long)(b0 + u) * kHid + tid] = acc[u];
-  }
-}
-
-inline size_t enc_lds_floats(int scn, int K) {
-  const size_t mt = (size_t)scn * (K + 4);
-  return mt * 48 + 2 * mt * kHid + mt * 32 + (size_t)scn * kFeat + (size_t)scn * 3 * 15 * 3;
 }
 
 // ---- the MLP chain kernel ---------------------------------------------------------------------------------------
@@ -1203,6 +1006,184 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   }
 }
 
+// ---- scene encoder (A1) -----------------------------------------------------------------------------------------
+// Three 3-layer MLPs (ego 6 -> 256 -> 256 -> 32, neighbour 7 -> ..., lane 45 -> ...) over the tokens of the whole batch,
+// ordered [bs ego | bs*K neighbours (scene-major) | 3*bs lanes (scene-major)] so that every encoder is three plain GEMMs
+// over contiguous rows:  k_tokens (ego-frame token inputs)  ->  k_enc_gemm x 3 layers (fp32 MFMA)  ->  k_feature_base
+// (min / mean / max over the neighbours, the 224-wide feature, and the scene-constant part of layer 1 of policy_net /
+// rect_net).  The activations between the layers are row-major (T,256) buffers in global memory (25 MB at 4096 scenes:
+// L2 / Infinity-Cache traffic); they are exactly what the encoders' backward pass needs (pstl_encode_scene_saved).
+// Round 1-2 had one fused VALU kernel with the activations in LDS (12 tokens per workgroup): every workgroup streamed all
+// three encoders' weights and both 224 x 256 layer-1 blocks from L2, 1.4 MB per 2 scenes -- 0.58 ms per 4096 scenes.
+
+// token inputs (normalize_xyth, nusc_model.py:238-263; lanes: first waypoint, then differences, :73-76), zero padded to 48
+__global__ void k_tokens(int bs, int K, const float* ego0, const float* neighbors, const float* lane0, const float* lane1,
+                         const float* lane2, const float* id0, const float* id1, const float* id2, float* tok_in) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long T = (long)bs * (K + 4);
+  if (i >= T) return;
+  float o[48];
+#pragma unroll
+  for (int c = 0; c < 48; ++c) o[c] = 0.0f;
+  if (i < bs) {
+    const float* ego = ego0 + i * 6;
+    o[3] = ego[3], o[4] = ego[4], o[5] = ego[5];
+  } else if (i < (long)bs * (K + 1)) {
+    const long j = i - bs, sc = j / K;
+    const float* ego = ego0 + sc * 6;
+    const float bx = ego[0], by = ego[1], bth = ego[2];
+    const float cb = cosf(bth), sb = sinf(bth);
+    const float* n = neighbors + j * 7;
+    const float v = n[0];
+    const float xt = n[1] - bx * v, yt = n[2] - by * v;
+    o[0] = v;
+    o[1] = xt * cb + yt * sb;
+    o[2] = -xt * sb + yt * cb;
+    o[3] = n[3] - bth * v;
+    o[4] = n[4];
+    o[5] = n[5];
+    o[6] = n[6];
+  } else {
+    const long j = i - (long)bs * (K + 1), sc = j / 3;
+    const int m = (int)(j % 3);
+    const float* ego = ego0 + sc * 6;
+    const float bx = ego[0], by = ego[1], bth = ego[2];
+    const float cb = cosf(bth), sb = sinf(bth);
+    const float* lp = (m == 0 ? lane0 : m == 1 ? lane1 : lane2) + sc * 45;
+    const float v = (m == 0 ? id0 : m == 1 ? id1 : id2)[sc];
+    float px = 0.0f, py = 0.0f, pt = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 15; ++w) {
+      const float xt = lp[3 * w] - bx * v, yt = lp[3 * w + 1] - by * v;
+      const float lx = xt * cb + yt * sb, ly = -xt * sb + yt * cb, lt = lp[3 * w + 2] - bth * v;
+      o[3 * w] = w == 0 ? lx : lx - px;
+      o[3 * w + 1] = w == 0 ? ly : ly - py;
+      o[3 * w + 2] = w == 0 ? lt : lt - pt;
+      px = lx, py = ly, pt = lt;
+    }
+  }
+  f32x4* dst = reinterpret_cast<f32x4*>(tok_in + i * 48);
+#pragma unroll
+  for (int q = 0; q < 12; ++q) dst[q] = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+}
+
+// out[row][f] = act(bias[f] + sum_k X[row][k] W[f][k]) on v_mfma_f32_16x16x4_f32, up to three problems per launch
+// (workgroup ranges).  Weights register-stationary as A operands (k_pack_a layout, k index permuted k = 16q + 4g + r as
+// in the chain kernel), a tile of 16 rows is the B operand, loaded straight from global memory: lane (g, c) takes the
+// 16-byte quad X[row c][16q + 4g .. +3] = its B values of the four k-steps (q, 0..3).  No LDS, no barrier: a wave is
+// independent of the others.
+//   ROWSPLIT = false (256 outputs): wave w owns features [32 w, 32 w + 32) of every tile its workgroup walks (the eight
+//                                   waves read the same rows: L1 hits).
+//   ROWSPLIT = true  (32 outputs):  every wave holds all of W and walks its own tiles.
+struct EncGemmProb {
+  const float* X;      // (rows, ldx), 16 K16 readable columns
+  const float* A;      // packed weights
+  const float* bias;
+  float* out;          // (rows, ldo)
+  long rows;
+  int ldx, ldo, relu;
+  int blk0, nblk;      // workgroups [blk0, blk0 + nblk)
+};
+struct EncGemmArgs {
+  EncGemmProb p[3];
+  int np;
+};
+
+template <int K16, bool ROWSPLIT>
+__global__ __launch_bounds__(512) void k_enc_gemm(EncGemmArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  int pi = 0;
+  if (a.np > 1 && (int)blockIdx.x >= a.p[1].blk0) pi = 1;
+  if (a.np > 2 && (int)blockIdx.x >= a.p[2].blk0) pi = 2;
+  const EncGemmProb P = a.p[pi];
+  const int lb = blockIdx.x - P.blk0;
+  float wt[2][K16 * 4];
+  f32x4 bq4[2];
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot) {
+    const int T = ROWSPLIT ? ot : 2 * w + ot;
+#pragma unroll
+    for (int m = 0; m < K16 * 4; ++m) wt[ot][m] = P.A[((long)T * K16 * 4 + m) * 64 + lane];
+    bq4[ot] = *reinterpret_cast<const f32x4*>(P.bias + 16 * T + 4 * g);
+  }
+  const long n_tiles = (P.rows + 15) / 16;
+  const long first = ROWSPLIT ? (long)lb * 8 + w : lb, stride = ROWSPLIT ? (long)P.nblk * 8 : P.nblk;
+  for (long t = first; t < n_tiles; t += stride) {
+    const long row = t * 16 + c;
+    const bool in = row < P.rows;
+    f32x4 bq[K16];
+#pragma unroll
+    for (int q = 0; q < K16; ++q)
+      bq[q] = in ? *reinterpret_cast<const f32x4*>(P.X + row * P.ldx + 16 * q + 4 * g) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc[2] = {bq4[0], bq4[1]};
+#pragma unroll
+    for (int q = 0; q < K16; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) acc[ot] = mfma4(wt[ot][q * 4 + r], bq[q][r], acc[ot]);
+    if (in) {
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        const int T = ROWSPLIT ? ot : 2 * w + ot;
+        *reinterpret_cast<f32x4*>(P.out + row * P.ldo + 16 * T + 4 * g) = P.relu ? relu4(acc[ot]) : acc[ot];
+      }
+    }
+  }
+}
+
+// feature = [ego 32 | nei min 32 | nei mean 32 | nei max 32 | lanes 3x32]  (nusc_model.py:82-93) and the scene-constant
+// 224 columns of layer 1 of policy_net / rect_net: base_x[b][h] = bias1[h] + sum_k W1[h][k] feature[b][k].  16 scenes per
+// workgroup share every layer-1 weight they stream from L2.
+constexpr int kFbScn = 16;
+__global__ __launch_bounds__(256) void k_feature_base(int bs, int K, const float* tok_out, const float* packed, ChainOff pol,
+                                                      ChainOff rect, float* feature, float* base_policy, float* base_rect) {
+  __shared__ float feat_s[kFbScn][kFeat];
+  const int tid = threadIdx.x;
+  const long b0 = (long)blockIdx.x * kFbScn;
+  const int ns = (bs - b0) < kFbScn ? (int)(bs - b0) : kFbScn;
+  for (int i = tid; i < ns * 32; i += 256) {
+    const int sc = i >> 5, o = i & 31;
+    const long b = b0 + sc;
+    feat_s[sc][o] = tok_out[b * 32 + o];
+    float mn = INFINITY, mx = -INFINITY, sm = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      const float v = tok_out[((long)bs + b * K + k) * 32 + o];
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+      sm += v;
+    }
+    feat_s[sc][32 + o] = mn;
+    feat_s[sc][64 + o] = sm / (float)K;
+    feat_s[sc][96 + o] = mx;
+    for (int m = 0; m < 3; ++m) feat_s[sc][128 + 32 * m + o] = tok_out[((long)bs * (K + 1) + b * 3 + m) * 32 + o];
+  }
+  __syncthreads();
+  const int which = blockIdx.y;   // 0: policy_net (and the feature itself), 1: rect_net
+  if (which == 0)
+    for (int i = tid; i < ns * kFeat; i += 256) feature[b0 * kFeat + i] = feat_s[i / kFeat][i % kFeat];
+  {
+    float* dst = which == 0 ? base_policy : base_rect;
+    if (!dst) return;
+    const ChainOff& co = which == 0 ? pol : rect;
+    const float bias = packed[co.b1 + tid];
+    const float* wp = packed + co.w1f;
+    float acc[kFbScn];
+#pragma unroll
+    for (int u = 0; u < kFbScn; ++u) acc[u] = bias;
+#pragma unroll 4
+    for (int k = 0; k < kFeat; ++k) {
+      const float wv = wp[k * kHid + tid];
+#pragma unroll
+      for (int u = 0; u < kFbScn; ++u) acc[u] += wv * feat_s[u][k];
+    }
+#pragma unroll
+    for (int u = 0; u < kFbScn; ++u)
+      if (u < ns) dst[(b0 + u) * kHid + tid] = acc[u];
+  }
+}
+
 // ---- merge_net + shard max-pool (nusc_model.py:186-196) -----------------------------------------------------------
 struct MergeArgs {
   int bs, S, n_shards;
@@ -1249,6 +1230,7 @@ __device__ __forceinline__ void merge_row(const float* x, const float* wt, float
   }
 }
 
+// (256 registers = two waves per SIMD is the best point: pinned to 1, 3, 4 or 6 waves per SIMD it ran 10 % slower)
 __global__ __launch_bounds__(64) void k_merge_pool(MergeArgs a) {
   __shared__ float wt[kMrgFloats];
   __shared__ float outs[64][41];
@@ -1625,9 +1607,17 @@ extern "C" int pstl_pack_weights(const pstl_weight_ptrs* w, float* packed, void*
   const PackLayout L = make_layout();
   if (hipMemsetAsync(packed, 0, L.total * sizeof(float), st) != hipSuccess) return PSTL_ERR_LAUNCH;
   const pstl_mlp3* encs[3] = {&w->ego_encoder, &w->neighbor_encoder, &w->lane_encoder};
-  for (int e = 0; e < 3; ++e) {
-    const long off6[6] = {L.enc[e].w0t, L.enc[e].b0, L.enc[e].w1t, L.enc[e].b1, L.enc[e].w2t, L.enc[e].b2};
-    if (int err = pack_mlp_t(*encs[e], enc_in(e), kHid, 32, off6, packed, st)) return err;
+  for (int e = 0; e < 3; ++e) {   // fp32 MFMA A operands (k_enc_gemm)
+    const pstl_mlp3& m = *encs[e];
+    const EncOff& o = L.enc[e];
+    hipLaunchKernelGGL(k_pack_a, dim3(16 * enc_k16(e)), dim3(256), 0, st, m.w0, enc_in(e), kHid, 16, enc_k16(e), 0,
+                       packed + o.a0, enc_in(e));
+    hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, st, m.b0, kHid, kHid, packed + o.b0);
+    hipLaunchKernelGGL(k_pack_a, dim3(16 * 16), dim3(256), 0, st, m.w1, kHid, kHid, 16, 16, 0, packed + o.a1, kHid);
+    hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, st, m.b1, kHid, kHid, packed + o.b1);
+    hipLaunchKernelGGL(k_pack_a, dim3(2 * 16), dim3(256), 0, st, m.w2, kHid, 32, 2, 16, 0, packed + o.a2, kHid);
+    hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, st, m.b2, 32, 32, packed + o.b2);
+    if (int err = launch_status()) return err;
   }
   if (int err = pack_chain(w->policy_net, 303, 1, true, L.pol, packed, st)) return err;
   if (mlp_ok(w->rect_net))
@@ -1655,53 +1645,88 @@ extern "C" int pstl_time_bias(const float* packed, int steps, float* tbias, void
   return launch_status();
 }
 
+extern "C" size_t pstl_encode_scene_work_floats(const pstl_cfg* cfg) {
+  if (check_cfg(cfg)) return 0;
+  return (size_t)cfg->bs * (cfg->K + 4) * (48 + 2 * kHid + 32);
+}
+
 static int encode_scene(const pstl_cfg* cfg, const float* packed, const float* ego0, const float* neighbors,
                         const float* currlane, const float* leftlane, const float* rightlane, const float* curr_id,
                         const float* left_id, const float* right_id, float* feature, float* base_policy, float* base_rect,
-                        float* sv_in, float* sv_h1, float* sv_h2, float* sv_out, void* stream) {
+                        float* tok_in, float* tok_h1, float* tok_h2, float* tok_out, void* stream) {
   if (int e = check_cfg(cfg)) return e;
-  if (!packed || !ego0 || !currlane || !leftlane || !rightlane || !curr_id || !left_id || !right_id || !feature ||
-      !base_policy)
+  if (!packed || !ego0 || !neighbors || !currlane || !leftlane || !rightlane || !curr_id || !left_id || !right_id ||
+      !feature || !base_policy || !tok_in || !tok_h1 || !tok_h2 || !tok_out)
     return PSTL_ERR_ARG;
-  if (cfg->K < 1 || cfg->K > kMaxTok - 4) return PSTL_ERR_SHAPE;
-  // scenes per workgroup: the kernel is latency-bound, so resident workgroups per CU (LDS) matter more than weight
-  // reuse: ~12 tokens per workgroup measured best (K=2: 2 scenes 0.45 ms vs 1 scene 0.75 / 8 scenes 1.0 ms per 4096
-  // scenes; K=8: 1 scene 0.84 ms)
-  int scn = 12 / (cfg->K + 4);
-  if (scn < 1) scn = 1;
-  if (scn > kMaxScn) scn = kMaxScn;
-  if (const char* ov = getenv("PSTL_ENC_SCN")) {   // tuning override
-    const int v = atoi(ov);
-    if (v >= 1 && v <= kMaxScn && v * (cfg->K + 4) <= kMaxTok) scn = v;
-  }
-  if (!neighbors) return PSTL_ERR_ARG;
-  EncArgs a;
-  a.bs = cfg->bs;
-  a.K = cfg->K;
-  a.L = make_layout();
-  a.packed = packed;
-  a.ego0 = ego0;
-  a.neighbors = neighbors;
-  a.lanes[0] = currlane, a.lanes[1] = leftlane, a.lanes[2] = rightlane;
-  a.ids[0] = curr_id, a.ids[1] = left_id, a.ids[2] = right_id;
-  a.feature = feature;
-  a.base_policy = base_policy;
-  a.base_rect = base_rect;
-  a.sv_in = sv_in, a.sv_h1 = sv_h1, a.sv_h2 = sv_h2, a.sv_out = sv_out;
-  const size_t lds = enc_lds_floats(scn, cfg->K) * sizeof(float);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_encode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-      hipSuccess)
-    return PSTL_ERR_LAUNCH;
-  hipLaunchKernelGGL(k_encode, dim3((cfg->bs + scn - 1) / scn), dim3(256), lds, as_stream(stream), a, scn);
+  hipStream_t st = as_stream(stream);
+  const PackLayout L = make_layout();
+  const long bs = cfg->bs, K = cfg->K, T = bs * (K + 4);
+  hipLaunchKernelGGL(k_tokens, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, (int)bs, (int)K, ego0, neighbors, currlane,
+                     leftlane, rightlane, curr_id, left_id, right_id, tok_in);
+  const long t0[3] = {0, bs, bs * (K + 1)}, tn[3] = {bs, bs * K, 3 * bs};
+  const int cus = cu_count();
+  // one launch per layer and input width; the workgroups of a launch are shared out by tile count
+  auto launch = [&](int layer, int e_lo, int e_hi) {
+    EncGemmArgs a = {};
+    const bool rowsplit = layer == 2;
+    long unit[3] = {0, 0, 0}, total = 0;   // tiles (layer 2: batches of 8 tiles, one per wave) to hand out
+    for (int e = e_lo; e < e_hi; ++e) {
+      const long tiles = (tn[e] + 15) / 16;
+      unit[e - e_lo] = rowsplit ? (tiles + 7) / 8 : tiles;
+      total += unit[e - e_lo];
+    }
+    int blk = 0;
+    for (int e = e_lo; e < e_hi; ++e) {
+      EncGemmProb& p = a.p[e - e_lo];
+      const long units = unit[e - e_lo];
+      long nb = units * cus / total;     // rounded down: one workgroup more than there are CUs would run as a second wave
+      if (nb > units) nb = units;
+      if (nb < 1) nb = 1;
+      const EncOff& o = L.enc[e];
+      p.X = (layer == 0 ? tok_in + t0[e] * 48 : layer == 1 ? tok_h1 + t0[e] * kHid : tok_h2 + t0[e] * kHid);
+      p.ldx = layer == 0 ? 48 : kHid;
+      p.A = packed + (layer == 0 ? o.a0 : layer == 1 ? o.a1 : o.a2);
+      p.bias = packed + (layer == 0 ? o.b0 : layer == 1 ? o.b1 : o.b2);
+      p.out = (layer == 0 ? tok_h1 + t0[e] * kHid : layer == 1 ? tok_h2 + t0[e] * kHid : tok_out + t0[e] * 32);
+      p.ldo = layer == 2 ? 32 : kHid;
+      p.rows = tn[e];
+      p.relu = layer < 2;
+      p.blk0 = blk;
+      p.nblk = (int)nb;
+      blk += (int)nb;
+    }
+    a.np = e_hi - e_lo;
+    if (layer == 0 && e_lo == 2)
+      hipLaunchKernelGGL((k_enc_gemm<3, false>), dim3(blk), dim3(512), 0, st, a);
+    else if (layer == 0)
+      hipLaunchKernelGGL((k_enc_gemm<1, false>), dim3(blk), dim3(512), 0, st, a);
+    else if (layer == 1)
+      hipLaunchKernelGGL((k_enc_gemm<16, false>), dim3(blk), dim3(512), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_enc_gemm<16, true>), dim3(blk), dim3(512), 0, st, a);
+  };
+  launch(0, 0, 2);   // ego + neighbours: 16 padded input columns
+  launch(0, 2, 3);   // lanes: 48
+  launch(1, 0, 3);
+  launch(2, 0, 3);
+  hipLaunchKernelGGL(k_feature_base, dim3((unsigned)((bs + kFbScn - 1) / kFbScn), base_rect ? 2 : 1), dim3(256), 0, st, (int)bs, (int)K,
+                     (const float*)tok_out, packed, L.pol, L.rect, feature, base_policy, base_rect);
   return launch_status();
 }
 
 extern "C" int pstl_encode_scene(const pstl_cfg* cfg, const float* packed, const float* ego0, const float* neighbors,
                                  const float* currlane, const float* leftlane, const float* rightlane,
-                                 const float* curr_id, const float* left_id, const float* right_id, float* feature,
-                                 float* base_policy, float* base_rect, void* stream) {
+                                 const float* curr_id, const float* left_id, const float* right_id, float* work,
+                                 float* feature, float* base_policy, float* base_rect, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!work) return PSTL_ERR_ARG;
+  const long T = (long)cfg->bs * (cfg->K + 4);
+  float* tok_in = work;
+  float* tok_h1 = tok_in + T * 48;
+  float* tok_h2 = tok_h1 + T * kHid;
+  float* tok_out = tok_h2 + T * kHid;
   return encode_scene(cfg, packed, ego0, neighbors, currlane, leftlane, rightlane, curr_id, left_id, right_id, feature,
-                      base_policy, base_rect, nullptr, nullptr, nullptr, nullptr, stream);
+                      base_policy, base_rect, tok_in, tok_h1, tok_h2, tok_out, stream);
 }
 
 extern "C" int pstl_encode_scene_saved(const pstl_cfg* cfg, const float* packed, const float* ego0, const float* neighbors,
@@ -1709,7 +1734,6 @@ extern "C" int pstl_encode_scene_saved(const pstl_cfg* cfg, const float* packed,
                                        const float* curr_id, const float* left_id, const float* right_id, float* feature,
                                        float* base_policy, float* base_rect, float* tok_in, float* tok_h1, float* tok_h2,
                                        float* tok_out, void* stream) {
-  if (!tok_in || !tok_h1 || !tok_h2 || !tok_out) return PSTL_ERR_ARG;
   return encode_scene(cfg, packed, ego0, neighbors, currlane, leftlane, rightlane, curr_id, left_id, right_id, feature,
                       base_policy, base_rect, tok_in, tok_h1, tok_h2, tok_out, stream);
 }

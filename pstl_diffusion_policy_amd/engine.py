@@ -172,11 +172,12 @@ class Sampler:
                                                      ffi.ptr(sv["tok_in"]), ffi.ptr(sv["tok_h1"]), ffi.ptr(sv["tok_h2"]),
                                                      ffi.ptr(sv["tok_out"]), ffi.stream()), "encode_scene_saved")
             return feature, base_p, base_r, sv
+        work = torch.empty(self.L.pstl_encode_scene_work_floats(ctypes.byref(cfg)), dtype=torch.float32, device=dev)
         ffi.check(self.L.pstl_encode_scene(ctypes.byref(cfg), ffi.ptr(self.w.packed), ffi.ptr(sb.ego0),
                                            ffi.ptr(sb.neighbors), ffi.ptr(sb.lanes[0]), ffi.ptr(sb.lanes[1]),
                                            ffi.ptr(sb.lanes[2]), ffi.ptr(sb.ids[0]), ffi.ptr(sb.ids[1]),
-                                           ffi.ptr(sb.ids[2]), ffi.ptr(feature), ffi.ptr(base_p), ffi.ptr(base_r),
-                                           ffi.stream()), "encode_scene")
+                                           ffi.ptr(sb.ids[2]), ffi.ptr(work), ffi.ptr(feature), ffi.ptr(base_p),
+                                           ffi.ptr(base_r), ffi.stream()), "encode_scene")
         return feature, base_p, base_r
 
     # ---- A3-A5, A7 ----

@@ -33,7 +33,7 @@ EXPORTS = ["pstl_version", "pstl_error_string", "pstl_packed_weight_floats", "ps
            "pstl_stl_program_forward", "pstl_stl_program_backward", "pstl_trajopt",
            "pstl_diversity_loss", "pstl_stl_signals", "pstl_refinement", "pstl_refinement_work_floats",
            "pstl_encode_scene_saved", "pstl_encoder_backward", "pstl_encoder_backward_work_floats", "pstl_merge_backward",
-           "pstl_merge_backward_work_floats"]
+           "pstl_merge_backward_work_floats", "pstl_encode_scene_work_floats"]
 
 
 class PstlCfg(ctypes.Structure):
@@ -77,6 +77,7 @@ def lib():
         L.pstl_refinement_work_floats.restype = ctypes.c_size_t
         L.pstl_encoder_backward_work_floats.restype = ctypes.c_size_t
         L.pstl_merge_backward_work_floats.restype = ctypes.c_size_t
+        L.pstl_encode_scene_work_floats.restype = ctypes.c_size_t
         _lib = L
     return _lib
 

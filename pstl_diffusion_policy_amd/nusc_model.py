@@ -98,10 +98,11 @@ class Net(nn.Module):
         base_p = torch.empty(bs, ffi.HID, dtype=torch.float32, device=dev)
         base_r = torch.empty(bs, ffi.HID, dtype=torch.float32, device=dev) if pw.has_rect else None
         cfg = ffi.make_cfg(bs, 1, 1, nei.shape[1], 2, self.hparams())
+        work = torch.empty(ffi.lib().pstl_encode_scene_work_floats(ctypes.byref(cfg)), dtype=torch.float32, device=dev)
         ffi.check(ffi.lib().pstl_encode_scene(ctypes.byref(cfg), ffi.ptr(pw.packed), ffi.ptr(ego0), ffi.ptr(nei),
                                               ffi.ptr(lanes[0]), ffi.ptr(lanes[1]), ffi.ptr(lanes[2]), ffi.ptr(ids[0]),
-                                              ffi.ptr(ids[1]), ffi.ptr(ids[2]), ffi.ptr(feature), ffi.ptr(base_p),
-                                              ffi.ptr(base_r), ffi.stream()), "encode_scene")
+                                              ffi.ptr(ids[1]), ffi.ptr(ids[2]), ffi.ptr(work), ffi.ptr(feature),
+                                              ffi.ptr(base_p), ffi.ptr(base_r), ffi.stream()), "encode_scene")
         return feature, base_p, base_r
 
     def encode_feat(self, nn_input, ext=None):
