@@ -14,6 +14,8 @@ rows = [("bench_default", "**e7 + guidance** (50 steps, K=2, last 10 steps × 1 
         ("bench_k8_s100", "e7 + guidance at the reference defaults (100 steps, K=8)"),
         ("bench_e8_train", "e8 training step (config 5, N1: sampling + RefineNet forward/backward + Adam)"),
         ("bench_e7_train", "e7 training step (N1: `--diverse_loss`, DPP diversity objective, merge_net architecture)"),
+        ("bench_e8_train_joint", "e8 training step with `--joint` (Adam over the whole net: + the three scene encoders' backward)"),
+        ("bench_e7_train_joint", "e7 training step with `--joint` (+ encoders and merge_net backward)"),
         ("bench_trajopt", "traj-opt loop (N4): 50 Adam iterations per batch in one launch")]
 print("| workload (786 432 rows = 4096 scenes × 64 × 3, S=64) | ms / batch | trajectories/s | STL-sat rate | chain launch: ms, TFLOP/s, frac |")
 print("|---|---|---|---|---|")

@@ -18,6 +18,8 @@ b bench_e7 --workload e7 --no_cpu_baseline
 b bench_k8_s100 --neighbors 8 --diffusion_steps 100 --no_cpu_baseline
 b bench_e8_train --workload e8_train --no_cpu_baseline
 b bench_e7_train --workload e7_train --no_cpu_baseline
+b bench_e8_train_joint --workload e8_train --joint --no_cpu_baseline
+b bench_e7_train_joint --workload e7_train --joint --no_cpu_baseline
 b bench_trajopt --workload trajopt --steps 3 --warmup 1
 b bench_big_shard --scenes 32768 --steps 3 --warmup 1 --no_cpu_baseline
 cd /tmp && export TMPDIR=/tmp
