@@ -10,9 +10,12 @@
 // xor-shuffles for sums and extrema).  The convex hulls are Andrew's monotone chain: a bitonic sort across the 64 lanes
 // puts the satisfied samples' points of every time step into LDS in lexicographic order, then 40 lanes (time step x
 // {lower, upper}) walk their chain (top two stack entries in registers, the rest as byte indices in LDS) and accumulate
-// the shoelace sum in float64 (MI355X runs fp64 VALU at full rate).  The p*log2(p) terms of the 41 entropy histograms
-// are spread over the lanes (six histograms per pass) instead of being evaluated redundantly by every lane.  Compile with -ffp-contract=off: histogram and entropy bin edges are
-// float32 expressions that must round like the reference's separate torch ops.
+// the shoelace sum in float64 (MI355X runs fp64 VALU at full rate).  The 40 control histograms (fixed, monotone edges) are
+// counted with one LDS atomic per value and their p*log2(p) terms spread over the lanes; the score histogram, whose edges
+// can degenerate, tests every bin on its own with ballots as the reference does.  Measured at 4096 scenes x 64 x 3
+// (tools/dbg/div_ablation.sh): 0.78 ms = hull sort 0.31 + hull scan 0.25 + entropies 0.08 + std 0.07 + occupancy 0.05 +
+// rollout/ADE 0.05 (the ballot form of the control histograms cost 0.28).  Compile with -ffp-contract=off: histogram and
+// entropy bin edges are float32 expressions that must round like the reference's separate torch ops.
 #include "pstl_common.hpp"
 
 namespace pstl {
@@ -101,6 +104,9 @@ __device__ __forceinline__ bool lex_less(float ax, float ay, float bx, float by)
   return ax < bx || (ax == bx && ay < by);
 }
 
+#ifndef PSTL_DIV_SKIP
+#define PSTL_DIV_SKIP 0   // timing-only ablations (tools/dbg): 1 std, 2 hull, 4 | 32 hull scan (32 keeps the sort), 8 entropies, 16 occupancy
+#endif
 __global__ __launch_bounds__(kWave) void k_diversity(DivArgs a) {
   __shared__ float2 s_pts[kT][kWave];          // satisfied samples' points per time step, sorted (x, then y)
   __shared__ uint8_t s_stack[2 * kT][kWave];   // chain stacks (indices into s_pts[t])
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(kWave) void k_diversity(DivArgs a) {
   // ---- masked std over the satisfied samples, mean over the 40 position features (nusc_api.py:824-831) ----------
   // variance of feature f lands in lane f, so that a single sqrt serves all 40 features
   double std_acc = 0.0;
-  if (n_sat > 0) {
+  if (n_sat > 0 && !(PSTL_DIV_SKIP & 1)) {
     const double inv = 1.0 / (double)n_sat;
     double var = 0.0;
 #pragma unroll
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(kWave) void k_diversity(DivArgs a) {
 
   // ---- per-step convex-hull area of the satisfied samples (nusc_api.py:838-865) --------------------------------
   double vol = 0.0;
-  if (mode_valid && n_sat >= 3) {
+  if (mode_valid && n_sat >= 3 && !(PSTL_DIV_SKIP & 2)) {
 #pragma unroll
     for (int t = 0; t < kT; ++t) {
       // bitonic sort across the 64 lanes, key (x, y); unsatisfied samples carry +inf and end up behind the others
@@ -203,7 +209,8 @@ __global__ __launch_bounds__(kWave) void k_diversity(DivArgs a) {
     }
     __syncthreads();
     double sh = 0.0;
-    if (lane < 2 * kT) {
+    if (PSTL_DIV_SKIP & 32) sh = (double)s_pts[lane % kT][lane].x;   // (keeps the sort alive when the scan is ablated)
+    if (lane < 2 * kT && !(PSTL_DIV_SKIP & (4 | 32))) {
       const int t = lane >> 1;
       const bool upper = lane & 1;
       const float2* P = s_pts[t];
@@ -239,28 +246,52 @@ __global__ __launch_bounds__(kWave) void k_diversity(DivArgs a) {
   }
 
   // ---- entropies (nusc_api.py:906-926): 41 histograms (scores, w_t, a_t), six at a time over the wavefront --------
-  float ent_s, ent_w, ent_a;
-  {
+  float ent_s = 0.0f, ent_w = 0.0f, ent_a = 0.0f;
+  if (!(PSTL_DIV_SKIP & 8)) {
     const float smin = wave_min(vsat ? score : INFINITY) - 1e-5f;
     const float smax = wave_max(vsat ? score : -INFINITY) + 1e-5f;
     float cnt = 0.0f, tot = 0.0f;
-    hist10(score, vsat, smin, smax, s_al, 0, lane, cnt, tot);
+    hist10(score, vsat, smin, smax, s_al, 0, lane, cnt, tot);   // (its edges may degenerate: every bin tested on its own)
     ent_s = (float)wave_sum((double)(lane < kEntBins ? entropy_term(cnt, tot, lane) : 0.0f));
-    double acc_w = 0.0, acc_a = 0.0;
+    // The 40 control histograms share two fixed edge sets (-w_max .. w_max, -a_max .. a_max; monotone, so "every bin on
+    // its own" is "the bin whose lower edge is the last one <= x"): a lane finds the bin of its value with 11 compares
+    // and counts it with one LDS atomic; the p*log2(p) terms are then spread over the lanes, one (histogram, bin) each.
+    // (bin counts of the w_t and a_t histograms: in the LDS of the hull points, which are no longer needed)
+    unsigned (*s_hist)[kEntBins] = reinterpret_cast<unsigned (*)[kEntBins]>(&s_pts[0][0]);
+    __syncthreads();
+    for (int i = lane; i < 2 * kT * kEntBins; i += kWave) (&s_hist[0][0])[i] = 0u;
+    __syncthreads();
+    float ew[kEntBins + 1], ea[kEntBins + 1];
 #pragma unroll
-    for (int t0 = 0; t0 < kT; t0 += 3) {        // slots 0..2: w of steps t0..t0+2, slots 3..5: a of the same steps
-      cnt = 0.0f;
-      tot = 0.0f;
+    for (int k = 0; k <= kEntBins; ++k) {
+      ew[k] = (-a.w_max) * (1.0f - s_al[k]) + a.w_max * s_al[k];
+      ea[k] = (-a.a_max) * (1.0f - s_al[k]) + a.a_max * s_al[k];
+    }
+    if (vsat) {
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        if (t0 + d < kT) {
-          hist10(u[2 * (t0 + d)], vsat, -a.w_max, a.w_max, s_al, d, lane, cnt, tot);
-          hist10(u[2 * (t0 + d) + 1], vsat, -a.a_max, a.a_max, s_al, 3 + d, lane, cnt, tot);
+      for (int t = 0; t < kT; ++t) {
+        const float wv = u[2 * t], av = u[2 * t + 1];
+        int cw = 0, ca = 0;
+#pragma unroll
+        for (int k = 0; k <= kEntBins; ++k) {
+          cw += wv >= ew[k] ? 1 : 0;
+          ca += av >= ea[k] ? 1 : 0;
         }
+        if (cw >= 1 && cw <= kEntBins) atomicAdd(&s_hist[t][cw - 1], 1u);               // ew[cw-1] <= w < ew[cw]
+        if (ca >= 1 && ca <= kEntBins) atomicAdd(&s_hist[kT + t][ca - 1], 1u);
       }
-      const float term = entropy_term(cnt, tot, lane);
-      acc_w += (double)(lane < 3 * kEntBins ? term : 0.0f);
-      acc_a += (double)(lane >= 3 * kEntBins ? term : 0.0f);
+    }
+    __syncthreads();
+    double acc_w = 0.0, acc_a = 0.0;
+    for (int i = lane; i < 2 * kT * kEntBins; i += kWave) {
+      const int h = i / kEntBins;
+      unsigned total = 0u;
+#pragma unroll
+      for (int k = 0; k < kEntBins; ++k) total += s_hist[h][k];
+      const float p = (float)s_hist[h][i % kEntBins] / fmaxf((float)total, 1e-5f);
+      const float term = (-p) * log2f(fmaxf(p, 1e-5f));
+      if (h < kT) acc_w += (double)term;
+      else acc_a += (double)term;
     }
     ent_w = (float)wave_sum(acc_w);
     ent_a = (float)wave_sum(acc_a);
@@ -292,7 +323,7 @@ __global__ __launch_bounds__(kWave) void k_diversity(DivArgs a) {
   if (ylo == yhi) { ylo -= 0.5f; yhi += 0.5f; }
   const float xlen = xhi - xlo, ylen = yhi - ylo;
   const float xstep = xlen / (float)kHist, ystep = ylen / (float)kHist;
-  if (live) {
+  if (live && !(PSTL_DIV_SKIP & 16)) {
 #pragma unroll
     for (int t = 0; t < kT; ++t) {
       const float gf = (gate >> t) & 1u ? 1.0f : 0.0f;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B timing of build variants of one translation unit ON the GPU box (nothing is built here and shipped):
-#   tools/dbg/ab.sh "<bench args>" name1:unit:"<extra hipcc flags>" name2:unit:"<flags>" ...      unit = mlp | stl
+#   tools/dbg/ab.sh "<bench args>" name1:unit:"<extra hipcc flags>" name2:unit:"<flags>" ...      unit = mlp | stl | div
 # Each variant is compiled into /tmp/pstl_variants/ (the other objects are the in-tree ones), then bench.py is run
 # against it through tools/dbg/with_lib.py.  "base" = the in-tree library.
 root=$(cd "$(dirname "$0")/../.." && pwd)
@@ -17,6 +17,9 @@ for v in "$@"; do
   if [ "$unit" = "mlp" ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xarch_device -mllvm=-misched-prera-direction=topdown $flags -c $c/mlp_kernels.hip -o $out/v_$n.o || { echo "$n: build failed"; continue; }
     objs=${objs/$c\/mlp_kernels.o/$out\/v_$n.o}
+  elif [ "$unit" = "div" ]; then
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $flags -c $c/diversity_kernels.hip -o $out/v_$n.o || { echo "$n: build failed"; continue; }
+    objs=${objs/$c\/diversity_kernels.o/$out\/v_$n.o}
   else
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Xarch_device -mllvm=-misched=gcn-iterative-ilp $flags -c $c/stl_kernels.hip -o $out/v_$n.o || { echo "$n: build failed"; continue; }
     objs=${objs/$c\/stl_kernels.o/$out\/v_$n.o}
