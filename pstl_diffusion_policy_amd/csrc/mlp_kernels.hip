@@ -1200,19 +1200,31 @@ constexpr int kMrgW0 = 0, kMrgB0 = 40 * 32, kMrgW1 = kMrgB0 + 32, kMrgB1 = kMrgW
 // merge_net on one row, lane-private: h0 / h1v = the two hidden layers BEFORE their ReLU, out[0..40) the output (LDS).
 // One k-ordered fma chain per output: the forward (k_merge_pool) and the backward's recomputation (k_merge_bwd) see the
 // same bits, so the backward finds the maximum the forward pooled.
-__device__ __forceinline__ void merge_row(const float* x, const float* wt, float (&h0)[32], float (&h1v)[32], float* out) {
-  const float* w0t = wt + kMrgW0;
-  const float* b0 = wt + kMrgB0;
-  const float* w1t = wt + kMrgW1;
-  const float* b1 = wt + kMrgB1;
-  const float* w2t = wt + kMrgW2;
-  const float* b2 = wt + kMrgB2;
+// WP: where the weights are read from -- an LDS copy (const float*) or the packed buffer through the constant address
+// space (kconst_f32: uniform indices become scalar loads, the weights reach the FMAs as SGPR operands and no LDS
+// bandwidth is spent on them; same operations, same bits).
+typedef const __attribute__((address_space(4))) float* kconst_f32;
+template <typename WP>
+__device__ __forceinline__ void merge_row(const float* x, WP wt, float (&h0)[32], float (&h1v)[32], float* out) {
+  const WP w0t = wt + kMrgW0;
+  const WP b0 = wt + kMrgB0;
+  const WP w1t = wt + kMrgW1;
+  const WP b1 = wt + kMrgB1;
+  const WP w2t = wt + kMrgW2;
+  const WP b2 = wt + kMrgB2;
+  // Every accumulation is an EXPLICIT fused multiply-add in k order: left to the compiler's contraction the same source
+  // came out partly as v_pk_mul + v_add and partly as v_fmac, differently in each instantiation -- forward and backward
+  // would then disagree on near-ties of the max-pool.
 #pragma unroll
   for (int o = 0; o < 32; ++o) h0[o] = b0[o];
-  for (int k = 0; k < 40; ++k) {
-    const float xv = x[k];
+  f32x4 xq[10];   // the row as ten 16-byte loads (a lane reads its own 160-byte row: 40 scalar loads touched 64 lines each)
 #pragma unroll
-    for (int o = 0; o < 32; ++o) h0[o] += w0t[k * 32 + o] * xv;
+  for (int q = 0; q < 10; ++q) xq[q] = reinterpret_cast<const f32x4*>(x)[q];
+#pragma unroll
+  for (int k = 0; k < 40; ++k) {
+    const float xv = xq[k >> 2][k & 3];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) h0[o] = __builtin_fmaf(w0t[k * 32 + o], xv, h0[o]);
   }
 #pragma unroll
   for (int o = 0; o < 32; ++o) h1v[o] = b1[o];
@@ -1220,22 +1232,26 @@ __device__ __forceinline__ void merge_row(const float* x, const float* wt, float
   for (int k = 0; k < 32; ++k) {
     const float hv = fmaxf(h0[k], 0.0f);
 #pragma unroll
-    for (int o = 0; o < 32; ++o) h1v[o] += w1t[k * 32 + o] * hv;
+    for (int o = 0; o < 32; ++o) h1v[o] = __builtin_fmaf(w1t[k * 32 + o], hv, h1v[o]);
   }
-  for (int o = 0; o < 40; ++o) {
-    float acc = b2[o];
+  float o2[40];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) acc += w2t[k * 40 + o] * fmaxf(h1v[k], 0.0f);
-    out[o] = acc;
+  for (int o = 0; o < 40; ++o) o2[o] = b2[o];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const float hv = fmaxf(h1v[k], 0.0f);
+#pragma unroll
+    for (int o = 0; o < 40; ++o) o2[o] = __builtin_fmaf(w2t[k * 40 + o], hv, o2[o]);
   }
+#pragma unroll
+  for (int o = 0; o < 40; ++o) out[o] = o2[o];
 }
 
 // (256 registers = two waves per SIMD is the best point: pinned to 1, 3, 4 or 6 waves per SIMD it ran 10 % slower)
 __global__ __launch_bounds__(64) void k_merge_pool(MergeArgs a) {
-  __shared__ float wt[kMrgFloats];
   __shared__ float outs[64][41];
   const int tid = threadIdx.x;
-  for (int i = tid; i < kMrgFloats; i += 64) wt[i] = a.packed[a.off.w0t + i];
+  const kconst_f32 wt = (kconst_f32)(a.packed + a.off.w0t);
   // one workgroup per (scene, mode); the S samples are walked 64 at a time (all lanes busy when S >= 64); the running
   // maximum of every shard is kept by the 40 x n_shards threads that own one (shard, output) pair each
   const long bm = blockIdx.x;
@@ -1290,14 +1306,13 @@ struct MergeBwdArgs {
 };
 
 __global__ __launch_bounds__(64) void k_merge_bwd(MergeBwdArgs a) {
-  __shared__ float wt[kMrgFloats];
+  const kconst_f32 wt = (kconst_f32)(a.packed + a.off.w0t);   // weights through scalar loads (see merge_row)
   __shared__ float outs[64][41];
   __shared__ float rowv[64][73];          // per layer: d output (<= 40) | layer input (<= 40)
   __shared__ float dpl[256];              // d pooled[(shard, output)]
   __shared__ int win[256];                // winning sample of (shard, output)
   __shared__ int live[64];                // row holds a winner
   const int tid = threadIdx.x;
-  for (int i = tid; i < kMrgFloats; i += 64) wt[i] = a.packed[a.off.w0t + i];
   const int sps = a.S / a.n_shards;
   float g2[20], g1[16], g0[20], gb[2];    // dW2[c = 2j + (tid>>5)][k = tid&31], dW1[o = 2j + (tid>>5)][k], dW0[o = e/40][k = e%40], biases
 #pragma unroll
