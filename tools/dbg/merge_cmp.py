@@ -1,3 +1,4 @@
+"""Saves pstl_refine outputs (merge_net architecture, 512 scenes, fixed seeds) to the file named on the command line, so that\ntwo builds of the library can be compared bit for bit (tools/dbg/variant_run.sh for the other build).  GPU only."""
 import sys, os, ctypes, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from pstl_diffusion_policy_amd import ffi
