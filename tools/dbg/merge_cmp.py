@@ -1,6 +1,7 @@
-"""Saves pstl_refine outputs (merge_net architecture, 512 scenes, fixed seeds) to the file named on the command line, so that\ntwo builds of the library can be compared bit for bit (tools/dbg/variant_run.sh for the other build).  GPU only."""
+"""Saves pstl_refine outputs (merge_net architecture, 512 scenes, fixed seeds) to the file named on the command line, so that
+two builds of the library can be compared bit for bit (tools/dbg/variant_run.sh for the other build).  GPU only."""
 import sys, os, ctypes, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pstl_diffusion_policy_amd import ffi
 from pstl_diffusion_policy_amd.engine import Sampler, PackedWeights, SceneBatch
 from pstl_diffusion_policy_amd.nusc_model import init_state_dict
