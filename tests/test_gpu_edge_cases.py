@@ -113,3 +113,29 @@ def test_abi_rejects_bad_arguments_with_status_codes(dev):
     assert L.pstl_error_string(-1).decode() and L.pstl_error_string(-3).decode()
     torch.cuda.synchronize()    # nothing was launched, nothing is pending, the device is healthy
     assert float(buf.sum()) == 0.0
+
+
+@pytest.mark.parametrize("bs,K", [(1, 1), (37, 6), (300, 2), (5, 50)])
+def test_scene_encoder_on_ragged_token_counts(dev, bs, K):
+    """The encoder runs its three MLPs as GEMMs over the batch's tokens (16-row tiles, workgroups shared out by tile
+    count): token counts that are no multiple of 16, a single scene, more workgroups than tiles, 50 neighbours (the fused
+    kernel of rounds 1-2 stopped at 44).  Feature and the scene-constant layer-1 rows against the CPU oracle."""
+    from oracle import pstl_oracle as orc
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    sdn = golden_weights()
+    scene = make_scene_batch(bs, K=K, S=2, seed=bs + K, invalid_lane_frac=0.3, stlp_mode="wide")
+    sm = Sampler(PackedWeights(sdn, dev), hp)
+    sb = SceneBatch(scene, 2, hp, dev)
+    feature, base_p, base_r, saved = sm.encode(sb, save=True)
+    f2, p2, r2 = sm.encode(sb)
+    assert torch.equal(feature, f2) and torch.equal(base_p, p2) and torch.equal(base_r, r2)
+    ref = orc.encode_feat(sdn, {k: v.numpy() for k, v in scene.items()})
+    np.testing.assert_allclose(feature.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    for base, net in ((base_p, "policy_net"), (base_r, "rect_net")):
+        w = torch.from_numpy(sdn[net + ".0.weight"])[:, :224]
+        want = ref @ w.t() + torch.from_numpy(sdn[net + ".0.bias"])
+        np.testing.assert_allclose(base.cpu().numpy(), want.numpy(), rtol=0, atol=5e-5)
+    T = bs * (K + 4)
+    assert saved["tok_h1"].shape == (T, 256) and bool((saved["tok_h1"] >= 0).all()) and bool((saved["tok_h2"] >= 0).all())
