@@ -410,12 +410,65 @@ struct MixArgs {
   float* work;               // kMixPlanes * n_slots floats
   float* out;                // (N,40)
   float* grad_trace;         // (iters,N,8) d loss / d lambda of every iteration, or null (tests)
+  int* mix_count;            // COMPACT: [scenes] rows to mix, and
+  int* mix_list;             //          [scenes][rows_per_scene] their row indices (k_mix_select)
 };
 
+// Which rows --refinement mixes (score of the current controls <= 0 on a valid lane, nusc_train.py:1045-1046), packed per
+// scene: the other rows copy their controls and are done.  Typically ~30 % of the rows are mixed; run where they sit,
+// a wavefront of k_mixopt would carry ~19 live lanes through all 50 iterations -- packed, a scene's rows fill one dense
+// wavefront instead of three sparse ones.  The order inside a scene's list depends on which wavefront reaches the counter
+// first; results do not (a row's arithmetic knows nothing of its lane, outputs go to out[row]).
 template <bool STAGED>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_mixopt(MixArgs a) {
+__global__ __launch_bounds__(kWave) void k_mix_select(MixArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const long row = map_row(a.by_mode, a.rows_per_scene);
+  const f4* lanes;
+  const float* nei;
+  scene_tables<STAGED>(lds, kScratchFwd, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes, nei);
+  constexpr int E = 2 * kT;
+  bool mix = false;
+  if (row < a.N) {
+    const Scratch st = {lds + threadIdx.x, kWave};
+    const long b = row / a.rows_per_scene;
+    const StlRow r = load_row(a.stlp, a.hl, row);
+    const float score0 = stl_eval<false, -1>(a.env, r, lanes, nei, a.K, DynSrc(a.s0 + b * 4, a.base[0] + row * E, 1.0f, 1.0f, a.env.dt),
+                                             st, 0, nullptr, nullptr);
+    mix = score0 <= 0.0f && a.valid[row] > 0.0f;
+    if (!mix) {
+      const f4* src = reinterpret_cast<const f4*>(a.base[0] + row * E);
+      f4* dst = reinterpret_cast<f4*>(a.out + row * E);
+      PSTL_UNROLL
+      for (int q = 0; q < E / 4; ++q) dst[q] = src[q];
+      if (a.grad_trace) {
+        PSTL_NOUNROLL
+        for (int it = 0; it < a.iters; ++it)
+          PSTL_NOUNROLL
+          for (int k = 0; k < kMixK; ++k) a.grad_trace[((long)it * a.N + row) * kMixK + k] = 0.0f;
+      }
+    }
+  }
+  const unsigned long long m = __ballot(mix);
+  if (m == 0ull) return;
+  const long scene = ((long)blockIdx.x * kWave) / a.rows_per_scene;   // uniform over the wavefront (rows_per_scene % 64 == 0)
+  int base = 0;
+  if (threadIdx.x == 0) base = atomicAdd(a.mix_count + scene, __popcll(m));
+  base = __shfl(base, 0);
+  if (mix) a.mix_list[scene * a.rows_per_scene + base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = (int)(row - scene * a.rows_per_scene);
+}
+
+template <bool STAGED, bool COMPACT = false>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_mixopt(MixArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  long row = map_row(a.by_mode, a.rows_per_scene);
+  if (COMPACT) {   // wavefront j of a scene takes entries [64 j, 64 j + 64) of the scene's list of rows to mix
+    const long scene = ((long)blockIdx.x * kWave) / a.rows_per_scene;
+    const int j = (int)(blockIdx.x % (a.rows_per_scene / kWave));
+    const int n = a.mix_count[scene];
+    if (j * kWave >= n) return;                               // whole wavefront: nothing left
+    const int idx = j * kWave + threadIdx.x;
+    row = idx < n ? scene * a.rows_per_scene + a.mix_list[scene * a.rows_per_scene + idx] : a.N;   // (a.N: idle lane)
+  }
   const long slot = (long)blockIdx.x * kWave + threadIdx.x;
   const long P = (long)gridDim.x * kWave;      // slots per plane
   const f4* lanes;
@@ -442,11 +495,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) v
     }
   }
   const float vr = a.valid[row];
-  // the rows to mix: score of the current controls <= 0 on a valid lane (nusc_train.py:1045-1046)
-  const float score0 = stl_eval<false, -1>(a.env, r, lanes, nei, a.K, DynSrc(a.s0 + b * 4, B, 1.0f, 1.0f, a.env.dt, P), st, 0,
-                                           nullptr, nullptr);
+  // the rows to mix: score of the current controls <= 0 on a valid lane (nusc_train.py:1045-1046); COMPACT: k_mix_select
+  // has sorted that out already
+  const float score0 = COMPACT ? 0.0f
+                               : stl_eval<false, -1>(a.env, r, lanes, nei, a.K, DynSrc(a.s0 + b * 4, B, 1.0f, 1.0f, a.env.dt, P),
+                                                     st, 0, nullptr, nullptr);
   float* out = a.out + row * E;
-  if (!(score0 <= 0.0f && vr > 0.0f)) {
+  if (!COMPACT && !(score0 <= 0.0f && vr > 0.0f)) {
     PSTL_NOUNROLL
     for (int e = 0; e < E; ++e) out[e] = B[(long)e * P];
     if (a.grad_trace) {
@@ -863,7 +918,8 @@ extern "C" int pstl_trajopt(const pstl_cfg* cfg, const float* s0, const float* n
 extern "C" size_t pstl_refinement_work_floats(const pstl_cfg* cfg) {
   if (check_cfg(cfg)) return 0;
   const long blocks = (n_rows(cfg) + kWave - 1) / kWave;
-  return (size_t)kMixPlanes * (size_t)blocks * kWave;
+  // element-major planes of the mixing loop + the per-scene lists of rows to mix (a count per scene, an index per row)
+  return (size_t)kMixPlanes * (size_t)blocks * kWave + (size_t)((cfg->bs + 63) / 64) * 64 + (size_t)n_rows(cfg);
 }
 
 extern "C" int pstl_refinement(const pstl_cfg* cfg, const float* s0, const float* nei_prep, const float* lane_prep,
@@ -903,9 +959,34 @@ extern "C" int pstl_refinement(const pstl_cfg* cfg, const float* s0, const float
   const bool staged = scene_staged(cfg);
   a.by_mode = rows_by_mode(cfg, staged) ? 1 : 0;
   const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged);
-  void (*fn)(MixArgs) = staged ? k_mixopt<true> : k_mixopt<false>;
+  const unsigned blocks = (unsigned)((a.N + kWave - 1) / kWave);
+  a.mix_count = nullptr;
+  a.mix_list = nullptr;
+#ifdef PSTL_MIX_NO_COMPACT   // timing/bit-comparison builds only (tools/dbg/refinement_time.py): the uncompacted walk
+  if (staged) {
+    void (*fl)(MixArgs) = k_mixopt<true>;
+    if (int e = allow_lds(reinterpret_cast<const void*>(fl), lds)) return e;
+    hipLaunchKernelGGL(fl, dim3(blocks), dim3(kWave), lds, as_stream(stream), a);
+    return launch_status();
+  }
+#endif
+  if (staged) {   // (rows_per_scene % 64 == 0: a wavefront's rows share a scene) pack the rows to mix per scene first
+    hipStream_t st = as_stream(stream);
+    int* ints = reinterpret_cast<int*>(work + (size_t)kMixPlanes * blocks * kWave);
+    a.mix_count = ints;
+    a.mix_list = ints + ((cfg->bs + 63) / 64) * 64;
+    if (hipMemsetAsync(a.mix_count, 0, (size_t)cfg->bs * sizeof(int), st) != hipSuccess) return PSTL_ERR_LAUNCH;
+    const size_t lds_sel = stl_lds_bytes(kScratchFwd, cfg->K, true);
+    if (int e = allow_lds(reinterpret_cast<const void*>(k_mix_select<true>), lds_sel)) return e;
+    hipLaunchKernelGGL(k_mix_select<true>, dim3(blocks), dim3(kWave), lds_sel, st, a);
+    void (*fc)(MixArgs) = k_mixopt<true, true>;
+    if (int e = allow_lds(reinterpret_cast<const void*>(fc), lds)) return e;
+    hipLaunchKernelGGL(fc, dim3(blocks), dim3(kWave), lds, st, a);
+    return launch_status();
+  }
+  void (*fn)(MixArgs) = k_mixopt<false>;
   if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
-  hipLaunchKernelGGL(fn, dim3((unsigned)((a.N + kWave - 1) / kWave)), dim3(kWave), lds, as_stream(stream), a);
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWave), lds, as_stream(stream), a);
   return launch_status();
 }
 
