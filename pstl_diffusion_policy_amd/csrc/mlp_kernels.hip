@@ -1450,7 +1450,15 @@ __global__ void k_merge_reduce(int nslabs, const float* slabs, float* dw0, float
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= kMrgFloats) return;
   float acc = 0.0f;
-  for (int sl = 0; sl < nslabs; ++sl) acc += slabs[(long)sl * kMrgFloats + i];
+  int sl = 0;
+  for (; sl + 8 <= nslabs; sl += 8) {   // eight loads in flight, added in slab order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slabs[(long)(sl + u) * kMrgFloats + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; sl < nslabs; ++sl) acc += slabs[(long)sl * kMrgFloats + i];
   if (i < 1280) dw0[i] = acc;
   else if (i < 1312) db0[i - 1280] = acc;
   else if (i < 2336) dw1[i - 1312] = acc;

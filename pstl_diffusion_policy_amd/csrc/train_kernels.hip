@@ -418,8 +418,18 @@ __global__ void k_slab_reduce(int nslabs, int F, int C, int fvalid, int cvalid, 
   if (i >= F * C) return;
   const int f = i / C, c = i % C;
   if (f >= fvalid || c >= cvalid) return;
+  // eight loads in flight, added in slab order (the same sum as a plain loop; as a plain loop every add waited for its
+  // own load: 0.107 ms per 256 x 256 reduction of 512 slabs)
   float acc = 0.0f;
-  for (int s = 0; s < nslabs; ++s) acc += slabs[(long)s * F * C + i];
+  int s = 0;
+  for (; s + 8 <= nslabs; s += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slabs[(long)(s + u) * F * C + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; s < nslabs; ++s) acc += slabs[(long)s * F * C + i];
   D[(long)f * ldd + c] = acc;
 }
 
