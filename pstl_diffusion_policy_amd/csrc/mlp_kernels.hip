@@ -316,10 +316,12 @@ __device__ __forceinline__ int xs_addr(int k, int c) { return (((k >> 4) * 64) +
 // carries over: lane (g, c) holds features 16 ot + 4 g + r of row c in acc[ot][r], which is slot s = 4 ot + r of its B
 // operand.  PT = 2 (half pieces of 2^10 w and 2^4 x, see k_pack_a_split): an operand to 2^-23, 1.9e-6 from the reference
 // after 99 chained steps like the fp32 kernel; PT = 1 (bfloat16 pieces): 2^-17, 8e-6.
+// SAVE (REFINE, split forms): the training forward pass -- the hidden layers' fp32 outputs go to a.h1_save / a.h2_save (a
+// template parameter, not a run-time test: the test alone cost the inference launch 6 %).
 // PERSIST: one workgroup per CU walks the 12-tile groups blockIdx.x, blockIdx.x + gridDim.x, ... with the weights loaded
 // into registers once (used for the single-step launches of the guided phase, where the 344 KB weight fetch and the
 // workgroup turnover are ~10 % of a 12-iteration workgroup).
-template <int NW, bool REFINE, int ABL = 0, bool UT = false, int PT = 0, bool PERSIST = false>
+template <int NW, bool REFINE, int ABL = 0, bool UT = false, int PT = 0, bool PERSIST = false, bool SAVE = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   constexpr bool BF = PT != 0;      // the operands are split into two 16-bit pieces
   constexpr bool F16 = PT == 2;     // ... of IEEE half (scaled, see k_pack_a_split); PT == 1: bfloat16 pieces
@@ -580,6 +582,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     if (F16) h0 *= kInvSW, h1v *= kInvSW;
     split8(h0, h1v, hi, lo);
   };
+  // training forward pass of the split forms (REFINE with activation buffers): a hidden layer's fp32 output relu(acc) /
+  // kAcc, this lane's 4*OT features of row `col` of tile p.tl (uniform row pointer + 32-bit lane offset, see here())
+  auto save_hidden = [&](float* dstbuf, Pos p, const f32x4 (&av)[OT]) {
+    if constexpr (REFINE && BF && SAVE) {
+      const long row0 = (t0(p.n) + p.tl) * kTileRows;
+      const unsigned cc = here((unsigned)col);
+      if (row0 + cc < a.N) {
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const unsigned off = cc * (unsigned)kHid + (unsigned)(16 * (w * OT + ot) + 4 * g);
+          *reinterpret_cast<f32x4*>((dstbuf + row0 * kHid) + off) = relu4(av[ot]) * kInvAcc;
+        }
+      }
+    }
+  };
   auto layer1 = [&](Pos p, int buf) {   // buf = tile-step index mod 3: the h1 buffer written and the crow slot read
     const int tl = p.tl;
     // fetched now, added after the MFMAs
@@ -609,6 +626,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       }
       pv8 hh, hl2;
       split_hidden(acc[0], acc[OT - 1], hh, hl2);
+      if constexpr (SAVE) save_hidden(a.h1_save, p, acc);
       u32x4* hwb = reinterpret_cast<u32x4*>(h1 + buf * 4096);   // [kb = producing wave][hi | lo][lane]
       hwb[(w * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
       hwb[(w * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, hl2);
@@ -887,7 +905,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vl, a1[ot]);
         }
         if (kb == 1) l1_const(p2, b1, a1);
-        if (kb == 5) split_hidden(a1[0], a1[OT - 1], hh, hl2);   // layer 1's output, in the shadow of layer 2's MFMAs
+        if (kb == 5) {
+          split_hidden(a1[0], a1[OT - 1], hh, hl2);   // layer 1's output, in the shadow of layer 2's MFMAs
+          if constexpr (SAVE)
+            if (it + 2 < total) save_hidden(a.h1_save, p2, a1);
+        }
         if (NOISE && kb == 6) {   // this wave's share of the noise of tile-step it (rows past N and the quads 10, 11 are never read)
           const int nt = tid - NT / 2;
           const int i = step_of(p0.n);
@@ -938,6 +960,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       // layer 3 of tile-step it; the ReLU + split of layer 1's output sits between its MFMAs
       pv8 bh, bl;
       split_hidden(acc[0], acc[OT - 1], bh, bl);
+      if constexpr (SAVE) save_hidden(a.h2_save, p0, acc);
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bh, acc3[j]);
 #pragma unroll
@@ -1505,13 +1528,13 @@ inline int cu_count() {
   return n;
 }
 
-template <int NW, bool REFINE, int ABL = 0, bool UT = false, int PT = 0, bool PERSIST = false>
+template <int NW, bool REFINE, int ABL = 0, bool UT = false, int PT = 0, bool PERSIST = false, bool SAVE = false>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
   const long n_groups = (n_tiles + a.tiles_per_group - 1) / a.tiles_per_group;
   const dim3 grid((unsigned)(PERSIST && n_groups > cu_count() ? cu_count() : n_groups));
   const size_t lds = chain_lds_bytes<NW>();
-  auto fn = k_chain<NW, REFINE, ABL, UT, PT, PERSIST>;
+  auto fn = k_chain<NW, REFINE, ABL, UT, PT, PERSIST, SAVE>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return PSTL_ERR_LAUNCH;
@@ -1531,10 +1554,13 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   const bool ut = (a.rows_per_scene % kTileRows == 0);  // every 16-row tile lies inside one scene
   if (chain_waves == 16) chain_waves = 0;
   if (REFINE && chain_waves == 32) chain_waves = 8;    // bf16 pieces cost the interval head up to 9e-5 per pass
-  if (REFINE && a.h1_save) chain_waves = chain_waves == 4 ? 4 : 8;   // the training forward pass saves fp32 activations
+  if (REFINE && a.h1_save && chain_waves != 0) chain_waves = chain_waves == 4 ? 4 : 8;   // (no bf16-piece training forward)
   if (chain_waves == 0) {
     if constexpr (!REFINE)
       if (ut && a.step_hi == a.step_lo) return launch_chain<8, false, 0, true, 2, true>(a, st);   // single step: persistent
+    if constexpr (REFINE)
+      if (a.h1_save && a.h2_save)   // training forward pass
+        return ut ? launch_chain<8, true, 0, true, 2, false, true>(a, st) : launch_chain<8, true, 0, false, 2, false, true>(a, st);
     return ut ? launch_chain<8, REFINE, 0, true, 2>(a, st) : launch_chain<8, REFINE, 0, false, 2>(a, st);
   }
   if (chain_waves == 32) {
