@@ -339,8 +339,8 @@ int pstl_trajopt(const pstl_cfg* cfg, const float* s0, const float* nei_prep, co
  * lambda (8 per row, start 1), on mask_mean(relu(thres - score(optim)), valid) with
  *   optim = softmax(lambda)_0 * controls + sum_i softmax(lambda)_i * list[list_idx[i-1]],  i = 1..7
  * (list = the rollout's normalised list (n_list,N,40), list_idx = the reference's {0,50,80,85,90,95,98}: a HOST array of 7);
- * out_controls = the optim of the last forward pass, or `controls` for the other rows.  All iterations of a row run in
- * ONE launch.  grad_scale = (1/clip(mean(valid),1e-2))/N_global; adam_* as for pstl_trajopt (DEVICE arrays [iters]);
+ * out_controls = the optim of the last forward pass, or `controls` for the other rows.  A first launch scores `controls`,
+ * copies the other rows through and packs each scene's rows to mix; all iterations of a row then run in ONE launch.  grad_scale = (1/clip(mean(valid),1e-2))/N_global; adam_* as for pstl_trajopt (DEVICE arrays [iters]);
  * work: pstl_refinement_work_floats(cfg) floats; grad_trace (iters,N,8) or null: d loss / d lambda per iteration (tests). */
 size_t pstl_refinement_work_floats(const pstl_cfg* cfg);
 int pstl_refinement(const pstl_cfg* cfg, const float* s0, const float* nei_prep, const float* lane_prep, const float* stlp,
