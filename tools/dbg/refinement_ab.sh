@@ -1,3 +1,6 @@
+#!/bin/bash
+# --refinement with and without the per-scene packing of the rows to mix (on the GPU box): times both builds at full size
+# and checks that their refined controls are bit-identical.
 root=$GRAFT_REPO_ROOT; c=$root/pstl_diffusion_policy_amd/csrc; out=/tmp/pv; mkdir -p $out
 cd $root
 python3 tools/dbg/refinement_time.py /tmp/new.pt 2>/dev/null | tail -1
