@@ -27,6 +27,6 @@ for stats, line, peak, what in (("bench_default_kernel_stats.csv", "bench_defaul
     if ms < 0.5 * float(k["MaxNs"]) / 1e6:   # the fp32 kernel has one instantiation for the multi- and the single-step
         ms, how = float(k["MaxNs"]) / 1e6, "LONGEST call (single-step launches share the row)"   # launches: no average
     ach = rows * steps_in_launch * F_STEP / (ms * 1e-3) / 1e12
-    print("%-28s %s calls, " + how + " %.3f ms  ->  %d rows x %d steps x %d FLOP = %.1f TFLOP/s, peak %.1f, frac %.3f   (bench line of "
-          "the same run: %.3f ms, frac %.3f)" % (what, k["Calls"], ms, rows, steps_in_launch, F_STEP, ach, peak, ach / peak,
-                                                 j["roofline"]["kernel_ms"], j["roofline"]["frac"]))
+    print(("%-28s %s calls, " + how + " %.3f ms  ->  %d rows x %d steps x %d FLOP = %.1f TFLOP/s, peak %.1f, frac %.3f   (bench "
+           "line of the same run: %.3f ms, frac %.3f)") % (what, k["Calls"], ms, rows, steps_in_launch, F_STEP, ach, peak,
+                                                           ach / peak, j["roofline"]["kernel_ms"], j["roofline"]["frac"]))
