@@ -34,6 +34,7 @@ struct StlArgs {
   float* sel_controls;    // (N,40) or null
   float* sel_scores;
   int32_t* sel_idx;
+  int rep_split;          // small batches: blockIdx.y is the rep (one candidate per wavefront, k_stl_select picks afterwards)
 };
 
 __device__ __forceinline__ StlRow load_row(const float* stlp, const float* hl, long row) {
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(kWave) void k_stl_forward(StlArgs a) {
   const StlRow r = load_row(a.stlp, a.hl, row);
   float best = -INFINITY;
   int best_rep = 0;
-  for (int rep = 0; rep < a.reps; ++rep) {
+  const int rep_lo = a.rep_split ? (int)blockIdx.y : 0, rep_hi = a.rep_split ? rep_lo + 1 : a.reps;
+  for (int rep = rep_lo; rep < rep_hi; ++rep) {
     float o3[3];
     float score;
     if (GIVEN) {
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(kWave) void k_stl_forward(StlArgs a) {
       a.scores3[stride + (long)rep * a.N + row] = o3[1];
       a.scores3[2 * stride + (long)rep * a.N + row] = o3[2];
     }
-    if (score > best || rep == 0) {  // first maximum wins, like torch.max(dim=0)
+    if (score > best || rep == rep_lo) {  // first maximum wins, like torch.max(dim=0)
       best = score;
       best_rep = rep;
     }
@@ -123,6 +125,26 @@ __global__ __launch_bounds__(kWave) void k_stl_forward(StlArgs a) {
     a.sel_scores[row] = best;
     a.sel_idx[row] = best_rep;
   }
+}
+
+// Candidate selection as a pass of its own (small batches, where k_stl_forward spreads the candidates over workgroups to cut
+// the latency of the launch): first maximum over the reps, like torch.max(dim=0); the chosen controls are gathered.
+__global__ void k_stl_select(long N, int reps, const float* scores, const float* controls, float* sel_controls,
+                             float* sel_scores, int32_t* sel_idx) {
+  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= N) return;
+  float best = scores[row];
+  int best_rep = 0;
+  for (int rep = 1; rep < reps; ++rep) {
+    const float sc = scores[(long)rep * N + row];
+    if (sc > best) best = sc, best_rep = rep;
+  }
+  const f4* src = reinterpret_cast<const f4*>(controls + ((long)best_rep * N + row) * (2 * kT));
+  f4* dst = reinterpret_cast<f4*>(sel_controls + row * (2 * kT));
+#pragma unroll
+  for (int i = 0; i < 10; ++i) dst[i] = src[i];
+  sel_scores[row] = best;
+  sel_idx[row] = best_rep;
 }
 
 // Row handled by this lane.  by_mode (scene-indexed rows r = (b*S + s)*3 + mode with S a multiple of 64): a wavefront
@@ -773,7 +795,15 @@ extern "C" int pstl_stl_forward(const pstl_cfg* cfg, const float* s0, const floa
   a.sel_controls = sel_controls;
   a.sel_scores = sel_scores;
   a.sel_idx = sel_idx;
-  const dim3 grid((unsigned)((a.N + kWave - 1) / kWave));
+  dim3 grid((unsigned)((a.N + kWave - 1) / kWave));
+  // fewer wavefronts than two per SIMD: one candidate per wavefront instead of `reps` in sequence (closed-loop caller:
+  // 192 rows x 5 candidates = 15 wavefronts of one candidate each instead of 3 of five)
+  a.rep_split = (reps > 1 && (long)grid.x * reps <= 2048) ? 1 : 0;
+  const bool select_after = a.rep_split && sel_controls && controls;
+  if (a.rep_split) {
+    grid.y = (unsigned)reps;
+    if (select_after) a.sel_controls = nullptr;
+  }
   const bool staged = scene_staged(cfg);
   const size_t lds = stl_lds_bytes(scores3 ? kScratchFwd3 : kScratchFwd, cfg->K, staged);
   void (*fn)(StlArgs);
@@ -785,6 +815,9 @@ extern "C" int pstl_stl_forward(const pstl_cfg* cfg, const float* s0, const floa
                  : (staged ? k_stl_forward<false, true, false> : k_stl_forward<false, false, false>);
   if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
   hipLaunchKernelGGL(fn, grid, dim3(kWave), lds, as_stream(stream), a);
+  if (select_after)
+    hipLaunchKernelGGL(k_stl_select, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, as_stream(stream), a.N, reps,
+                       (const float*)scores, controls, sel_controls, sel_scores, sel_idx);
   return launch_status();
 }
 
