@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PSTL_ABI_VERSION 1
+#define PSTL_ABI_VERSION 2   /* 2: pstl_encode_scene takes a work buffer; --joint and --refinement entry points */
 
 /* compile-time shape of the path (reference defaults: nt=20, n_segs=15, hiddens=[256,256], feat 7*32) */
 #define PSTL_T 20

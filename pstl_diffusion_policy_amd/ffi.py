@@ -24,6 +24,7 @@ HID = 256
 FEAT = 224
 NEI_PREP = 12
 
+ABI_VERSION = 2      # include/pstl_hip.h PSTL_ABI_VERSION
 EXPORTS = ["pstl_version", "pstl_error_string", "pstl_packed_weight_floats", "pstl_pack_weights", "pstl_time_bias",
            "pstl_fill_normal",
            "pstl_prepare_scene", "pstl_encode_scene", "pstl_rollout", "pstl_generate_trajs", "pstl_stl_forward",
@@ -68,6 +69,9 @@ def lib():
                 "(hipcc, gfx950). There is no CPU fallback for this path." % LIB_PATH)
         L = ctypes.CDLL(LIB_PATH)    # always the in-tree build (tools/dbg/with_lib.py re-points LIB_PATH for experiments)
         L.pstl_version.restype = ctypes.c_int
+        if L.pstl_version() != ABI_VERSION:
+            raise RuntimeError("libpstl_hip.so has ABI version %d, this binding expects %d: rebuild with "
+                               "`python -m pstl_diffusion_policy_amd.build`" % (L.pstl_version(), ABI_VERSION))
         L.pstl_error_string.restype = ctypes.c_char_p
         L.pstl_error_string.argtypes = [ctypes.c_int]
         L.pstl_packed_weight_floats.restype = ctypes.c_size_t

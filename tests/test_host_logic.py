@@ -14,7 +14,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     from pstl_diffusion_policy_amd import build, ffi
     build.build(verbose=False)
     L = ffi.lib()
-    assert L.pstl_version() == 1
+    assert L.pstl_version() == 2
     header = open(os.path.join(ROOT, "include", "pstl_hip.h")).read()
     declared = sorted(set(re.findall(r"^(?:int|size_t|const char\*)\s+(pstl_\w+)\s*\(", header, flags=re.M)))
     assert declared, "no declarations parsed"
