@@ -142,6 +142,14 @@ __global__ void k_loss_grad(long N, const float* scores, const float* valid, flo
 //   d loss / d L = -c (M M)^T ;  d/d sim_ij = (.)_ij q_i q_j ;  d/d q_i = sum_j ((.)_ij + (.)_ji) sim_ij q_j ;
 //   d/d dist_ij = -scale sim_ij d/d sim_ij ;  d/d x_i = sum_j (d/d dist_ij + d/d dist_ji) (x_i - x_j)/dist_ij  (0 at dist 0,
 //   as torch.norm's backward defines it) ;  d/d score_i = d/d q_i * q_i   (0 with --diverse_detach).
+constexpr int kDppWave = 64;
+// LDS of one group: A, Q (n x (n+1) doubles), X (n x 40), SIM, DST (n x (n+1)), q (n, padded to even), trace terms (n doubles)
+__host__ __device__ inline size_t dpp_group_bytes(int n) {
+  const size_t ld = n + 1;
+  size_t b = 2 * n * ld * sizeof(double) + ((size_t)n * kCtrl + 2 * n * ld + ((n + 1) & ~1)) * sizeof(float) + n * sizeof(double);
+  return (b + 15) & ~(size_t)15;
+}
+
 struct DppArgs {
   int bs, S, n_shards;
   float w_max, a_max, scale, c;
@@ -153,44 +161,51 @@ struct DppArgs {
   float* dscore;         // (N,) written
 };
 
-__global__ __launch_bounds__(64) void k_dpp(DppArgs a) {
+// A wavefront carries gpw = 64 / n groups side by side (n = 16: four; lane = sub * n + l, l = the group's column / row),
+// each with its own LDS block: with one group per wavefront three quarters of the lanes of the default shape idled.
+__global__ __launch_bounds__(64) void k_dpp(DppArgs a, int n_groups) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int n = a.S / a.n_shards;
   const int ld = n + 1;                                   // padded leading dimension (doubles)
-  double* A = reinterpret_cast<double*>(smem);            // n x ld : L + I, then M
+  const int gpw = kDppWave / n;                            // groups per wavefront
+  const size_t per = dpp_group_bytes(n);
+  const int sub = threadIdx.x / n, l = threadIdx.x % n;
+  const int g = blockIdx.x * gpw + sub;
+  const bool own = sub < gpw && g < n_groups;
+  unsigned char* mine = smem + (size_t)(sub < gpw ? sub : 0) * per;
+  double* A = reinterpret_cast<double*>(mine);            // n x ld : L + I, then M
   double* Q = A + n * ld;                                 // n x ld : M M
   float* X = reinterpret_cast<float*>(Q + n * ld);        // n x 40 normalised controls
   float* SIM = X + n * kCtrl;                             // n x ld
   float* DST = SIM + n * ld;                              // n x ld
   float* qv = DST + n * ld;                               // n
-  const int lane = threadIdx.x;
-  const int g = blockIdx.x;
-  const int shard = g % a.n_shards, bm = g / a.n_shards, mode = bm % 3, b = bm / 3;
-  const bool own = lane < n;
-  const long row = ((long)b * a.S + shard * n + (own ? lane : 0)) * 3 + mode;
+  double* trs = reinterpret_cast<double*>(qv + ((n + 1) & ~1));   // n: the diagonal terms of the trace
+  const int gg = own ? g : 0;
+  const int shard = gg % a.n_shards, bm = gg / a.n_shards, mode = bm % 3, b = bm / 3;
+  const long row = ((long)b * a.S + shard * n + l) * 3 + mode;
   float score = 0.0f, q = 0.0f;
   if (own) {
     score = a.scores[row];
     const float pos = score > 0.0f ? 1.0f : 0.0f;
     q = a.detach ? pos : expf(score) * pos;
-    qv[lane] = q;
+    qv[l] = q;
     const float* src = a.rect + row * kCtrl;
 #pragma unroll 8
-    for (int f = 0; f < kCtrl; ++f) X[lane * kCtrl + f] = src[f] / ((f & 1) ? a.a_max : a.w_max);
+    for (int f = 0; f < kCtrl; ++f) X[l * kCtrl + f] = src[f] / ((f & 1) ? a.a_max : a.w_max);
   }
   __syncthreads();
-  if (own) {   // column j = lane
+  if (own) {   // column j = l
     for (int i = 0; i < n; ++i) {
       float acc = 0.0f;
       for (int f = 0; f < kCtrl; ++f) {
-        const float d = X[i * kCtrl + f] - X[lane * kCtrl + f];
+        const float d = X[i * kCtrl + f] - X[l * kCtrl + f];
         acc += d * d;
       }
       const float dist = sqrtf(acc);
       const float sim = expf(-a.scale * dist);
-      DST[i * ld + lane] = dist;
-      SIM[i * ld + lane] = sim;
-      A[i * ld + lane] = (double)((qv[i] * sim) * q) + (i == lane ? 1.0 : 0.0);
+      DST[i * ld + l] = dist;
+      SIM[i * ld + l] = sim;
+      A[i * ld + l] = (double)((qv[i] * sim) * q) + (i == l ? 1.0 : 0.0);
     }
   }
   __syncthreads();
@@ -198,33 +213,35 @@ __global__ __launch_bounds__(64) void k_dpp(DppArgs a) {
   for (int k = 0; k < n; ++k) {
     const double p = A[k * ld + k];
     __syncthreads();
-    if (own) A[k * ld + lane] = (lane == k ? 1.0 : A[k * ld + lane]) / p;
+    if (own) A[k * ld + l] = (l == k ? 1.0 : A[k * ld + l]) / p;
     __syncthreads();
     if (own) {
-      const double rk = A[k * ld + lane];
+      const double rk = A[k * ld + l];
       for (int i = 0; i < n; ++i) {
         if (i == k) continue;
         const double f = A[i * ld + k];                 // column k is only rewritten by lane k, after it has read f
-        const double cur = (lane == k) ? 0.0 : A[i * ld + lane];
-        A[i * ld + lane] = cur - f * rk;
+        const double cur = (l == k) ? 0.0 : A[i * ld + l];
+        A[i * ld + l] = cur - f * rk;
       }
     }
     __syncthreads();
   }
-  if (own) {   // Q = M M (column j = lane), trace
+  if (own) {   // Q = M M (column j = l), trace
     for (int i = 0; i < n; ++i) {
       double acc = 0.0;
-      for (int k = 0; k < n; ++k) acc += A[i * ld + k] * A[k * ld + lane];
-      Q[i * ld + lane] = acc;
+      for (int k = 0; k < n; ++k) acc += A[i * ld + k] * A[k * ld + l];
+      Q[i * ld + l] = acc;
     }
+    trs[l] = 1.0 - A[l * ld + l];
   }
-  double tr = own ? 1.0 - A[lane * ld + lane] : 0.0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
-  if (lane == 0) a.group_div[g] = (float)tr;
   __syncthreads();
-  if (own) {   // row i = lane
-    const int i = lane;
+  if (own && l == 0) {
+    double tr = 0.0;
+    for (int i = 0; i < n; ++i) tr += trs[i];
+    a.group_div[g] = (float)tr;
+  }
+  if (own) {   // row i = l
+    const int i = l;
     double dq = 0.0;
     float dx[kCtrl];
 #pragma unroll
@@ -777,13 +794,13 @@ extern "C" int pstl_diversity_loss(const pstl_cfg* cfg, const float* rect_contro
   a.group_div = group_div;
   a.dcontrols = dcontrols;
   a.dscore = dscore;
-  const int ld = n + 1;
-  const size_t lds = (size_t)2 * n * ld * sizeof(double) + ((size_t)n * kCtrl + 2 * (size_t)n * ld + n) * sizeof(float);
+  const int gpw = kDppWave / n;                     // groups per wavefront (n <= 64 is checked above)
+  const size_t lds = dpp_group_bytes(n) * gpw;
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(k_dpp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
           hipSuccess)
     return PSTL_ERR_LAUNCH;
-  hipLaunchKernelGGL(k_dpp, dim3((unsigned)groups), dim3(64), lds, st, a);
+  hipLaunchKernelGGL(k_dpp, dim3((unsigned)((groups + gpw - 1) / gpw)), dim3(64), lds, st, a, groups);
   if (rect_reg_weight != 0.0f || reg_out) {
     if (!init_controls || !reg_out || !reg_work) return PSTL_ERR_ARG;
     const int nb = 256;
