@@ -12,3 +12,5 @@ run -e e4 --diffusion --load_stlp --flex --run_sampling_test --test --norm_stl -
 run -e e7_train --diffusion --stl_weight 0.0 --load_stlp -P e5_ddpm --rect_head --flex --diverse_loss --multi_cands 5 --epochs 1 --print_freq 1
 run -e e8_train --diffusion --stl_weight 1.0 --load_stlp --load_tj --rect_head --flex -P e5_ddpm --diversity_weight 0.0 --n_shards 4 --interval --multi_cands 5 --diff_full --epochs 1 --print_freq 1
 run -e tj --trajopt_only --traj_opt_iters 30 --load_stlp
+run -e e7_joint --diffusion --stl_weight 1.0 --load_stlp -P e5_ddpm --rect_head --flex --diverse_loss --multi_cands 5 --epochs 1 --print_freq 1 --joint
+run -e e7_refinement --diffusion --stl_weight 0.0 --load_stlp --rect_head --flex --diverse_loss --multi_cands 5 --test -P e7_ours --run_sampling_test --skip_nusc_load --viz_correct --refinement --diffusion_steps 100
