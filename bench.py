@@ -51,7 +51,7 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(a, hp, sd, guidance, rect_head, sampler=None, dev=None):
+def cpu_baseline(a, hp, sd, guidance, rect_head, sampler=None, dev=None, sampler_exact=None):
     """The CPU oracle (a float32 torch restatement of the reference path; the reference itself cannot travel to the
     GPU box) timed on the host cores on a bounded sample of the same workload.  The HIP path is then run on the very same
     scenes and noise, so that the line also carries the satisfaction rate of both and their largest control difference."""
@@ -76,15 +76,46 @@ def cpu_baseline(a, hp, sd, guidance, rect_head, sampler=None, dev=None):
     if sampler is not None:
         from pstl_diffusion_policy_amd.engine import SceneBatch, acc_from_counts
         sb = SceneBatch(scene_t, S, hp, dev)
-        got = sampler.sampling_region(sb, steps, x_T.to(dev), z.to(dev), rect_head=rect_head, multi_cands=mc, guidance=guidance,
-                                      want_scores3=False)
-        torch.cuda.synchronize()
-        acc, _ = acc_from_counts(got["counts"])
-        err = (got["final_controls"].reshape(N, 20, 2).cpu() - ref["final_controls"]).abs()
-        out.update(gpu_same_inputs={"stl_sat_rate": acc, "max_abs_dcontrols": float(err.max()),
-                                    "frac_controls_within_1e-4": float((err <= 1e-4).float().mean()),
-                                    "masks_differing": int(((got["final_scores"].cpu() > 0) != (ref["final_scores"] > 0)).sum())})
+
+        def same_inputs(sm):
+            got = sm.sampling_region(sb, steps, x_T.to(dev), z.to(dev), rect_head=rect_head, multi_cands=mc, guidance=guidance,
+                                     want_scores3=False)
+            torch.cuda.synchronize()
+            acc, _ = acc_from_counts(got["counts"])
+            err = (got["final_controls"].reshape(N, 20, 2).cpu() - ref["final_controls"]).abs()
+            return {"chain_waves": sm.chain_waves, "stl_sat_rate": acc, "max_abs_dcontrols": float(err.max()),
+                    "frac_controls_within_1e-4": float((err <= 1e-4).float().mean()),
+                    "masks_differing": int(((got["final_scores"].cpu() > 0) != (ref["final_scores"] > 0)).sum())}
+
+        out.update(gpu_same_inputs=same_inputs(sampler))
+        if sampler_exact is not None:     # the same inputs through the exact-fp32 MFMA kernels: the second opinion
+            out.update(gpu_same_inputs_fp32_exact=same_inputs(sampler_exact))
     return out
+
+
+def count_gpus():
+    """Number of GPUs this process may use, WITHOUT touching torch's CUDA module or the HIP runtime (the parent of the rank
+    processes must stay provably GPU-free): the KFD topology in sysfs (nodes with SIMDs are GPUs), narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one of them is set."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    n = None
+    if os.path.isdir(base):
+        n = 0
+        for node in os.listdir(base):
+            try:
+                props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([x for x in v.split(",") if x.strip() != ""])
+            n = listed if n is None else min(n, listed)
+    if n is None:       # no KFD sysfs (not a ROCm box): the last resort does not initialise the GPU either on this image
+        n = torch.cuda.device_count()
+    return n
 
 
 def spawn_ranks(a):
@@ -93,7 +124,7 @@ def spawn_ranks(a):
     line on the inherited stdout.  Children are separate processes started with Popen -- never an exec of this one."""
     n = a.gpus
     backend = os.environ.get("PSTL_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()          # counts devices without initialising the GPU
+    ndev = count_gpus()                        # sysfs + environment only: this process never touches the GPU
     if backend == "nccl" and ndev < n:
         print("bench: --gpus %d but only %d GPU(s) visible; refusing to measure fewer ranks than asked for" % (n, ndev),
               file=sys.stderr)
@@ -138,7 +169,7 @@ def main():
     # PSTL_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs than ranks (ranks then
     # share devices); the real runs use nccl (= RCCL over xGMI), one process per GPU.
     backend = os.environ.get("PSTL_BENCH_BACKEND", "nccl")
-    ndev = max(torch.cuda.device_count(), 1)
+    ndev = max(count_gpus(), 1)
     if backend == "nccl" and world > ndev:
         sys.exit("bench: %d ranks but %d GPU(s): one process per GPU" % (world, ndev))
     local = local % ndev
@@ -257,6 +288,8 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+    if not train:
+        sampler.check_chain_domain(fallback=False)     # a split-f16 launch that left its domain would have produced NaNs
     ms = [e0.elapsed_time(e1) for (e0, e1, _, _) in sampler.trace]
     nst, nrows = sampler.trace[0][2], sampler.trace[0][3]
     k_ms = float(np.mean(ms))
@@ -288,10 +321,49 @@ def main():
                               "algorithmic_bytes_per_row_eval": stl_bytes * (2 if kind == "guidance" else 1),
                               "achieved_GBps": rate * stl_bytes * (2 if kind == "guidance" else 1) / 1e9,
                               "frac_of_hbm_peak": rate * stl_bytes * (2 if kind == "guidance" else 1) / 8e12}
+    # Second opinion inside the same run: the same step with both MLP chains on the exact-fp32 MFMA
+    # kernels (chain_waves 8: bit-for-bit a k-ordered fmaf chain), three timed steps after one warm-up, priced against the
+    # dense fp32 matrix peak.
+    fp32_exact = None
+    sampler_exact = None
+    if world == 1 and not train and a.chain_waves != 8:
+        main_sampler = sampler
+        sampler_exact = Sampler(main_sampler.w, hp, chain_waves=8)
+        sampler = sampler_exact
+        one_step()
+        sampler_exact.trace = []
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        dt_x = (time.perf_counter() - t1) / 3
+        sampler = main_sampler
+        ms_x = float(np.mean([e0.elapsed_time(e1) for (e0, e1, _, _) in sampler_exact.trace]))
+        ach_x = float(sampler_exact.trace[0][3]) * sampler_exact.trace[0][2] * F_STEP_MIN / (ms_x * 1e-3) / 1e12
+        fp32_exact = {"chain_waves": 8, "steps": 3, "ms_per_step": dt_x * 1e3, "value": N / dt_x, "kernel_ms": ms_x,
+                      "achieved": ach_x, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach_x / PEAK_FP32_MATRIX_TFLOPS,
+                      "note": "v_mfma_f32_16x16x4_f32 chains (exact f32), same step, same run"}
+    # VALU-issue roofline of the one-row-per-lane STL kernels: vector instructions per launch (SQ_INSTS_VALU of the committed
+    # PMC pass, per wavefront) x 4 issue cycles / 1024 SIMDs / (launch time x clock)
+    pmc_r3 = os.path.join(ROOT, "profiles", "r3", "pmc_summary.json")
+    if os.path.exists(pmc_r3):
+        pj = json.load(open(pmc_r3))
+        for kind, info in stl_info.items():
+            v = pj.get("stl_kernels", {}).get(kind)
+            if v and v.get("rows_per_launch") == (N * a.multi_cands if kind == "score" else N) and a.neighbors == v.get("K"):
+                clk = float(v.get("clock_GHz", 2.4)) * 1e9
+                n_launch = {"guidance": 10, "score": 2}[kind]      # launches per step of this kind in the default workload
+                per_launch_s = info["ms_per_step"] * 1e-3 / n_launch if kind == "guidance" else None
+                if kind == "guidance":
+                    info["valu_insts_per_launch"] = v["SQ_INSTS_VALU"]
+                    info["valu_issue_frac"] = v["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (per_launch_s * clk)
+                    info["valu_issue_note"] = ("SQ_INSTS_VALU (profiles/r3/pmc_summary.json) x 4 cycles / 1024 SIMDs / (launch "
+                                               "time x %.2f GHz)" % (clk / 1e9))
     # HBM bytes of that launch from the committed PMC passes (FETCH_SIZE/WRITE_SIZE cannot be read inside this process);
     # only quoted when this run is the configuration those passes were collected on
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")
+    pmc = pmc_r3 if os.path.exists(pmc_r3) else os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")
     is_default = (a.workload == "e7_guid" and bs == 4096 and S == 64 and a.neighbors == 2 and steps == 50
                   and a.noise == "kernel" and not a.chain_waves)
     if is_default and os.path.exists(pmc):
@@ -321,14 +393,16 @@ def main():
                                        if (split_f16 or split_bf16) else "dense f32 MFMA peak"),
                          "matrix_pipe_frac_issued": (achieved * F_STEP_ISSUED_BF16 / F_STEP_MIN / PEAK_BF16_MATRIX_TFLOPS)
                                                     if (split_f16 or split_bf16) else achieved / peak,
-                         "traffic_source": "profiles/r2/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
+                         "traffic_source": "%s (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)" % os.path.relpath(pmc, ROOT)
                                            if traffic else None,
+                         "fp32_exact": fp32_exact,
                          "kernel_ms": k_ms, "flop_per_launch": flop, "stl_kernels": stl_info,
                          "note": "algorithmic FLOP = rows x steps x 172032 (hoisted layer-1 columns not counted); achieved "
                                  "counts every f32 multiply-add once, whatever the kernel issues for it"},
         }
         if not a.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
-            line["cpu_baseline"] = cpu_baseline(a, hp, sd, guidance, rect_head, None if (train or trajopt) else sampler, dev)
+            line["cpu_baseline"] = cpu_baseline(a, hp, sd, guidance, rect_head, None if (train or trajopt) else sampler, dev,
+                                                sampler_exact=sampler_exact)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

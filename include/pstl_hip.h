@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define PSTL_ABI_VERSION 2   /* 2: pstl_encode_scene takes a work buffer; --joint and --refinement entry points */
+#define PSTL_ABI_VERSION 3   /* 2: pstl_encode_scene takes a work buffer; --joint and --refinement entry points
+                                3: status block in the packed weight buffer (pstl_packed_status_offset) */
 
 /* compile-time shape of the path (reference defaults: nt=20, n_segs=15, hiddens=[256,256], feat 7*32) */
 #define PSTL_T 20
@@ -66,7 +67,12 @@ typedef struct pstl_cfg {
                               v_mfma_f32_16x16x32_f16 products per fp32 product, fp32 accumulate -- as close to
                               the reference as an fp32 fmaf chain in another summation order; 8 or 4 = fp32
                               MFMA (v_mfma_f32_16x16x4_f32) with 8 / 4 waves per workgroup; 32 = policy_net
-                              on bfloat16 pieces (2^-17 per operand), rect_net on fp32 MFMA                  */
+                              on bfloat16 pieces (2^-17 per operand), rect_net on fp32 MFMA.
+                              DOMAIN of 0 / 16: the pieces are halves of 2^10 w and 2^4 x, so the chain weights must
+                              satisfy |w| < PSTL_SPLIT_F16_WMAX and every layer input |x| < 4094; outside it the
+                              result is NaN (never a plausible wrong number) and the status block of the packed
+                              buffer says so (pstl_packed_status_offset).  8 / 4 / 32 have fp32's range.
+                              Any other value: PSTL_ERR_SHAPE.                                                */
   float tau;               /* --smoothing_factor                                          */
   float thres;             /* --stl_nn_thres                                              */
   float w_max, a_max;      /* --mul_w_max, --mul_a_max                                    */
@@ -99,6 +105,19 @@ const char* pstl_error_string(int code);
 /* ---- weights ----------------------------------------------------------------------------------------------- */
 /* Number of floats of the packed (kernel-layout) weight buffer. */
 size_t pstl_packed_weight_floats(void);
+/* Float offset, inside the packed buffer, of its 16-word STATUS BLOCK -- the only part of the buffer that is written after
+ * pstl_pack_weights, and the way the asynchronous entry points report the domain of the default (split-f16) arithmetic:
+ *   word 0 (float): max |w| over the weights of policy_net that the MLP-chain kernel carries as half pieces (layer-1
+ *                   columns of x / highlevel / stlp, layers 2 and 3), written by pstl_pack_weights; NaN if one is NaN;
+ *   word 1 (float): the same for rect_net (0 without --rect_head weights);
+ *   word 2 (uint32): 0 after pstl_pack_weights; set to 1 by pstl_rollout / pstl_refine / pstl_refine_train_forward when a
+ *                   launch on the split-f16 arithmetic (chain_waves 0 / 16) produced a non-finite state, i.e. a weight or
+ *                   a layer input was outside the domain above.  Sticky: the caller reads it when it synchronises anyway
+ *                   (after the timed region), re-runs the batch with chain_waves = 8 and may clear the word.
+ * A caller reads words 0-1 once after packing (one synchronisation) and selects chain_waves = 8 when either is not
+ * below PSTL_SPLIT_F16_WMAX (engine.PackedWeights does). */
+#define PSTL_SPLIT_F16_WMAX 63.9f
+size_t pstl_packed_status_offset(void);
 /* Re-lays the state_dict out for the kernels (MFMA operand order, transposed encoder matrices).
  * Replaces: Net.load_state_dict + the implicit layout of nn.Linear (nusc_train.py:1213-1215). */
 int pstl_pack_weights(const pstl_weight_ptrs* w, float* packed, void* stream);
@@ -130,10 +149,11 @@ int pstl_encode_scene(const pstl_cfg* cfg, const float* packed, const float* ego
  * (the reference draws zeros there).  mu_only (requires step_hi == step_lo): 1 = x_inout receives mu and no noise
  * is added (the guidance kernel finishes the step); 2 = x_inout receives the predicted noise eps itself, i.e. one
  * Net.forward evaluation (nusc_model.py:159-162).
- * emit: for every step with i <= n_emit the new state, normalised (x * (w_max,a_max), clipped iff PSTL_FLAG_CLIP), is
+ * emit: for every step with i <= n_emit the new state, normalised (x * (w_max,a_max), clipped iff PSTL_FLAG_CLIP -- with
+ * torch.clip's semantics: a NaN stays a NaN), is
  * written to emit_out[n_emit - i] (N,40) -- i.e. the last n_emit entries of the reference's diff_full list
  * (nusc_train.py:633-634); n_emit may be 0. */
-int pstl_rollout(const pstl_cfg* cfg, const float* packed, const float* base_policy, const float* tbias,
+int pstl_rollout(const pstl_cfg* cfg, float* packed /* status block written */, const float* base_policy, const float* tbias,
                  const float* stlp /* (N,6) */, const float* hl /* (N,) */, const float* beta, const float* alpha,
                  const float* alpha_hat, const float* noise, int step_hi, int step_lo, int mu_only,
                  float* x_inout /* (N,40) */, float* emit_out, int n_emit, void* stream);
@@ -191,14 +211,14 @@ int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const float* nei_pr
  * pooled = max over each shard of S/n_shards samples of merge_net(init) per (scene, mode); fused = init + pooled;
  * raw = tanh(rect_net([feature|hl|stlp|fused])); out = init + interval(raw, init) * [score < 0].
  * pooled_work (bs,3,n_shards,40) scratch.  Requires rows_per_scene == 3*S. */
-int pstl_refine(const pstl_cfg* cfg, const float* packed, const float* base_rect, const float* stlp, const float* hl,
+int pstl_refine(const pstl_cfg* cfg, float* packed /* status block written */, const float* base_rect, const float* stlp, const float* hl,
                 const float* init_controls /* (N,40) */, const float* scores /* (N,) */, float* pooled_work,
                 float* out_controls /* (N,40) */, void* stream);
 
 /* ---- RefineNet training step (config 5, nusc_train.py:1400-1427,1522-1525) ----------------------- */
 /* pstl_refine with the activations kept for the backward pass: h1_save, h2_save (N,256) = relu of layers 1, 2;
  * pre_save (N,40) = layer-3 output before tanh. */
-int pstl_refine_train_forward(const pstl_cfg* cfg, const float* packed, const float* base_rect, const float* stlp,
+int pstl_refine_train_forward(const pstl_cfg* cfg, float* packed, const float* base_rect, const float* stlp,
                               const float* hl, const float* init_controls, const float* scores, float* pooled_work,
                               float* out_controls, float* h1_save, float* h2_save, float* pre_save, void* stream);
 /* Loss mask_mean(relu(thres - score), valid) (compute_policy_loss :411): dscore[r] = -grad_scale*valid[r]*[thres-score>0]

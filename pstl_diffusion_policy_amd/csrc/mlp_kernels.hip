@@ -75,6 +75,7 @@ struct PackLayout {
   EncOff enc[3];
   ChainOff pol, rect;
   MergeOff mrg;
+  long status;   // 16 words, see pstl_packed_status_offset() in the header
   long total;
 };
 
@@ -115,6 +116,8 @@ __host__ __device__ inline PackLayout make_layout() {
   L.mrg.b1 = o;  o += 32;
   L.mrg.w2t = o; o += 32 * 40;
   L.mrg.b2 = o;  o += 40;
+  o = (o + 15) / 16 * 16;
+  L.status = o;  o += 16;
   L.total = (o + 63) / 64 * 64;
   return L;
 }
@@ -168,8 +171,11 @@ constexpr float kSplitX = 16.0f;     // activations as pieces of 2^4 x (|x| < 40
 __device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ unsigned f16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); }
 
+// wmax (F16 only): running maximum of |w| over the packed weights, as the bit pattern of a non-negative float (monotone in
+// the value; a NaN weight ranks above everything) -- the domain check of the split-f16 arithmetic, read by the host.
 template <bool F16>
-__global__ void k_pack_a_split(const float* W, int ld, int rows_valid, int n_tiles, int nkb, int mode, unsigned* dst) {
+__global__ void k_pack_a_split(const float* W, int ld, int rows_valid, int n_tiles, int nkb, int mode, unsigned* dst,
+                               unsigned* wmax = nullptr) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)n_tiles * nkb * 512) return;
   const int lane = (int)((i >> 2) & 63), m = (int)((i & 3) | (((i >> 8) & 1) << 2));
@@ -185,6 +191,10 @@ __global__ void k_pack_a_split(const float* W, int ld, int rows_valid, int n_til
     if (mode == 2) col = k < 40 ? 231 + k : k == 40 ? 224 : k < 47 ? 225 + (k - 41) : -1;
     float wv = (row < rows_valid && col >= 0) ? W[(long)row * ld + col] : 0.0f;
     if (F16) {
+      if (wmax) {
+        const unsigned bits = __builtin_bit_cast(unsigned, wv) & 0x7fffffffu;
+        if (bits > *wmax) atomicMax(wmax, bits);
+      }
       wv *= kSplitW;
       const _Float16 hi = (_Float16)wv;
       const float piece = m < 4 ? (float)hi : wv - (float)hi;
@@ -252,6 +262,7 @@ struct ChainArgs {
   float* h1_save;        // (N,256) relu(layer 1)
   float* h2_save;        // (N,256) relu(layer 2)
   float* pre_save;       // (N,40)  layer-3 output before tanh
+  unsigned* status;      // word 2 of the packed buffer's status block: set when a split-f16 launch leaves a non-finite value
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -301,6 +312,10 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   for (int i = 0; i < 4; ++i) b[i] = b[i] > 0 ? b[i] : 0;
   return __builtin_bit_cast(f32x4, b);
 }
+
+// torch.clip semantics: a NaN stays a NaN (fminf / fmaxf would return the bound and hide an operand that left the
+// split-f16 domain behind a plausible control); identical to fminf(fmaxf(v, -m), m) for every other input
+__device__ __forceinline__ float clip_keep_nan(float v, float m) { return v < -m ? -m : (v > m ? m : v); }
 
 // LDS address (in floats) of activation element k (0..47) of tile column c in the B-operand image [q][lane][r]
 __device__ __forceinline__ int xs_addr(int k, int c) { return (((k >> 4) * 64) + (((k >> 2) & 3) * 16 + c)) * 4 + (k & 3); }
@@ -472,7 +487,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       if (row < a.N) {
         const float sc = (f & 1) ? a.a_max : a.w_max;
         float v = a.x_inout[row * kCtrl + f] * sc;
-        if (a.clip) v = fminf(fmaxf(v, -sc), sc);
+        if (a.clip) v = clip_keep_nan(v, sc);
         a.emit_out[((long)(a.n_emit - a.steps) * a.N + row) * kCtrl + f] = v;
       }
     }
@@ -698,12 +713,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         const f32x4 xn = a.mu_only == 2 ? eps : a.mu_only ? mu : mu + sbeta * z4;
         if (!cont) *xp = xn;   // (CONT: one reverse step per launch, the slot is refilled from the next round's rows)
         if (row < a.N) {
-          if (i == s_lo) *reinterpret_cast<f32x4*>((a.x_inout + row0 * kCtrl) + loff) = xn;
+          if (i == s_lo) {
+            *reinterpret_cast<f32x4*>((a.x_inout + row0 * kCtrl) + loff) = xn;
+            // split-f16 domain (|w| < 64, |x| < 4094 for every layer input): an operand outside it turns into inf in the
+            // half cast and the state into NaN, which then stays NaN through the remaining steps -- one test per launch
+            if (F16 && !(fabsf((xn[0] + xn[1]) + (xn[2] + xn[3])) <= 3.0e38f)) atomicOr(a.status, 1u);
+          }
           if (i <= a.n_emit && !a.mu_only) {
             f32x4 v = xn * sc;
             if (a.clip) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], -sc[r]), sc[r]);
+              for (int r = 0; r < 4; ++r) v[r] = clip_keep_nan(v[r], sc[r]);
             }
             *reinterpret_cast<f32x4*>((a.emit_out + ((long)(a.n_emit - i) * a.N + row0) * kCtrl) + loff) = v;
           }
@@ -712,6 +732,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         // interval head (nusc_model.py:212-229): tanh output scales into the remaining headroom of init
         const f32x4 init = *reinterpret_cast<const f32x4*>((a.init + row0 * kCtrl) + loff);
         if (a.pre_save) *reinterpret_cast<f32x4*>((a.pre_save + row0 * kCtrl) + loff) = o;
+        if (F16 && !(fabsf((o[0] + o[1]) + (o[2] + o[3])) <= 3.0e38f)) atomicOr(a.status, 1u);
         const float viol = (a.scores + row0)[(unsigned)c] < 0.0f ? 1.0f : 0.0f;
         f32x4 v;
 #pragma unroll
@@ -719,7 +740,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           const float raw = tanhf(o[r]);
           const float d = raw >= 0.0f ? raw * (sc[r] - init[r]) : raw * (init[r] - (-sc[r]));
           v[r] = init[r] + d * viol;
-          if (a.clip) v[r] = fminf(fmaxf(v[r], -sc[r]), sc[r]);
+          if (a.clip) v[r] = clip_keep_nan(v[r], sc[r]);
         }
         *reinterpret_cast<f32x4*>((a.out + row0 * kCtrl) + loff) = v;
       }
@@ -1571,8 +1592,10 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   }
   if (chain_waves == 8) return ut ? launch_chain<8, REFINE, 0, true>(a, st) : launch_chain<8, REFINE>(a, st);
   if (chain_waves == 4) return launch_chain<4, REFINE>(a, st);
+#ifdef PSTL_DIAG
+  // Timing-only diagnostic instantiations (see the comment above k_chain; results are wrong by construction).  They exist
+  // only in builds made with -DPSTL_DIAG (tools/dbg); the shipped library answers PSTL_ERR_SHAPE to these values.
   if (REFINE) return chain_waves > 100 ? launch_chain<8, true>(a, st) : PSTL_ERR_SHAPE;
-  // diagnostic builds of the rollout kernel (see the comment above k_chain); results are not meaningful
   switch (chain_waves) {
     case 108: return launch_chain<8, false, 1>(a, st);
     case 708: return ut ? launch_chain<8, false, 7, true>(a, st) : launch_chain<8, false, 7>(a, st);
@@ -1581,6 +1604,9 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
     case 716: return launch_chain<8, false, 7, true, 2>(a, st);
     default: return PSTL_ERR_SHAPE;
   }
+#else
+  return PSTL_ERR_SHAPE;   // unknown chain_waves
+#endif
 }
 
 }  // namespace
@@ -1601,6 +1627,7 @@ extern "C" const char* pstl_error_string(int code) {
 }
 
 extern "C" size_t pstl_packed_weight_floats(void) { return (size_t)make_layout().total; }
+extern "C" size_t pstl_packed_status_offset(void) { return (size_t)make_layout().status; }
 
 static int pack_mlp_t(const pstl_mlp3& m, int in, int hid, int out, const long* off6, float* packed, hipStream_t st) {
   // off6: w0t, b0, w1t, b1, w2t, b2
@@ -1623,7 +1650,7 @@ static int pack_mlp_t(const pstl_mlp3& m, int in, int hid, int out, const long* 
 static bool mlp_ok(const pstl_mlp3& m) { return m.w0 && m.b0 && m.w1 && m.b1 && m.w2 && m.b2; }
 
 static int pack_chain(const pstl_mlp3& m, int in, int kext_mode, bool with_time, const ChainOff& o, float* packed,
-                      hipStream_t st) {
+                      unsigned* wmax, hipStream_t st) {
   long n = (long)kFeat * kHid;
   hipLaunchKernelGGL(k_transpose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.w0, kHid, in, 0, kFeat,
                      packed + o.w1f);
@@ -1642,9 +1669,9 @@ static int pack_chain(const pstl_mlp3& m, int in, int kext_mode, bool with_time,
   hipLaunchKernelGGL(k_pack_a_split<false>, dim3(16 * 2 * 2), dim3(256), 0, st, m.w0, in, kHid, 16, 2, kext_mode, pw + o.w1xb);
   hipLaunchKernelGGL(k_pack_a_split<false>, dim3(16 * 8 * 2), dim3(256), 0, st, m.w1, kHid, kHid, 16, 8, 0, pw + o.w2b);
   hipLaunchKernelGGL(k_pack_a_split<false>, dim3(3 * 8 * 2), dim3(256), 0, st, m.w2, kHid, kCtrl, 3, 8, 0, pw + o.w3b);
-  hipLaunchKernelGGL(k_pack_a_split<true>, dim3(16 * 2 * 2), dim3(256), 0, st, m.w0, in, kHid, 16, 2, kext_mode, pw + o.w1xh);
-  hipLaunchKernelGGL(k_pack_a_split<true>, dim3(16 * 8 * 2), dim3(256), 0, st, m.w1, kHid, kHid, 16, 8, 0, pw + o.w2h);
-  hipLaunchKernelGGL(k_pack_a_split<true>, dim3(3 * 8 * 2), dim3(256), 0, st, m.w2, kHid, kCtrl, 3, 8, 0, pw + o.w3h);
+  hipLaunchKernelGGL(k_pack_a_split<true>, dim3(16 * 2 * 2), dim3(256), 0, st, m.w0, in, kHid, 16, 2, kext_mode, pw + o.w1xh, wmax);
+  hipLaunchKernelGGL(k_pack_a_split<true>, dim3(16 * 8 * 2), dim3(256), 0, st, m.w1, kHid, kHid, 16, 8, 0, pw + o.w2h, wmax);
+  hipLaunchKernelGGL(k_pack_a_split<true>, dim3(3 * 8 * 2), dim3(256), 0, st, m.w2, kHid, kCtrl, 3, 8, 0, pw + o.w3h, wmax);
   return launch_status();
 }
 
@@ -1668,9 +1695,10 @@ extern "C" int pstl_pack_weights(const pstl_weight_ptrs* w, float* packed, void*
     hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, st, m.b2, 32, 32, packed + o.b2);
     if (int err = launch_status()) return err;
   }
-  if (int err = pack_chain(w->policy_net, 303, 1, true, L.pol, packed, st)) return err;
+  unsigned* status = reinterpret_cast<unsigned*>(packed + L.status);   // (zeroed by the memset above)
+  if (int err = pack_chain(w->policy_net, 303, 1, true, L.pol, packed, status + 0, st)) return err;
   if (mlp_ok(w->rect_net))
-    if (int err = pack_chain(w->rect_net, 271, 2, false, L.rect, packed, st)) return err;
+    if (int err = pack_chain(w->rect_net, 271, 2, false, L.rect, packed, status + 1, st)) return err;
   if (mlp_ok(w->merge_net)) {
     const long off6[6] = {L.mrg.w0t, L.mrg.b0, L.mrg.w1t, L.mrg.b1, L.mrg.w2t, L.mrg.b2};
     if (int err = pack_mlp_t(w->merge_net, 40, 32, 40, off6, packed, st)) return err;
@@ -1787,7 +1815,7 @@ extern "C" int pstl_encode_scene_saved(const pstl_cfg* cfg, const float* packed,
                       base_policy, base_rect, tok_in, tok_h1, tok_h2, tok_out, stream);
 }
 
-extern "C" int pstl_rollout(const pstl_cfg* cfg, const float* packed, const float* base_policy, const float* tbias,
+extern "C" int pstl_rollout(const pstl_cfg* cfg, float* packed, const float* base_policy, const float* tbias,
                             const float* stlp, const float* hl, const float* beta, const float* alpha,
                             const float* alpha_hat, const float* noise, int step_hi, int step_lo, int mu_only,
                             float* x_inout, float* emit_out, int n_emit, void* stream) {
@@ -1824,6 +1852,7 @@ extern "C" int pstl_rollout(const pstl_cfg* cfg, const float* packed, const floa
   a.row_offset = (long)cfg->row_offset;
   a.x_inout = x_inout;
   a.emit_out = emit_out;
+  a.status = reinterpret_cast<unsigned*>(packed + make_layout().status) + 2;
   // one launch covers at most kMaxLaunchSteps reverse steps (the per-step coefficients sit in LDS)
   for (int hi = step_hi; hi >= step_lo; hi -= kMaxLaunchSteps) {
     a.step_hi = hi;
@@ -1833,18 +1862,18 @@ extern "C" int pstl_rollout(const pstl_cfg* cfg, const float* packed, const floa
   return PSTL_OK;
 }
 
-static int refine_impl(const pstl_cfg* cfg, const float* packed, const float* base_rect, const float* stlp,
+static int refine_impl(const pstl_cfg* cfg, float* packed, const float* base_rect, const float* stlp,
                        const float* hl, const float* init_controls, const float* scores, float* pooled_work,
                        float* out_controls, float* h1_save, float* h2_save, float* pre_save, void* stream);
 
-extern "C" int pstl_refine(const pstl_cfg* cfg, const float* packed, const float* base_rect, const float* stlp,
+extern "C" int pstl_refine(const pstl_cfg* cfg, float* packed, const float* base_rect, const float* stlp,
                            const float* hl, const float* init_controls, const float* scores, float* pooled_work,
                            float* out_controls, void* stream) {
   return refine_impl(cfg, packed, base_rect, stlp, hl, init_controls, scores, pooled_work, out_controls, nullptr, nullptr,
                      nullptr, stream);
 }
 
-extern "C" int pstl_refine_train_forward(const pstl_cfg* cfg, const float* packed, const float* base_rect,
+extern "C" int pstl_refine_train_forward(const pstl_cfg* cfg, float* packed, const float* base_rect,
                                          const float* stlp, const float* hl, const float* init_controls,
                                          const float* scores, float* pooled_work, float* out_controls, float* h1_save,
                                          float* h2_save, float* pre_save, void* stream) {
@@ -1853,7 +1882,7 @@ extern "C" int pstl_refine_train_forward(const pstl_cfg* cfg, const float* packe
                      pre_save, stream);
 }
 
-static int refine_impl(const pstl_cfg* cfg, const float* packed, const float* base_rect, const float* stlp,
+static int refine_impl(const pstl_cfg* cfg, float* packed, const float* base_rect, const float* stlp,
                        const float* hl, const float* init_controls, const float* scores, float* pooled_work,
                        float* out_controls, float* h1_save, float* h2_save, float* pre_save, void* stream) {
   if (int e = check_cfg(cfg)) return e;
@@ -1901,6 +1930,7 @@ static int refine_impl(const pstl_cfg* cfg, const float* packed, const float* ba
   a.h1_save = h1_save;
   a.h2_save = h2_save;
   a.pre_save = pre_save;
+  a.status = reinterpret_cast<unsigned*>(packed + L.status) + 2;
   return launch_chain_nw<true>(cfg->chain_waves, a, st);
 }
 

@@ -6,6 +6,7 @@ Host code only sequences launches; all arithmetic on rows happens in the HIP ker
 import ctypes
 import os
 import math
+import warnings
 
 import numpy as np
 import torch
@@ -52,8 +53,25 @@ class PackedWeights:
         self.has_merge = "merge_net.0.weight" in state_dict
         self.packed = torch.empty(L.pstl_packed_weight_floats(), dtype=torch.float32, device=self.device)
         ffi.check(L.pstl_pack_weights(ctypes.byref(wp), ffi.ptr(self.packed), ffi.stream()), "pack_weights")
-        torch.cuda.current_stream().synchronize()   # the source blobs in `keep` may be freed after this
+        # Status block of the packed buffer (include/pstl_hip.h, pstl_packed_status_offset): max |w| of the weights the MLP
+        # chains carry as half pieces, per network.  Reading it is the synchronisation this constructor needs anyway (the
+        # source blobs in `keep` may be freed after it).
+        so = int(L.pstl_packed_status_offset())
+        self.status = self.packed[so:so + 16]
+        wmax = [float(v) for v in self.status[:2].cpu()]
+        self.chain_wmax = dict(policy_net=wmax[0], rect_net=wmax[1])
+        # domain of the default (split-f16) chain arithmetic: |w| < 63.9 (NaN compares false)
+        self.split_f16_ok = all(m < ffi.SPLIT_F16_WMAX for m in wmax)
         self._tbias = {}
+
+    def chain_overflowed(self, clear=False):
+        """True when a launch on the split-f16 arithmetic since the last clear left a non-finite state: a layer input was
+        outside the half range (|x| >= 4094).  Synchronises -- call it where the caller synchronises anyway."""
+        flag = self.status[2:3].view(torch.int32)
+        hit = bool(flag.item() != 0)
+        if clear:
+            flag.zero_()
+        return hit
 
     def tbias(self, steps):
         if steps not in self._tbias:
@@ -133,6 +151,10 @@ class Sampler:
         if chain_waves is None:
             chain_waves = int(os.environ.get("PSTL_CHAIN_WAVES", "0"))
         self.w, self.hp, self.chain_waves = weights, hp, int(chain_waves)
+        self.chain_fallback = None       # why the exact-fp32 kernels replaced the requested arithmetic, if they did
+        if self.chain_waves in (0, 16) and not weights.split_f16_ok:
+            self.use_exact_fp32("a chain weight is outside the split-f16 domain |w| < %g (max |w|: policy_net %g, rect_net %g)"
+                                % (ffi.SPLIT_F16_WMAX, weights.chain_wmax["policy_net"], weights.chain_wmax["rect_net"]))
         self.L = ffi.lib()
         # when set to a list, every multi-step rollout launch appends (start_event, end_event, n_steps, n_rows):
         # HIP events recorded on the launch stream, used by bench.py to time the dominant kernel live
@@ -140,6 +162,26 @@ class Sampler:
         # when set to a dict, STL launches append (start_event, end_event, row_evaluations) under "guidance" / "score"
         self.trace_stl = None
         self.debug_buf = None   # diagnostic builds only (chain_waves 708): receives the kernel's cycle stamps
+
+    def use_exact_fp32(self, why):
+        """Switch the MLP chains to the exact-fp32 MFMA kernels (chain_waves 8: fp32's range, 0.36x the throughput)."""
+        self.chain_fallback = why
+        self.chain_waves = 8
+        warnings.warn("pstl: MLP chains fall back to the exact-fp32 kernels (chain_waves = 8): " + why, RuntimeWarning,
+                      stacklevel=3)
+
+    def check_chain_domain(self, fallback=True):
+        """Call after a region, where the caller synchronises anyway: did a split-f16 launch overflow the half range (a layer
+        input |x| >= 4094)?  Returns False when all is well.  Otherwise the results of the region hold NaNs; with
+        fallback=True the sampler is switched to the exact-fp32 kernels, the flag cleared and True returned -- the caller
+        re-runs the batch; with fallback=False a FloatingPointError is raised."""
+        if self.chain_waves not in (0, 16) or not self.w.chain_overflowed(clear=True):
+            return False
+        why = "a layer input left the split-f16 domain |x| < 4094 (the state became non-finite)"
+        if not fallback:
+            raise FloatingPointError("pstl: " + why + "; re-run with chain_waves = 8")
+        self.use_exact_fp32(why)
+        return True
 
     def _stl_event(self, kind, row_evals):
         """HIP events (recorded on the launch stream) around one STL launch, kept for bench.py; None when not tracing."""

@@ -24,18 +24,8 @@ HID = 256
 FEAT = 224
 NEI_PREP = 12
 
-ABI_VERSION = 2      # include/pstl_hip.h PSTL_ABI_VERSION
-EXPORTS = ["pstl_version", "pstl_error_string", "pstl_packed_weight_floats", "pstl_pack_weights", "pstl_time_bias",
-           "pstl_fill_normal",
-           "pstl_prepare_scene", "pstl_encode_scene", "pstl_rollout", "pstl_generate_trajs", "pstl_stl_forward",
-           "pstl_stl_backward", "pstl_guidance_step", "pstl_refine", "pstl_reduce_metrics",
-           "pstl_refine_train_forward", "pstl_loss_grad", "pstl_train_create", "pstl_train_destroy",
-           "pstl_train_work_floats", "pstl_refine_backward", "pstl_diversity",
-           "pstl_stl_program_forward", "pstl_stl_program_backward", "pstl_trajopt",
-           "pstl_diversity_loss", "pstl_stl_signals", "pstl_refinement", "pstl_refinement_work_floats",
-           "pstl_encode_scene_saved", "pstl_encoder_backward", "pstl_encoder_backward_work_floats", "pstl_merge_backward",
-           "pstl_merge_backward_work_floats", "pstl_encode_scene_work_floats"]
-
+ABI_VERSION = 3      # include/pstl_hip.h PSTL_ABI_VERSION
+SPLIT_F16_WMAX = 63.9   # include/pstl_hip.h PSTL_SPLIT_F16_WMAX
 
 class PstlCfg(ctypes.Structure):
     _fields_ = [("bs", ctypes.c_int32), ("rows_per_scene", ctypes.c_int32), ("S", ctypes.c_int32),
@@ -56,6 +46,54 @@ class WeightPtrs(ctypes.Structure):
                                     "rect_net")]
 
 
+# One table for the exported symbols: (name, restype, argtypes).  `lib()` installs both, so that a wrong argument count or
+# a Python float where the C side expects an int is a TypeError here instead of undefined behaviour there.
+# C = const pstl_cfg*, P = pointer (device pointer, host array or struct, passed as void*), I = int, F = float,
+# L = int64_t, Z = size_t.
+_C = ctypes.POINTER(PstlCfg)
+_P, _I, _F, _L, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_size_t
+SIGNATURES = [
+    ("pstl_version", _I, []),
+    ("pstl_error_string", ctypes.c_char_p, [_I]),
+    ("pstl_packed_weight_floats", _Z, []),
+    ("pstl_packed_status_offset", _Z, []),
+    ("pstl_pack_weights", _I, [ctypes.POINTER(WeightPtrs), _P, _P]),
+    ("pstl_time_bias", _I, [_P, _I, _P, _P]),
+    ("pstl_fill_normal", _I, [_C, _I, _P, _P]),
+    ("pstl_prepare_scene", _I, [_C] + [_P] * 7),
+    ("pstl_encode_scene_work_floats", _Z, [_C]),
+    ("pstl_encode_scene", _I, [_C] + [_P] * 14),
+    ("pstl_rollout", _I, [_C] + [_P] * 9 + [_I, _I, _I, _P, _P, _I, _P]),
+    ("pstl_generate_trajs", _I, [_C] + [_P] * 4),
+    ("pstl_stl_forward", _I, [_C, _P, _P, _P, _I] + [_P] * 10),
+    ("pstl_stl_signals", _I, [_C] + [_P] * 7),
+    ("pstl_stl_backward", _I, [_C] + [_P] * 10),
+    ("pstl_guidance_step", _I, [_C] + [_P] * 6 + [_F, _I, _P, _P, _F, _I] + [_P] * 5),
+    ("pstl_refine", _I, [_C] + [_P] * 9),
+    ("pstl_reduce_metrics", _I, [_C] + [_P] * 5),
+    ("pstl_refine_train_forward", _I, [_C] + [_P] * 12),
+    ("pstl_loss_grad", _I, [_C, _P, _P, _F, _P, _P, _P]),
+    ("pstl_train_create", _I, [_P]),
+    ("pstl_train_destroy", _I, [_P]),
+    ("pstl_train_work_floats", _Z, [_C]),
+    ("pstl_refine_backward", _I, [_C] + [_P] * 21),
+    ("pstl_diversity", _I, [_C, _P, _P, _I] + [_P] * 8),
+    ("pstl_stl_program_forward", _I, [_P, _I, _P, _L, _I, _P, _F, _I, _P, _P, _P]),
+    ("pstl_stl_program_backward", _I, [_P, _I, _P, _L, _I, _P, _F, _I, _P, _P, _P, _P]),
+    ("pstl_trajopt", _I, [_C] + [_P] * 6 + [_F, _F, _F, _I, _P, _P, _I, _P, _P, _P, _P]),
+    ("pstl_diversity_loss", _I, [_C, _P, _P, _P, _F, _F, _I, _F] + [_P] * 6),
+    ("pstl_stl_signals", _I, [_C] + [_P] * 7),
+    ("pstl_refinement_work_floats", _Z, [_C]),
+    ("pstl_refinement", _I, [_C] + [_P] * 6 + [_F, _F, _I, _P, _P, _P, _P, _I] + [_P] * 5),
+    ("pstl_encode_scene_saved", _I, [_C] + [_P] * 17),
+    ("pstl_encoder_backward_work_floats", _Z, [_C]),
+    ("pstl_encoder_backward", _I, [_C] + [_P] * 17),
+    ("pstl_merge_backward_work_floats", _Z, [_C]),
+    ("pstl_merge_backward", _I, [_C, _P, _P, _P, _I] + [_P] * 8),
+]
+EXPORTS = sorted(set(n for n, _, _ in SIGNATURES))
+
+
 _lib = None
 
 
@@ -72,16 +110,10 @@ def lib():
         if L.pstl_version() != ABI_VERSION:
             raise RuntimeError("libpstl_hip.so has ABI version %d, this binding expects %d: rebuild with "
                                "`python -m pstl_diffusion_policy_amd.build`" % (L.pstl_version(), ABI_VERSION))
-        L.pstl_error_string.restype = ctypes.c_char_p
-        L.pstl_error_string.argtypes = [ctypes.c_int]
-        L.pstl_packed_weight_floats.restype = ctypes.c_size_t
-        for name in EXPORTS[3:]:
-            getattr(L, name).restype = ctypes.c_int
-        L.pstl_train_work_floats.restype = ctypes.c_size_t
-        L.pstl_refinement_work_floats.restype = ctypes.c_size_t
-        L.pstl_encoder_backward_work_floats.restype = ctypes.c_size_t
-        L.pstl_merge_backward_work_floats.restype = ctypes.c_size_t
-        L.pstl_encode_scene_work_floats.restype = ctypes.c_size_t
+        for name, restype, argtypes in SIGNATURES:
+            fn = getattr(L, name)     # AttributeError when the library lacks a symbol the header declares
+            fn.restype = restype
+            fn.argtypes = argtypes
         _lib = L
     return _lib
 

@@ -10,6 +10,8 @@ Scope: the diffusion branch (`--diffusion`, multi-sample rows).  The VAE / BC / 
 reference Net.forward (nusc_model.py:128-154) are baselines outside the hot path and raise NotImplementedError.
 """
 import ctypes
+import os
+import warnings
 
 import torch
 import torch.nn as nn
@@ -68,6 +70,9 @@ class Net(nn.Module):
             self.rect_net = build_relu_nn(latent_dim - self.time_dim + feat_dim * 7, args.nt * 2, [256, 256])
         self._packed = None
         self._packed_key = None
+        # arithmetic of the MLP chains (include/pstl_hip.h, cfg.chain_waves): None = PSTL_CHAIN_WAVES or the default
+        # (split-f16); set to 8 (exact fp32 MFMA) by the harness when a batch left the split-f16 domain
+        self.chain_waves = None
 
     # ---- kernel-layout weights, re-packed whenever a parameter changed (load_state_dict, optimiser step) ----
     def packed(self):
@@ -79,6 +84,20 @@ class Net(nn.Module):
             self._packed = PackedWeights({k: v for k, v in self.state_dict().items()}, ps[0].device)
             self._packed_key = key
         return self._packed
+
+    def chain_arith(self):
+        """cfg.chain_waves for this net's weights: the requested arithmetic, or the exact-fp32 kernels when a chain weight is
+        outside the split-f16 domain (|w| < 63.9; PackedWeights reads the maximum the packer recorded)."""
+        cw = self.chain_waves if self.chain_waves is not None else int(os.environ.get("PSTL_CHAIN_WAVES", "0"))
+        pw = self.packed()
+        if cw in (0, 16) and not pw.split_f16_ok:
+            if not getattr(pw, "_warned", False):
+                pw._warned = True
+                warnings.warn("pstl: a chain weight is outside the split-f16 domain |w| < %g (policy_net %g, rect_net %g): "
+                              "the MLP chains run on the exact-fp32 kernels (chain_waves = 8)"
+                              % (ffi.SPLIT_F16_WMAX, pw.chain_wmax["policy_net"], pw.chain_wmax["rect_net"]), RuntimeWarning)
+            return 8
+        return cw
 
     def hparams(self):
         a = self.args
@@ -141,7 +160,7 @@ class Net(nn.Module):
         stlp = ffi.f32(nn_input["stlp_dense"][:, 0], dev)
         hl = ffi.f32(ext["highlevel"].reshape(N), dev)
         rps = info["rows_per_scene"]
-        cfg = ffi.make_cfg(N // rps, rps, max(rps // 3, 1), 1, steps, self.hparams())
+        cfg = ffi.make_cfg(N // rps, rps, max(rps // 3, 1), 1, steps, self.hparams(), chain_waves=self.chain_arith())
         from .engine import diffusion_coeffs
         beta, alpha, alpha_hat = diffusion_coeffs(steps, dev)
         ffi.check(ffi.lib().pstl_rollout(ctypes.byref(cfg), ffi.ptr(pw.packed), ffi.ptr(info["base_policy"]),
@@ -161,7 +180,7 @@ class Net(nn.Module):
         rps = info["rows_per_scene"]
         diverse = bool(getattr(a, "diverse_loss", False)) and not getattr(a, "no_arch", False)
         flags = (0 if diverse else ffi.PSTL_FLAG_NO_MERGE) | (ffi.PSTL_FLAG_CLIP_RECT if getattr(a, "clip_rect", False) else 0)
-        cfg = ffi.make_cfg(N // rps, rps, rps // 3, 1, 2, self.hparams(), flags)
+        cfg = ffi.make_cfg(N // rps, rps, rps // 3, 1, 2, self.hparams(), flags, chain_waves=self.chain_arith())
         if diverse and rps // 3 != a.n_randoms:
             raise ValueError("merge_net pooling needs sampling_size == n_randoms (reference nusc_model.py:187-196)")
         init = ffi.f32(init_controls.reshape(N, -1), dev)

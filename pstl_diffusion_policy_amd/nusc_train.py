@@ -234,7 +234,12 @@ def _scene_tables(stl_input, R, dev, hp):
     sb = stl_input.get("_pstl")
     reps = stl_input.get("_pstl_reps", 1)
     if sb is not None and sb.N * reps == R:
-        return sb.cfg(2), sb.s0, sb.nei_prep, sb.lane_prep, sb.stlp, reps, sb.N
+        # the STL parameters are the ones the caller hands over NOW (stl_input["stlp"], reference nusc_train.py:266), not the
+        # ones captured when the batch was augmented: the closed-loop caller overwrites them in between (nusc_sim.py:442-472)
+        stlp = sb.stlp
+        if stl_input.get("stlp") is not None and stl_input["stlp"].shape[0] == R:
+            stlp = ffi.f32(stl_input["stlp"].reshape(reps, sb.N, 6)[0], dev)
+        return sb.cfg(2), sb.s0, sb.nei_prep, sb.lane_prep, stlp, reps, sb.N
     nei = ffi.f32(stl_input["neighbors"][..., :7], dev)
     lanes = [ffi.f32(stl_input["%slane_wpts" % k], dev) for k in ("curr", "left", "right")]
     K = nei.shape[1]
@@ -356,6 +361,36 @@ def _stl_metrics_tail(stl_input, scores_list, scores, mask, args, debug, tj_scor
 # ---------------------------------------------------------------------------------------------------------------
 # reverse diffusion
 # ---------------------------------------------------------------------------------------------------------------
+def _scene_batch_of(batch_cuda, n, n_randoms, args, dev, guidance_extras=None):
+    """The scene-indexed tables of a batch for the rollout / guidance kernels.  `batch_cuda["_pstl"]` (written by this
+    package's augment_batch_data) when it is there and fits; otherwise built from what the reference's own callers hold in
+    the dict: the scene-level tensors Net.forward reads (ego_traj, neighbors, *lane_wpts, *_id) and the neighbour futures
+    (`neighbor_trajs_aug`, or one row per scene of the row-replicated `neighbors_dense`)."""
+    sb = batch_cuda.get("_pstl")
+    if sb is not None and sb.N == n:
+        return sb
+    m = n_randoms * 3
+    src = batch_cuda
+    if "neighbor_trajs_aug" not in src and "neighbors_dense" not in src and guidance_extras is not None:
+        src = dict(batch_cuda, **{k: v for k, v in guidance_extras[0].items() if k in ("neighbor_trajs_aug", "neighbors_dense")})
+    scene = {k: src[k] for k in ("ego_traj", "neighbors", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
+                                 "curr_id", "left_id", "right_id")}
+    if "neighbor_trajs_aug" in src:
+        scene["neighbors_traj"] = src["neighbor_trajs_aug"]
+    elif "neighbors_dense" in src:
+        scene["neighbors_traj"] = src["neighbors_dense"][::m]
+    else:
+        raise KeyError("diffusion_rollout needs the neighbours' futures: batch['neighbor_trajs_aug'] (bs,K,nt,7) or the "
+                       "row-replicated batch['neighbors_dense']")
+    scene["stlp_rows"] = batch_cuda["stlp_dense"].reshape(n, 6)
+    sb = SceneBatch(scene, n_randoms, _hp(args), dev)
+    if sb.N != n:
+        raise ValueError("batch holds %d scenes x %d samples x 3 modes = %d rows, the noise has %d" % (sb.bs, n_randoms, sb.N, n))
+    if guidance_extras is not None:     # the states the guidance block rolls out from (reference :612): one row per scene
+        sb.s0 = ffi.f32(guidance_extras[1].reshape(n, -1)[::m, :4], dev)
+    return sb
+
+
 def diffusion_rollout(noise, net, batch_cuda, highlevel_dense, feature, args, coeffs=None, fastforward=False,
                       n_randoms=None, return_feature=False, mono=False, tmp_stlp=None, guidance_extras=None,
                       maximize=False):
@@ -371,8 +406,12 @@ def diffusion_rollout(noise, net, batch_cuda, highlevel_dense, feature, args, co
         n_randoms = args.n_randoms
     if feature is None:
         feature = net.scene_feature(batch_cuda, n_randoms * 3)
-    sb = batch_cuda["_pstl"]
-    assert sb.N == n, "batch rows and noise rows disagree"
+    sb = _scene_batch_of(batch_cuda, n, n_randoms, args, dev, guidance_extras)
+    # Per-row constants as they are at CALL time, as the reference reads them (ext["stlp"] = batch_cuda["stlp_dense"], :574;
+    # highlevel_dense is an argument): its closed-loop caller overwrites stlp_dense between augment_batch_data and this call
+    # (nusc_sim.py:442-472) -- in place or by assigning a new tensor, both must count.
+    sb.stlp = ffi.f32(batch_cuda["stlp_dense"].reshape(n, 6), dev)
+    sb.hl = ffi.f32(highlevel_dense.reshape(n), dev)
     with torch.no_grad():
         x = torch.randn_like(noise).float().contiguous()
         zs = torch.empty(max(steps - 1, 1), n, ffi.CTRL, dtype=torch.float32, device=dev)
@@ -385,7 +424,7 @@ def diffusion_rollout(noise, net, batch_cuda, highlevel_dense, feature, args, co
             guidance = dict(enabled=True, before=args.guidance_before, niters=args.guidance_niters,
                             lr=args.guidance_lr, reverse=args.guidance_reverse, sets=args.guidance_sets,
                             freq=args.guidance_freq, maximize=maximize)
-        sm = Sampler(net.packed(), net.hparams())
+        sm = Sampler(net.packed(), net.hparams(), chain_waves=net.chain_arith())
         n_emit = steps if args.diff_full else 1
         if fastforward:
             emit = normalize_diff(x, n, args.nt, args.mul_w_max, args.mul_a_max, args.diffusion_clip).reshape(1, n, -1)
@@ -479,7 +518,7 @@ def run_sampling_test(stls_cac, data_loader, net, coeffs, args, result_queue=Non
             tj_batch = augment_batch_data({k: batch_cuda[k] for k in batch_cuda if not k.startswith("_")}, gt_stlp, args)
             tsb = tj_batch["_pstl"]
             tj_controls = batch_cuda["params"].reshape(tsb.N, -1).float().contiguous()
-            tsm = Sampler(net.packed(), net.hparams())
+            tsm = Sampler(net.packed(), net.hparams(), chain_waves=net.chain_arith())
             if args.norm_stl:   # the generic evaluator honours the normalised formulas
                 tj_in = pre_prepare_stl_cache(tj_batch, dense_trajs=tsm.trajs(tsb, tj_controls)[:, :-1].contiguous())
                 tj_scores = compute_stl_dense(tj_in, stls_cac, tj_batch["highlevel_dense"], tj_in["dense_valids"], args)[1]
@@ -493,60 +532,73 @@ def run_sampling_test(stls_cac, data_loader, net, coeffs, args, result_queue=Non
             _, _, tj_tot = tsm.diversity(tsb, tj_controls, tj_scores)
             for k, v in diversity_from_totals(tj_tot).items():
                 md.update("tj_" + k, v)
-        torch.cuda.synchronize()
-        tttt1 = time.time()
-        if myt:
-            myt.next_batch()
-        new_batch = {k: batch_cuda[k] for k in ("ego_traj", "neighbors", "currlane_wpts", "leftlane_wpts",
-                                                "rightlane_wpts", "curr_id", "left_id", "right_id", "gt_high_level",
-                                                "pre_stlp") if k in batch_cuda}
-        new_batch["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
-        new_batch = augment_batch_data(new_batch, gt_stlp, args, n_randoms=args.sampling_size)
-        highlevel_new = new_batch["highlevel_dense"]
-        states_flat_new = states.unsqueeze(1).unsqueeze(1).repeat(1, args.sampling_size, 3, 1).reshape(N, 4)
-        noise = torch.empty(N, args.nt * 2, device=states.device)
-        guidance_extras = (new_batch, states_flat_new, stls_cac) if args.guidance else None
-        if myt:
-            myt.add("start_diffusion")
-        res = diffusion_rollout(noise, net, new_batch, highlevel_new, None, args, coeffs, fastforward=False,
-                                n_randoms=args.sampling_size, return_feature=True, guidance_extras=guidance_extras)
-        if myt:
-            myt.add("end_diffusion")
-        if args.diff_full:
-            nn_controls, feature, nn_controls_list = res
-        else:
-            nn_controls, feature = res
-            nn_controls_list = None
-        sb = new_batch["_pstl"]
-        sm = Sampler(net.packed(), net.hparams())
-        if args.rect_head and not args.not_use_rect:
-            if args.multi_cands is not None:
-                cands = torch.stack(nn_controls_list[-args.multi_cands:], dim=0).reshape(args.multi_cands, N, -1).contiguous()
-                r = sm.score(sb, cands, select=True)
-                nn_controls, prev_scores = r["sel_controls"].reshape(N, args.nt, 2), r["sel_scores"]
-                if myt:
-                    myt.add("selected_stl_max")
-            else:
-                prev_scores = sm.score(sb, nn_controls.reshape(1, N, -1).contiguous())["scores"][0]
-            if not args.no_refinenet:
-                nn_controls = net.rect_forward(feature, highlevel_new, new_batch["stlp_dense"][:, 0], nn_controls, prev_scores)
+        def timed_region(first=True):
+            torch.cuda.synchronize()
+            tttt1 = time.time()
+            if myt and first:
+                myt.next_batch()
+            new_batch = {k: batch_cuda[k] for k in ("ego_traj", "neighbors", "currlane_wpts", "leftlane_wpts",
+                                                    "rightlane_wpts", "curr_id", "left_id", "right_id", "gt_high_level",
+                                                    "pre_stlp") if k in batch_cuda}
+            new_batch["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
+            new_batch = augment_batch_data(new_batch, gt_stlp, args, n_randoms=args.sampling_size)
+            highlevel_new = new_batch["highlevel_dense"]
+            states_flat_new = states.unsqueeze(1).unsqueeze(1).repeat(1, args.sampling_size, 3, 1).reshape(N, 4)
+            noise = torch.empty(N, args.nt * 2, device=states.device)
+            guidance_extras = (new_batch, states_flat_new, stls_cac) if args.guidance else None
             if myt:
-                myt.add("rect_forward()")
-            for _ in range(args.n_rolls or 0):
-                sc = sm.score(sb, nn_controls.reshape(1, N, -1).contiguous())["scores"][0]
-                nn_controls = net.rect_forward(feature, highlevel_new, new_batch["stlp_dense"][:, 0], nn_controls, sc)
-            if args.refinement:      # "further gradient" (reference :1034-1071): K = 8, 50 iterations, lr 0.3, thres 5e-4
-                clist = torch.stack(nn_controls_list, dim=0).reshape(len(nn_controls_list), N, -1).contiguous()
-                nn_controls = sm.refinement(sb, nn_controls.reshape(N, -1).contiguous(), clist).reshape(N, args.nt, 2)
-        nn_trajs = generate_trajs(states_flat_new, nn_controls, args.dt).reshape(N, args.nt + 1, 4)
-        stl_input = pre_prepare_stl_cache(new_batch, dense_trajs=nn_trajs[:, :-1])
-        scores_list, scores, acc, scene_acc = compute_stl_dense(stl_input, stls_cac, new_batch["highlevel_dense"],
-                                                                stl_input["dense_valids"], args, scene=True)
-        torch.cuda.synchronize()
-        tttt2 = time.time()
+                myt.add("start_diffusion")
+            res = diffusion_rollout(noise, net, new_batch, highlevel_new, None, args, coeffs, fastforward=False,
+                                    n_randoms=args.sampling_size, return_feature=True, guidance_extras=guidance_extras)
+            if myt:
+                myt.add("end_diffusion")
+            if args.diff_full:
+                nn_controls, feature, nn_controls_list = res
+            else:
+                nn_controls, feature = res
+                nn_controls_list = None
+            sb = new_batch["_pstl"]
+            sm = Sampler(net.packed(), net.hparams(), chain_waves=net.chain_arith())
+            if args.rect_head and not args.not_use_rect:
+                if args.multi_cands is not None:
+                    cands = torch.stack(nn_controls_list[-args.multi_cands:], dim=0).reshape(args.multi_cands, N, -1).contiguous()
+                    r = sm.score(sb, cands, select=True)
+                    nn_controls, prev_scores = r["sel_controls"].reshape(N, args.nt, 2), r["sel_scores"]
+                    if myt:
+                        myt.add("selected_stl_max")
+                else:
+                    prev_scores = sm.score(sb, nn_controls.reshape(1, N, -1).contiguous())["scores"][0]
+                if not args.no_refinenet:
+                    nn_controls = net.rect_forward(feature, highlevel_new, new_batch["stlp_dense"][:, 0], nn_controls, prev_scores)
+                if myt:
+                    myt.add("rect_forward()")
+                for _ in range(args.n_rolls or 0):
+                    sc = sm.score(sb, nn_controls.reshape(1, N, -1).contiguous())["scores"][0]
+                    nn_controls = net.rect_forward(feature, highlevel_new, new_batch["stlp_dense"][:, 0], nn_controls, sc)
+                if args.refinement:      # "further gradient" (reference :1034-1071): K = 8, 50 iterations, lr 0.3, thres 5e-4
+                    clist = torch.stack(nn_controls_list, dim=0).reshape(len(nn_controls_list), N, -1).contiguous()
+                    nn_controls = sm.refinement(sb, nn_controls.reshape(N, -1).contiguous(), clist).reshape(N, args.nt, 2)
+            nn_trajs = generate_trajs(states_flat_new, nn_controls, args.dt).reshape(N, args.nt + 1, 4)
+            stl_input = pre_prepare_stl_cache(new_batch, dense_trajs=nn_trajs[:, :-1])
+            scores_list, scores, acc, scene_acc = compute_stl_dense(stl_input, stls_cac, new_batch["highlevel_dense"],
+                                                                    stl_input["dense_valids"], args, scene=True)
+            torch.cuda.synchronize()
+            tttt2 = time.time()
+            return nn_controls, scores, acc, scene_acc, sm, sb, tttt2 - tttt1
+
+        nn_controls, scores, acc, scene_acc, sm, sb, elapsed = timed_region()
+        # Domain of the default (split-f16) chain arithmetic, checked where the harness synchronises anyway: a layer input
+        # beyond the half range turns the state into NaN and sets the packed buffer's status word.  The batch is then run
+        # again on the exact-fp32 kernels, and so is everything after it.
+        if net.chain_arith() in (0, 16) and net.packed().chain_overflowed(clear=True):
+            import warnings
+            warnings.warn("pstl: a layer input left the split-f16 domain |x| < 4094 in batch %d; re-running it, and running the "
+                          "rest, on the exact-fp32 kernels (chain_waves = 8)" % bi, RuntimeWarning)
+            net.chain_waves = 8
+            nn_controls, scores, acc, scene_acc, sm, sb, elapsed = timed_region(first=False)
         md.update("acc", acc.item())
         md.update("scene_acc", scene_acc.item())
-        md.update("time", tttt2 - tttt1)
+        md.update("time", elapsed)
         # after the timer, as in the reference (nusc_train.py:1107-1130): diversity + ADE/FDE of the final samples
         _, _, div_totals = sm.diversity(sb, nn_controls.reshape(N, -1).contiguous(), scores.contiguous())
         for k, v in diversity_from_totals(div_totals).items():
@@ -668,7 +720,7 @@ def run_training(data_loader, net, coeffs, args):
             gt_stlp = infer_gt_stlp(new_batch, batch_cuda["ego_traj"][..., :4], args)
             new_batch = augment_batch_data(new_batch, gt_stlp, args)
             sb = new_batch["_pstl"]
-            tr = RectTrainer(Sampler(net.packed(), net.hparams()))     # packed() re-packs after the optimiser moved weights
+            tr = RectTrainer(Sampler(net.packed(), net.hparams(), chain_waves=net.chain_arith()))     # packed() re-packs after the optimiser moved weights
             step += 1
             loss, scores = tr.train_step(sb, params, optimizer, args.diffusion_steps, seed=args.seed * 100003 + step,
                                          multi_cands=args.multi_cands or 1, coeffs=coeffs, e7=e7, stl_weight=args.stl_weight,

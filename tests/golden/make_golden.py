@@ -46,7 +46,9 @@ def load_net(ref, args, sd):
 
 
 def sampling_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=0.0, stlp_mode="loose",
-                  zero_net_out=False, maximize=False):
+                  zero_net_out=False, maximize=False, weights_variant=None):
+    """weights_variant: name of the tests/heavy_weights.py derivation `sd` was made with (stored, so that the tests derive
+    the same weights; None = weights_seed1007.npz as it is)."""
     nt = ref.nusc_train
     argv = list(argv) + ["--diffusion_steps", str(steps), "--sampling_size", str(S), "--n_randoms", str(S),
                          "--n_neighbors", str(K), "--test", "--run_sampling_test"]
@@ -153,6 +155,8 @@ def sampling_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=
                               -1 if args.guidance_freq is None else args.guidance_freq], dtype=np.int64)
     out["guid_sets"] = np.array(args.guidance_sets if args.guidance_sets is not None else [], dtype=np.int64)
     out["meta_refinement"] = np.array([50 if args.refinement else 0], dtype=np.int64)
+    if weights_variant is not None:
+        out["weights_variant"] = np.array(weights_variant)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print("%-28s N=%d acc=%.4f scene_acc=%.4f sat=%d/%d -> %s (%.1f KB)" % (
@@ -236,11 +240,11 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided", "--refinement-case", "--train-joint")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided", "--refinement-case", "--train-joint", "--heavy")):
     main()
 
 
-def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None, joint=False):
+def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None, joint=False, weights_variant=None):
     """One training step of config 5 (e8_ours_ablation: --rect_head, STL loss through RefineNet; reference
     nusc_train.py:1365-1427 + compute_policy_loss :370-478 + optimizer :1522-1525), driven through the reference's own
     functions.  Stored: inputs, every noise draw, the loss, d loss / d rect_net parameters and the parameters after
@@ -345,6 +349,8 @@ def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None, joint=Fal
         out["in_" + k] = np_(batch[k])
     out["meta"] = np.array([bs, S, K, steps, seed, mc], dtype=np.int64)
     out["meta_f"] = np.array([args.lr, args.stl_nn_thres], dtype=np.float64)
+    if weights_variant is not None:
+        out["weights_variant"] = np.array(weights_variant)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     gn = float(sum((g ** 2).sum() for g in grads.values())) ** 0.5
@@ -629,6 +635,28 @@ def main_baseline_shape():
 
 if __name__ == "__main__" and "--baseline-shape" in sys.argv:
     main_baseline_shape()
+
+
+def main_heavy():
+    """Weights with a trained network's dynamic range (tests/heavy_weights.py: per-row power-of-two rescaling of the hidden
+    layers, outlier weights up to 8 / 24, outlier biases +-2; hidden activations O(10-100)) through the reference: e7 +
+    guidance at 50 steps (ten guided steps) and one config-5 training step.  Pins the default split-f16 chain arithmetic
+    outside the random-init regime of every other fixture."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from heavy_weights import heavy_weights
+    ref = ref_harness.load_reference()
+    sd = dict(np.load(WEIGHTS_FILE))
+    e7c5 = ["--diffusion", "--load_stlp", "--rect_head", "--flex", "--diverse_loss", "--multi_cands", "5"]
+    gd = ["--guidance", "--guidance_before", "10", "--guidance_niters", "1", "--guidance_lr", "0.01"]
+    sampling_case(ref, heavy_weights(sd, "a"), "e7_heavy_a", e7c5 + gd, bs=2, S=16, K=3, steps=50, seed=91,
+                  stlp_mode="wide", invalid_lane_frac=0.25, weights_variant="a")
+    sampling_case(ref, heavy_weights(sd, "b"), "e7_heavy_b", e7c5 + gd, bs=1, S=64, K=2, steps=50, seed=92,
+                  stlp_mode="wide", weights_variant="b")
+    train_case(ref, heavy_weights(sd, "a"), "train_e8_heavy", bs=3, S=16, K=3, steps=10, seed=93, weights_variant="a")
+
+
+if __name__ == "__main__" and "--heavy" in sys.argv:
+    main_heavy()
 
 
 def harness_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=0.0, stlp_mode="loose"):

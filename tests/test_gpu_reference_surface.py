@@ -158,3 +158,69 @@ def test_infer_gt_stlp_matches_reference():
         args = nt.generate_parser(["--diffusion", "--load_stlp"] + (["--flex"] if flex else []))
         got = nt.infer_gt_stlp(bc, bc["ego_traj"][..., :4], args).cpu().numpy()
         np.testing.assert_allclose(got, g["stlp_flex%d" % flex], rtol=1e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("name", ["sim_maximize", "sim_maximize_b"])
+@pytest.mark.parametrize("how", ["inplace", "replace", "no_side_channel"])
+def test_closed_loop_calling_sequence_of_the_reference(name, how):
+    """The reference's closed-loop caller (nusc_sim.py:429-548), replayed literally through the mirror: augment_batch_data
+    with the parameters it happens to have, THEN overwrite new_batch["stlp_dense"] with the fixed values (:467-472) -- in
+    place, by assigning a new tensor, or (no_side_channel) with this package's `_pstl` entry removed altogether, as for a
+    batch built by the reference's own augment_batch_data -- then diffusion_rollout(maximize=True), candidate scoring through
+    generate_trajs / pre_prepare_stl_cache(repeat_n) / compute_stl_dense, torch.max over the candidates, rect_forward and
+    the final compute_stl_dense.  Fixtures sim_maximize*: the reference run with those fixed parameters."""
+    nt, d, meta, args, net, batch, scene, dev = _setup(name, extra=["--guidance_lr", "0.04"])
+    assert meta["maximize"] and args.guidance and args.rect_head
+    bs, S = meta["bs"], meta["S"]
+    N = bs * S * 3
+    stls = nt.build_stl_cache(args)
+    coeffs = nt.get_diffusion_coeffs(args)
+    fixed = torch.from_numpy(d["in_stlp_dense"]).to(dev)                    # (N,1,6): what the reference run used
+    # parameters the caller "happens to have" when it augments: deliberately different from the fixed ones
+    batch["pre_stlp"] = batch["pre_stlp"] * 0.5 + 0.3
+    new_batch = nt.augment_batch_data(batch, scene["stlp_modes"][:, 0], args, n_randoms=S, dense=(how == "no_side_channel"))
+    assert not torch.equal(new_batch["stlp_dense"], fixed)
+    if how == "inplace":
+        for c in range(6):
+            new_batch["stlp_dense"][..., c:c + 1] = fixed[..., c:c + 1]
+    else:
+        new_batch["stlp_dense"] = fixed.clone()
+    if how == "no_side_channel":
+        del new_batch["_pstl"]
+    hl = new_batch["highlevel_dense"]
+    states_flat = scene["ego_traj"][:, 0, :4].unsqueeze(1).unsqueeze(1).repeat(1, S, 3, 1).reshape(N, 4)
+    draws = [torch.from_numpy(d["x_T"])] + [torch.from_numpy(z) for z in d["z"][:-1]]
+    noise = torch.empty(N, 40, device=dev)
+    gex = (new_batch, states_flat.detach(), stls)
+    with replay_randn_like(draws):
+        controls, feature, clist = nt.diffusion_rollout(noise, net, new_batch, hl, None, args, coeffs, return_feature=True,
+                                                        guidance_extras=gex, maximize=True)
+    got = torch.stack(clist, 0).cpu().numpy()
+    err = np.abs(got - d["controls_list"])
+    from conftest import guided_outlier_rows
+    bad_rows, bad_groups = guided_outlier_rows(err, d, meta, TOL)
+    assert err[:, ~bad_rows].max() <= TOL
+    mc = args.multi_cands
+    states_mul = states_flat.repeat(mc, 1)
+    ctrls_mul = torch.cat(clist[-mc:], dim=0)
+    trajs_mul = nt.generate_trajs(states_mul, ctrls_mul, args.dt)
+    prev_in = nt.pre_prepare_stl_cache(new_batch, dense_trajs=trajs_mul[:, :-1], repeat_n=mc)
+    _, sc_hist, _ = nt.compute_stl_dense(prev_in, stls, hl.repeat((mc, *[1] * (hl.dim() - 1))),
+                                         prev_in["dense_valids"].reshape(-1), args)
+    sc_hist = sc_hist.reshape(mc, N)
+    keep = ~bad_rows
+    np.testing.assert_allclose(sc_hist.cpu().numpy()[:, keep], d["cand_scores"][:, keep], rtol=5e-5, atol=1e-3)
+    sc_max, sc_idx = torch.max(sc_hist, dim=0)
+    c_max = ctrls_mul.reshape(mc, N, args.nt, 2)[sc_idx, torch.arange(N, device=dev)]
+    rect = net.rect_forward(feature, hl, new_batch["stlp_dense"][:, 0], c_max.detach(), sc_max.detach(), extras=clist)
+    top2 = np.sort(d["cand_scores"], axis=0)[-2:]
+    ok = ((top2[1] - top2[0]) > 1e-3) & ~bad_groups
+    np.testing.assert_allclose(rect.cpu().numpy()[ok], d["rect_controls"][ok], rtol=0, atol=TOL)
+    rect_trajs = nt.generate_trajs(states_flat, rect, args.dt)
+    stl_in = nt.pre_prepare_stl_cache(new_batch, dense_trajs=rect_trajs[:, :-1])
+    _, scores_all, acc = nt.compute_stl_dense(stl_in, stls, hl, stl_in["dense_valids"], args)
+    fs, fr = scores_all.cpu().numpy(), d["final_scores"]
+    np.testing.assert_allclose(fs[ok], fr[ok], rtol=1e-4, atol=2e-3)
+    np.testing.assert_array_equal((fs > 0)[ok], (fr > 0)[ok])                 # satisfaction masks: exact
+    if ok.all():
+        assert float(acc) == float(d["final_acc"])

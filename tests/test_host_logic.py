@@ -14,16 +14,75 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     from pstl_diffusion_policy_amd import build, ffi
     build.build(verbose=False)
     L = ffi.lib()
-    assert L.pstl_version() == 2
     header = open(os.path.join(ROOT, "include", "pstl_hip.h")).read()
+    assert L.pstl_version() == ffi.ABI_VERSION == int(re.search(r"#define PSTL_ABI_VERSION (\d+)", header).group(1))
     declared = sorted(set(re.findall(r"^(?:int|size_t|const char\*)\s+(pstl_\w+)\s*\(", header, flags=re.M)))
     assert declared, "no declarations parsed"
     for name in declared:
         assert hasattr(L, name), name
     assert sorted(ffi.EXPORTS) == declared
+    assert float(re.search(r"#define PSTL_SPLIT_F16_WMAX ([0-9.]+)f", header).group(1)) == ffi.SPLIT_F16_WMAX
     assert L.pstl_packed_weight_floats() > 540952          # at least the reference parameter count
     assert L.pstl_error_string(-2).decode().startswith("shape")
     assert ctypes.sizeof(ffi.PstlCfg) == 80
+
+
+def test_binding_signatures_match_the_header_prototypes():
+    """ffi.SIGNATURES (restype + argtypes of every export) against the prototypes of include/pstl_hip.h: argument count
+    and kind (pointer / int / float / int64), so that the table cannot drift from the C side."""
+    from pstl_diffusion_policy_amd import ffi
+    header = open(os.path.join(ROOT, "include", "pstl_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = re.findall(r"^(int|size_t|const char\*)\s+(pstl_\w+)\s*\(([^;]*?)\)\s*;", header, flags=re.M | re.S)
+    assert len(protos) == len(ffi.EXPORTS)
+    table = {n: (r, a) for n, r, a in ffi.SIGNATURES}
+    kinds = {ffi._I: "i", ffi._F: "f", ffi._L: "l", ffi._P: "p", ffi._C: "p", ctypes.POINTER(ffi.WeightPtrs): "p"}
+    for ret, name, args in protos:
+        want = []
+        for a in [x.strip() for x in args.split(",")]:
+            if a in ("void", ""):
+                continue
+            want.append("p" if "*" in a else "f" if a.startswith("float") else "l" if a.startswith("int64_t") else "i")
+        restype, argtypes = table[name]
+        assert [kinds[t] for t in argtypes] == want, name
+        assert restype is {"int": ffi._I, "size_t": ffi._Z, "const char*": ctypes.c_char_p}[ret], name
+
+
+def test_wrong_argument_types_are_a_typeerror():
+    from pstl_diffusion_policy_amd import ffi
+    from pstl_diffusion_policy_amd.synthetic import default_hparams
+    L = ffi.lib()
+    cfg = ffi.make_cfg(2, 24, 8, 3, 10, default_hparams())
+    null = ctypes.c_void_p(0)
+    with pytest.raises((TypeError, ctypes.ArgumentError)):
+        L.pstl_fill_normal(ctypes.byref(cfg), 1.5, null, null)          # a float where `int step` is expected
+    with pytest.raises((TypeError, ctypes.ArgumentError)):
+        L.pstl_fill_normal(ctypes.byref(cfg), 1, null)                  # an argument short
+    with pytest.raises((TypeError, ctypes.ArgumentError)):
+        L.pstl_fill_normal(ffi.Mlp3(), 1, null, null)                   # not a pstl_cfg
+
+
+def test_graft_entry_build_succeeds():
+    """__graft_entry__.build() asserted a stale ABI version.  It must compile everything and import cleanly."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
+    assert os.path.exists(os.path.join(ROOT, "tests", "hostsim", "libpstl_hostsim.so"))
+
+
+def test_unknown_chain_arithmetic_is_refused():
+    """the timing-only diagnostic instantiations (chain_waves 108 / 116 / 708 / 716 / 1008) are not in the shipped
+    library (-DPSTL_DIAG builds only)."""
+    src = open(os.path.join(ROOT, "pstl_diffusion_policy_amd", "csrc", "mlp_kernels.hip")).read()
+    body = src[src.index("int launch_chain_nw("):]
+    body = body[:body.index("}  // namespace")]
+    diag = body[body.index("#ifdef PSTL_DIAG"):body.index("#else")]
+    for v in ("108", "116", "708", "716", "1008"):
+        assert "case %s:" % v in diag and "case %s:" % v not in body.replace(diag, "")
+    from pstl_diffusion_policy_amd import build
+    assert not any("PSTL_DIAG" in f for _, fl in build.UNITS for f in fl)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -44,7 +103,7 @@ def test_null_and_bad_arguments_are_rejected_without_a_gpu():
                           null) == -1
     assert L.pstl_stl_forward(ctypes.byref(cfg), null, null, null, 1, null, null, null, null, null, null, null, null,
                               null, null) == -1
-    assert L.pstl_pack_weights(null, null, null) == -1
+    assert L.pstl_pack_weights(None, null, null) == -1
 
 
 def test_schedule_is_bit_identical_to_the_reference():

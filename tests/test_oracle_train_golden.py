@@ -8,12 +8,12 @@ from oracle import pstl_oracle as orc
 from pstl_diffusion_policy_amd.synthetic import default_hparams
 
 
-@pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b"])
+@pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b", "train_e8_heavy"])
 def test_rect_train_step_matches_reference(name):
     d = load_golden(name)
     bs, S, K, steps, seed, mc = [int(v) for v in d["meta"]]
     lr = float(d["meta_f"][0])
-    sd = {k: v for k, v in golden_weights().items()}
+    sd = {k: v for k, v in golden_weights(d).items()}
     out = orc.rect_train_step(sd, scene_from_golden(d), S, default_hparams(), d["sel_controls"], d["sel_scores"], lr)
     np.testing.assert_allclose(out["rect_controls"].numpy(), d["rect_controls"], rtol=0, atol=5e-6)
     np.testing.assert_allclose(float(out["loss"]), float(d["loss"]), rtol=1e-5)

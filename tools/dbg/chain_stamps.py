@@ -1,5 +1,6 @@
 """Cycle stamps of the MLP-chain kernel's diagnostic build (chain_waves 708 = fp32, 716 = split-bf16): where one
-workgroup's waves spend an iteration.  GPU only:  python tools/dbg/chain_stamps.py [716]"""
+workgroup's waves spend an iteration.  GPU only, against a -DPSTL_DIAG build of mlp_kernels.hip (the shipped library has no
+diagnostic instantiations):  tools/dbg/variant_run.sh "-DPSTL_DIAG" tools/dbg/chain_stamps.py [716]"""
 import sys, os
 import numpy as np
 import torch

@@ -1,6 +1,7 @@
 """Times the multi-step denoiser launch (39 reverse steps, 786 432 rows) for a list of chain variants / noise modes:
     python tools/dbg/chain_time.py 0 116 0:nonoise 8
-`cw[:nonoise]`; 116 = split-f16 loop without epilogue and noise (timing only)."""
+`cw[:nonoise]`; 116 = split-f16 loop without epilogue and noise (timing only; needs a -DPSTL_DIAG build:
+tools/dbg/variant_run.sh "-DPSTL_DIAG" tools/dbg/chain_time.py 0 116)."""
 import sys, os
 import torch
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Where k_diversity's time goes (on the GPU box): builds diversity_kernels.hip with sections compiled out (PSTL_DIV_SKIP bit mask,
 # timing only) and times each build with tools/dbg/div_time.py.   DIV_VARIANTS="1 2 32" tools/dbg/div_ablation.sh
-root=$GRAFT_REPO_ROOT; c=$root/pstl_diffusion_policy_amd/csrc; out=/tmp/pv; mkdir -p $out
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; c=$root/pstl_diffusion_policy_amd/csrc; out=/tmp/pv; mkdir -p $out
 cd $root; python3 tools/dbg/div_time.py 2>/dev/null | tail -1
 for v in ${DIV_VARIANTS:-1 2 32 8 16 31}; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPSTL_DIV_SKIP=$v -c $c/diversity_kernels.hip -o $out/d$v.o || continue

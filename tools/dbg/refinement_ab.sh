@@ -1,7 +1,7 @@
 #!/bin/bash
 # --refinement with and without the per-scene packing of the rows to mix (on the GPU box): times both builds at full size
 # and checks that their refined controls are bit-identical.
-root=$GRAFT_REPO_ROOT; c=$root/pstl_diffusion_policy_amd/csrc; out=/tmp/pv; mkdir -p $out
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; c=$root/pstl_diffusion_policy_amd/csrc; out=/tmp/pv; mkdir -p $out
 cd $root
 python3 tools/dbg/refinement_time.py /tmp/new.pt 2>/dev/null | tail -1
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Xarch_device -mllvm=-misched=gcn-iterative-ilp -DPSTL_MIX_NO_COMPACT -c $c/stl_kernels.hip -o $out/s.o || exit 1
