@@ -70,8 +70,10 @@ typedef struct pstl_cfg {
                               on bfloat16 pieces (2^-17 per operand), rect_net on fp32 MFMA.
                               DOMAIN of 0 / 16: the pieces are halves of 2^10 w and 2^4 x, so the chain weights must
                               satisfy |w| < PSTL_SPLIT_F16_WMAX and every layer input |x| < 4094; outside it the
-                              result is NaN (never a plausible wrong number) and the status block of the packed
-                              buffer says so (pstl_packed_status_offset).  8 / 4 / 32 have fp32's range.
+                              results are undefined (an overflowed piece is an infinity: NaNs where it reaches the
+                              output, but max(NaN, 0) = 0 inside a ReLU) and the status block of the packed buffer
+                              says so (pstl_packed_status_offset): every conversion to half is checked where it
+                              happens.  8 / 4 / 32 have fp32's range.
                               Any other value: PSTL_ERR_SHAPE.                                                */
   float tau;               /* --smoothing_factor                                          */
   float thres;             /* --stl_nn_thres                                              */
@@ -111,9 +113,10 @@ size_t pstl_packed_weight_floats(void);
  *                   columns of x / highlevel / stlp, layers 2 and 3), written by pstl_pack_weights; NaN if one is NaN;
  *   word 1 (float): the same for rect_net (0 without --rect_head weights);
  *   word 2 (uint32): 0 after pstl_pack_weights; set to 1 by pstl_rollout / pstl_refine / pstl_refine_train_forward when a
- *                   launch on the split-f16 arithmetic (chain_waves 0 / 16) produced a non-finite state, i.e. a weight or
- *                   a layer input was outside the domain above.  Sticky: the caller reads it when it synchronises anyway
- *                   (after the timed region), re-runs the batch with chain_waves = 8 and may clear the word.
+ *                   launch on the split-f16 arithmetic (chain_waves 0 / 16) ran outside the domain above: word 0 / 1 not
+ *                   below PSTL_SPLIT_F16_WMAX, a layer input (state, hidden activation) whose half piece overflowed, or a
+ *                   non-finite state / RefineNet output.  Sticky: the caller reads it when it synchronises anyway (after
+ *                   the timed region), re-runs the batch with chain_waves = 8 and may clear the word.
  * A caller reads words 0-1 once after packing (one synchronisation) and selects chain_waves = 8 when either is not
  * below PSTL_SPLIT_F16_WMAX (engine.PackedWeights does). */
 #define PSTL_SPLIT_F16_WMAX 63.9f

@@ -295,6 +295,35 @@ __device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, PV& hi, P
 
 
 
+// Domain guard of the split-f16 arithmetic: the running maximum, per 16-bit half, of the hi pieces' bit patterns
+// (v_pk_max_u16).  A layer input that left the half range shows up as the pattern of infinity (0x7c00) in its hi piece at
+// the very conversion that overflowed -- before any NaN exists, so the test does not depend on NaNs surviving the ReLUs
+// (max(NaN, 0) is 0, and so is the integer form used here for a NaN with the sign bit set).  `mask_sign`: the values are
+// signed (the layer-1 input); hidden activations are >= 0 after the ReLU.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+template <typename PV>
+__device__ __forceinline__ void note_pieces(unsigned& ovf, const PV& hi, bool mask_sign) {
+  const u32x4 w = __builtin_bit_cast(u32x4, hi);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned v = mask_sign ? (w[r] & 0x7fff7fffu) : w[r];
+    ovf = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, ovf), __builtin_bit_cast(u16x2, v)));
+  }
+}
+__device__ __forceinline__ bool pieces_overflowed(unsigned ovf) { return (ovf & 0xffffu) >= 0x7c00u || (ovf >> 16) >= 0x7c00u; }
+
+// Issue-order pin for the matrix instructions of the fused block: `next` (the accumulator the following MFMA adds to) is
+// made to depend on `prev` (the result of the MFMA issued before it) through an empty asm statement, so that the MFMAs are
+// emitted in SOURCE order -- accumulators alternating.  Left to itself the scheduler groups up to nine MFMAs on one
+// accumulator back to back (a dependent chain issues every ~26 cycles instead of every 16 whenever the SIMD's other wave
+// has no MFMA of its own to put in between) and renames accumulators into operand registers, which costs `s_nop 6` pads.
+#ifndef PSTL_EXP_PIN
+#define PSTL_EXP_PIN 0
+#endif
+__device__ __forceinline__ void pin_after(f32x4& next, const f32x4& prev) {
+  if (PSTL_EXP_PIN) asm volatile("" : "+v"(next) : "v"(prev));
+}
+
 // A value the optimiser must take as it comes at this point of the loop: stops it from hoisting `uniform pointer +
 // lane offset` out of the tile-step loop as a per-lane 64-bit pointer (five of those were live across the loop, spilled,
 // and reloaded in the epilogue behind a full vmcnt wait)
@@ -430,6 +459,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       coef[4 * tid + 2] = sqrtf(be);
       coef[4 * tid + 3] = 0.0f;
     }
+  }
+
+  // split-f16 domain guard (see note_pieces): per-lane maximum of the hi pieces this lane made; tested once after the loop
+  unsigned ovf = 0;
+  if (F16 && tid == 0) {   // the weights themselves: max |w| as the packer recorded it (status words 0 = policy_net, 1 = rect_net)
+    const float wm = reinterpret_cast<const float*>(a.status)[REFINE ? -1 : -2];
+    if (!(wm < PSTL_SPLIT_F16_WMAX)) atomicOr(a.status, 1u);
   }
 
   // CONT (single-step launches of the split kernels, PERSIST): the workgroup's groups blockIdx.x, blockIdx.x + gridDim.x,
@@ -596,6 +632,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     f32x4 h0 = relu4(a0), h1v = relu4(a1);
     if (F16) h0 *= kInvSW, h1v *= kInvSW;
     split8(h0, h1v, hi, lo);
+    if constexpr (F16) note_pieces(ovf, hi, false);
   };
   // training forward pass of the split forms (REFINE with activation buffers): a hidden layer's fp32 output relu(acc) /
   // kAcc, this lane's 4*OT features of row `col` of tile p.tl (uniform row pointer + 32-bit lane offset, see here())
@@ -632,6 +669,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         const f32x4 x1 = kb == 0 ? xb[64] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         pv8 bh, bl;
         split8(x0 * kSX, x1 * kSX, bh, bl);
+        if constexpr (F16) note_pieces(ovf, bh, true);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w1h[ot][kb], bh, acc[ot]);
 #pragma unroll
@@ -788,11 +826,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       if (w == 7) {
         const f32x4 q0 = xb[0], q1 = xb[64];
         split8(q0 * kSX, q1 * kSX, ph, pl);
+        if constexpr (F16) note_pieces(ovf, ph, true);
         dst[0] = __builtin_bit_cast(u32x4, ph);
         dst[64] = __builtin_bit_cast(u32x4, pl);
       } else {
         const f32x4 q2 = xb[128], zero = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         split8(q2 * kSX, zero, ph, pl);
+        if constexpr (F16) note_pieces(ovf, ph, true);
         dst[128] = __builtin_bit_cast(u32x4, ph);
         dst[192] = __builtin_bit_cast(u32x4, pl);
       }
@@ -908,22 +948,42 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           nl = hbb[(2 * kb + 3) * 64];
         }
         const pv8 bh = __builtin_bit_cast(pv8, ch), bl = __builtin_bit_cast(pv8, cl);
+        // (pin_after: source order = issue order; `last` is the accumulator of the MFMA issued before)
+        if (kb > 0) pin_after(acc[0], (kb == 3 || kb == 4) ? a1[OT - 1] : acc[OT - 1]);
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2h[ot][kb], bh, acc[ot]);
+        for (int ot = 0; ot < OT; ++ot) {
+          if (ot > 0) pin_after(acc[ot], acc[ot - 1]);
+          acc[ot] = mfma_bf(w2h[ot][kb], bh, acc[ot]);
+        }
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2l[ot][kb], bh, acc[ot]);
+        for (int ot = 0; ot < OT; ++ot) {
+          pin_after(acc[ot], acc[ot == 0 ? OT - 1 : ot - 1]);
+          acc[ot] = mfma_bf(w2l[ot][kb], bh, acc[ot]);
+        }
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2h[ot][kb], bl, acc[ot]);
+        for (int ot = 0; ot < OT; ++ot) {
+          pin_after(acc[ot], acc[ot == 0 ? OT - 1 : ot - 1]);
+          acc[ot] = mfma_bf(w2h[ot][kb], bl, acc[ot]);
+        }
         if (kb == 0) x0h = __builtin_bit_cast(pv8, xq0h), x0l = __builtin_bit_cast(pv8, xq0l);
         if (kb == 1) x1h = __builtin_bit_cast(pv8, xq1h), x1l = __builtin_bit_cast(pv8, xq1l);
         if (kb == 2 || kb == 3) {
           const pv8 vh = kb == 2 ? x0h : x1h, vl = kb == 2 ? x0l : x1l;
 #pragma unroll
-          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vh, a1[ot]);
+          for (int ot = 0; ot < OT; ++ot) {
+            pin_after(a1[ot], ot == 0 ? acc[OT - 1] : a1[ot - 1]);
+            a1[ot] = mfma_bf(w1h[ot][kb - 2], vh, a1[ot]);
+          }
 #pragma unroll
-          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1l[ot][kb - 2], vh, a1[ot]);
+          for (int ot = 0; ot < OT; ++ot) {
+            pin_after(a1[ot], a1[ot == 0 ? OT - 1 : ot - 1]);
+            a1[ot] = mfma_bf(w1l[ot][kb - 2], vh, a1[ot]);
+          }
 #pragma unroll
-          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vl, a1[ot]);
+          for (int ot = 0; ot < OT; ++ot) {
+            pin_after(a1[ot], a1[ot == 0 ? OT - 1 : ot - 1]);
+            a1[ot] = mfma_bf(w1h[ot][kb - 2], vl, a1[ot]);
+          }
         }
         if (kb == 1) l1_const(p2, b1, a1);
         if (kb == 5) {
@@ -983,11 +1043,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       split_hidden(acc[0], acc[OT - 1], bh, bl);
       if constexpr (SAVE) save_hidden(a.h2_save, p0, acc);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bh, acc3[j]);
+      for (int j = 0; j < 3; ++j) {
+        pin_after(acc3[j], j == 0 ? acc[OT - 1] : acc3[j - 1]);
+        acc3[j] = mfma_bf(w3h[j], bh, acc3[j]);
+      }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3l[j], bh, acc3[j]);
+      for (int j = 0; j < 3; ++j) {
+        pin_after(acc3[j], acc3[j == 0 ? 2 : j - 1]);
+        acc3[j] = mfma_bf(w3l[j], bh, acc3[j]);
+      }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bl, acc3[j]);
+      for (int j = 0; j < 3; ++j) {
+        pin_after(acc3[j], acc3[j == 0 ? 2 : j - 1]);
+        acc3[j] = mfma_bf(w3h[j], bl, acc3[j]);
+      }
       u32x4* hwb = reinterpret_cast<u32x4*>(h1 + b1 * 4096);
       hwb[(w * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
       hwb[(w * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, hl2);
@@ -1048,6 +1117,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   if (ABL != 0 && a.N < 0) epilogue(p0, 0, zreg);  // keep the code reachable for the compiler, never executed
   if (!PERSIST || cont) break;
   }
+  if constexpr (F16)
+    if (pieces_overflowed(ovf)) atomicOr(a.status, 1u);   // a layer input left |x| < 4094 somewhere in this launch
 }
 
 // ---- scene encoder (A1) -----------------------------------------------------------------------------------------

@@ -89,7 +89,7 @@ def test_abi_rejects_bad_arguments_with_status_codes(dev):
     st = ffi.stream()
     ok_cfg = ffi.make_cfg(2, 24, 8, 2, 10, hp)
     assert L.pstl_generate_trajs(ctypes.byref(ok_cfg), null, p, p, st) == -1                     # null s0
-    assert L.pstl_generate_trajs(null, p, p, p, st) == -1                                        # null cfg
+    assert L.pstl_generate_trajs(None, p, p, p, st) == -1                                        # null cfg
     for bad in (ffi.make_cfg(0, 24, 8, 2, 10, hp), ffi.make_cfg(2, 0, 8, 2, 10, hp), ffi.make_cfg(2, 24, 8, 0, 10, hp),
                 ffi.make_cfg(2, 24, 8, 2, 1, hp)):
         assert L.pstl_generate_trajs(ctypes.byref(bad), p, p, p, st) == -1
