@@ -320,6 +320,12 @@ __device__ __forceinline__ bool pieces_overflowed(unsigned ovf) { return (ovf & 
 #ifndef PSTL_EXP_PIN
 #define PSTL_EXP_PIN 0
 #endif
+// Experiment: the first B operands of layer 2 of the NEXT tile-step (its h1 buffer has been complete for a whole iteration)
+// are requested before the barrier that ends this one and stay in flight across it (raw s_barrier behind a counted
+// lgkmcnt wait that covers this iteration's LDS writes only), so that the MFMA stream restarts without an LDS round trip.
+#ifndef PSTL_EXP_PREFETCH
+#define PSTL_EXP_PREFETCH 0
+#endif
 __device__ __forceinline__ void pin_after(f32x4& next, const f32x4& prev) {
   if (PSTL_EXP_PIN) asm volatile("" : "+v"(next) : "v"(prev));
 }
@@ -873,13 +879,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       for (int k_ = 0; k_ < 8; ++k_) dbg[((it - 64) * NW + w) * 8 + k_] = stamp_t[k_];          \
   }
 
+  // ABL == 8: the full kernel with four s_memtime reads per iteration (start, after the role work, before and after the
+  // barrier), accumulated per wave: role / body / barrier-wait cycles of workgroup 7's waves, written after the loop to the
+  // buffer passed as emit_out as [wave][role, body, barrier, iterations] (64-bit).  Perturbs the schedule far less than the
+  // eight fenced stamps of ABL == 7.
+  unsigned long long lt_role = 0, lt_body = 0, lt_bar = 0;
+#define PSTL_LITE(var)                                                   \
+  unsigned long long var = 0;                                            \
+  if (ABL == 8) {                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+  }
   layer1(p0, 0);
   if (total > 1) layer1(p1, 1);
   split_x(p2, 0);      // pieces for the layer 1 woven into iteration 0
   __syncthreads();
   // BF, in-kernel noise: waves 4..6 draw it INSIDE their layer-2 MFMA stream (branch-free, one basic block) instead of in
   // a phase of their own in front of it
-  bool woven_noise = BF && !REFINE && (ABL == 0 || ABL == 7) && a.rng && !a.mu_only && w >= NW / 2 && w < NW / 2 + 3;
+  bool woven_noise = BF && !REFINE && (ABL == 0 || ABL >= 7) && a.rng && !a.mu_only && w >= NW / 2 && w < NW / 2 + 3;
   // (stamp build: its scalar stamps must not cross a branch the compiler takes for divergent)
   if (ABL == 7) woven_noise = __builtin_amdgcn_readfirstlane((int)woven_noise) != 0;
   // (Tried in round 2: deferring layer 3 of every tile-step to the head of the next iteration -- accumulators kept across
@@ -887,12 +905,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // tail split -> layer 3 -> partial sums -> barrier.  Bit-identical, 5.8 % SLOWER (15.42 vs 14.57 ms): behind the barrier
   // the split has no MFMAs of its own wave to hide under.)
   int hbuf = 0;  // it % 3
+  u32x4 pre_h = u32x4{0, 0, 0, 0}, pre_l = u32x4{0, 0, 0, 0};
+  if (BF && PSTL_EXP_PREFETCH) {
+    const u32x4* h0p = reinterpret_cast<const u32x4*>(h1) + lane;
+    pre_h = h0p[0], pre_l = h0p[64];
+  }
   for (int it = 0; it < total; ++it) {
+    PSTL_LITE(lt0)
     PSTL_STAMP(0)
     if (UT && w == kStager && it + 3 < total) stage_cst(p3, hbuf);
     if (cont && w == kStager && it >= 2 && it - 2 + G < total) stage_x(Pos{pm2.tl, pm2.n + 1});
     split_x(p3, (it + 1) & 1);      // pieces for the layer 1 woven into iteration it + 1
-    if (NOISE_SPLIT && (ABL == 0 || ABL == 7)) {
+    if (NOISE_SPLIT && (ABL == 0 || ABL >= 7)) {
       if (w >= NW / 2 && w < NW / 2 + NCW && !woven_noise) {
         const int nt = tid - NT / 2;
         f32x4 z;
@@ -903,7 +927,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         const f32x4 z = tid < 160 ? zbuf[((it - 1) & 1) * 192 + tid] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         epilogue(pm1, (it - 1) & 1, z);
       }
-    } else if (epi_wave && (ABL == 0 || ABL == 7)) {
+    } else if (epi_wave && (ABL == 0 || ABL >= 7)) {
       // While this half finishes the previous tile-step, the partner wave on the same SIMD already issues MFMAs: the
       // matrix pipe never waits for the epilogue (the stagger of MI355X_MICROARCH.md "Two waves per SIMD", item 9).
       const int et = EPI_FIRST ? tid : tid - (NT - NCT);
@@ -912,6 +936,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       if (it > 0) epilogue(pm1, (it - 1) & 1, zprev);
     }
     PSTL_STAMP(1)
+    PSTL_LITE(lt1)
     // ---------------- layer 1 of tile-step it + 2 (two ahead) ------------------------------------------------------
     // (BF: woven into layers 2 + 3 below)
     if (!BF && it + 2 < total) layer1(p2, hbuf == 0 ? 2 : hbuf - 1);
@@ -933,7 +958,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       // two tile-steps past the end as well (results never read) to keep the loop body one basic block.
       const int b1 = hbuf == 0 ? 2 : hbuf - 1;
       const u32x4* hbb = reinterpret_cast<const u32x4*>(h1 + hbuf * 4096) + lane;
-      u32x4 ch = hbb[0], cl = hbb[64];
+      u32x4 ch, cl;
+      if (PSTL_EXP_PREFETCH) ch = pre_h, cl = pre_l;
+      else ch = hbb[0], cl = hbb[64];
       const u32x4* xr = xpb + (it & 1) * 256 + lane;
       const u32x4 xq0h = xr[0], xq0l = xr[64], xq1h = xr[128], xq1l = xr[192];
       f32x4 a1[OT];   // starts from the scene/timestep constant part (fetched at k-block 1, used from k-block 2 on)
@@ -1106,14 +1133,30 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     for (int j = 0; j < 3; ++j) pw[(w * 3 + j) * 64 + lane] = acc3[j];
     PSTL_STAMP(4)
     if (UT && w == kStager) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged rows have landed
-    __syncthreads();
+    PSTL_LITE(lt2)
+    if (BF && PSTL_EXP_PREFETCH) {
+      const u32x4* hnp = reinterpret_cast<const u32x4*>(h1 + (hbuf == 2 ? 0 : hbuf + 1) * 4096) + lane;
+      __builtin_amdgcn_sched_barrier(0);      // every LDS write of this iteration is issued before the two reads ...
+      pre_h = hnp[0];
+      pre_l = hnp[64];
+      __builtin_amdgcn_sched_barrier(0);
+      // ... LDS operations of a wave complete in issue order: all but the two youngest done = the writes have landed
+      asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
+    } else {
+      __syncthreads();
+    }
+    PSTL_LITE(lt3)
+    if (ABL == 8) lt_role += lt1 - lt0, lt_body += lt2 - lt1, lt_bar += lt3 - lt2;
     PSTL_STAMP(5)
     PSTL_STAMP_FLUSH()
     hbuf = hbuf == 2 ? 0 : hbuf + 1;
     pm2 = pm1, pm1 = p0, p0 = p1, p1 = p2, p2 = p3, p3 = next_pos(p3);
   }
+  if (ABL == 8 && blockIdx.x == 7 && lane == 0) {
+    dbg[w * 4 + 0] = lt_role, dbg[w * 4 + 1] = lt_body, dbg[w * 4 + 2] = lt_bar, dbg[w * 4 + 3] = (unsigned long long)total;
+  }
   if (NOISE_SPLIT && epi_wave && tid < 160) zreg = zbuf[((total - 1) & 1) * 192 + tid];
-  if (epi_wave && (ABL == 0 || ABL == 7)) epilogue(pm1, (total - 1) & 1, zreg);
+  if (epi_wave && (ABL == 0 || ABL >= 7)) epilogue(pm1, (total - 1) & 1, zreg);
   if (ABL != 0 && a.N < 0) epilogue(p0, 0, zreg);  // keep the code reachable for the compiler, never executed
   if (!PERSIST || cont) break;
   }
@@ -1673,6 +1716,7 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
     case 1008: return launch_chain<8, false>(a, st);   // force the general (non-uniform-tile) path
     case 116: return launch_chain<8, false, 1, true, 2>(a, st);
     case 716: return launch_chain<8, false, 7, true, 2>(a, st);
+    case 816: return launch_chain<8, false, 8, true, 2>(a, st);   // role / body / barrier-wait cycles per wave
     default: return PSTL_ERR_SHAPE;
   }
 #else

@@ -413,12 +413,19 @@ def diffusion_rollout(noise, net, batch_cuda, highlevel_dense, feature, args, co
     sb.stlp = ffi.f32(batch_cuda["stlp_dense"].reshape(n, 6), dev)
     sb.hl = ffi.f32(highlevel_dense.reshape(n), dev)
     with torch.no_grad():
-        x = torch.randn_like(noise).float().contiguous()
-        zs = torch.empty(max(steps - 1, 1), n, ffi.CTRL, dtype=torch.float32, device=dev)
-        if not fastforward:
-            for k, i in enumerate(reversed(range(1, steps))):
-                if i > 1:
-                    zs[k] = torch.randn_like(x)
+        kernel_noise = bool(getattr(args, "kernel_noise", False)) and not fastforward
+        seed = None
+        if kernel_noise:     # one draw from torch's generator keys the in-kernel streams (x_T and every step's noise)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            x = Sampler(net.packed(), net.hparams()).fill_normal(sb, steps, steps, seed)
+            zs = None
+        else:
+            x = torch.randn_like(noise).float().contiguous()
+            zs = torch.empty(max(steps - 1, 1), n, ffi.CTRL, dtype=torch.float32, device=dev)
+            if not fastforward:
+                for k, i in enumerate(reversed(range(1, steps))):
+                    if i > 1:
+                        zs[k] = torch.randn_like(x)
         guidance = None
         if args.guidance and guidance_extras is not None:
             guidance = dict(enabled=True, before=args.guidance_before, niters=args.guidance_niters,
@@ -430,7 +437,7 @@ def diffusion_rollout(noise, net, batch_cuda, highlevel_dense, feature, args, co
             emit = normalize_diff(x, n, args.nt, args.mul_w_max, args.mul_a_max, args.diffusion_clip).reshape(1, n, -1)
         else:
             emit = sm.rollout(sb, feature.pstl["base_policy"], x, zs, steps, n_emit=n_emit, clip=args.diffusion_clip,
-                              guidance=guidance, coeffs=coeffs)
+                              guidance=guidance, coeffs=coeffs, seed=seed)
     diffused_result = emit[-1].reshape(n, args.nt, 2)
     if args.diff_full:
         final_list = [e.reshape(n, args.nt, 2) for e in emit]
@@ -464,12 +471,13 @@ class MyTimer:
 
 class MeterDict:
     def __init__(self):
-        self.sum, self.cnt, self.last = {}, {}, {}
+        self.sum, self.cnt, self.last, self.hist = {}, {}, {}, {}
 
     def update(self, k, v):
         self.sum[k] = self.sum.get(k, 0.0) + v
         self.cnt[k] = self.cnt.get(k, 0) + 1
         self.last[k] = v
+        self.hist.setdefault(k, []).append(v)      # every value, in order (tools/paper_metric.py reads md.hist["time"])
 
     def __getitem__(self, k):
         return self.last.get(k, float("nan"))
@@ -482,7 +490,10 @@ class SyntheticLoader:
     """Stand-in for the nuScenes DataLoader: seeded synthetic scenes with the dataset's output schema."""
     def __init__(self, args, n_batches=None):
         self.args = args
-        self.n_batches = n_batches if n_batches is not None else min(args.n_trials + 1, 3)
+        # the reference walks its whole validation loader (--n_trials 100 batches by default); the synthetic stand-in stops
+        # after 3 batches unless --n_trials asks for a specific number
+        self.n_batches = n_batches if n_batches is not None else (min(args.n_trials + 1, 3) if args.n_trials >= 100
+                                                                  else args.n_trials + 1)
 
     def __len__(self):
         return self.n_batches
@@ -749,6 +760,9 @@ def generate_parser(argv=None):
     add("--test", action="store_true", default=False)
     add("--net_pretrained_path", "-P", type=str, default=None)
     add("--allow_random_init", action="store_true", default=False)   # not a reference flag: -P may name a missing file
+    # not a reference flag: x_T and the per-step noise of diffusion_rollout are drawn inside the HIP kernels (Philox4x32-10
+    # keyed by a seed taken from torch's generator) instead of by one torch.randn_like call per reverse step
+    add("--kernel_noise", action="store_true", default=False)
     add("--num_workers", type=int, default=8)
     add("--batch_size", "-b", type=int, default=128)
     add("--lr", type=float, default=3e-4)

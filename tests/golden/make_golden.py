@@ -240,7 +240,7 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided", "--refinement-case", "--train-joint", "--heavy")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided", "--refinement-case", "--train-joint", "--heavy", "--readme-guidance")):
     main()
 
 
@@ -657,6 +657,22 @@ def main_heavy():
 
 if __name__ == "__main__" and "--heavy" in sys.argv:
     main_heavy()
+
+
+def main_readme_guidance():
+    """The README's "Ours+guidance" command line (reference README.md:120) at the reference's defaults -- 100 diffusion
+    steps, 8 neighbours, 10 candidates, guidance on the last 10 steps, THREE RefineNet re-rolls: no other fixture runs
+    multi_cands = 10 with n_rolls = 3."""
+    ref = ref_harness.load_reference()
+    sd = dict(np.load(WEIGHTS_FILE))
+    argv = ["--diffusion", "--load_stlp", "--rect_head", "--flex", "--diverse_loss", "--multi_cands", "10", "--guidance",
+            "--guidance_before", "10", "--guidance_niters", "1", "--guidance_lr", "0.01", "--n_rolls", "3", "--other"]
+    sampling_case(ref, sd, "e7_readme_guidance", argv, bs=2, S=16, K=8, steps=100, seed=95, stlp_mode="wide",
+                  invalid_lane_frac=0.25)
+
+
+if __name__ == "__main__" and "--readme-guidance" in sys.argv:
+    main_readme_guidance()
 
 
 def harness_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=0.0, stlp_mode="loose"):

@@ -175,7 +175,7 @@ def test_sampling_region_matches_reference(dev, name, chain_waves):
             amb = ~clear & keep
             _, amb_g = _groups(amb, meta["S"])
             keep_r = keep_r & ~amb_g
-    for k in ["rect_controls", "roll0_controls", "roll1_controls"]:
+    for k in ["rect_controls", "roll0_controls", "roll1_controls", "roll2_controls"]:
         if k in d:
             close(out[k], d[k], keep_r, k)
     fs, fr = out["final_scores"].cpu().numpy(), d["final_scores"]

@@ -52,7 +52,7 @@ def test_sampling_region_matches_reference(name):
         keep = ~(bad_groups if (meta["diverse"] and meta["rect_head"]) else bad_rows)
     np.testing.assert_allclose(out["controls_list"].numpy()[:, keep], d["controls_list"][:, keep], rtol=0, atol=tol)
     np.testing.assert_allclose(out["final_controls"].numpy()[keep], d["final_controls"][keep], rtol=0, atol=tol)
-    for k in ["cand_scores", "sel_scores", "sel_controls", "rect_controls", "roll0_scores", "roll1_controls"]:
+    for k in ["cand_scores", "sel_scores", "sel_controls", "rect_controls", "roll0_scores", "roll1_controls", "roll2_controls"]:
         if k in d:
             np.testing.assert_allclose(out[k].numpy()[..., keep, :, :] if out[k].ndim >= 3 else out[k].numpy()[..., keep],
                                        d[k][..., keep, :, :] if d[k].ndim >= 3 else d[k][..., keep],
