@@ -344,22 +344,22 @@ def main():
         fp32_exact = {"chain_waves": 8, "steps": 3, "ms_per_step": dt_x * 1e3, "value": N / dt_x, "kernel_ms": ms_x,
                       "achieved": ach_x, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach_x / PEAK_FP32_MATRIX_TFLOPS,
                       "note": "v_mfma_f32_16x16x4_f32 chains (exact f32), same step, same run"}
-    # VALU-issue roofline of the one-row-per-lane STL kernels: vector instructions per launch (SQ_INSTS_VALU of the committed
-    # PMC pass, per wavefront) x 4 issue cycles / 1024 SIMDs / (launch time x clock)
+    # VALU-issue roofline of the one-row-per-lane STL kernels (they are instruction-issue-bound, not HBM-bound): vector
+    # instructions per row-evaluation from the committed PMC pass (SQ_INSTS_VALU / rows of that launch) x the row-evaluation
+    # rate measured live in this run x 4 issue cycles per wavefront instruction / (1024 SIMDs x the clock of the PMC run)
     pmc_r3 = os.path.join(ROOT, "profiles", "r3", "pmc_summary.json")
     if os.path.exists(pmc_r3):
         pj = json.load(open(pmc_r3))
         for kind, info in stl_info.items():
             v = pj.get("stl_kernels", {}).get(kind)
-            if v and v.get("rows_per_launch") == (N * a.multi_cands if kind == "score" else N) and a.neighbors == v.get("K"):
-                clk = float(v.get("clock_GHz", 2.4)) * 1e9
-                n_launch = {"guidance": 10, "score": 2}[kind]      # launches per step of this kind in the default workload
-                per_launch_s = info["ms_per_step"] * 1e-3 / n_launch if kind == "guidance" else None
-                if kind == "guidance":
-                    info["valu_insts_per_launch"] = v["SQ_INSTS_VALU"]
-                    info["valu_issue_frac"] = v["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (per_launch_s * clk)
-                    info["valu_issue_note"] = ("SQ_INSTS_VALU (profiles/r3/pmc_summary.json) x 4 cycles / 1024 SIMDs / (launch "
-                                               "time x %.2f GHz)" % (clk / 1e9))
+            if v and v.get("rows_per_launch") and v.get("K") == a.neighbors and v.get("clock_GHz"):
+                per_row = v["SQ_INSTS_VALU"] / v["rows_per_launch"]       # wavefront instructions per row-evaluation (1/64 each)
+                clk = float(v["clock_GHz"]) * 1e9
+                info["valu_wave_insts_per_row_eval"] = per_row
+                info["valu_issue_frac"] = per_row * info["row_evals_per_s"] * 4.0 / (1024.0 * clk)
+                info["valu_issue_frac_pmc_run"] = v.get("valu_issue_frac")
+                info["valu_issue_note"] = ("SQ_INSTS_VALU per row-evaluation (profiles/r3/pmc_summary.json) x live row-evaluations/s x 4 "
+                                           "cycles / (1024 SIMDs x %.2f GHz)" % (clk / 1e9))
     # HBM bytes of that launch from the committed PMC passes (FETCH_SIZE/WRITE_SIZE cannot be read inside this process);
     # only quoted when this run is the configuration those passes were collected on
     traffic = None

@@ -152,3 +152,52 @@ def test_split_bf16_chain_tracks_the_fp32_chain_full_size(ctx):
     assert clear.float().mean().item() > 0.9
     d_fin = (outs[8]["final_controls"] - outs[0]["final_controls"]).abs().reshape(sb.N, -1).amax(dim=1)[clear]
     assert d_fin.max().item() < 6e-5, "refined controls, split-bf16 vs fp32 chain: %.3e" % d_fin.max().item()
+
+
+def test_config5_training_step_full_size(ctx):
+    """Config 5 (e8_ours_ablation: RefineNet under the STL loss) at BASELINE's single-GPU size, 786 432 rows, through
+    size-independent properties -- the oracle cannot run here:
+      * the loss of a batch is the mean over its rows, so the gradients of the two half batches (each scaled with the
+        GLOBAL valid-row statistics, as a rank of a two-GPU run does) add up to the full batch's, to summation order;
+      * the same for the loss itself; every gradient is finite and non-trivial;
+      * three optimisation steps on frozen noise lower the loss."""
+    from pstl_diffusion_policy_amd.engine import PackedWeights, RectTrainer, Sampler
+    dev, hp, sb = ctx["dev"], ctx["hp"], ctx["sb"]
+    sd = {k: torch.from_numpy(v).to(dev) for k, v in golden_weights().items()}
+    params = {k: sd[k].clone().requires_grad_() for k in RectTrainer.NAMES}
+    steps, mc = 10, 5
+
+    def grads_of(sbx, seed_rows):
+        sm = Sampler(PackedWeights(dict(sd, **{k: v.detach() for k, v in params.items()}), dev), hp)
+        tr = RectTrainer(sm)
+        feature, base_p, base_r = sm.encode(sbx, need_rect=True)
+        x = sm.fill_normal(sbx, steps, steps, 21)
+        emit = sm.rollout(sbx, base_p, x, None, steps, n_emit=mc, clip=True, seed=21)
+        r = sm.score(sbx, emit[-mc:].contiguous(), select=True)
+        loss, rect, scores, g = tr.loss_and_grads(sbx, feature, base_r, params["rect_net.2.weight"],
+                                                  params["rect_net.4.weight"], r["sel_controls"], r["sel_scores"])
+        return loss, g, scores
+
+    loss_full, g_full, scores = grads_of(sb, 0)
+    assert sb.N == 786432 and torch.isfinite(loss_full)
+    vsum = float(sb.valid.sum().item())
+    half = BS // 2
+    halves = [_sub(ctx, 0, half, global_valid_sum=vsum, global_rows=sb.N, row_offset=0),
+              _sub(ctx, half, BS, global_valid_sum=vsum, global_rows=sb.N, row_offset=half * S * 3)]
+    parts = [grads_of(h, 0) for h in halves]
+    np.testing.assert_allclose(float(parts[0][0] + parts[1][0]), float(loss_full), rtol=2e-5)
+    for k in RectTrainer.NAMES:
+        full = g_full[k].cpu().numpy()
+        two = (parts[0][1][k] + parts[1][1][k]).cpu().numpy()
+        assert np.isfinite(full).all() and np.abs(full).max() > 0, k
+        np.testing.assert_allclose(two, full, rtol=2e-3, atol=2e-5 * np.abs(full).max(), err_msg=k)
+    # the rows of the two halves are the rows of the full batch (in-kernel noise is keyed by the global row)
+    assert torch.equal(torch.cat([parts[0][2], parts[1][2]]), scores)
+    opt = torch.optim.Adam([params[k] for k in RectTrainer.NAMES], lr=3e-4)
+    losses = []
+    for it in range(3):
+        sm = Sampler(PackedWeights(dict(sd, **{k: v.detach() for k, v in params.items()}), dev), hp)
+        loss, _ = RectTrainer(sm).train_step(sb, params, opt, steps, seed=21, multi_cands=mc)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    print("config 5 at 786432 rows: loss over three Adam steps", losses)

@@ -13,7 +13,9 @@ SIMDS = 256 * 4
 
 
 def short(name):
-    n = name.split("(")[0].split("::")[-1]
+    import re
+    m = re.search(r"\b(k_\w+)", name)
+    n = m.group(1) if m else name.split("(")[0]
     if "k_chain" in name:
         n = "k_chain<8,%s>" % ("true" if "k_chain<8, true" in name else "false")
     return n
@@ -34,7 +36,7 @@ def load(tag):
 
 
 out = {"per_kernel": {}}
-passes = {t: load(t) for t in ("FETCH_SIZE", "WRITE_SIZE", "SQ")}
+passes = {t: load(t) for t in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "VALU")}
 for tag, per in passes.items():
     out["per_kernel"][tag] = {}
     for k, disp in per.items():
@@ -65,5 +67,31 @@ if sq:
     if clock and "SQ_VALU_MFMA_BUSY_CYCLES" in sq:
         summ["mfma_pipe_util"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (clock * dur * SIMDS)
     summ["mfma_insts"] = sq.get("SQ_INSTS_MFMA")
-out = {"summary_dominant_kernel": summ, "per_kernel": out["per_kernel"]}
+# The one-row-per-lane STL kernels against their real roofline, the vector issue port: every VALU instruction of a wavefront
+# takes 4 issue cycles on its SIMD (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'), so
+#   valu_issue_frac = SQ_INSTS_VALU x 4 / (1024 SIMDs x launch cycles).
+# (k_guidance_iter: one launch per guided step over all rows; k_stl_forward: the largest launch = the 5-candidate scoring.)
+stl = {}
+val = out["per_kernel"].get("VALU", {})
+for kind, kname in (("guidance", "k_guidance_iter"), ("score", "k_stl_forward")):
+    v = val.get(kname)
+    if not v or "SQ_INSTS_VALU" not in v:
+        continue
+    disp = list(passes["VALU"][kname].values())
+    if kind == "score":      # the candidate-scoring launch is the long one (the final scoring is 5x shorter)
+        top = max(e["dur_ns"] for e in disp)
+        disp = [e for e in disp if e["dur_ns"] > 0.5 * top]
+    n = len(disp)
+    avg = lambda key: sum(e.get(key, 0.0) for e in disp) / n
+    dur = avg("dur_ns")
+    clock = avg("GRBM_GUI_ACTIVE") / 8.0 / dur if dur else None
+    stl[kind] = {"kernel": kname, "launches_averaged": n, "dur_ns": dur, "clock_GHz": clock,
+                 "SQ_INSTS_VALU": avg("SQ_INSTS_VALU"), "SQ_ACTIVE_INST_VALU": avg("SQ_ACTIVE_INST_VALU"),
+                 "SQ_WAIT_INST_LDS": avg("SQ_WAIT_INST_LDS"), "SQ_WAVES": avg("SQ_WAVES"), "SQ_INSTS_SALU": avg("SQ_INSTS_SALU"),
+                 "SQ_INSTS_LDS": avg("SQ_INSTS_LDS"),
+                 "valu_insts_per_wave": avg("SQ_INSTS_VALU") / avg("SQ_WAVES") if avg("SQ_WAVES") else None,
+                 "valu_issue_frac": avg("SQ_INSTS_VALU") * 4.0 / (SIMDS * clock * dur) if clock else None,
+                 "rows_per_launch": int(sys.argv[2]) * (5 if kind == "score" else 1) if len(sys.argv) > 2 else None,
+                 "K": int(sys.argv[3]) if len(sys.argv) > 3 else None}
+out = {"summary_dominant_kernel": summ, "stl_kernels": stl, "per_kernel": out["per_kernel"]}
 print(json.dumps(out, indent=1))
