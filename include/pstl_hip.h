@@ -50,8 +50,12 @@ enum {
   PSTL_FLAG_MAXIMIZE = 2,   /* guidance loss relu(100 - score)     (nusc_train.py:616-617)                 */
   PSTL_FLAG_CLIP_RECT = 4,  /* --clip_rect (nusc_model.py:230-233)                                         */
   PSTL_FLAG_NO_MERGE = 8,   /* rect_forward without merge_net pooling (not diverse_loss / --no_arch)       */
-  PSTL_FLAG_RNG = 16        /* kernels draw the diffusion noise themselves (cfg.seed, cfg.row_offset); the  */
+  PSTL_FLAG_RNG = 16,       /* kernels draw the diffusion noise themselves (cfg.seed, cfg.row_offset); the  */
                             /* `noise` / `z` pointer arguments are then ignored                              */
+  PSTL_FLAG_NORM_STL = 32   /* --norm_stl (nusc_train.py:88-91,97-113): the speed, lane-distance and clearance       */
+                            /* predicates divided by v_factor = clip(vmax - vmin, 0.3), d_factor = clip((dmax - dmin)*5, */
+                            /* 0.3), safe_factor = clip(dsafe, 0.3) in pstl_stl_forward / _backward / pstl_guidance_step; */
+                            /* pstl_trajopt and pstl_refinement answer PSTL_ERR_SHAPE                                   */
 };
 
 typedef struct pstl_cfg {

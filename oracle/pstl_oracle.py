@@ -210,21 +210,28 @@ def stl_signals(traj, nei, lanes, ego_L, ego_W):
     return sig
 
 
-def stl_scores_from_signals(sig, stlp, hl, tau, nt):
+def stl_scores_from_signals(sig, stlp, hl, tau, nt, norm=False):
+    """norm: --norm_stl (nusc_train.py:88-91,97-113): the speed, lane-distance and clearance predicates are divided by
+    v_factor = clip(vmax - vmin, 0.3), d_factor = clip((dmax - dmin) * 5, 0.3), safe_factor = clip(dsafe, 0.3)."""
     vmin, vmax, dmin, dmax, dsafe, thmax = [stlp[:, i:i + 1] for i in range(6)]
     g = lambda s: always_from(s, tau)
     f = lambda s: eventually_within(s, tau, nt // 2)
-    keep_vmin = g(sig["v"] - vmin)
-    keep_vmax = g(-sig["v"] + vmax)
-    safe = g(sig["nei"] - dsafe)
+    if norm:
+        vf, df, sf = torch.clip(vmax - vmin, 0.3), torch.clip((dmax - dmin) * 5, 0.3), torch.clip(dsafe, 0.3)
+    else:
+        vf = df = sf = None
+    over = lambda a, fac: a / fac if norm else a
+    keep_vmin = g(over(sig["v"] - vmin, vf))
+    keep_vmax = g(over(-sig["v"] + vmax, vf))
+    safe = g(over(sig["nei"] - dsafe, sf))
     out = []
     # stay in lane: conjunction of six "always" terms (nusc_train.py:115-118,130,132,136)
-    terms = [keep_vmin, keep_vmax, g(sig["d_curr"] - dmin), g(-sig["d_curr"] + dmax),
+    terms = [keep_vmin, keep_vmax, g(over(sig["d_curr"] - dmin, df)), g(over(-sig["d_curr"] + dmax, df)),
              g((thmax - sig["th_curr"]) / thmax), safe]
     out.append(soft_min(torch.stack(terms, dim=1), tau)[:, 0])
     # change lane: eventually-always inside the target lane band and aligned (nusc_train.py:119-128,133-138)
     for key in ("left", "right"):
-        band = -soft_max(torch.stack([-(sig["d_" + key] - dmin), -(-sig["d_" + key] + dmax)], dim=1), tau)
+        band = -soft_max(torch.stack([-over(sig["d_" + key] - dmin, df), -over(-sig["d_" + key] + dmax, df)], dim=1), tau)
         terms = [keep_vmin, keep_vmax, f(g(band)), f(g((thmax - sig["th_" + key]) / thmax)), safe]
         out.append(soft_min(torch.stack(terms, dim=1), tau)[:, 0])
     scores3 = torch.stack(out, dim=0)
@@ -237,7 +244,7 @@ def stl_scores_from_signals(sig, stlp, hl, tau, nt):
 def stl_scores(traj, nei, lanes, stlp, hl, hp):
     """traj (R,T,4) -> scores of the three formulas (3,R) and the mode-selected score (R,)."""
     sig = stl_signals(traj, nei, lanes, hp["ego_L"], hp["ego_W"])
-    s3, s = stl_scores_from_signals(sig, stlp, hl, hp["smoothing_factor"], traj.shape[1])
+    s3, s = stl_scores_from_signals(sig, stlp, hl, hp["smoothing_factor"], traj.shape[1], norm=bool(hp.get("norm_stl", False)))
     return s3, s, sig
 
 

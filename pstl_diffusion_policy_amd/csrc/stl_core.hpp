@@ -116,7 +116,19 @@ struct StlEnv {
 struct StlRow {
   float vmin, vmax, dmin, dmax, dsafe, thmax;
   int mode;  // 0 keep lane, 1 left, 2 right, 3 outlier (score == 1)
+  // --norm_stl (nusc_train.py:88-91): divisors of the speed / lane-distance / clearance predicates (set by norm_factors;
+  // only read by the NORM instantiations)
+  float vf, df, sf;
 };
+// v_factor = clip(vmax - vmin, 0.3), d_factor = clip((dmax - dmin) * 5, 0.3), safe_factor = clip(dsafe, 0.3)
+PSTL_HD void norm_factors(StlRow& r) {
+  r.vf = fmaxf(r.vmax - r.vmin, 0.3f);
+  r.df = fmaxf((r.dmax - r.dmin) * 5.0f, 0.3f);
+  r.sf = fmaxf(r.dsafe, 0.3f);
+}
+// a predicate under --norm_stl: the reference divides (an IEEE division, kept: scores must agree with it sign for sign)
+template <bool NORM>
+PSTL_HD float over(float a, float f) { return NORM ? a / f : a; }
 
 // Circle row of a car (utils.py:474-486 with num_L = 4, num_W = 1): radius and the 4 centre offsets along the body axis.
 PSTL_HD void circle_row(float L, float W, float* off, float& r) {
@@ -566,7 +578,7 @@ struct FwdOut {  // what the adjoint needs from the forward sweep
 //   XY != -1    : additionally parks the state of every 4th step at scratch[XY ...] (x, y, th, v; 5 each)  (adjoint)
 //   REC         : records the winners of the hard minima (lane segment, neighbour, circle pair) per step in `rec`
 //                 (for the adjoint; !ALL3)
-template <bool ALL3, int XY, bool REC, class Src>
+template <bool ALL3, int XY, bool REC, bool NORM, class Src>
 PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Src src, Scratch st,
                            int tab, float* out3, FwdOut* fo, Rec& rec) {
   static_assert(!(ALL3 && REC), "winners are recorded for the selected formula only");
@@ -594,16 +606,17 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
       st.at(XY + 2 * kCk + k) = th;
       st.at(XY + 3 * kCk + k) = v;
     }
-    gv1.add(-(v - r.vmin) * tau);
-    gv2.add(-(-v + r.vmax) * tau);
+    gv1.add(-over<NORM>(v - r.vmin, r.vf) * tau);
+    gv2.add(-over<NORM>(-v + r.vmax, r.vf) * tau);
     ClearHit ch;
     clearance_eval<false, REC>(env, nei, K, t, x, y, c, s, ch);
-    gsafe.add(-(ch.dn - r.dsafe) * tau);
+    gsafe.add(-over<NORM>(ch.dn - r.dsafe, r.sf) * tau);
     LaneHit h;
     lane_eval<false>(ALL3 ? lanes : sel_lane, x, y, th, h);
     if (REC) rec_put(rec, t, (unsigned)h.jb, ch.win);
     {
-      const float s1 = h.d - r.dmin, s2 = -h.d + r.dmax, a3 = -((r.thmax - h.th) / r.thmax) * tau;
+      const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df);
+      const float a3 = -((r.thmax - h.th) / r.thmax) * tau;
       g1.add(-s1 * tau);
       g2.add(-s2 * tau);
       g3.add(a3);
@@ -611,9 +624,10 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
     }
     if (ALL3) {
       lane_eval<false>(lanes + kNseg, x, y, th, h);
-      R1.step(tau, t, h.d - r.dmin, -h.d + r.dmax, -((r.thmax - h.th) / r.thmax) * tau, st, tab);
+      R1.step(tau, t, over<NORM>(h.d - r.dmin, r.df), over<NORM>(-h.d + r.dmax, r.df), -((r.thmax - h.th) / r.thmax) * tau, st, tab);
       lane_eval<false>(lanes + 2 * kNseg, x, y, th, h);
-      R2.step(tau, t, h.d - r.dmin, -h.d + r.dmax, -((r.thmax - h.th) / r.thmax) * tau, st, tab + 2 * kFwin);
+      R2.step(tau, t, over<NORM>(h.d - r.dmin, r.df), over<NORM>(-h.d + r.dmax, r.df), -((r.thmax - h.th) / r.thmax) * tau, st,
+              tab + 2 * kFwin);
     }
   }
   const float Lv1 = gv1.value(), Lv2 = gv2.value(), Ls = gsafe.value();
@@ -657,11 +671,11 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
   return score;
 }
 
-template <bool ALL3, int XY, class Src>
+template <bool ALL3, int XY, bool NORM = false, class Src>
 PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Src src, Scratch st,
                        int tab, float* out3, FwdOut* fo) {
   Rec none;
-  return stl_eval_rec<ALL3, XY, false>(env, r, lanes, nei, K, src, st, tab, out3, fo, none);
+  return stl_eval_rec<ALL3, XY, false, NORM>(env, r, lanes, nei, K, src, st, tab, out3, fo, none);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -680,7 +694,7 @@ PSTL_HD float pick4(const float (&a)[kCkStride], int i) {   // register array, d
   return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
 }
 
-template <class DScoreFn, class EmitFn>
+template <bool NORM = false, class DScoreFn, class EmitFn>
 PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, const float* s0,
                             const float* u, Scratch st, float wscale, float ascale, DScoreFn dscore_fn, EmitFn emit,
                             long us = 1, bool inert = false) {
@@ -704,8 +718,8 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   Rec rec;
   rec_clear(rec);
   const bool use_rec = K <= kRecMaxK;   // uniform; with more neighbours the record is written but not trusted
-  const float score = stl_eval_rec<false, 0, true>(env, r, lanes, nei, K, DynSrc(s0, u, wscale, ascale, env.dt, us), st, LB,
-                                                   nullptr, &fo, rec);
+  const float score = stl_eval_rec<false, 0, true, NORM>(env, r, lanes, nei, K, DynSrc(s0, u, wscale, ascale, env.dt, us), st,
+                                                         LB, nullptr, &fo, rec);
   const float Lv1 = fo.Lv1, Lv2 = fo.Lv2, Ls = fo.Ls, L1 = fo.L1, L2 = fo.L2, L3 = fo.L3, Lfb = fo.Lfb, Lft = fo.Lft;
   float V[6];
   int n;
@@ -794,17 +808,20 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     const float x = pick4(bx, i), y = pick4(by, i), th = pick4(bth, i), v = pick4(bv, i), c = pick4(bc, i), s = pick4(bs, i);
     // direct partials of the score w.r.t. state t
     float gx, gy, gth, gv;
-    gv = o_v1 * PSTL_EXP(-(v - r.vmin) * tau - Lv1) - o_v2 * PSTL_EXP(-(-v + r.vmax) * tau - Lv2);
+    // (--norm_stl: the predicates are a / f; the chain rule adds the factor 1 / f, as autograd's division does)
+    gv = o_v1 * PSTL_EXP(-over<NORM>(v - r.vmin, r.vf) * tau - Lv1) - o_v2 * PSTL_EXP(-over<NORM>(-v + r.vmax, r.vf) * tau - Lv2);
+    if (NORM) gv = gv / r.vf;
     ClearHit ch;
     if (use_rec) clearance_from_winner(env, nei, t, x, y, c, s, rec_win(rec, t), ch);
     else clearance_eval<true>(env, nei, K, t, x, y, c, s, ch);
-    const float gs = o_s * PSTL_EXP(-(ch.dn - r.dsafe) * tau - Ls);
+    float gs = o_s * PSTL_EXP(-over<NORM>(ch.dn - r.dsafe, r.sf) * tau - Ls);
+    if (NORM) gs = gs / r.sf;
     gx = gs * ch.d_dx;
     gy = gs * ch.d_dy;
     gth = gs * ch.d_dth;
     LaneHit h;
     lane_eval<true>(lane, x, y, th, h, use_rec ? (int)rec_seg(rec, t) : -1);
-    const float s1 = h.d - r.dmin, s2 = -h.d + r.dmax, s3 = (r.thmax - h.th) / r.thmax;
+    const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df), s3 = (r.thmax - h.th) / r.thmax;
     float gd, gsth;  // d score / d d_t , d score / d s3_t
     if (mode == 0) {
       gd = om[2] * PSTL_EXP(-s1 * tau - L1) - om[3] * PSTL_EXP(-s2 * tau - L2);
@@ -820,6 +837,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
       gd = om[2] * wb * (PSTL_EXP(a1 - lp) - PSTL_EXP(a2 - lp));
       gsth = om[3] * wt;
     }
+    if (NORM) gd = gd / r.df;
     gx += gd * h.dd_dx;
     gy += gd * h.dd_dy;
     gth += gsth * (-1.0f / r.thmax) * h.dth_dth;

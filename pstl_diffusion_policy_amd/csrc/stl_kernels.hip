@@ -37,6 +37,7 @@ struct StlArgs {
   int rep_split;          // small batches: blockIdx.y is the rep (one candidate per wavefront, k_stl_select picks afterwards)
 };
 
+template <bool NORM = false>
 __device__ __forceinline__ StlRow load_row(const float* stlp, const float* hl, long row) {
   StlRow r;
   const float* p = stlp + row * 6;
@@ -48,6 +49,8 @@ __device__ __forceinline__ StlRow load_row(const float* stlp, const float* hl, l
   r.thmax = p[5];
   const float h = hl[row];
   r.mode = (h == 0.0f) ? 0 : (h == 1.0f) ? 1 : (h == 2.0f) ? 2 : 3;  // anything else scores the outlier constant
+  r.vf = r.df = r.sf = 1.0f;
+  if (NORM) norm_factors(r);   // --norm_stl (PSTL_FLAG_NORM_STL)
   return r;
 }
 
@@ -80,7 +83,7 @@ inline size_t stl_lds_bytes(int n_scratch, int K, bool staged) {
   return ((size_t)n_scratch * kWave + (staged ? (size_t)(3 * kNseg + 3) * 4 + (size_t)K * kT * kNeiPrep : 0)) * sizeof(float);
 }
 
-template <bool ALL3, bool STAGED, bool GIVEN>
+template <bool ALL3, bool STAGED, bool GIVEN, bool NORM = false>
 __global__ __launch_bounds__(kWave) void k_stl_forward(StlArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NS = ALL3 ? kScratchFwd3 : kScratchFwd;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(kWave) void k_stl_forward(StlArgs a) {
   if (row >= a.N) return;
   const Scratch st = {lds + threadIdx.x, kWave};
   const long b = row / a.rows_per_scene;
-  const StlRow r = load_row(a.stlp, a.hl, row);
+  const StlRow r = load_row<NORM>(a.stlp, a.hl, row);
   float best = -INFINITY;
   int best_rep = 0;
   const int rep_lo = a.rep_split ? (int)blockIdx.y : 0, rep_hi = a.rep_split ? rep_lo + 1 : a.reps;
@@ -100,10 +103,10 @@ __global__ __launch_bounds__(kWave) void k_stl_forward(StlArgs a) {
     float score;
     if (GIVEN) {
       const GivenSrc src = {reinterpret_cast<const f4*>(a.states) + ((long)rep * a.N + row) * kT};
-      score = stl_eval<ALL3, -1>(a.env, r, lanes, nei, a.K, src, st, 0, o3, nullptr);
+      score = stl_eval<ALL3, -1, NORM>(a.env, r, lanes, nei, a.K, src, st, 0, o3, nullptr);
     } else {
       const DynSrc src(a.s0 + b * 4, a.controls + ((long)rep * a.N + row) * (2 * kT), 1.0f, 1.0f, a.env.dt);
-      score = stl_eval<ALL3, -1>(a.env, r, lanes, nei, a.K, src, st, 0, o3, nullptr);
+      score = stl_eval<ALL3, -1, NORM>(a.env, r, lanes, nei, a.K, src, st, 0, o3, nullptr);
     }
     a.scores[(long)rep * a.N + row] = score;
     if (ALL3 && a.scores3) {
@@ -184,7 +187,7 @@ struct GradArgs {
   float* scores;        // (N,) or null
 };
 
-template <bool STAGED>
+template <bool STAGED, bool NORM = false>
 __global__ __launch_bounds__(kWave) void k_stl_backward(GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const long row = map_row(a.by_mode, a.rows_per_scene);
@@ -195,10 +198,10 @@ __global__ __launch_bounds__(kWave) void k_stl_backward(GradArgs a) {
   if (row >= a.N) return;
   const Scratch st = {lds + threadIdx.x, kWave};
   const long b = row / a.rows_per_scene;
-  const StlRow r = load_row(a.stlp, a.hl, row);
+  const StlRow r = load_row<NORM>(a.stlp, a.hl, row);
   const float ds = a.dscore ? a.dscore[row] : 1.0f;
   float* out = a.dcontrols + row * (2 * kT);
-  const float score = stl_eval_grad(
+  const float score = stl_eval_grad<NORM>(
       a.env, r, lanes, nei, a.K, a.s0 + b * 4, a.u + row * (2 * kT), st, a.wscale, a.ascale, [=](float) { return ds; },
       [=](int t, float gw, float ga, float, float) {
         store_pair(out + 2 * t, gw, ga);   // one 8-byte gather store per time step
@@ -236,7 +239,7 @@ struct GuideArgs {
   float* emit_out;  // (N,40) or null
 };
 
-template <bool MULTI, bool STAGED>
+template <bool MULTI, bool STAGED, bool NORM = false>
 __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const long row = map_row(a.by_mode, a.rows_per_scene);
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
   if (row >= a.N) return;
   const Scratch st = {lds + threadIdx.x, kWave};
   const long b = row / a.rows_per_scene;
-  const StlRow r = load_row(a.stlp, a.hl, row);
+  const StlRow r = load_row<NORM>(a.stlp, a.hl, row);
   float* mu = a.mu + row * (2 * kT);
   const float vr = a.valid[row];
   const float gs = a.grad_scale * vr;
@@ -283,13 +286,13 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
     const float zv = a.rng ? zdrawn : (zr ? zr[e] : 0.0f);
     const float x = p + a.sqrt_beta * zv;
     float c = x * nscale;
-    if (a.clip) c = fminf(fmaxf(c, -nscale), nscale);
+    if (a.clip) c = c < -nscale ? -nscale : (c > nscale ? nscale : c);   // torch.clip: a NaN stays a NaN
     *emit_v = c;
     return x;
   };
   // mu[2t], mu[2t+1] are rewritten by emit(t) while the adjoint walks t = T-1 ... 0; the adjoint has already taken every
   // value it still needs from earlier time steps only (and hands the current one to emit, so mu is not read here)
-  stl_eval_grad(
+  stl_eval_grad<NORM>(
       a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
       [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
       [=, z4 = f4{0.0f, 0.0f, 0.0f, 0.0f}](int t, float gw, float ga, float w0, float a0) mutable {
@@ -807,7 +810,14 @@ extern "C" int pstl_stl_forward(const pstl_cfg* cfg, const float* s0, const floa
   const bool staged = scene_staged(cfg);
   const size_t lds = stl_lds_bytes(scores3 ? kScratchFwd3 : kScratchFwd, cfg->K, staged);
   void (*fn)(StlArgs);
-  if (states)
+  if (cfg->flags & PSTL_FLAG_NORM_STL) {
+    if (states)
+      fn = scores3 ? (staged ? k_stl_forward<true, true, true, true> : k_stl_forward<true, false, true, true>)
+                   : (staged ? k_stl_forward<false, true, true, true> : k_stl_forward<false, false, true, true>);
+    else
+      fn = scores3 ? (staged ? k_stl_forward<true, true, false, true> : k_stl_forward<true, false, false, true>)
+                   : (staged ? k_stl_forward<false, true, false, true> : k_stl_forward<false, false, false, true>);
+  } else if (states)
     fn = scores3 ? (staged ? k_stl_forward<true, true, true> : k_stl_forward<true, false, true>)
                  : (staged ? k_stl_forward<false, true, true> : k_stl_forward<false, false, true>);
   else
@@ -847,7 +857,8 @@ extern "C" int pstl_stl_backward(const pstl_cfg* cfg, const float* s0, const flo
   const bool staged = scene_staged(cfg);
   a.by_mode = rows_by_mode(cfg, staged) ? 1 : 0;
   const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged);
-  void (*fn)(GradArgs) = staged ? k_stl_backward<true> : k_stl_backward<false>;
+  void (*fn)(GradArgs) = (cfg->flags & PSTL_FLAG_NORM_STL) ? (staged ? k_stl_backward<true, true> : k_stl_backward<false, true>)
+                                                           : (staged ? k_stl_backward<true> : k_stl_backward<false>);
   if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
   hipLaunchKernelGGL(fn, dim3((unsigned)((a.N + kWave - 1) / kWave)), dim3(kWave), lds, as_stream(stream), a);
   return launch_status();
@@ -896,6 +907,9 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
   const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged);
   void (*fn)(GuideArgs) = niters > 1 ? (staged ? k_guidance_iter<true, true> : k_guidance_iter<true, false>)
                                      : (staged ? k_guidance_iter<false, true> : k_guidance_iter<false, false>);
+  if (cfg->flags & PSTL_FLAG_NORM_STL)
+    fn = niters > 1 ? (staged ? k_guidance_iter<true, true, true> : k_guidance_iter<true, false, true>)
+                    : (staged ? k_guidance_iter<false, true, true> : k_guidance_iter<false, false, true>);
   if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
   for (int j = 0; j < niters; ++j) {
     a.iter = j;
@@ -912,6 +926,7 @@ extern "C" int pstl_trajopt(const pstl_cfg* cfg, const float* s0, const float* n
                             float reg_scale, int iters, const float* adam_neg_step, const float* adam_bc2_sqrt, int resume,
                             float* params_inout, float* work, float* scores, void* stream) {
   if (int e = check_cfg(cfg)) return e;
+  if (cfg->flags & PSTL_FLAG_NORM_STL) return PSTL_ERR_SHAPE;   // the traj-opt loop is built for the default formulas only
   if (!s0 || !lane_prep || !stlp || !hl || !valid || !params_inout || !work || !adam_neg_step || !adam_bc2_sqrt ||
       iters < 1)
     return PSTL_ERR_ARG;
@@ -961,6 +976,7 @@ extern "C" int pstl_refinement(const pstl_cfg* cfg, const float* s0, const float
                                const float* list, int n_list, const int32_t* list_idx, float* work, float* out_controls,
                                float* grad_trace, void* stream) {
   if (int e = check_cfg(cfg)) return e;
+  if (cfg->flags & PSTL_FLAG_NORM_STL) return PSTL_ERR_SHAPE;   // --refinement: default formulas only
   if (!s0 || !lane_prep || !stlp || !hl || !valid || !controls || !list || !list_idx || !work || !out_controls ||
       !adam_neg_step || !adam_bc2_sqrt || iters < 1)
     return PSTL_ERR_ARG;

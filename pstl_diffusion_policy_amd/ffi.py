@@ -16,6 +16,7 @@ PSTL_FLAG_MAXIMIZE = 2
 PSTL_FLAG_CLIP_RECT = 4
 PSTL_FLAG_NO_MERGE = 8
 PSTL_FLAG_RNG = 16
+PSTL_FLAG_NORM_STL = 32
 
 T = 20
 NSEG = 15
@@ -140,6 +141,8 @@ def ptr(t, dtype=torch.float32):
 
 
 def make_cfg(bs, rows_per_scene, S, K, steps, hp, flags=0, chain_waves=0, seed=0, row_offset=0):
+    if hp.get("norm_stl", False):     # --norm_stl travels with the hyper-parameters: every launch of the batch sees it
+        flags = int(flags) | PSTL_FLAG_NORM_STL
     return PstlCfg(bs=int(bs), rows_per_scene=int(rows_per_scene), S=int(S), K=int(K), steps=int(steps),
                    n_shards=int(hp.get("n_shards", 4)), flags=int(flags), chain_waves=int(chain_waves),
                    tau=float(hp["smoothing_factor"]), thres=float(hp["stl_nn_thres"]), w_max=float(hp["mul_w_max"]),

@@ -103,7 +103,8 @@ class Net(nn.Module):
         a = self.args
         return dict(nt=a.nt, dt=a.dt, mul_w_max=a.mul_w_max, mul_a_max=a.mul_a_max,
                     smoothing_factor=a.smoothing_factor, stl_nn_thres=a.stl_nn_thres, ego_L=a.ego_L, ego_W=a.ego_W,
-                    refined_nL=a.refined_nL, refined_nW=a.refined_nW, n_segs=a.n_segs, n_shards=a.n_shards)
+                    refined_nL=a.refined_nL, refined_nW=a.refined_nW, n_segs=a.n_segs, n_shards=a.n_shards,
+                    norm_stl=bool(getattr(a, "norm_stl", False)))
 
     def _encode(self, nn_input):
         pw = self.packed()

@@ -65,7 +65,7 @@ def _hp(args):
     return dict(nt=args.nt, dt=args.dt, mul_w_max=args.mul_w_max, mul_a_max=args.mul_a_max,
                 smoothing_factor=args.smoothing_factor, stl_nn_thres=args.stl_nn_thres, ego_L=args.ego_L,
                 ego_W=args.ego_W, refined_nL=args.refined_nL, refined_nW=args.refined_nW, n_segs=args.n_segs,
-                n_shards=args.n_shards)
+                n_shards=args.n_shards, norm_stl=bool(getattr(args, "norm_stl", False)))
 
 
 def generate_trajs(s, us, dt):
@@ -313,14 +313,15 @@ def infer_gt_stlp(batch_cuda, gt_trajs, args, data_loader=None):
 def compute_stl_dense(stl_input, stls_cac, stl_idx, mask, args, debug=False, tj_scores=None, scene=False):
     """Scores trajectories stl_input["ego_traj"] (R,T,4) (reference nusc_train.py:318-345).
     Returns (scores_list [curr, left, right, ones], scores (R,), acc[, scene_acc]).
-    Default: the fused kernel (pstl_stl_forward) evaluates the three fixed formulas without materialising any signal.
-    --norm_stl: the signals are prepared (prep_stl_cache) and the formula objects of build_stl_cache are evaluated by the
-    generic program kernel, as the reference's code path reads (:319-323)."""
+    The fused kernel (pstl_stl_forward) evaluates the three fixed formulas without materialising any signal, --norm_stl
+    included (PSTL_FLAG_NORM_STL).  stls_cac == "generic" (or objects other than build_stl_cache's): the signals are prepared
+    (prep_stl_cache) and the formula objects are evaluated by the generic program kernel, as the reference's code path
+    reads (:319-323)."""
     traj = stl_input["ego_traj"]
     dev = traj.device
     R = traj.shape[0]
     hp = _hp(args)
-    if getattr(args, "norm_stl", False):
+    if getattr(args, "generic_stl", False):
         x = prep_stl_cache(stl_input, args)
         scores_list = [stl(x, args.smoothing_factor)[:, 0] for stl in stls_cac]
         scores_list.append(torch.ones_like(scores_list[0]))
@@ -530,12 +531,7 @@ def run_sampling_test(stls_cac, data_loader, net, coeffs, args, result_queue=Non
             tsb = tj_batch["_pstl"]
             tj_controls = batch_cuda["params"].reshape(tsb.N, -1).float().contiguous()
             tsm = Sampler(net.packed(), net.hparams(), chain_waves=net.chain_arith())
-            if args.norm_stl:   # the generic evaluator honours the normalised formulas
-                tj_in = pre_prepare_stl_cache(tj_batch, dense_trajs=tsm.trajs(tsb, tj_controls)[:, :-1].contiguous())
-                tj_scores = compute_stl_dense(tj_in, stls_cac, tj_batch["highlevel_dense"], tj_in["dense_valids"], args)[1]
-                tj_scores = tj_scores.contiguous()
-            else:
-                tj_scores = tsm.score(tsb, tj_controls.reshape(1, tsb.N, -1))["scores"][0]
+            tj_scores = tsm.score(tsb, tj_controls.reshape(1, tsb.N, -1))["scores"][0]
             tcounts, _ = tsm.metrics(tsb, tj_scores)
             tacc, tsacc = acc_from_counts(tcounts)
             md.update("tj_acc", tacc)
@@ -925,6 +921,9 @@ def main(argv=None):
         return SyntheticLoader(args, n_batches=n_batches)
 
     if args.trajopt_only:
+        if args.norm_stl:
+            raise SystemExit("--norm_stl is not supported together with --trajopt_only (the traj-opt loop is built for the "
+                             "default formulas)")
         torch.manual_seed(args.seed)
         if args.cache_path and not args.model_dir:
             import os
@@ -932,11 +931,10 @@ def main(argv=None):
         return run_trajopt(loader_for("train", n_batches=min(args.n_trials, 2)), args)
     if args.sampling_size != args.n_randoms:
         raise SystemExit("--sampling_size must equal --n_randoms (merge_net pooling, reference nusc_model.py:187-196)")
-    if args.norm_stl and (args.rect_head or args.guidance or not args.run_sampling_test):
-        # compute_stl_dense / prep_stl_cache / the formula objects honour --norm_stl (generic evaluator); the fused kernels
-        # that score candidates, drive guidance and train RefineNet evaluate the un-normalised formulas only
-        raise SystemExit("--norm_stl is supported for scoring (compute_stl_dense), not together with --rect_head / --guidance "
-                         "/ training: the fused STL kernels evaluate the default (un-normalised) formulas")
+    if args.norm_stl and args.refinement:
+        # the fused scoring / guidance / training kernels honour --norm_stl (PSTL_FLAG_NORM_STL); the two many-iteration
+        # loops (--refinement, --trajopt_only) are built for the default formulas
+        raise SystemExit("--norm_stl is not supported together with --refinement")
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     loader = loader_for("val")

@@ -28,6 +28,15 @@ def golden_weights(d=None):
     return sd
 
 
+def hparams_for(d=None):
+    """default_hparams(), with norm_stl switched on for fixtures recorded under --norm_stl (`meta_norm`)."""
+    from pstl_diffusion_policy_amd.synthetic import default_hparams
+    hp = default_hparams()
+    if d is not None and "meta_norm" in d and int(d["meta_norm"][0]):
+        hp = dict(hp, norm_stl=True)
+    return hp
+
+
 def scene_from_golden(d):
     keys = ["ego_traj", "neighbors", "neighbors_traj", "currlane_wpts", "leftlane_wpts", "rightlane_wpts",
             "curr_id", "left_id", "right_id", "stlp_modes"]
@@ -72,7 +81,7 @@ def region_kwargs(meta):
 SAMPLING_CASES = ["e5_steps10", "e5_steps100", "e7_steps12", "e7_steps50_k8", "e7_damped", "e7_wide", "e7_guid",
                   "e7_guid_n2_rolls", "e5_guid_all", "sim_maximize", "sim_maximize_b",
                   "fl_e8_clip_rect", "fl_no_arch", "fl_no_refinenet", "fl_not_use_rect", "fl_guid_sets", "fl_guid_freq_rev", "e7_s64_guid", "e7_guid_c4",
-                  "e7_heavy_a", "e7_heavy_b", "e7_readme_guidance"]
+                  "e7_heavy_a", "e7_heavy_b", "e7_readme_guidance", "e7_guid_norm", "e7_guid_norm_n2"]
 HEAVY_CASES = ["e7_heavy_a", "e7_heavy_b"]      # weights with a trained network's dynamic range (tests/heavy_weights.py)
 STL_CASES = ["stl_mixed", "stl_mixed_k8", "stl_wild"]
 REFINEMENT_CASES = ["e7_refinement", "e7_refinement_b"]

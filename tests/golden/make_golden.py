@@ -155,6 +155,7 @@ def sampling_case(ref, sd, name, argv, bs, S, K, steps, seed, invalid_lane_frac=
                               -1 if args.guidance_freq is None else args.guidance_freq], dtype=np.int64)
     out["guid_sets"] = np.array(args.guidance_sets if args.guidance_sets is not None else [], dtype=np.int64)
     out["meta_refinement"] = np.array([50 if args.refinement else 0], dtype=np.int64)
+    out["meta_norm"] = np.array([int(bool(args.norm_stl))], dtype=np.int64)
     if weights_variant is not None:
         out["weights_variant"] = np.array(weights_variant)
     path = os.path.join(HERE, name + ".npz")
@@ -240,11 +241,11 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided", "--refinement-case", "--train-joint", "--heavy", "--readme-guidance")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided", "--refinement-case", "--train-joint", "--heavy", "--readme-guidance", "--norm-fused")):
     main()
 
 
-def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None, joint=False, weights_variant=None):
+def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None, joint=False, weights_variant=None, extra_argv=()):
     """One training step of config 5 (e8_ours_ablation: --rect_head, STL loss through RefineNet; reference
     nusc_train.py:1365-1427 + compute_policy_loss :370-478 + optimizer :1522-1525), driven through the reference's own
     functions.  Stored: inputs, every noise draw, the loss, d loss / d rect_net parameters and the parameters after
@@ -261,7 +262,7 @@ def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None, joint=Fal
                 "--diffusion_steps", str(steps), "--n_randoms", str(S), "--sampling_size", str(S), "--n_neighbors", str(K),
                 "--lr", str(lr)] + (["--diverse_detach"] if e7.get("detach") else []) + (
                     ["--no_arch"] if e7.get("no_arch") else []) + (["--clip_rect"] if e7.get("clip_rect") else [])
-    args = ref_harness.parse_reference_args(argv + (["--joint"] if joint else []))
+    args = ref_harness.parse_reference_args(argv + (["--joint"] if joint else []) + list(extra_argv))
     args.measure_diversity = False        # CPU-side metric (scipy hull), not part of the loss
     net = ref.nusc_model.Net(args)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()
@@ -349,6 +350,7 @@ def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None, joint=Fal
         out["in_" + k] = np_(batch[k])
     out["meta"] = np.array([bs, S, K, steps, seed, mc], dtype=np.int64)
     out["meta_f"] = np.array([args.lr, args.stl_nn_thres], dtype=np.float64)
+    out["meta_norm"] = np.array([int(bool(args.norm_stl))], dtype=np.int64)
     if weights_variant is not None:
         out["weights_variant"] = np.array(weights_variant)
     path = os.path.join(HERE, name + ".npz")
@@ -590,6 +592,23 @@ def main_formats():
 
 if __name__ == "__main__" and "--formats" in sys.argv:
     main_formats()
+
+
+def main_norm_fused():
+    """--norm_stl through the whole path (candidate scoring, guidance, RefineNet training): reference runs with the
+    normalised predicates (nusc_train.py:88-91,97-113)."""
+    ref = ref_harness.load_reference()
+    sd = dict(np.load(WEIGHTS_FILE))
+    e7 = ["--diffusion", "--load_stlp", "--rect_head", "--flex", "--diverse_loss", "--multi_cands", "5", "--norm_stl"]
+    gd = ["--guidance", "--guidance_before", "4", "--guidance_niters", "1", "--guidance_lr", "0.01"]
+    sampling_case(ref, sd, "e7_guid_norm", e7 + gd, bs=2, S=16, K=3, steps=12, seed=96, stlp_mode="wide", invalid_lane_frac=0.25)
+    sampling_case(ref, sd, "e7_guid_norm_n2", e7 + gd[:4] + ["2", "--guidance_lr", "0.02"], bs=2, S=8, K=4, steps=10, seed=97,
+                  stlp_mode="loose", zero_net_out=True)
+    train_case(ref, sd, "train_e8_norm", bs=3, S=8, K=3, steps=10, seed=98, extra_argv=["--norm_stl"])
+
+
+if __name__ == "__main__" and "--norm-fused" in sys.argv:
+    main_norm_fused()
 
 
 def main_norm_stl():

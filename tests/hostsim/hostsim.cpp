@@ -25,41 +25,47 @@ void hostsim_prepare(int bs, int K, const float* nei, const float* l0, const flo
       }
 }
 
-// scores (N), scores3 (3,N) ; controls (N,40) physical units
-void hostsim_stl_forward(int N, int rows_per_scene, int K, float tau, float dt, float ego_L, float ego_W, const float* s0,
-                         const float* controls, const float* nei_prep, const float* lane_prep, const float* stlp,
-                         const float* hl, int all3, float* scores, float* scores3) {
+}  // extern "C"
+
+// scores (N), scores3 (3,N) ; controls (N,40) physical units.  NORM: --norm_stl
+template <bool NORM>
+static void stl_forward_t(int N, int rows_per_scene, int K, float tau, float dt, float ego_L, float ego_W, const float* s0,
+                          const float* controls, const float* nei_prep, const float* lane_prep, const float* stlp,
+                          const float* hl, int all3, float* scores, float* scores3) {
   StlEnv env = make_env(tau, dt, ego_L, ego_W);
   std::vector<float> scratch(kScratchFwd3);
   for (int r = 0; r < N; ++r) {
     const int b = r / rows_per_scene;
     StlRow row = {stlp[r * 6 + 0], stlp[r * 6 + 1], stlp[r * 6 + 2], stlp[r * 6 + 3], stlp[r * 6 + 4], stlp[r * 6 + 5],
                   (int)hl[r]};
+    if (NORM) norm_factors(row);
     Scratch st = {scratch.data(), 1};
     DynSrc src(s0 + b * 4, controls + (long)r * 40, 1.0f, 1.0f, dt);
     const f4* lanes = reinterpret_cast<const f4*>(lane_prep + (long)b * 3 * kNseg * 4);
     const float* nei = nei_prep + (long)b * K * kT * kNeiPrep;
     float o3[3] = {0, 0, 0};
     if (all3) {
-      scores[r] = stl_eval<true, -1>(env, row, lanes, nei, K, src, st, 0, o3, nullptr);
+      scores[r] = stl_eval<true, -1, NORM>(env, row, lanes, nei, K, src, st, 0, o3, nullptr);
       scores3[r] = o3[0], scores3[N + r] = o3[1], scores3[2 * N + r] = o3[2];
     } else {
-      scores[r] = stl_eval<false, -1>(env, row, lanes, nei, K, src, st, 0, nullptr, nullptr);
+      scores[r] = stl_eval<false, -1, NORM>(env, row, lanes, nei, K, src, st, 0, nullptr, nullptr);
     }
   }
 }
 
 // dcontrols (N,40) = dscore[r] * dscore/dcontrols ; relu_mode: dscore[r] is instead -gscale*valid[r]*[thres - score > 0]
-void hostsim_stl_grad(int N, int rows_per_scene, int K, float tau, float dt, float ego_L, float ego_W, const float* s0,
-                      const float* controls, float wscale, float ascale, const float* nei_prep, const float* lane_prep,
-                      const float* stlp, const float* hl, const float* dscore, int relu_mode, float thres, float gscale,
-                      const float* valid, float* scores, float* dcontrols) {
+template <bool NORM>
+static void stl_grad_t(int N, int rows_per_scene, int K, float tau, float dt, float ego_L, float ego_W, const float* s0,
+                       const float* controls, float wscale, float ascale, const float* nei_prep, const float* lane_prep,
+                       const float* stlp, const float* hl, const float* dscore, int relu_mode, float thres, float gscale,
+                       const float* valid, float* scores, float* dcontrols) {
   StlEnv env = make_env(tau, dt, ego_L, ego_W);
   std::vector<float> scratch(kScratchGrad);
   for (int r = 0; r < N; ++r) {
     const int b = r / rows_per_scene;
     StlRow row = {stlp[r * 6 + 0], stlp[r * 6 + 1], stlp[r * 6 + 2], stlp[r * 6 + 3], stlp[r * 6 + 4], stlp[r * 6 + 5],
                   (int)hl[r]};
+    if (NORM) norm_factors(row);
     Scratch st = {scratch.data(), 1};
     const f4* lanes = reinterpret_cast<const f4*>(lane_prep + (long)b * 3 * kNseg * 4);
     const float* nei = nei_prep + (long)b * K * kT * kNeiPrep;
@@ -71,7 +77,23 @@ void hostsim_stl_grad(int N, int rows_per_scene, int K, float tau, float dt, flo
       out[2 * t] = gw;
       out[2 * t + 1] = ga;
     };
-    scores[r] = stl_eval_grad(env, row, lanes, nei, K, s0 + b * 4, controls + (long)r * 40, st, wscale, ascale, dfn, emit);
+    scores[r] = stl_eval_grad<NORM>(env, row, lanes, nei, K, s0 + b * 4, controls + (long)r * 40, st, wscale, ascale, dfn, emit);
   }
 }
+
+extern "C" {
+#define FWD_ARGS int N, int rows_per_scene, int K, float tau, float dt, float ego_L, float ego_W, const float* s0,            \
+                 const float* controls, const float* nei_prep, const float* lane_prep, const float* stlp, const float* hl,      \
+                 int all3, float* scores, float* scores3
+#define FWD_PASS N, rows_per_scene, K, tau, dt, ego_L, ego_W, s0, controls, nei_prep, lane_prep, stlp, hl, all3, scores, scores3
+void hostsim_stl_forward(FWD_ARGS) { stl_forward_t<false>(FWD_PASS); }
+void hostsim_stl_forward_norm(FWD_ARGS) { stl_forward_t<true>(FWD_PASS); }
+#define GRAD_ARGS int N, int rows_per_scene, int K, float tau, float dt, float ego_L, float ego_W, const float* s0,           \
+                  const float* controls, float wscale, float ascale, const float* nei_prep, const float* lane_prep,             \
+                  const float* stlp, const float* hl, const float* dscore, int relu_mode, float thres, float gscale,            \
+                  const float* valid, float* scores, float* dcontrols
+#define GRAD_PASS N, rows_per_scene, K, tau, dt, ego_L, ego_W, s0, controls, wscale, ascale, nei_prep, lane_prep, stlp, hl,     \
+                  dscore, relu_mode, thres, gscale, valid, scores, dcontrols
+void hostsim_stl_grad(GRAD_ARGS) { stl_grad_t<false>(GRAD_PASS); }
+void hostsim_stl_grad_norm(GRAD_ARGS) { stl_grad_t<true>(GRAD_PASS); }
 }

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (HEAVY_CASES, SAMPLING_CASES, STL_CASES, golden_meta, golden_weights, guidance_cfg, guided_outlier_rows,
+from conftest import (HEAVY_CASES, SAMPLING_CASES, STL_CASES, golden_meta, hparams_for, golden_weights, guidance_cfg, guided_outlier_rows,
                       load_golden, region_kwargs, scene_from_golden)
 from pstl_diffusion_policy_amd.engine import guidance_triggered
 
@@ -40,7 +40,7 @@ def _weights(dev, zero_out=False, d=None):
 
 def _scene_batch(d, S, dev):
     from pstl_diffusion_policy_amd.engine import SceneBatch
-    return SceneBatch({k: torch.from_numpy(v) for k, v in scene_from_golden(d).items()}, S, _hp(), dev)
+    return SceneBatch({k: torch.from_numpy(v) for k, v in scene_from_golden(d).items()}, S, hparams_for(d), dev)
 
 
 def _mask_equal_outside_band(mine, ref, band=1e-4):
@@ -118,7 +118,7 @@ def _run_region(dev, name, chain_waves=0):
     meta = golden_meta(d)
     w, _ = _weights(dev, zero_out=bool(meta["zero_net_out"]), d=d)
     sb = _scene_batch(d, meta["S"], dev)
-    sm = Sampler(w, _hp(), chain_waves=chain_waves)
+    sm = Sampler(w, hparams_for(d), chain_waves=chain_waves)
     assert sm.chain_waves == chain_waves and sm.chain_fallback is None      # every fixture's weights are inside the domain
     out = sm.sampling_region(sb, meta["steps"], torch.from_numpy(d["x_T"]).to(dev), torch.from_numpy(d["z"]).to(dev),
                              full_list=True, **region_kwargs(meta))

@@ -147,8 +147,11 @@ def test_prep_stl_cache_signals_match_reference(dev, name):
             np.testing.assert_allclose(got, want, rtol=1e-5, atol=tol, err_msg=k)
 
 
-def test_norm_stl_variant_matches_reference(dev):
-    """--norm_stl (nusc_train.py:88-91,97-113): signals by pstl_stl_signals, formulas by the generic program kernel."""
+@pytest.mark.parametrize("generic", [False, True])
+def test_norm_stl_variant_matches_reference(dev, generic):
+    """--norm_stl (nusc_train.py:88-91,97-113) through compute_stl_dense: the fused kernel (PSTL_FLAG_NORM_STL), and -- generic
+    -- signals by pstl_stl_signals + the formula objects on the generic program kernel; both against the reference, the
+    fused scores with exact satisfaction masks, and its adjoint against the reference's autograd."""
     from conftest import load_golden, scene_from_golden
     from pstl_diffusion_policy_amd import nusc_train as nt
     from pstl_diffusion_policy_amd.engine import SceneBatch
@@ -161,7 +164,22 @@ def test_norm_stl_variant_matches_reference(dev):
          "_pstl": sb}
     hl = torch.from_numpy(d["in_highlevel_dense"]).to(dev)
     valid = torch.from_numpy(d["in_valids_dense"]).to(dev)
+    args.generic_stl = generic
     scores_list, scores, acc, scene_acc = nt.compute_stl_dense(x, stls, hl, valid, args, scene=True)
     np.testing.assert_allclose(torch.stack(scores_list[:3]).cpu().numpy(), d["scores3"], rtol=1e-4, atol=2e-4)
     np.testing.assert_allclose(scores.cpu().numpy(), d["scores"], rtol=1e-4, atol=2e-4)
     assert float(acc) == pytest.approx(float(d["acc"]), abs=1e-6) and float(scene_acc) == pytest.approx(float(d["scene_acc"]), abs=1e-6)
+    if not generic:
+        from pstl_diffusion_policy_amd.engine import PackedWeights, Sampler
+        from conftest import golden_weights
+        np.testing.assert_array_equal(scores.cpu().numpy() > 0, d["scores"] > 0)
+        sm = Sampler(PackedWeights(golden_weights(), dev), nt._hp(args))
+        c = torch.from_numpy(d["controls"]).reshape(sb.N, 40).to(dev)
+        sc, g = sm.score_grad(sb, c)
+        np.testing.assert_allclose(sc.cpu().numpy(), d["scores"], rtol=1e-4, atol=2e-4)
+        ref = d["grad_sum"].reshape(-1, 40)
+        scale = np.abs(ref).max(axis=1, keepdims=True) + 1e-20
+        np.testing.assert_allclose(g.cpu().numpy() / scale, ref / scale, rtol=5e-3, atol=5e-4)
+        # the two many-iteration loops are built for the default formulas and say so
+        with pytest.raises(RuntimeError, match="shape"):
+            sm.trajopt(sb, c.clone(), 2, 0.005)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_weights, load_golden, scene_from_golden
+from conftest import golden_weights, hparams_for, load_golden, scene_from_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -13,7 +13,7 @@ def _setup(d, dev):
     from pstl_diffusion_policy_amd.engine import PackedWeights, RectTrainer, SceneBatch, Sampler
     from pstl_diffusion_policy_amd.synthetic import default_hparams
     bs, S, K, steps, seed, mc = [int(v) for v in d["meta"]]
-    hp = default_hparams()
+    hp = hparams_for(d)
     sd = {k: torch.from_numpy(v).to(dev) for k, v in golden_weights(d).items()}
     sm = Sampler(PackedWeights(sd, dev), hp)
     sb = SceneBatch({k: torch.from_numpy(v) for k, v in scene_from_golden(d).items()}, S, hp, dev)
@@ -22,7 +22,7 @@ def _setup(d, dev):
 
 # train_e8_heavy: rect_net with a trained network's dynamic range (tests/heavy_weights.py): the training forward pass runs
 # on the split-f16 chain too
-@pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b", "train_e8_heavy"])
+@pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b", "train_e8_heavy", "train_e8_norm"])
 def test_rect_train_step_matches_reference(name):
     dev = torch.device("cuda:0")
     d = load_golden(name)

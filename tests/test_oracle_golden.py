@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (REFINEMENT_CASES, SAMPLING_CASES, STL_CASES, golden_meta, golden_weights, guided_outlier_rows,
+from conftest import (REFINEMENT_CASES, SAMPLING_CASES, STL_CASES, golden_meta, golden_weights, guided_outlier_rows, hparams_for,
                       load_golden, refinement_gate, region_kwargs, scene_from_golden)
 from oracle import pstl_oracle as orc
 from pstl_diffusion_policy_amd.synthetic import default_hparams
@@ -37,7 +37,7 @@ def test_schedule_matches_reference():
 def test_sampling_region_matches_reference(name):
     d = load_golden(name)
     meta = golden_meta(d)
-    hp = default_hparams()
+    hp = hparams_for(d)
     out = orc.sampling_region(_weights_for(meta, d), scene_from_golden(d), meta["S"], meta["steps"], hp, d["x_T"], d["z"],
                               **region_kwargs(meta))
     np.testing.assert_allclose(out["feature_scene"].numpy(), d["feature_scene"], rtol=0, atol=2e-6)

@@ -3,18 +3,18 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_weights, load_golden, scene_from_golden
+from conftest import golden_weights, hparams_for, load_golden, scene_from_golden
 from oracle import pstl_oracle as orc
 from pstl_diffusion_policy_amd.synthetic import default_hparams
 
 
-@pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b", "train_e8_heavy"])
+@pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b", "train_e8_heavy", "train_e8_norm"])
 def test_rect_train_step_matches_reference(name):
     d = load_golden(name)
     bs, S, K, steps, seed, mc = [int(v) for v in d["meta"]]
     lr = float(d["meta_f"][0])
     sd = {k: v for k, v in golden_weights(d).items()}
-    out = orc.rect_train_step(sd, scene_from_golden(d), S, default_hparams(), d["sel_controls"], d["sel_scores"], lr)
+    out = orc.rect_train_step(sd, scene_from_golden(d), S, hparams_for(d), d["sel_controls"], d["sel_scores"], lr)
     np.testing.assert_allclose(out["rect_controls"].numpy(), d["rect_controls"], rtol=0, atol=5e-6)
     np.testing.assert_allclose(float(out["loss"]), float(d["loss"]), rtol=1e-5)
     for k, g in out["grads"].items():

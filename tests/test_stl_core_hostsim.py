@@ -53,7 +53,8 @@ class HostRows:
         scores = np.zeros(self.N, np.float32)
         s3 = np.zeros((3, self.N), np.float32)
         hp = self.hp
-        self.hs.hostsim_stl_forward(self.N, 3 * self.S, self.K, ctypes.c_float(hp["smoothing_factor"]),
+        fn = self.hs.hostsim_stl_forward_norm if hp.get("norm_stl") else self.hs.hostsim_stl_forward
+        fn(self.N, 3 * self.S, self.K, ctypes.c_float(hp["smoothing_factor"]),
                                     ctypes.c_float(hp["dt"]), ctypes.c_float(hp["ego_L"]), ctypes.c_float(hp["ego_W"]),
                                     _ptr(self.s0), _ptr(c), _ptr(self.nei_prep), _ptr(self.lane_prep), _ptr(self.stlp),
                                     _ptr(self.hl), int(all3), _ptr(scores), _ptr(s3))
@@ -64,7 +65,8 @@ class HostRows:
         scores = np.zeros(self.N, np.float32)
         g = np.zeros((self.N, 40), np.float32)
         hp = self.hp
-        self.hs.hostsim_stl_grad(self.N, 3 * self.S, self.K, ctypes.c_float(hp["smoothing_factor"]),
+        fn = self.hs.hostsim_stl_grad_norm if hp.get("norm_stl") else self.hs.hostsim_stl_grad
+        fn(self.N, 3 * self.S, self.K, ctypes.c_float(hp["smoothing_factor"]),
                                  ctypes.c_float(hp["dt"]), ctypes.c_float(hp["ego_L"]), ctypes.c_float(hp["ego_W"]),
                                  _ptr(self.s0), _ptr(c), ctypes.c_float(wscale), ctypes.c_float(ascale),
                                  _ptr(self.nei_prep), _ptr(self.lane_prep), _ptr(self.stlp), _ptr(self.hl),
@@ -84,6 +86,25 @@ def test_scores_match_reference_golden(hs, name):
     np.testing.assert_array_equal(scores > 0, d["scores"] > 0)            # satisfaction mask: exact
     sel, _ = rows.forward(d["controls"], all3=False)
     np.testing.assert_array_equal(sel, scores)                             # selected-formula path is the same arithmetic
+
+
+def test_norm_stl_scores_and_adjoint_match_reference(hs):
+    """--norm_stl (nusc_train.py:88-91,97-113) in the fused per-row arithmetic: scores, masks and autograd gradients of the
+    reference's normalised formulas (stl_norm.npz)."""
+    d = load_golden("stl_norm")
+    bs, S, K, seed = [int(v) for v in d["meta"]]
+    hp = dict(default_hparams(), norm_stl=True)
+    rows = HostRows(hs, scene_from_golden(d), S, hp)
+    scores, s3 = rows.forward(d["controls"], all3=True)
+    np.testing.assert_allclose(s3, d["scores3"], rtol=2e-5, atol=2e-4)
+    np.testing.assert_array_equal(scores > 0, d["scores"] > 0)
+    plain, _ = HostRows(hs, scene_from_golden(d), S, default_hparams()).forward(d["controls"], all3=True)
+    assert np.abs(plain - scores).max() > 1e-2            # the normalisation does change the scores
+    sc, g = rows.grad(d["controls"])
+    np.testing.assert_array_equal(sc, scores)
+    ref = d["grad_sum"].reshape(-1, 40)
+    scale = np.abs(ref).max(axis=1, keepdims=True) + 1e-20
+    np.testing.assert_allclose(g / scale, ref / scale, rtol=2e-3, atol=2e-4)
 
 
 @pytest.mark.parametrize("name", ["e7_wide", "e7_steps50_k8", "e7_steps12"])
