@@ -326,6 +326,22 @@ __device__ __forceinline__ bool pieces_overflowed(unsigned ovf) { return (ovf & 
 #ifndef PSTL_EXP_PREFETCH
 #define PSTL_EXP_PREFETCH 0
 #endif
+// Experiment: layer 1's second k-block holds only 16 real input columns (k = 32..47 of the 47 + 1 padded to 64): its three
+// products run on v_mfma_f32_16x16x16_f16 over the first four slots of the packed operands (k = 32 + 4 g + j, exactly that
+// instruction's operand order), which halves the registers of those A operands (8 fewer) and of the x pieces (4 fewer).
+#ifndef PSTL_EXP_K16
+#define PSTL_EXP_K16 0
+#endif
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 mfma_k16(f16x4 a, f16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+template <typename PV>
+__device__ __forceinline__ f16x4 low4(const PV& v) {   // slots 0..3 of a packed 8-slot operand
+  const u32x4 w = __builtin_bit_cast(u32x4, v);
+  return __builtin_bit_cast(f16x4, u32x2{w[0], w[1]});
+}
 __device__ __forceinline__ void pin_after(f32x4& next, const f32x4& prev) {
   if (PSTL_EXP_PIN) asm volatile("" : "+v"(next) : "v"(prev));
 }
@@ -418,7 +434,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 
   // ---- weights -> registers (A operands), once per launch ----
   float w1x[BF ? 1 : OT][12], w2[BF ? 1 : OT][64], w3[3][BF ? 1 : OT][4];
+  constexpr bool K16 = F16 && PSTL_EXP_K16;
   pv8 w1h[OT][2], w1l[OT][2], w2h[OT][8], w2l[OT][8], w3h[3], w3l[3];
+  f16x4 w1h1[OT], w1l1[OT];   // K16: layer 1's second k-block, slots 0..3 only
   {
     const float* p1 = a.packed + a.off.w1x;
     const float* p2 = a.packed + a.off.w2;
@@ -436,7 +454,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       for (int ot = 0; ot < OT; ++ot) {
         const int T = w * OT + ot;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) load_pair(q1, (long)T * 2 + kb, w1h[ot][kb], w1l[ot][kb]);
+        for (int kb = 0; kb < (K16 ? 1 : 2); ++kb) load_pair(q1, (long)T * 2 + kb, w1h[ot][kb], w1l[ot][kb]);
+        if constexpr (K16) {
+          const u32x2* q2p = reinterpret_cast<const u32x2*>(q1);     // the first 8 of the 16 bytes of each entry
+          w1h1[ot] = __builtin_bit_cast(f16x4, q2p[(((long)T * 2 + 1) * 2 + 0) * 128 + 2 * lane]);
+          w1l1[ot] = __builtin_bit_cast(f16x4, q2p[(((long)T * 2 + 1) * 2 + 1) * 128 + 2 * lane]);
+        }
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) load_pair(q2, (long)T * 8 + kb, w2h[ot][kb], w2l[ot][kb]);
       }
@@ -676,6 +699,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         pv8 bh, bl;
         split8(x0 * kSX, x1 * kSX, bh, bl);
         if constexpr (F16) note_pieces(ovf, bh, true);
+        if constexpr (K16) {
+          if (kb == 1) {
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_k16(w1h1[ot], low4(bh), acc[ot]);
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_k16(w1l1[ot], low4(bh), acc[ot]);
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_k16(w1h1[ot], low4(bl), acc[ot]);
+            continue;
+          }
+        }
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w1h[ot][kb], bh, acc[ot]);
 #pragma unroll
@@ -962,7 +996,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       if (PSTL_EXP_PREFETCH) ch = pre_h, cl = pre_l;
       else ch = hbb[0], cl = hbb[64];
       const u32x4* xr = xpb + (it & 1) * 256 + lane;
-      const u32x4 xq0h = xr[0], xq0l = xr[64], xq1h = xr[128], xq1l = xr[192];
+      const u32x4 xq0h = xr[0], xq0l = xr[64];
+      u32x4 xq1h = u32x4{0, 0, 0, 0}, xq1l = u32x4{0, 0, 0, 0};
+      u32x2 xk1h = u32x2{0, 0}, xk1l = u32x2{0, 0};
+      if constexpr (K16) {
+        xk1h = *reinterpret_cast<const u32x2*>(xr + 128);
+        xk1l = *reinterpret_cast<const u32x2*>(xr + 192);
+      } else {
+        xq1h = xr[128], xq1l = xr[192];
+      }
       f32x4 a1[OT];   // starts from the scene/timestep constant part (fetched at k-block 1, used from k-block 2 on)
       pv8 x0h, x0l, x1h, x1l, hh, hl2;
       f32x4 zv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -994,7 +1036,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         }
         if (kb == 0) x0h = __builtin_bit_cast(pv8, xq0h), x0l = __builtin_bit_cast(pv8, xq0l);
         if (kb == 1) x1h = __builtin_bit_cast(pv8, xq1h), x1l = __builtin_bit_cast(pv8, xq1l);
-        if (kb == 2 || kb == 3) {
+        if (K16 && kb == 3) {
+          const f16x4 vh4 = __builtin_bit_cast(f16x4, xk1h), vl4 = __builtin_bit_cast(f16x4, xk1l);
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_k16(w1h1[ot], vh4, a1[ot]);
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_k16(w1l1[ot], vh4, a1[ot]);
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_k16(w1h1[ot], vl4, a1[ot]);
+        } else if (kb == 2 || kb == 3) {
           const pv8 vh = kb == 2 ? x0h : x1h, vl = kb == 2 ? x0l : x1l;
 #pragma unroll
           for (int ot = 0; ot < OT; ++ot) {
