@@ -312,40 +312,6 @@ __device__ __forceinline__ void note_pieces(unsigned& ovf, const PV& hi, bool ma
 }
 __device__ __forceinline__ bool pieces_overflowed(unsigned ovf) { return (ovf & 0xffffu) >= 0x7c00u || (ovf >> 16) >= 0x7c00u; }
 
-// Issue-order pin for the matrix instructions of the fused block: `next` (the accumulator the following MFMA adds to) is
-// made to depend on `prev` (the result of the MFMA issued before it) through an empty asm statement, so that the MFMAs are
-// emitted in SOURCE order -- accumulators alternating.  Left to itself the scheduler groups up to nine MFMAs on one
-// accumulator back to back (a dependent chain issues every ~26 cycles instead of every 16 whenever the SIMD's other wave
-// has no MFMA of its own to put in between) and renames accumulators into operand registers, which costs `s_nop 6` pads.
-#ifndef PSTL_EXP_PIN
-#define PSTL_EXP_PIN 0
-#endif
-// Experiment: the first B operands of layer 2 of the NEXT tile-step (its h1 buffer has been complete for a whole iteration)
-// are requested before the barrier that ends this one and stay in flight across it (raw s_barrier behind a counted
-// lgkmcnt wait that covers this iteration's LDS writes only), so that the MFMA stream restarts without an LDS round trip.
-#ifndef PSTL_EXP_PREFETCH
-#define PSTL_EXP_PREFETCH 0
-#endif
-// Experiment: layer 1's second k-block holds only 16 real input columns (k = 32..47 of the 47 + 1 padded to 64): its three
-// products run on v_mfma_f32_16x16x16_f16 over the first four slots of the packed operands (k = 32 + 4 g + j, exactly that
-// instruction's operand order), which halves the registers of those A operands (8 fewer) and of the x pieces (4 fewer).
-#ifndef PSTL_EXP_K16
-#define PSTL_EXP_K16 0
-#endif
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 mfma_k16(f16x4 a, f16x4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
-}
-template <typename PV>
-__device__ __forceinline__ f16x4 low4(const PV& v) {   // slots 0..3 of a packed 8-slot operand
-  const u32x4 w = __builtin_bit_cast(u32x4, v);
-  return __builtin_bit_cast(f16x4, u32x2{w[0], w[1]});
-}
-__device__ __forceinline__ void pin_after(f32x4& next, const f32x4& prev) {
-  if (PSTL_EXP_PIN) asm volatile("" : "+v"(next) : "v"(prev));
-}
-
 // A value the optimiser must take as it comes at this point of the loop: stops it from hoisting `uniform pointer +
 // lane offset` out of the tile-step loop as a per-lane 64-bit pointer (five of those were live across the loop, spilled,
 // and reloaded in the epilogue behind a full vmcnt wait)
@@ -434,9 +400,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 
   // ---- weights -> registers (A operands), once per launch ----
   float w1x[BF ? 1 : OT][12], w2[BF ? 1 : OT][64], w3[3][BF ? 1 : OT][4];
-  constexpr bool K16 = F16 && PSTL_EXP_K16;
   pv8 w1h[OT][2], w1l[OT][2], w2h[OT][8], w2l[OT][8], w3h[3], w3l[3];
-  f16x4 w1h1[OT], w1l1[OT];   // K16: layer 1's second k-block, slots 0..3 only
   {
     const float* p1 = a.packed + a.off.w1x;
     const float* p2 = a.packed + a.off.w2;
@@ -454,12 +418,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       for (int ot = 0; ot < OT; ++ot) {
         const int T = w * OT + ot;
 #pragma unroll
-        for (int kb = 0; kb < (K16 ? 1 : 2); ++kb) load_pair(q1, (long)T * 2 + kb, w1h[ot][kb], w1l[ot][kb]);
-        if constexpr (K16) {
-          const u32x2* q2p = reinterpret_cast<const u32x2*>(q1);     // the first 8 of the 16 bytes of each entry
-          w1h1[ot] = __builtin_bit_cast(f16x4, q2p[(((long)T * 2 + 1) * 2 + 0) * 128 + 2 * lane]);
-          w1l1[ot] = __builtin_bit_cast(f16x4, q2p[(((long)T * 2 + 1) * 2 + 1) * 128 + 2 * lane]);
-        }
+        for (int kb = 0; kb < 2; ++kb) load_pair(q1, (long)T * 2 + kb, w1h[ot][kb], w1l[ot][kb]);
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) load_pair(q2, (long)T * 8 + kb, w2h[ot][kb], w2l[ot][kb]);
       }
@@ -699,17 +658,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
         pv8 bh, bl;
         split8(x0 * kSX, x1 * kSX, bh, bl);
         if constexpr (F16) note_pieces(ovf, bh, true);
-        if constexpr (K16) {
-          if (kb == 1) {
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_k16(w1h1[ot], low4(bh), acc[ot]);
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_k16(w1l1[ot], low4(bh), acc[ot]);
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_k16(w1h1[ot], low4(bl), acc[ot]);
-            continue;
-          }
-        }
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w1h[ot][kb], bh, acc[ot]);
 #pragma unroll
@@ -934,16 +882,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   bool woven_noise = BF && !REFINE && (ABL == 0 || ABL >= 7) && a.rng && !a.mu_only && w >= NW / 2 && w < NW / 2 + 3;
   // (stamp build: its scalar stamps must not cross a branch the compiler takes for divergent)
   if (ABL == 7) woven_noise = __builtin_amdgcn_readfirstlane((int)woven_noise) != 0;
+  // (Tried in round 3, measured with tools/dbg/time_variants.py, results in profiles/r3/chain_variants_pin_prefetch.txt, code in
+  // commit dbcba2c: pinning the MFMAs to source order -- accumulators strictly alternating instead of the scheduler's runs of up
+  // to nine MFMAs on one accumulator -- +3.3 %; the first B operands of the next tile-step requested before the barrier and
+  // carried across it behind a counted lgkmcnt wait, +16 % with the spills it caused and +1.1 % without them (layer 1's
+  // half-empty second k-block on v_mfma_f32_16x16x16_f16 frees 8-12 registers; by itself +0.9 %, and it rounds differently).
+  // Per-wave phase stamps (chain_waves 816, profiles/r3/chain_phases_per_wave.txt): the noise waves 4-6 arrive last, the
+  // epilogue waves 0-2 wait ~700 cycles at the barrier, yet removing the noise altogether gains 1.4 %: the two waves of a SIMD
+  // share one issue port -- SQ_ACTIVE_INST_ANY of the pair covers 78 % of the wall time -- and what one sheds the other takes.)
   // (Tried in round 2: deferring layer 3 of every tile-step to the head of the next iteration -- accumulators kept across
   // the barrier, epilogue two iterations behind -- so that an iteration ends with layer 2's MFMAs instead of the serial
   // tail split -> layer 3 -> partial sums -> barrier.  Bit-identical, 5.8 % SLOWER (15.42 vs 14.57 ms): behind the barrier
   // the split has no MFMAs of its own wave to hide under.)
   int hbuf = 0;  // it % 3
-  u32x4 pre_h = u32x4{0, 0, 0, 0}, pre_l = u32x4{0, 0, 0, 0};
-  if (BF && PSTL_EXP_PREFETCH) {
-    const u32x4* h0p = reinterpret_cast<const u32x4*>(h1) + lane;
-    pre_h = h0p[0], pre_l = h0p[64];
-  }
   for (int it = 0; it < total; ++it) {
     PSTL_LITE(lt0)
     PSTL_STAMP(0)
@@ -992,19 +943,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       // two tile-steps past the end as well (results never read) to keep the loop body one basic block.
       const int b1 = hbuf == 0 ? 2 : hbuf - 1;
       const u32x4* hbb = reinterpret_cast<const u32x4*>(h1 + hbuf * 4096) + lane;
-      u32x4 ch, cl;
-      if (PSTL_EXP_PREFETCH) ch = pre_h, cl = pre_l;
-      else ch = hbb[0], cl = hbb[64];
+      u32x4 ch = hbb[0], cl = hbb[64];
       const u32x4* xr = xpb + (it & 1) * 256 + lane;
-      const u32x4 xq0h = xr[0], xq0l = xr[64];
-      u32x4 xq1h = u32x4{0, 0, 0, 0}, xq1l = u32x4{0, 0, 0, 0};
-      u32x2 xk1h = u32x2{0, 0}, xk1l = u32x2{0, 0};
-      if constexpr (K16) {
-        xk1h = *reinterpret_cast<const u32x2*>(xr + 128);
-        xk1l = *reinterpret_cast<const u32x2*>(xr + 192);
-      } else {
-        xq1h = xr[128], xq1l = xr[192];
-      }
+      const u32x4 xq0h = xr[0], xq0l = xr[64], xq1h = xr[128], xq1l = xr[192];
       f32x4 a1[OT];   // starts from the scene/timestep constant part (fetched at k-block 1, used from k-block 2 on)
       pv8 x0h, x0l, x1h, x1l, hh, hl2;
       f32x4 zv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -1017,50 +958,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           nl = hbb[(2 * kb + 3) * 64];
         }
         const pv8 bh = __builtin_bit_cast(pv8, ch), bl = __builtin_bit_cast(pv8, cl);
-        // (pin_after: source order = issue order; `last` is the accumulator of the MFMA issued before)
-        if (kb > 0) pin_after(acc[0], (kb == 3 || kb == 4) ? a1[OT - 1] : acc[OT - 1]);
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-          if (ot > 0) pin_after(acc[ot], acc[ot - 1]);
-          acc[ot] = mfma_bf(w2h[ot][kb], bh, acc[ot]);
-        }
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2h[ot][kb], bh, acc[ot]);
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-          pin_after(acc[ot], acc[ot == 0 ? OT - 1 : ot - 1]);
-          acc[ot] = mfma_bf(w2l[ot][kb], bh, acc[ot]);
-        }
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2l[ot][kb], bh, acc[ot]);
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-          pin_after(acc[ot], acc[ot == 0 ? OT - 1 : ot - 1]);
-          acc[ot] = mfma_bf(w2h[ot][kb], bl, acc[ot]);
-        }
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma_bf(w2h[ot][kb], bl, acc[ot]);
         if (kb == 0) x0h = __builtin_bit_cast(pv8, xq0h), x0l = __builtin_bit_cast(pv8, xq0l);
         if (kb == 1) x1h = __builtin_bit_cast(pv8, xq1h), x1l = __builtin_bit_cast(pv8, xq1l);
-        if (K16 && kb == 3) {
-          const f16x4 vh4 = __builtin_bit_cast(f16x4, xk1h), vl4 = __builtin_bit_cast(f16x4, xk1l);
-#pragma unroll
-          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_k16(w1h1[ot], vh4, a1[ot]);
-#pragma unroll
-          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_k16(w1l1[ot], vh4, a1[ot]);
-#pragma unroll
-          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_k16(w1h1[ot], vl4, a1[ot]);
-        } else if (kb == 2 || kb == 3) {
+        if (kb == 2 || kb == 3) {
           const pv8 vh = kb == 2 ? x0h : x1h, vl = kb == 2 ? x0l : x1l;
 #pragma unroll
-          for (int ot = 0; ot < OT; ++ot) {
-            pin_after(a1[ot], ot == 0 ? acc[OT - 1] : a1[ot - 1]);
-            a1[ot] = mfma_bf(w1h[ot][kb - 2], vh, a1[ot]);
-          }
+          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vh, a1[ot]);
 #pragma unroll
-          for (int ot = 0; ot < OT; ++ot) {
-            pin_after(a1[ot], a1[ot == 0 ? OT - 1 : ot - 1]);
-            a1[ot] = mfma_bf(w1l[ot][kb - 2], vh, a1[ot]);
-          }
+          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1l[ot][kb - 2], vh, a1[ot]);
 #pragma unroll
-          for (int ot = 0; ot < OT; ++ot) {
-            pin_after(a1[ot], a1[ot == 0 ? OT - 1 : ot - 1]);
-            a1[ot] = mfma_bf(w1h[ot][kb - 2], vl, a1[ot]);
-          }
+          for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vl, a1[ot]);
         }
         if (kb == 1) l1_const(p2, b1, a1);
         if (kb == 5) {
@@ -1120,20 +1033,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       split_hidden(acc[0], acc[OT - 1], bh, bl);
       if constexpr (SAVE) save_hidden(a.h2_save, p0, acc);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        pin_after(acc3[j], j == 0 ? acc[OT - 1] : acc3[j - 1]);
-        acc3[j] = mfma_bf(w3h[j], bh, acc3[j]);
-      }
+      for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bh, acc3[j]);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        pin_after(acc3[j], acc3[j == 0 ? 2 : j - 1]);
-        acc3[j] = mfma_bf(w3l[j], bh, acc3[j]);
-      }
+      for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3l[j], bh, acc3[j]);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        pin_after(acc3[j], acc3[j == 0 ? 2 : j - 1]);
-        acc3[j] = mfma_bf(w3h[j], bl, acc3[j]);
-      }
+      for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bl, acc3[j]);
       u32x4* hwb = reinterpret_cast<u32x4*>(h1 + b1 * 4096);
       hwb[(w * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
       hwb[(w * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, hl2);
@@ -1184,17 +1088,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     PSTL_STAMP(4)
     if (UT && w == kStager) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged rows have landed
     PSTL_LITE(lt2)
-    if (BF && PSTL_EXP_PREFETCH) {
-      const u32x4* hnp = reinterpret_cast<const u32x4*>(h1 + (hbuf == 2 ? 0 : hbuf + 1) * 4096) + lane;
-      __builtin_amdgcn_sched_barrier(0);      // every LDS write of this iteration is issued before the two reads ...
-      pre_h = hnp[0];
-      pre_l = hnp[64];
-      __builtin_amdgcn_sched_barrier(0);
-      // ... LDS operations of a wave complete in issue order: all but the two youngest done = the writes have landed
-      asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
-    } else {
-      __syncthreads();
-    }
+    __syncthreads();
     PSTL_LITE(lt3)
     if (ABL == 8) lt_role += lt1 - lt0, lt_body += lt2 - lt1, lt_bar += lt3 - lt2;
     PSTL_STAMP(5)
