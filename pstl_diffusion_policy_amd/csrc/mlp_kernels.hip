@@ -273,7 +273,12 @@ __device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 mfma_bf(f16x8 a, f16x8 b, f32x4 c) {
+#ifdef PSTL_ABL_NO_MFMA      // timing-only ablation (tools/dbg): the instruction stream without its matrix instructions
+  asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
 }
 
 // eight fp32 values -> their 16-bit hi pieces and the 16-bit rounding of what the hi pieces miss
@@ -311,6 +316,15 @@ __device__ __forceinline__ void note_pieces(unsigned& ovf, const PV& hi, bool ma
   }
 }
 __device__ __forceinline__ bool pieces_overflowed(unsigned ovf) { return (ovf & 0xffffu) >= 0x7c00u || (ovf >> 16) >= 0x7c00u; }
+
+// Timing-only ablations of the fused tile-step loop (tools/dbg/build_variants.sh + time_variants.py; results are garbage):
+// PSTL_ABL_SKIP bits: 1 epilogue, 2 noise, 4 the ReLU + half-piece conversions, 8 layer 2's B-operand reads (one k-block is
+// read, the rest reuse it), 16 the input split (waves 3 / 7), 32 layer 1's constant rows, 64 the LDS writes (h1 pieces,
+// partial sums).  PSTL_ABL_NO_MFMA / PSTL_ABL_NO_BARRIER: see mfma_bf and the end of the loop.
+#ifndef PSTL_ABL_SKIP
+#define PSTL_ABL_SKIP 0
+#endif
+
 
 // A value the optimiser must take as it comes at this point of the loop: stops it from hoisting `uniform pointer +
 // lane offset` out of the tile-step loop as a per-lane 64-bit pointer (five of those were live across the loop, spilled,
@@ -618,6 +632,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // a hidden layer's output as the next layer's input: relu, (F16) the accumulator's weight factor divided out, pieces
   auto split_hidden = [&](const f32x4& a0, const f32x4& a1, pv8& hi, pv8& lo) {
     f32x4 h0 = relu4(a0), h1v = relu4(a1);
+    if (PSTL_ABL_SKIP & 4) {
+      hi = __builtin_bit_cast(pv8, a0);
+      lo = __builtin_bit_cast(pv8, a1);
+      return;
+    }
     if (F16) h0 *= kInvSW, h1v *= kInvSW;
     split8(h0, h1v, hi, lo);
     if constexpr (F16) note_pieces(ovf, hi, false);
@@ -879,7 +898,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   __syncthreads();
   // BF, in-kernel noise: waves 4..6 draw it INSIDE their layer-2 MFMA stream (branch-free, one basic block) instead of in
   // a phase of their own in front of it
-  bool woven_noise = BF && !REFINE && (ABL == 0 || ABL >= 7) && a.rng && !a.mu_only && w >= NW / 2 && w < NW / 2 + 3;
+  bool woven_noise = BF && !REFINE && (ABL == 0 || ABL >= 7) && a.rng && !a.mu_only && w >= NW / 2 && w < NW / 2 + 3 &&
+                     !(PSTL_ABL_SKIP & 2);
   // (stamp build: its scalar stamps must not cross a branch the compiler takes for divergent)
   if (ABL == 7) woven_noise = __builtin_amdgcn_readfirstlane((int)woven_noise) != 0;
   // (Tried in round 3, measured with tools/dbg/time_variants.py, results in profiles/r3/chain_variants_pin_prefetch.txt, code in
@@ -887,6 +907,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // to nine MFMAs on one accumulator -- +3.3 %; the first B operands of the next tile-step requested before the barrier and
   // carried across it behind a counted lgkmcnt wait, +16 % with the spills it caused and +1.1 % without them (layer 1's
   // half-empty second k-block on v_mfma_f32_16x16x16_f16 frees 8-12 registers; by itself +0.9 %, and it rounds differently).
+  // The input split of waves 3 / 7 woven into their fused block as a third variant of it (loads at k-block 4, conversions and
+  // stores at k-block 6, where the x pieces of this iteration are dead): 14 registers spilled in the multi-step kernel, dropped.
   // Per-wave phase stamps (chain_waves 816, profiles/r3/chain_phases_per_wave.txt): the noise waves 4-6 arrive last, the
   // epilogue waves 0-2 wait ~700 cycles at the barrier, yet removing the noise altogether gains 1.4 %: the two waves of a SIMD
   // share one issue port -- SQ_ACTIVE_INST_ANY of the pair covers 78 % of the wall time -- and what one sheds the other takes.)
@@ -898,17 +920,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   for (int it = 0; it < total; ++it) {
     PSTL_LITE(lt0)
     PSTL_STAMP(0)
-    if (UT && w == kStager && it + 3 < total) stage_cst(p3, hbuf);
+    if (UT && w == kStager && it + 3 < total && !(PSTL_ABL_SKIP & 32)) stage_cst(p3, hbuf);
     if (cont && w == kStager && it >= 2 && it - 2 + G < total) stage_x(Pos{pm2.tl, pm2.n + 1});
-    split_x(p3, (it + 1) & 1);      // pieces for the layer 1 woven into iteration it + 1
+    if (!(PSTL_ABL_SKIP & 16)) split_x(p3, (it + 1) & 1);      // pieces for the layer 1 woven into iteration it + 1
     if (NOISE_SPLIT && (ABL == 0 || ABL >= 7)) {
-      if (w >= NW / 2 && w < NW / 2 + NCW && !woven_noise) {
+      if (w >= NW / 2 && w < NW / 2 + NCW && !woven_noise && !(PSTL_ABL_SKIP & 2)) {
         const int nt = tid - NT / 2;
         f32x4 z;
         fetch_noise(p0, nt, z);
         if (nt < 160) zbuf[(it & 1) * 192 + nt] = z;
       }
-      if (epi_wave && it > 0) {
+      if (epi_wave && it > 0 && !(PSTL_ABL_SKIP & 1)) {
         const f32x4 z = tid < 160 ? zbuf[((it - 1) & 1) * 192 + tid] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         epilogue(pm1, (it - 1) & 1, z);
       }
@@ -949,13 +971,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       f32x4 a1[OT];   // starts from the scene/timestep constant part (fetched at k-block 1, used from k-block 2 on)
       pv8 x0h, x0l, x1h, x1l, hh, hl2;
       f32x4 zv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
         u32x4 nh = ch, nl = cl;
         if (kb < 7) {
-          nh = hbb[(2 * kb + 2) * 64];
-          nl = hbb[(2 * kb + 3) * 64];
+          if (!(PSTL_ABL_SKIP & 8)) {
+            nh = hbb[(2 * kb + 2) * 64];
+            nl = hbb[(2 * kb + 3) * 64];
+          }
         }
         const pv8 bh = __builtin_bit_cast(pv8, ch), bl = __builtin_bit_cast(pv8, cl);
 #pragma unroll
@@ -975,7 +1000,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 #pragma unroll
           for (int ot = 0; ot < OT; ++ot) a1[ot] = mfma_bf(w1h[ot][kb - 2], vl, a1[ot]);
         }
-        if (kb == 1) l1_const(p2, b1, a1);
+        if (kb == 1) {
+          if (PSTL_ABL_SKIP & 32) {
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) a1[ot] = acc[ot];
+          } else {
+            l1_const(p2, b1, a1);
+          }
+        }
         if (kb == 5) {
           split_hidden(a1[0], a1[OT - 1], hh, hl2);   // layer 1's output, in the shadow of layer 2's MFMAs
           if constexpr (SAVE)
@@ -1039,8 +1071,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bl, acc3[j]);
       u32x4* hwb = reinterpret_cast<u32x4*>(h1 + b1 * 4096);
-      hwb[(w * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
-      hwb[(w * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, hl2);
+      if (!(PSTL_ABL_SKIP & 64)) {
+        hwb[(w * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
+        hwb[(w * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, hl2);
+      } else {
+        asm volatile("" :: "v"(hh), "v"(hl2));
+      }
 #pragma unroll
       for (int m = 0; m < 9; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1084,11 +1120,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
     f32x4* pw = reinterpret_cast<f32x4*>(part + (it & 1) * (NW * 768));
 #pragma unroll
-    for (int j = 0; j < 3; ++j) pw[(w * 3 + j) * 64 + lane] = acc3[j];
+    for (int j = 0; j < 3; ++j) {
+      if (PSTL_ABL_SKIP & 64) asm volatile("" :: "v"(acc3[j]));
+      else pw[(w * 3 + j) * 64 + lane] = acc3[j];
+    }
     PSTL_STAMP(4)
     if (UT && w == kStager) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged rows have landed
     PSTL_LITE(lt2)
+#ifdef PSTL_ABL_NO_BARRIER   // timing-only ablation: no workgroup barrier in the tile-step loop (results are garbage)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     __syncthreads();
+#endif
     PSTL_LITE(lt3)
     if (ABL == 8) lt_role += lt1 - lt0, lt_body += lt2 - lt1, lt_bar += lt3 - lt2;
     PSTL_STAMP(5)
