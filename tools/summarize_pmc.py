@@ -10,13 +10,18 @@ import sys
 
 d = sys.argv[1]
 SIMDS = 256 * 4
+PT = sys.argv[4] if len(sys.argv) > 4 else "2"      # which arithmetic the summarised bench ran by default
+DOM = "k_chain<8,false,pt%s>" % PT
 
 
 def short(name):
     import re
     m = re.search(r"\b(k_\w+)", name)
     n = m.group(1) if m else name.split("(")[0]
-    if "k_chain" in name:
+    m = re.search(r"k_chain<(\d+), (true|false), \d+, (?:true|false), (\d+)", name)
+    if m:      # waves, REFINE, PT (0 = exact fp32 MFMA, 1 = bfloat16 pieces, 2 = half pieces): the bench runs an fp32 leg too
+        n = "k_chain<%s,%s,pt%s>" % m.groups()
+    elif "k_chain" in name:
         n = "k_chain<8,%s>" % ("true" if "k_chain<8, true" in name else "false")
     return n
 
@@ -43,13 +48,13 @@ for tag, per in passes.items():
         if not (k.startswith("k_") or "k_chain" in k):
             continue
         ds = list(disp.values())
-        if k == "k_chain<8,false>":   # the multi-step launch only (the single-step launches of the guided steps are 30x shorter)
+        if k.startswith("k_chain<8,false"):   # the multi-step launch only (the single-step launches of the guided steps are 30x shorter)
             top = max(e["dur_ns"] for e in ds)
             ds = [e for e in ds if e["dur_ns"] > 0.5 * top]
         keys = sorted(set().union(*[set(e) for e in ds]))
         out["per_kernel"][tag][k] = {name: sum(e.get(name, 0.0) for e in ds) / len(ds) for name in keys}
         out["per_kernel"][tag][k]["launches_averaged"] = len(ds)
-dom = "k_chain<8,false>"
+dom = DOM
 f = out["per_kernel"]["FETCH_SIZE"].get(dom, {})
 w = out["per_kernel"]["WRITE_SIZE"].get(dom, {})
 sq = out["per_kernel"]["SQ"].get(dom, {})
