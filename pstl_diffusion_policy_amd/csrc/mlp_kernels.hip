@@ -299,7 +299,6 @@ __device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, PV& hi, P
 }
 
 
-
 // Domain guard of the split-f16 arithmetic: the running maximum, per 16-bit half, of the hi pieces' bit patterns
 // (v_pk_max_u16).  A layer input that left the half range shows up as the pattern of infinity (0x7c00) in its hi piece at
 // the very conversion that overflowed -- before any NaN exists, so the test does not depend on NaNs surviving the ReLUs
@@ -320,7 +319,7 @@ __device__ __forceinline__ bool pieces_overflowed(unsigned ovf) { return (ovf & 
 // Timing-only ablations of the fused tile-step loop (tools/dbg/build_variants.sh + time_variants.py; results are garbage):
 // PSTL_ABL_SKIP bits: 1 epilogue, 2 noise, 4 the ReLU + half-piece conversions, 8 layer 2's B-operand reads (one k-block is
 // read, the rest reuse it), 16 the input split (waves 3 / 7), 32 layer 1's constant rows, 64 the LDS writes (h1 pieces,
-// partial sums).  PSTL_ABL_NO_MFMA / PSTL_ABL_NO_BARRIER: see mfma_bf and the end of the loop.
+// partial sums), 128 / 256 only the conversion in front of layer 3 / only the one of layer 1's output (k-block 5).  PSTL_ABL_NO_MFMA / PSTL_ABL_NO_BARRIER: see mfma_bf and the end of the loop.
 #ifndef PSTL_ABL_SKIP
 #define PSTL_ABL_SKIP 0
 #endif
@@ -630,9 +629,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   };
 
   // a hidden layer's output as the next layer's input: relu, (F16) the accumulator's weight factor divided out, pieces
-  auto split_hidden = [&](const f32x4& a0, const f32x4& a1, pv8& hi, pv8& lo) {
+  auto split_hidden = [&](const f32x4& a0, const f32x4& a1, pv8& hi, pv8& lo, int which = 0) {
     f32x4 h0 = relu4(a0), h1v = relu4(a1);
-    if (PSTL_ABL_SKIP & 4) {
+    if ((PSTL_ABL_SKIP & 4) || ((PSTL_ABL_SKIP & 128) && which == 1) || ((PSTL_ABL_SKIP & 256) && which == 2)) {
       hi = __builtin_bit_cast(pv8, a0);
       lo = __builtin_bit_cast(pv8, a1);
       return;
@@ -911,7 +910,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // stores at k-block 6, where the x pieces of this iteration are dead): 14 registers spilled in the multi-step kernel, dropped.
   // Per-wave phase stamps (chain_waves 816, profiles/r3/chain_phases_per_wave.txt): the noise waves 4-6 arrive last, the
   // epilogue waves 0-2 wait ~700 cycles at the barrier, yet removing the noise altogether gains 1.4 %: the two waves of a SIMD
-  // share one issue port -- SQ_ACTIVE_INST_ANY of the pair covers 78 % of the wall time -- and what one sheds the other takes.)
+  // share one issue port -- SQ_ACTIVE_INST_ANY of the pair covers 78 % of the wall time -- and what one sheds the other takes.
+  // Wave priorities (s_setprio; profiles/r3/chain_variants_setprio_mix.txt): waves 4-7 above 0-3 +9.7 %, a wave in its fused
+  // block above a partner in its role work +13.8 %, the role work above the fused block +1.8 %, waves 0-3 above 4-7 -0.1 %.
+  // With the MFMAs in place, deleting the ReLU + piece conversions gains 12-13 % (each of the two sites ~5 %), layer 2's operand
+  // reads 3.2 %, the LDS writes 4.5 %, layer 1's constant rows 1.7 % -- it is the instruction count that costs.  Both pieces
+  // straight from v_fma_mixlo/hi_f16 (3 instructions per value with the ReLU instead of 4; inline asm, since the SLP vectoriser
+  // turns the C++ form into v_pk_fma_f32 + conversions): same bits, +1.8 % -- the scheduler's issue groups do not see asm
+  // statements as vector instructions and push them out of the MFMA shadow; the C++ form built with -fno-slp-vectorize does
+  // select them, and is +3.7 % (the build flag alone: +3.5 %, the packed fp32 operations elsewhere in the loop are lost).)
   // (Tried in round 2: deferring layer 3 of every tile-step to the head of the next iteration -- accumulators kept across
   // the barrier, epilogue two iterations behind -- so that an iteration ends with layer 2's MFMAs instead of the serial
   // tail split -> layer 3 -> partial sums -> barrier.  Bit-identical, 5.8 % SLOWER (15.42 vs 14.57 ms): behind the barrier
@@ -1009,7 +1016,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           }
         }
         if (kb == 5) {
-          split_hidden(a1[0], a1[OT - 1], hh, hl2);   // layer 1's output, in the shadow of layer 2's MFMAs
+          split_hidden(a1[0], a1[OT - 1], hh, hl2, 2);   // layer 1's output, in the shadow of layer 2's MFMAs
           if constexpr (SAVE)
             if (it + 2 < total) save_hidden(a.h1_save, p2, a1);
         }
@@ -1062,7 +1069,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       PSTL_STAMP(3)
       // layer 3 of tile-step it; the ReLU + split of layer 1's output sits between its MFMAs
       pv8 bh, bl;
-      split_hidden(acc[0], acc[OT - 1], bh, bl);
+      split_hidden(acc[0], acc[OT - 1], bh, bl, 1);
       if constexpr (SAVE) save_hidden(a.h2_save, p0, acc);
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc3[j] = mfma_bf(w3h[j], bh, acc3[j]);
