@@ -66,10 +66,13 @@ typedef struct pstl_cfg {
   int32_t steps;           /* --diffusion_steps                                           */
   int32_t n_shards;        /* --n_shards (merge_net max-pool groups)                      */
   int32_t flags;           /* PSTL_FLAG_*                                                 */
-  int32_t chain_waves;     /* arithmetic of the MLP chains (policy_net, rect_net): 0 (= 16) = default: every fp32
+  int32_t chain_waves;     /* arithmetic of the MLP chains (policy_net, rect_net): 0 or 16 = default: every fp32
                               operand as two IEEE-half pieces (2^-23 per operand), three
                               v_mfma_f32_16x16x32_f16 products per fp32 product, fp32 accumulate -- as close to
-                              the reference as an fp32 fmaf chain in another summation order; 8 or 4 = fp32
+                              the reference as an fp32 fmaf chain in another summation order (0: batches with
+                              fewer than five 16-row tiles per CU -- the closed-loop caller's 192 rows -- run
+                              the multi-step launch in a latency layout, 1..4 tiles per workgroup; 16: always
+                              the throughput layout; the results are bit-identical); 8 or 4 = fp32
                               MFMA (v_mfma_f32_16x16x4_f32) with 8 / 4 waves per workgroup; 32 = policy_net
                               on bfloat16 pieces (2^-17 per operand), rect_net on fp32 MFMA.
                               DOMAIN of 0 / 16: the pieces are halves of 2^10 w and 2^4 x, so the chain weights must

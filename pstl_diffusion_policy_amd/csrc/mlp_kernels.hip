@@ -366,7 +366,8 @@ __device__ __forceinline__ int xs_addr(int k, int c) { return (((k >> 4) * 64) +
 // PERSIST: one workgroup per CU walks the 12-tile groups blockIdx.x, blockIdx.x + gridDim.x, ... with the weights loaded
 // into registers once (used for the single-step launches of the guided phase, where the 344 KB weight fetch and the
 // workgroup turnover are ~10 % of a 12-iteration workgroup).
-template <int NW, bool REFINE, int ABL = 0, bool UT = false, int PT = 0, bool PERSIST = false, bool SAVE = false>
+template <int NW, bool REFINE, int ABL = 0, bool UT = false, int PT = 0, bool PERSIST = false, bool SAVE = false,
+          bool SPARSE = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   constexpr bool BF = PT != 0;      // the operands are split into two 16-bit pieces
   constexpr bool F16 = PT == 2;     // ... of IEEE half (scaled, see k_pack_a_split); PT == 1: bfloat16 pieces
@@ -481,6 +482,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   const long tile0 = grp * a.tiles_per_group;
   auto t0 = [&](int n) { return cont ? ((long)blockIdx.x + (long)n * gridDim.x) * a.tiles_per_group : tile0; };
   int G = (int)((n_tiles - tile0) < a.tiles_per_group ? (n_tiles - tile0) : a.tiles_per_group);
+  // SPARSE (latency layout for small batches, tiles_per_group 1..4): the workgroup owns Gr < 5 tiles; the other slots of the
+  // five-deep software pipeline are EMPTY rather than phantom tiles: an iteration does only the stages whose tile exists
+  // (nothing at all -- just the barrier -- when neither layer 1's nor layer 2's position is a tile).  Same arithmetic per
+  // row, so the same bits as the throughput layout.
+  const int Gr = G;
+  auto real = [&](int tl) { return !SPARSE || tl < Gr; };
   // Layer 1 runs two tile-steps ahead and the epilogue one behind, so >= 4 tiles must be in flight (see the hazard
   // notes below); short tail blocks process phantom tiles whose rows are clamped on load and masked on store.
   // (XONCE: the pieces of a tile's image are made one more iteration ahead: >= 5.)
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     *reinterpret_cast<f32x4*>(xs + tl * 768 + xs_addr(4 * j, c)) = v;   // (unscaled: the split-f16 factor kSX is applied where the pieces are made)
   }
   if (!REFINE && a.n_emit >= a.steps && a.step_hi == a.steps - 1) {  // x_T itself is entry 0 of the full list
-    for (int e = tid; e < G * kTileRows * kCtrl; e += NT) {
+    for (int e = tid; e < (SPARSE ? Gr : G) * kTileRows * kCtrl; e += NT) {
       const long row = tile0 * kTileRows + e / kCtrl;
       const int f = e % kCtrl;
       if (row < a.N) {
@@ -927,17 +934,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   for (int it = 0; it < total; ++it) {
     PSTL_LITE(lt0)
     PSTL_STAMP(0)
-    if (UT && w == kStager && it + 3 < total && !(PSTL_ABL_SKIP & 32)) stage_cst(p3, hbuf);
+    if (UT && w == kStager && it + 3 < total && !(PSTL_ABL_SKIP & 32) && real(p3.tl)) stage_cst(p3, hbuf);
     if (cont && w == kStager && it >= 2 && it - 2 + G < total) stage_x(Pos{pm2.tl, pm2.n + 1});
-    if (!(PSTL_ABL_SKIP & 16)) split_x(p3, (it + 1) & 1);      // pieces for the layer 1 woven into iteration it + 1
+    if (!(PSTL_ABL_SKIP & 16) && real(p3.tl)) split_x(p3, (it + 1) & 1);      // pieces for the layer 1 woven into iteration it + 1
     if (NOISE_SPLIT && (ABL == 0 || ABL >= 7)) {
-      if (w >= NW / 2 && w < NW / 2 + NCW && !woven_noise && !(PSTL_ABL_SKIP & 2)) {
+      if (w >= NW / 2 && w < NW / 2 + NCW && !woven_noise && !(PSTL_ABL_SKIP & 2) && real(p0.tl)) {
         const int nt = tid - NT / 2;
         f32x4 z;
         fetch_noise(p0, nt, z);
         if (nt < 160) zbuf[(it & 1) * 192 + nt] = z;
       }
-      if (epi_wave && it > 0 && !(PSTL_ABL_SKIP & 1)) {
+      if (epi_wave && it > 0 && !(PSTL_ABL_SKIP & 1) && real(pm1.tl)) {
         const f32x4 z = tid < 160 ? zbuf[((it - 1) & 1) * 192 + tid] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         epilogue(pm1, (it - 1) & 1, z);
       }
@@ -956,6 +963,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     if (!BF && it + 2 < total) layer1(p2, hbuf == 0 ? 2 : hbuf - 1);
     PSTL_STAMP(2)
     // ---------------- layer 2: 256 -> 256 (B from LDS), layer 3: this wave's 16*OT features -> 48 ----------------
+    if (SPARSE && BF && !real(p0.tl)) {   // an empty layer-2 slot: at most layer 1 of tile-step it + 2, stand-alone
+      if (real(p2.tl) && it + 2 < total) layer1(p2, hbuf == 0 ? 2 : hbuf - 1);
+    } else {
     f32x4 acc[OT];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) acc[ot] = reinterpret_cast<const f32x4*>(b2s)[(w * OT + ot) * 4 + g];
@@ -1131,6 +1141,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       if (PSTL_ABL_SKIP & 64) asm volatile("" :: "v"(acc3[j]));
       else pw[(w * 3 + j) * 64 + lane] = acc3[j];
     }
+    }
     PSTL_STAMP(4)
     if (UT && w == kStager) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged rows have landed
     PSTL_LITE(lt2)
@@ -1150,7 +1161,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     dbg[w * 4 + 0] = lt_role, dbg[w * 4 + 1] = lt_body, dbg[w * 4 + 2] = lt_bar, dbg[w * 4 + 3] = (unsigned long long)total;
   }
   if (NOISE_SPLIT && epi_wave && tid < 160) zreg = zbuf[((total - 1) & 1) * 192 + tid];
-  if (epi_wave && (ABL == 0 || ABL >= 7)) epilogue(pm1, (total - 1) & 1, zreg);
+  if (epi_wave && (ABL == 0 || ABL >= 7) && real(pm1.tl)) epilogue(pm1, (total - 1) & 1, zreg);
   if (ABL != 0 && a.N < 0) epilogue(p0, 0, zreg);  // keep the code reachable for the compiler, never executed
   if (!PERSIST || cont) break;
   }
@@ -1640,6 +1651,16 @@ inline int tiles_per_group(long N) {
   return (int)g;
 }
 
+// The latency layout: fewer than five tiles per CU -> 1..4 tiles per workgroup, spread over as many CUs as there are tiles
+// (0 = enough work for the throughput layout).
+inline int cu_count();
+inline int sparse_tiles_per_group(long N) {
+  const long n_tiles = (N + kTileRows - 1) / kTileRows;
+  const long cus = cu_count();
+  if (n_tiles >= 5 * cus) return 0;
+  return (int)((n_tiles + cus - 1) / cus);
+}
+
 template <int NW>
 size_t chain_lds_bytes() {
   return (size_t)(kG * 768 + 3 * 16 * 256 + 2 * NW * 768 + 256 + 48 + 4 * kMaxLaunchSteps + 3 * 512 + 2 * 192 * 4 +
@@ -1657,13 +1678,14 @@ inline int cu_count() {
   return n;
 }
 
-template <int NW, bool REFINE, int ABL = 0, bool UT = false, int PT = 0, bool PERSIST = false, bool SAVE = false>
+template <int NW, bool REFINE, int ABL = 0, bool UT = false, int PT = 0, bool PERSIST = false, bool SAVE = false,
+          bool SPARSE = false>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
   const long n_tiles = (a.N + kTileRows - 1) / kTileRows;
   const long n_groups = (n_tiles + a.tiles_per_group - 1) / a.tiles_per_group;
   const dim3 grid((unsigned)(PERSIST && n_groups > cu_count() ? cu_count() : n_groups));
   const size_t lds = chain_lds_bytes<NW>();
-  auto fn = k_chain<NW, REFINE, ABL, UT, PT, PERSIST, SAVE>;
+  auto fn = k_chain<NW, REFINE, ABL, UT, PT, PERSIST, SAVE, SPARSE>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return PSTL_ERR_LAUNCH;
@@ -1681,6 +1703,9 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
 template <bool REFINE>
 int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   const bool ut = (a.rows_per_scene % kTileRows == 0);  // every 16-row tile lies inside one scene
+  // 0: the latency layout for batches that cannot give every CU a full five-tile pipeline (SPARSE, see k_chain); 16: the same
+  // arithmetic in the throughput layout whatever the batch size (what large batches get either way; bit-identical results)
+  const bool latency = chain_waves == 0;
   if (chain_waves == 16) chain_waves = 0;
   if (REFINE && chain_waves == 32) chain_waves = 8;    // bf16 pieces cost the interval head up to 9e-5 per pass
   if (REFINE && a.h1_save && chain_waves != 0) chain_waves = chain_waves == 4 ? 4 : 8;   // (no bf16-piece training forward)
@@ -1690,6 +1715,15 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
     if constexpr (REFINE)
       if (a.h1_save && a.h2_save)   // training forward pass
         return ut ? launch_chain<8, true, 0, true, 2, false, true>(a, st) : launch_chain<8, true, 0, false, 2, false, true>(a, st);
+    if constexpr (!REFINE)
+      if (ut && latency && a.step_hi > a.step_lo) {
+        const int g = sparse_tiles_per_group(a.N);
+        if (g > 0) {
+          ChainArgs b = a;
+          b.tiles_per_group = g;
+          return launch_chain<8, false, 0, true, 2, false, false, true>(b, st);
+        }
+      }
     return ut ? launch_chain<8, REFINE, 0, true, 2>(a, st) : launch_chain<8, REFINE, 0, false, 2>(a, st);
   }
   if (chain_waves == 32) {

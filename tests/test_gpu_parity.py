@@ -125,7 +125,7 @@ def _run_region(dev, name, chain_waves=0):
     return d, meta, sb, out
 
 
-@pytest.mark.parametrize("chain_waves", [8, 4, 0, 32])
+@pytest.mark.parametrize("chain_waves", [8, 4, 0, 16, 32])
 @pytest.mark.parametrize("name", SAMPLING_CASES)
 def test_sampling_region_matches_reference(dev, name, chain_waves):
     from pstl_diffusion_policy_amd.engine import acc_from_counts
@@ -394,6 +394,34 @@ def test_streamed_single_step_launches_equal_the_grouped_ones(dev, noise):
         for k in ("final_controls", "final_scores", "sel_controls", "cand_scores"):
             a, b = part[k], (full[k][:, r0:r1] if k == "cand_scores" else full[k][r0:r1])
             assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("bs,S,steps", [(1, 64, 100), (3, 16, 12), (7, 32, 20), (40, 64, 9), (100, 64, 6)])
+@pytest.mark.parametrize("noise", ["kernel", "tensor"])
+def test_latency_layout_equals_throughput_layout(dev, bs, S, steps, noise):
+    """`chain_waves = 0` runs the multi-step denoiser launch of a batch with fewer than five tiles per CU in the latency
+    layout (1..4 tiles per workgroup, empty pipeline slots skipped: SPARSE in mlp_kernels.hip); `chain_waves = 16` is the
+    same arithmetic in the throughput layout whatever the size (what the bench's batch gets, and what every small fixture
+    ran before round 3).  Same arithmetic per row, noise keyed by the global row: every output must agree bit for bit --
+    192 rows (the closed loop's batch), 144 and 672 rows, 480 tiles (two per workgroup), 1200 tiles (five: nothing skipped)."""
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=2, S=S, seed=21 + bs, invalid_lane_frac=0.2, stlp_mode="wide").items()
+             if k not in ("params", "pre_stlp", "tj_scores_prior")}
+    w = PackedWeights(golden_weights(), dev)
+    N = bs * S * 3
+    g = torch.Generator(device=dev).manual_seed(5)
+    x_T = torch.randn(N, 40, device=dev, generator=g) if noise == "tensor" else None
+    z = torch.randn(steps - 1, N, 40, device=dev, generator=g) if noise == "tensor" else None
+    kw = dict(rect_head=True, multi_cands=5, guidance=dict(enabled=True, before=3, niters=1, lr=0.01), want_scores3=False,
+              seed=77 if noise == "kernel" else None, full_list=(noise == "tensor"))
+    outs = [Sampler(w, hp, chain_waves=cw).sampling_region(SceneBatch(scene, S, hp, dev), steps, x_T, z, **kw) for cw in (0, 16)]
+    keys = ["final_controls", "final_scores", "sel_controls", "cand_scores"] + (["controls_list"] if noise == "tensor" else [])
+    for k in keys:
+        assert torch.isfinite(outs[0][k]).all(), k
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert torch.equal(outs[0]["counts"], outs[1]["counts"])
 
 
 def test_stl_masks_at_scale_match_reference(dev):
