@@ -469,6 +469,153 @@ int wgrad(long N, const float* G, int ldg, int fvalid, const float* H, int ldh, 
   return launch_status();
 }
 
+// ---- the same contraction on the bfloat16 matrix pipe (round 3) ----------------------------------------------------------
+// Every fp32 operand as two bfloat16 pieces (hi = bf16(v), lo = bf16(v - hi): 2^-17 per operand, fp32's exponent range --
+// the gradients are ~1e-7), three v_mfma_f32_16x16x32_bf16 per fp32 product (hi hi + lo hi + hi lo), fp32 accumulators: the
+// scheme of k_dgrad and of the forward chain's bfloat16 form, against a 5e-3 gate on the gradients.  The contraction index is
+// the ROW: a 32-row chunk is one k-block.  Staging turns the row-major chunk into MFMA operand order on the way into LDS: a
+// thread takes a 4-row x 4-column block (four 16-byte loads, rows of a wave coalesced), splits it, and writes per column the
+// 4 rows' pieces as one 8-byte store to [tile = col / 16][g = row / 8][i = col % 16][row % 8] -- the slot a lane (i, g) of
+// the MFMA reads as ONE ds_read_b128 (tile blocks padded by 16 bytes: the stores of a wave otherwise fall 16-fold into the
+// same banks).  Double-buffered, next chunk's loads in flight during the MFMAs; the pieces of G serve as A operands, those of
+// H as B operands, same k order on both sides.  Slabs and their fixed-order reduction as above (deterministic).
+typedef __bf16 wg_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf4 __attribute__((ext_vector_type(4)));
+constexpr int kWbRows = 32;
+constexpr int kWbTile = 1024 + 16;   // bytes of one (16 columns x 32 rows) tile block of 2-byte pieces, padded
+
+template <int FT, int CT>
+constexpr size_t wgrad_bf_lds() { return (size_t)2 * (2 * FT + 2 * CT) * kWbTile; }
+
+template <int FT, int CT, int WF, int WC>
+__global__ __launch_bounds__(512, 1) void k_wgrad_bf(long N, const float* G, int ldg, int fvalid, const float* H, int ldh,
+                                                     int cvalid, float* slabs) {
+  static_assert(WF * WC == 8 && FT % WF == 0 && CT % WC == 0, "tile split");
+  constexpr int F = 16 * FT, C = 16 * CT;
+  constexpr int MF = FT / WF, MC = CT / WC;
+  constexpr int IG = 8 * (F / 4), IH = 8 * (C / 4);                  // 4x4 blocks per chunk
+  constexpr int VG = (IG + 511) / 512, VH = (IH + 511) / 512;        // ... per thread
+  extern __shared__ __attribute__((aligned(16))) char wlds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wf = w / WC, wc = w % WC;
+  const int li = lane & 15, kk = lane >> 4;
+  const long n_chunks = (N + kWbRows - 1) / kWbRows;
+  const long per = (n_chunks + gridDim.x - 1) / gridDim.x;
+  const long c0 = blockIdx.x * per, c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
+  auto tile = [&](int buf, int t) { return wlds + ((size_t)buf * (2 * FT + 2 * CT) + t) * kWbTile; };   // t: G hi | G lo | H hi | H lo
+
+  f32x4 acc[MF][MC];
+#pragma unroll
+  for (int a = 0; a < MF; ++a)
+#pragma unroll
+    for (int b = 0; b < MC; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  f32x4 rg[VG][4], rh[VH][4];
+  auto load_block = [&](const float* X, int ld, int valid, int W, long ch, int item, f32x4 (&dst)[4]) {
+    const int rgp = item / (W / 4), c4 = item % (W / 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long row = ch * kWbRows + 4 * rgp + q;
+      f32x4 val = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (item < 8 * (W / 4) && row < N) {
+        const float* src = X + row * ld + 4 * c4;
+        if (4 * c4 + 3 < valid && (ld % 4 == 0)) {
+          val = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[e] = (4 * c4 + e < valid) ? src[e] : 0.0f;
+        }
+      }
+      dst[q] = val;
+    }
+  };
+  auto store_block = [&](int buf, int thi, int NT_, int W, int item, const f32x4 (&src)[4]) {
+    if (item >= 8 * (W / 4)) return;
+    const int rgp = item / (W / 4), c4 = item % (W / 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = 4 * c4 + j;
+      wg_bf4 hi, lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        hi[q] = (__bf16)src[q][j];
+        lo[q] = (__bf16)(src[q][j] - (float)hi[q]);
+      }
+      const int off = ((rgp >> 1) * 16 + (col & 15)) * 16 + (rgp & 1) * 8;
+      *reinterpret_cast<wg_bf4*>(tile(buf, thi + (col >> 4)) + off) = hi;
+      *reinterpret_cast<wg_bf4*>(tile(buf, thi + NT_ + (col >> 4)) + off) = lo;
+    }
+  };
+  auto load_chunk = [&](long ch) {
+#pragma unroll
+    for (int v = 0; v < VG; ++v) load_block(G, ldg, fvalid, F, ch, tid + v * 512, rg[v]);
+#pragma unroll
+    for (int v = 0; v < VH; ++v) load_block(H, ldh, cvalid, C, ch, tid + v * 512, rh[v]);
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < VG; ++v) store_block(buf, 0, FT, F, tid + v * 512, rg[v]);
+#pragma unroll
+    for (int v = 0; v < VH; ++v) store_block(buf, 2 * FT, CT, C, tid + v * 512, rh[v]);
+  };
+
+  if (c0 < c1) {
+    load_chunk(c0);
+    store_chunk(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (long ch = c0; ch < c1; ++ch) {
+    if (ch + 1 < c1) load_chunk(ch + 1);          // in flight during the MFMAs below
+    wg_bf8 bh[MC], bl[MC];
+#pragma unroll
+    for (int b = 0; b < MC; ++b) {
+      bh[b] = *reinterpret_cast<const wg_bf8*>(tile(buf, 2 * FT + wc * MC + b) + lane * 16);
+      bl[b] = *reinterpret_cast<const wg_bf8*>(tile(buf, 2 * FT + CT + wc * MC + b) + lane * 16);
+    }
+#pragma unroll
+    for (int a = 0; a < MF; ++a) {
+      const wg_bf8 ah = *reinterpret_cast<const wg_bf8*>(tile(buf, wf * MF + a) + lane * 16);
+      const wg_bf8 al = *reinterpret_cast<const wg_bf8*>(tile(buf, FT + wf * MF + a) + lane * 16);
+#pragma unroll
+      for (int b = 0; b < MC; ++b) {
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < c1) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* out = slabs + (long)blockIdx.x * F * C;
+#pragma unroll
+  for (int a = 0; a < MF; ++a)
+#pragma unroll
+    for (int b = 0; b < MC; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(16 * (wf * MF + a) + 4 * kk + r) * C + 16 * (wc * MC + b) + li] = acc[a][b][r];
+}
+
+// Used for dW2 = dH2^T h1 (256 x 256 over N rows): 0.81 -> 0.34 ms per 786 432 rows = 1.6 GB of operands at 4.7 TB/s, i.e. the
+// contraction now runs at the speed its two inputs stream from HBM.  The thin ones (dW3: 40 x 256, dW1's 47 columns) were
+// already there on the exact fp32 kernel (0.19 ms for 0.93 GB) and stay on it, as do the short contractions of the scene
+// encoders and the per-scene sums.
+template <int FT, int CT, int WF, int WC>
+int wgrad_bf(long N, const float* G, int ldg, int fvalid, const float* H, int ldh, int cvalid, float* slabs, float* D, int ldd,
+             hipStream_t st) {
+  const long n_chunks = (N + kWbRows - 1) / kWbRows;
+  const int nb = (int)(n_chunks < kRedBlocks ? n_chunks : kRedBlocks);
+  auto fn = k_wgrad_bf<FT, CT, WF, WC>;
+  const size_t lds = wgrad_bf_lds<FT, CT>();
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PSTL_ERR_LAUNCH;
+  hipLaunchKernelGGL(fn, dim3(nb), dim3(512), lds, st, N, G, ldg, fvalid, H, ldh, cvalid, slabs);
+  hipLaunchKernelGGL(k_slab_reduce, dim3((16 * FT * 16 * CT + 255) / 256), dim3(256), 0, st, nb, 16 * FT, 16 * CT, fvalid,
+                     cvalid, slabs, D, ldd);
+  return launch_status();
+}
 
 // ---- activation gradients: out[row][f] = [H[row][f] > 0] * sum_k G[row][k] * W[k][f],  f < 256 -----------------------
 // (dH2 = dO W3 with K = 40, dH1 = dH2 W2 with K = 256; W is the layer's (out = K, in = 256) weight matrix, so the product
@@ -757,7 +904,7 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
   if (int e = wgrad<3, 16, 1, 8>(N, dO, kCtrl, kCtrl, h2, kHid, kHid, slabs, dw3, kHid, st)) return e;  // dW3 = dO^T h2
   // layer 2: dH2 = (dO W3) * [h2 > 0], db2 = column sums of dH2
   if (int e = dgrad<2>(N, dO, kCtrl, kCtrl, w3, wpack, h2, dH2, part, db2, st)) return e;
-  if (int e = wgrad<16, 16, 4, 2>(N, dH2, kHid, kHid, h1, kHid, kHid, slabs, dw2, kHid, st)) return e;  // dW2 = dH2^T h1
+  if (int e = wgrad_bf<16, 16, 2, 4>(N, dH2, kHid, kHid, h1, kHid, kHid, slabs, dw2, kHid, st)) return e;  // dW2 = dH2^T h1
   // layer 1: dH1 = (dH2 W2) * [h1 > 0], db1 = column sums of dH1
   if (int e = dgrad<8>(N, dH2, kHid, kHid, w2, wpack, h1, dH1, part, db1, st)) return e;
   hipLaunchKernelGGL(k_scene_sum, dim3(cfg->bs), dim3(256), 0, st, cfg->rows_per_scene, dH1, S);
