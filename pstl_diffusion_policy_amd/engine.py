@@ -81,6 +81,19 @@ class PackedWeights:
         return self._tbias[steps]
 
 
+_MODE_COLUMNS = {}
+
+
+def _mode_column(n, dev):
+    """(0, 1, 2) repeated n times (the `highlevel` column of the reference's dense rows), built once per size and device."""
+    key = (int(n), str(dev))
+    if key not in _MODE_COLUMNS:
+        if len(_MODE_COLUMNS) > 16:
+            _MODE_COLUMNS.clear()
+        _MODE_COLUMNS[key] = torch.tensor([0.0, 1.0, 2.0], device=dev).repeat(int(n)).contiguous()
+    return _MODE_COLUMNS[key]
+
+
 class SceneBatch:
     """Device-resident, scene-indexed inputs of one batch (schema: SURVEY.md 3.0) + per-row constants.
 
@@ -91,7 +104,25 @@ class SceneBatch:
     def __init__(self, scene, S, hp, device, global_valid_sum=None, global_rows=None, row_offset=0):
         dev = torch.device(device)
         self.row_offset = int(row_offset)   # global index of the first row (in-kernel noise is keyed by global row)
-        f = lambda k: ffi.f32(torch.as_tensor(scene[k]), dev)
+        # A batch that arrives in host memory (the closed-loop caller builds one scene per simulation step) crosses PCIe as
+        # ONE staged copy instead of one per tensor, and the guidance-loss scale is taken from the host copy of the lane ids:
+        # no device synchronisation while the batch is set up.
+        keys = ["ego_traj", "neighbors", "neighbors_traj", "currlane_wpts", "leftlane_wpts", "rightlane_wpts", "curr_id",
+                "left_id", "right_id", "stlp_rows" if "stlp_rows" in scene else "stlp_modes"]
+        src = {k: torch.as_tensor(scene[k]) for k in keys}
+        host = dev.type == "cuda" and all(not t.is_cuda for t in src.values())
+        if host:
+            pad = lambda t: torch.nn.functional.pad(t.reshape(-1).to(torch.float32), (0, -t.numel() % 4))   # 16-byte slots
+            flat = torch.cat([pad(t) for t in src.values()]).to(dev)
+            parts, o = {}, 0
+            for k, t in src.items():
+                parts[k] = flat[o:o + t.numel()].reshape(t.shape)
+                o += t.numel() + (-t.numel() % 4)
+            f = lambda k: parts[k]
+            if global_valid_sum is None:
+                global_valid_sum = float(sum(src[k].to(torch.float32).sum() for k in ("curr_id", "left_id", "right_id"))) * int(S)
+        else:
+            f = lambda k: ffi.f32(src[k], dev)
         self.hp, self.S, self.device = hp, int(S), dev
         ego = f("ego_traj")
         self.bs = ego.shape[0]
@@ -111,7 +142,7 @@ class SceneBatch:
             self.stlp = f("stlp_rows").reshape(self.N, 6).contiguous()
         else:   # every sample of a (scene, mode) shares the STL parameters (reference nusc_train.py:745)
             self.stlp = f("stlp_modes").reshape(self.bs, 1, 3, 6).expand(self.bs, self.S, 3, 6).reshape(self.N, 6).contiguous()
-        self.hl = torch.tensor([0.0, 1.0, 2.0], device=dev).repeat(self.bs * self.S).contiguous()      # nusc_train.py:753
+        self.hl = _mode_column(self.bs * self.S, dev)                                                     # nusc_train.py:753
         ids3 = torch.stack(self.ids, dim=-1)                                                             # (bs,3)
         self.valid = ids3.reshape(self.bs, 1, 3).expand(self.bs, self.S, 3).reshape(self.N).contiguous()  # :751-752
         # scale of d loss / d score in the guidance loss mask_mean(relu(thres - score), valid) (nusc_train.py:23-27,619)

@@ -4,7 +4,7 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 export PYTHONPATH=$root
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/st_sim
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_sim -o run -- python3 -m pstl_diffusion_policy_amd.nusc_sim --diffusion --load_stlp --rect_head --flex --diverse_loss --multi_cands 5 --guidance --guidance_before 10 --guidance_niters 1 --guidance_lr 0.04 --n_neighbors 8 --n_randoms 64 --diffusion_steps 100 --n_trials 12 --allow_random_init 2>&1 | grep -i "median\|sim 1" | tail -4
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_sim -o run -- python3 -m pstl_diffusion_policy_amd.nusc_sim --diffusion --load_stlp --rect_head --flex --diverse_loss --multi_cands 5 --guidance --guidance_before 10 --guidance_niters 1 --guidance_lr 0.04 --n_neighbors ${SIM_K:-8} --n_randoms 64 --diffusion_steps 100 --n_trials 12 --allow_random_init 2>&1 | grep -i "median\|sim 1" | tail -4
 f=$(find /tmp/st_sim -name "*kernel_stats.csv")
 python3 - "$f" <<'P'
 import csv, sys
