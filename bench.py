@@ -107,6 +107,12 @@ def count_gpus():
             except OSError:
                 continue
             if int(props.get("simd_count", "0")) > 0:
+                # a container may see the whole topology but only some of the devices: a GPU counts when its render node is
+                # there and usable (drm_render_minor; older KFDs do not list it: counted)
+                minor = int(props.get("drm_render_minor", "0"))
+                dev = "/dev/dri/renderD%d" % minor
+                if minor > 0 and os.path.isdir("/dev/dri") and not (os.path.exists(dev) and os.access(dev, os.R_OK | os.W_OK)):
+                    continue
                 n += 1
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)

@@ -88,14 +88,16 @@ def closed_loop(state_dict, n_sim_steps=20, K=8, S=64, diffusion_steps=100, mult
         sb = SceneBatch(obs, S, hp, dev)
         out = sm.sampling_region(sb, diffusion_steps, None, None, rect_head=True, multi_cands=multi_cands, guidance=g,
                                  seed=seed * 100003 + it, want_scores3=False)
-        scores = out["final_scores"].reshape(S, 3).clone()
-        scores[:, 1:3] = -10000.0                                            # lane-keeping samples only (:676-677)
-        best = int(torch.argmax(scores))                                      # flat index into (S,3): row = best
-        ctrl = out["final_controls"].reshape(S * 3, ffi.T, 2)[best, 0].cpu()  # first control of the chosen sample
-        torch.cuda.synchronize()
+        # lane-keeping samples only (the reference sets the other two modes' scores to -10000 before its argmax, :676-677):
+        # the best of column 0, its first control and its score, selected on the device and brought back in ONE copy
+        keep = out["final_scores"].reshape(S, 3)[:, 0]
+        bi = torch.argmax(keep)
+        first = out["final_controls"].reshape(S, 3, ffi.T, 2)[:, 0, 0, :]     # (S,2): first control of every mode-0 sample
+        pick = torch.cat([first.index_select(0, bi.reshape(1)).reshape(2), keep.index_select(0, bi.reshape(1))]).cpu()
+        ctrl = pick[:2]
         lat = time.perf_counter() - t0
         world.step(ctrl)
-        rec = dict(step=it, latency_s=lat, best_score=float(scores.flatten()[best]), x=float(world.state[0]),
+        rec = dict(step=it, latency_s=lat, best_score=float(pick[2]), x=float(world.state[0]),
                    y=float(world.state[1]), v=float(world.state[3]), clearance=world.min_clearance())
         records.append(rec)
         if verbose:
