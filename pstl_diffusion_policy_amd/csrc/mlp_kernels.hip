@@ -921,7 +921,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // Wave priorities (s_setprio; profiles/r3/chain_variants_setprio_mix.txt): waves 4-7 above 0-3 +9.7 %, a wave in its fused
   // block above a partner in its role work +13.8 %, the role work above the fused block +1.8 %, waves 0-3 above 4-7 -0.1 %.
   // With the MFMAs in place, deleting the ReLU + piece conversions gains 12-13 % (each of the two sites ~5 %), layer 2's operand
-  // reads 3.2 %, the LDS writes 4.5 %, layer 1's constant rows 1.7 % -- it is the instruction count that costs.  Both pieces
+  // reads 3.2 %, the LDS writes 4.5 %, layer 1's constant rows 1.7 %.  Both pieces
   // straight from v_fma_mixlo/hi_f16 (3 instructions per value with the ReLU instead of 4; inline asm, since the SLP vectoriser
   // turns the C++ form into v_pk_fma_f32 + conversions): same bits, +1.8 % -- the scheduler's issue groups do not see asm
   // statements as vector instructions and push them out of the MFMA shadow; the C++ form built with -fno-slp-vectorize does
