@@ -568,6 +568,67 @@ PSTL_HD float conj6(const float* v, int n, float tau) {  // softmin over n <= 6 
   return -((PSTL_LOG(s) + m) / tau);
 }
 
+// The geometry of the forward sweep, computed ahead (latency layout of the guidance kernel: four waves of a workgroup each
+// take five of the 20 time steps; the sweep itself then only reads): per time step the clearance, the lane distance and
+// heading term, and the winners' record (lane segment | clearance winner << 8, carried as a bit pattern).
+//   slots 0-3  (forward sweep): clearance, lane distance, heading term 1 - cos, winners (segment | clearance winner << 8)
+//   slots 4-13 (adjoint): the clearance's partials (x, y, heading), the heading term as the adjoint's own evaluation yields
+//                         it and the lane distance's partials (x, y) and the heading term's, then v, cos, sin of the state
+constexpr int kGeoSlots = 14;
+struct GeoPre {
+  const float* p;   // element (t, c) of this lane at p[(kGeoSlots t + c) * stride]
+  int stride;
+  PSTL_HD float at(int t, int c) const { return p[(kGeoSlots * t + c) * stride]; }
+};
+PSTL_HD unsigned geo_bits(float f) {
+  unsigned u;
+  __builtin_memcpy(&u, &f, 4);
+  return u;
+}
+PSTL_HD float geo_float(unsigned u) {
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+// Steps [t0, t1) of the row whose states `src` yields (the states of the steps before t0 are generated and dropped: the
+// dynamics are a handful of operations per step).  The very calls of stl_eval_rec<false, ., true, .>: same values, bit for bit.
+// ... and of stl_eval_grad's adjoint for the same step (the partials at the recorded winners; K > kRecMaxK: ranked again).
+template <class Src>
+PSTL_HD void stl_geometry(const StlEnv& env, const f4* sel_lane, const float* nei, int K, Src src, int t0, int t1, float* out,
+                          int stride) {
+  const bool use_rec = K <= kRecMaxK;
+  PSTL_NOUNROLL
+  for (int t = 0; t < t1; ++t) {
+    float x, y, th, v, c, s;
+    src.get(t, x, y, th, v, c, s);
+    if (t < t0) continue;
+    float* o = out + (kGeoSlots * t) * stride;
+    ClearHit ch;
+    clearance_eval<false, true>(env, nei, K, t, x, y, c, s, ch);
+    LaneHit h;
+    lane_eval<false>(sel_lane, x, y, th, h);
+    o[0 * stride] = ch.dn;
+    o[1 * stride] = h.d;
+    o[2 * stride] = h.th;
+    o[3 * stride] = geo_float((unsigned)h.jb | (ch.win << 8));
+    ClearHit cg;
+    if (use_rec) clearance_from_winner(env, nei, t, x, y, c, s, ch.win, cg);
+    else clearance_eval<true>(env, nei, K, t, x, y, c, s, cg);
+    LaneHit hg;
+    lane_eval<true>(sel_lane, x, y, th, hg, use_rec ? h.jb : -1);
+    o[4 * stride] = cg.d_dx;
+    o[5 * stride] = cg.d_dy;
+    o[6 * stride] = cg.d_dth;
+    o[7 * stride] = hg.th;
+    o[8 * stride] = hg.dd_dx;
+    o[9 * stride] = hg.dd_dy;
+    o[10 * stride] = hg.dth_dth;
+    o[11 * stride] = v;
+    o[12 * stride] = c;
+    o[13 * stride] = s;
+  }
+}
+
 struct FwdOut {  // what the adjoint needs from the forward sweep
   float Lv1, Lv2, Ls, L1, L2, L3, Lfb, Lft, score;
 };
@@ -578,10 +639,12 @@ struct FwdOut {  // what the adjoint needs from the forward sweep
 //   XY != -1    : additionally parks the state of every 4th step at scratch[XY ...] (x, y, th, v; 5 each)  (adjoint)
 //   REC         : records the winners of the hard minima (lane segment, neighbour, circle pair) per step in `rec`
 //                 (for the adjoint; !ALL3)
-template <bool ALL3, int XY, bool REC, bool NORM, class Src>
+//   PRE         : the geometry of every step was computed ahead (stl_geometry): read from `pre` instead   (REC, !ALL3)
+template <bool ALL3, int XY, bool REC, bool NORM, class Src, bool PRE = false>
 PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Src src, Scratch st,
-                           int tab, float* out3, FwdOut* fo, Rec& rec) {
+                           int tab, float* out3, FwdOut* fo, Rec& rec, GeoPre pre = GeoPre{nullptr, 0}) {
   static_assert(!(ALL3 && REC), "winners are recorded for the selected formula only");
+  static_assert(!PRE || (REC && !ALL3), "the precomputed geometry is that of the selected formula");
   const float tau = env.tau;
   Lse gv1, gv2, gsafe, g1, g2, g3;
   gv1.init();
@@ -609,10 +672,19 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
     gv1.add(-over<NORM>(v - r.vmin, r.vf) * tau);
     gv2.add(-over<NORM>(-v + r.vmax, r.vf) * tau);
     ClearHit ch;
-    clearance_eval<false, REC>(env, nei, K, t, x, y, c, s, ch);
-    gsafe.add(-over<NORM>(ch.dn - r.dsafe, r.sf) * tau);
     LaneHit h;
-    lane_eval<false>(ALL3 ? lanes : sel_lane, x, y, th, h);
+    if (PRE) {
+      ch.dn = pre.at(t, 0);
+      h.d = pre.at(t, 1);
+      h.th = pre.at(t, 2);
+      const unsigned bits = geo_bits(pre.at(t, 3));
+      h.jb = (int)(bits & 255u);
+      ch.win = bits >> 8;
+    } else {
+      clearance_eval<false, REC>(env, nei, K, t, x, y, c, s, ch);
+    }
+    gsafe.add(-over<NORM>(ch.dn - r.dsafe, r.sf) * tau);
+    if (!PRE) lane_eval<false>(ALL3 ? lanes : sel_lane, x, y, th, h);
     if (REC) rec_put(rec, t, (unsigned)h.jb, ch.win);
     {
       const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df);
@@ -694,10 +766,10 @@ PSTL_HD float pick4(const float (&a)[kCkStride], int i) {   // register array, d
   return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
 }
 
-template <bool NORM = false, class DScoreFn, class EmitFn>
+template <bool NORM = false, bool PRE = false, class DScoreFn, class EmitFn>
 PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, const float* s0,
                             const float* u, Scratch st, float wscale, float ascale, DScoreFn dscore_fn, EmitFn emit,
-                            long us = 1, bool inert = false) {
+                            long us = 1, bool inert = false, GeoPre pre = GeoPre{nullptr, 0}) {
   const float tau = env.tau;
   const int mode = r.mode;
   // inert: the caller knows that this row's score cannot reach the result (its loss weight is zero -- an invalid lane):
@@ -718,8 +790,8 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   Rec rec;
   rec_clear(rec);
   const bool use_rec = K <= kRecMaxK;   // uniform; with more neighbours the record is written but not trusted
-  const float score = stl_eval_rec<false, 0, true, NORM>(env, r, lanes, nei, K, DynSrc(s0, u, wscale, ascale, env.dt, us), st,
-                                                         LB, nullptr, &fo, rec);
+  const float score = stl_eval_rec<false, 0, true, NORM, DynSrc, PRE>(env, r, lanes, nei, K, DynSrc(s0, u, wscale, ascale, env.dt, us),
+                                                                      st, LB, nullptr, &fo, rec, pre);
   const float Lv1 = fo.Lv1, Lv2 = fo.Lv2, Ls = fo.Ls, L1 = fo.L1, L2 = fo.L2, L3 = fo.L3, Lfb = fo.Lfb, Lft = fo.Lft;
   float V[6];
   int n;
@@ -777,7 +849,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   for (int blk = kCk - 1; blk >= 0; --blk) {
     float bx[kCkStride], by[kCkStride], bth[kCkStride], bv[kCkStride], bc[kCkStride], bs[kCkStride];
     float bw[kCkStride], ba[kCkStride];   // stored controls of steps 4blk-1, 4blk, 4blk+1, 4blk+2: the ones emit() is called for
-    {
+    if (!PRE) {
       float x = st.at(CKP + blk), y = st.at(CKP + kCk + blk), th = st.at(CKP + 2 * kCk + blk), v = st.at(CKP + 3 * kCk + blk);
       CtrlReader rd(u, us);
       if (blk > 0) ctrl_pair(u, us, blk * kCkStride - 1, bw[0], ba[0]);
@@ -805,22 +877,36 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   for (int i = kCkStride - 1; i >= 0; --i) {
     const int t = blk * kCkStride + i;
     if (t == 0) break;
-    const float x = pick4(bx, i), y = pick4(by, i), th = pick4(bth, i), v = pick4(bv, i), c = pick4(bc, i), s = pick4(bs, i);
+    float x = 0.0f, y = 0.0f, th = 0.0f, v, c, s;
+    if (PRE) {
+      v = pre.at(t, 11), c = pre.at(t, 12), s = pre.at(t, 13);
+    } else {
+      x = pick4(bx, i), y = pick4(by, i), th = pick4(bth, i), v = pick4(bv, i), c = pick4(bc, i), s = pick4(bs, i);
+    }
     // direct partials of the score w.r.t. state t
     float gx, gy, gth, gv;
     // (--norm_stl: the predicates are a / f; the chain rule adds the factor 1 / f, as autograd's division does)
     gv = o_v1 * PSTL_EXP(-over<NORM>(v - r.vmin, r.vf) * tau - Lv1) - o_v2 * PSTL_EXP(-over<NORM>(-v + r.vmax, r.vf) * tau - Lv2);
     if (NORM) gv = gv / r.vf;
     ClearHit ch;
-    if (use_rec) clearance_from_winner(env, nei, t, x, y, c, s, rec_win(rec, t), ch);
-    else clearance_eval<true>(env, nei, K, t, x, y, c, s, ch);
+    if (PRE) {   // (the clearance itself: the winner's operations repeated on the same operands give the forward sweep's value)
+      ch.dn = pre.at(t, 0), ch.d_dx = pre.at(t, 4), ch.d_dy = pre.at(t, 5), ch.d_dth = pre.at(t, 6);
+    } else if (use_rec) {
+      clearance_from_winner(env, nei, t, x, y, c, s, rec_win(rec, t), ch);
+    } else {
+      clearance_eval<true>(env, nei, K, t, x, y, c, s, ch);
+    }
     float gs = o_s * PSTL_EXP(-over<NORM>(ch.dn - r.dsafe, r.sf) * tau - Ls);
     if (NORM) gs = gs / r.sf;
     gx = gs * ch.d_dx;
     gy = gs * ch.d_dy;
     gth = gs * ch.d_dth;
     LaneHit h;
-    lane_eval<true>(lane, x, y, th, h, use_rec ? (int)rec_seg(rec, t) : -1);
+    if (PRE) {
+      h.d = pre.at(t, 1), h.th = pre.at(t, 7), h.dd_dx = pre.at(t, 8), h.dd_dy = pre.at(t, 9), h.dth_dth = pre.at(t, 10);
+    } else {
+      lane_eval<true>(lane, x, y, th, h, use_rec ? (int)rec_seg(rec, t) : -1);
+    }
     const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df), s3 = (r.thmax - h.th) / r.thmax;
     float gd, gsth;  // d score / d d_t , d score / d s3_t
     if (mode == 0) {
@@ -849,7 +935,13 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     lth = nlth;
     lv = nlv;
     // state_t = f(state_{t-1}, u_{t-1}):  th_t = th_{t-1} + w dt ; v_t = v_{t-1} + a dt
-    emit(t - 1, lth * dt * wscale, lv * dt * ascale, pick4(bw, i), pick4(ba, i));
+    if (PRE) {
+      float w0, a0;
+      ctrl_pair(u, us, t - 1, w0, a0);   // (not yet rewritten: emit() has only reached later steps)
+      emit(t - 1, lth * dt * wscale, lv * dt * ascale, w0, a0);
+    } else {
+      emit(t - 1, lth * dt * wscale, lv * dt * ascale, pick4(bw, i), pick4(ba, i));
+    }
   }
   }
   return score;

@@ -67,8 +67,8 @@ __device__ __forceinline__ void scene_tables(float* lds, int n_scratch, const fl
     f4* sn = sl + 3 * kNseg + 3;  // keep 16-byte alignment and a little padding
     const f4* gl = reinterpret_cast<const f4*>(lane_prep) + b * 3 * kNseg;
     const f4* gn = reinterpret_cast<const f4*>(nei_prep + b * (long)K * kT * kNeiPrep);
-    for (int i = threadIdx.x; i < 3 * kNseg; i += kWave) sl[i] = gl[i];
-    for (int i = threadIdx.x; i < K * kT * 3; i += kWave) sn[i] = gn[i];
+    for (int i = threadIdx.x; i < 3 * kNseg; i += blockDim.x) sl[i] = gl[i];
+    for (int i = threadIdx.x; i < K * kT * 3; i += blockDim.x) sn[i] = gn[i];
     __syncthreads();
     lanes = sl;
     nei = reinterpret_cast<const float*>(sn);
@@ -79,6 +79,7 @@ __device__ __forceinline__ void scene_tables(float* lds, int n_scratch, const fl
   }
 }
 
+__host__ __device__ inline int stl_table_floats(int K) { return (3 * kNseg + 3) * 4 + K * kT * kNeiPrep; }   // staged lanes + neighbours
 inline size_t stl_lds_bytes(int n_scratch, int K, bool staged) {
   return ((size_t)n_scratch * kWave + (staged ? (size_t)(3 * kNseg + 3) * 4 + (size_t)K * kT * kNeiPrep : 0)) * sizeof(float);
 }
@@ -155,9 +156,9 @@ __global__ void k_stl_select(long N, int reps, const float* scores, const float*
 // validity and mostly their fate (satisfied or not), so whole wavefronts take the cheap exits of stl_eval_grad -- an
 // invalid lane skips both sweeps, a satisfied row the adjoint -- instead of idling beside the lanes that cannot.
 // The workgroup -> scene map is unchanged (blockIdx.x * 64 / rows_per_scene), which is what scene_tables relies on.
-__device__ __forceinline__ long map_row(int by_mode, int rows_per_scene) {
+__device__ __forceinline__ long map_row(int by_mode, int rows_per_scene, int lane = -1) {
   const long blk = blockIdx.x;
-  const int lane = threadIdx.x;
+  if (lane < 0) lane = threadIdx.x;
   if (!by_mode) return blk * kWave + lane;
   const int gps = rows_per_scene / kWave;   // workgroups per scene = 3 * (S / 64)
   const long b = blk / gps;
@@ -239,16 +240,42 @@ struct GuideArgs {
   float* emit_out;  // (N,40) or null
 };
 
-template <bool MULTI, bool STAGED, bool NORM = false>
-__global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
+// SPLIT (latency layout, small batches -- the closed-loop caller's 192 rows are three wavefronts on a 256-CU chip): the
+// workgroup is FOUR wavefronts over the same 64 rows.  Wave q first computes the geometry of time steps [5q, 5q + 5) of its
+// lane's row -- clearance, lane distance, heading term, the winners -- into LDS (stl_geometry: the forward sweep's own calls
+// on the same states; the few dynamics steps before 5q are regenerated); after one barrier wave 0 runs the sweep, the adjoint
+// and the update exactly as the one-wave kernel does, reading the geometry instead of computing it.  Same operations on the
+// same operands in the same order: bit-identical results, with three quarters of the forward geometry -- the bulk of the
+// sweep at K = 8 -- off the critical wavefront.
+constexpr int kGeoFloats = kGeoSlots * kT;   // per lane
+
+template <bool MULTI, bool STAGED, bool NORM = false, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 4 * kWave : kWave) void k_guidance_iter(GuideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const long row = map_row(a.by_mode, a.rows_per_scene);
+  static_assert(!SPLIT || STAGED, "the latency layout stages its scene tables");
+  const int lane = SPLIT ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
+  const int wq = SPLIT ? (int)(threadIdx.x / kWave) : 0;
+  long row = map_row(a.by_mode, a.rows_per_scene, lane);
   const f4* lanes;
   const float* nei;
   scene_tables<STAGED>(lds, kScratchGrad, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes,
                        nei);
+  GeoPre pre = {nullptr, 0};
+  if (SPLIT) {
+    const bool live = row < a.N;
+    if (!live) row = a.N - 1;
+    float* geo = lds + kScratchGrad * kWave + stl_table_floats(a.K);
+    const StlRow rq = load_row<NORM>(a.stlp, a.hl, row);
+    if (live && rq.mode < 3 && a.grad_scale * a.valid[row] != 0.0f)
+      stl_geometry(a.env, lanes + rq.mode * kNseg, nei, a.K,
+                   DynSrc(a.s0 + (row / a.rows_per_scene) * 4, a.mu + row * (2 * kT), a.wscale, a.ascale, a.env.dt),
+                   (kT / 4) * wq, (kT / 4) * (wq + 1), geo + lane, kWave);
+    __syncthreads();
+    if (wq != 0 || !live) return;
+    pre = GeoPre{geo + lane, kWave};
+  }
   if (row >= a.N) return;
-  const Scratch st = {lds + threadIdx.x, kWave};
+  const Scratch st = {lds + lane, kWave};
   const long b = row / a.rows_per_scene;
   const StlRow r = load_row<NORM>(a.stlp, a.hl, row);
   float* mu = a.mu + row * (2 * kT);
@@ -292,7 +319,7 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
   };
   // mu[2t], mu[2t+1] are rewritten by emit(t) while the adjoint walks t = T-1 ... 0; the adjoint has already taken every
   // value it still needs from earlier time steps only (and hands the current one to emit, so mu is not read here)
-  stl_eval_grad<NORM>(
+  stl_eval_grad<NORM, SPLIT>(
       a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
       [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
       [=, z4 = f4{0.0f, 0.0f, 0.0f, 0.0f}](int t, float gw, float ga, float w0, float a0) mutable {
@@ -310,7 +337,7 @@ __global__ __launch_bounds__(kWave) void k_guidance_iter(GuideArgs a) {
         store_pair(mu + 2 * t, nw, na);                      // 8-byte gather stores: (w, a) of a step together
         if (last && er) store_pair(er + 2 * t, ew, ea);
       },
-      1, gs == 0.0f);   // an invalid lane has zero loss weight: Adam sees exact zeros, only the noise is added
+      1, gs == 0.0f, pre);   // an invalid lane has zero loss weight: Adam sees exact zeros, only the noise is added
 }
 
 // ---- trajectory optimisation (nusc_train.py:1302-1325 with compute_trajopt_loss_lite :287-316) --------
@@ -741,6 +768,17 @@ using namespace pstl;
 
 // the 64 rows of every workgroup share one scene (and the staged tables fit comfortably in LDS)
 static bool scene_staged(const pstl_cfg* cfg) { return cfg->rows_per_scene % kWave == 0 && cfg->K <= 16; }
+// up to one 64-row group per CU, the guidance kernel runs its latency layout (k_guidance_iter<.., SPLIT>)
+static long guidance_split_max_groups() {
+  static long n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+            ? p.multiProcessorCount : 256;
+  }
+  return n;
+}
 
 static int allow_lds(const void* fn, size_t bytes) {
   if (bytes <= 48 * 1024) return PSTL_OK;
@@ -910,12 +948,20 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
   if (cfg->flags & PSTL_FLAG_NORM_STL)
     fn = niters > 1 ? (staged ? k_guidance_iter<true, true, true> : k_guidance_iter<true, false, true>)
                     : (staged ? k_guidance_iter<false, true, true> : k_guidance_iter<false, false, true>);
-  if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
+  // fewer wavefronts than CUs: the latency layout (four waves per 64 rows, the forward geometry split over them by time step)
+  const bool split = staged && (long)grid.x <= guidance_split_max_groups();
+  size_t lds_total = lds;
+  if (split) {
+    lds_total += (size_t)kGeoFloats * kWave * sizeof(float);
+    if (cfg->flags & PSTL_FLAG_NORM_STL) fn = niters > 1 ? k_guidance_iter<true, true, true, true> : k_guidance_iter<false, true, true, true>;
+    else fn = niters > 1 ? k_guidance_iter<true, true, false, true> : k_guidance_iter<false, true, false, true>;
+  }
+  if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds_total)) return e;
   for (int j = 0; j < niters; ++j) {
     a.iter = j;
     a.neg_step = adam_neg_step[j];
     a.bc2_sqrt = adam_bc2_sqrt[j];
-    hipLaunchKernelGGL(fn, grid, dim3(kWave), lds, as_stream(stream), a);
+    hipLaunchKernelGGL(fn, grid, dim3(split ? 4 * kWave : kWave), lds_total, as_stream(stream), a);
     if (int e = launch_status()) return e;
   }
   return PSTL_OK;
