@@ -1711,12 +1711,7 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   if (REFINE && a.h1_save && chain_waves != 0) chain_waves = chain_waves == 4 ? 4 : 8;   // (no bf16-piece training forward)
   if (chain_waves == 0) {
     if constexpr (!REFINE)
-      if (ut && a.step_hi == a.step_lo) return launch_chain<8, false, 0, true, 2, true>(a, st);   // single step: persistent
-    if constexpr (REFINE)
-      if (a.h1_save && a.h2_save)   // training forward pass
-        return ut ? launch_chain<8, true, 0, true, 2, false, true>(a, st) : launch_chain<8, true, 0, false, 2, false, true>(a, st);
-    if constexpr (!REFINE)
-      if (ut && latency && a.step_hi > a.step_lo) {
+      if (ut && latency) {   // small batch: the latency layout, for multi-step and single-step launches alike
         const int g = sparse_tiles_per_group(a.N);
         if (g > 0) {
           ChainArgs b = a;
@@ -1724,6 +1719,11 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
           return launch_chain<8, false, 0, true, 2, false, false, true>(b, st);
         }
       }
+    if constexpr (!REFINE)
+      if (ut && a.step_hi == a.step_lo) return launch_chain<8, false, 0, true, 2, true>(a, st);   // single step: persistent
+    if constexpr (REFINE)
+      if (a.h1_save && a.h2_save)   // training forward pass
+        return ut ? launch_chain<8, true, 0, true, 2, false, true>(a, st) : launch_chain<8, true, 0, false, 2, false, true>(a, st);
     return ut ? launch_chain<8, REFINE, 0, true, 2>(a, st) : launch_chain<8, REFINE, 0, false, 2>(a, st);
   }
   if (chain_waves == 32) {

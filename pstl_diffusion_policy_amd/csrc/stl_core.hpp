@@ -593,7 +593,8 @@ PSTL_HD float geo_float(unsigned u) {
 // Steps [t0, t1) of the row whose states `src` yields (the states of the steps before t0 are generated and dropped: the
 // dynamics are a handful of operations per step).  The very calls of stl_eval_rec<false, ., true, .>: same values, bit for bit.
 // ... and of stl_eval_grad's adjoint for the same step (the partials at the recorded winners; K > kRecMaxK: ranked again).
-template <class Src>
+// ADJ = false: the forward values only (slots 0-2; value-only callers -- scoring -- run clearance_eval without the record).
+template <bool ADJ = true, class Src>
 PSTL_HD void stl_geometry(const StlEnv& env, const f4* sel_lane, const float* nei, int K, Src src, int t0, int t1, float* out,
                           int stride) {
   const bool use_rec = K <= kRecMaxK;
@@ -604,12 +605,13 @@ PSTL_HD void stl_geometry(const StlEnv& env, const f4* sel_lane, const float* ne
     if (t < t0) continue;
     float* o = out + (kGeoSlots * t) * stride;
     ClearHit ch;
-    clearance_eval<false, true>(env, nei, K, t, x, y, c, s, ch);
+    clearance_eval<false, ADJ>(env, nei, K, t, x, y, c, s, ch);
     LaneHit h;
     lane_eval<false>(sel_lane, x, y, th, h);
     o[0 * stride] = ch.dn;
     o[1 * stride] = h.d;
     o[2 * stride] = h.th;
+    if (!ADJ) continue;
     o[3 * stride] = geo_float((unsigned)h.jb | (ch.win << 8));
     ClearHit cg;
     if (use_rec) clearance_from_winner(env, nei, t, x, y, c, s, ch.win, cg);
@@ -644,7 +646,7 @@ template <bool ALL3, int XY, bool REC, bool NORM, class Src, bool PRE = false>
 PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Src src, Scratch st,
                            int tab, float* out3, FwdOut* fo, Rec& rec, GeoPre pre = GeoPre{nullptr, 0}) {
   static_assert(!(ALL3 && REC), "winners are recorded for the selected formula only");
-  static_assert(!PRE || (REC && !ALL3), "the precomputed geometry is that of the selected formula");
+  static_assert(!PRE || !ALL3, "the precomputed geometry is that of the selected formula");
   const float tau = env.tau;
   Lse gv1, gv2, gsafe, g1, g2, g3;
   gv1.init();
@@ -677,9 +679,11 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
       ch.dn = pre.at(t, 0);
       h.d = pre.at(t, 1);
       h.th = pre.at(t, 2);
-      const unsigned bits = geo_bits(pre.at(t, 3));
-      h.jb = (int)(bits & 255u);
-      ch.win = bits >> 8;
+      if (REC) {
+        const unsigned bits = geo_bits(pre.at(t, 3));
+        h.jb = (int)(bits & 255u);
+        ch.win = bits >> 8;
+      }
     } else {
       clearance_eval<false, REC>(env, nei, K, t, x, y, c, s, ch);
     }
@@ -743,11 +747,11 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
   return score;
 }
 
-template <bool ALL3, int XY, bool NORM = false, class Src>
+template <bool ALL3, int XY, bool NORM = false, bool PRE = false, class Src>
 PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Src src, Scratch st,
-                       int tab, float* out3, FwdOut* fo) {
+                       int tab, float* out3, FwdOut* fo, GeoPre pre = GeoPre{nullptr, 0}) {
   Rec none;
-  return stl_eval_rec<ALL3, XY, false, NORM>(env, r, lanes, nei, K, src, st, tab, out3, fo, none);
+  return stl_eval_rec<ALL3, XY, false, NORM, Src, PRE>(env, r, lanes, nei, K, src, st, tab, out3, fo, none, pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

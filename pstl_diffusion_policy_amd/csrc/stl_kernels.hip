@@ -84,16 +84,25 @@ inline size_t stl_lds_bytes(int n_scratch, int K, bool staged) {
   return ((size_t)n_scratch * kWave + (staged ? (size_t)(3 * kNseg + 3) * 4 + (size_t)K * kT * kNeiPrep : 0)) * sizeof(float);
 }
 
-template <bool ALL3, bool STAGED, bool GIVEN, bool NORM = false>
-__global__ __launch_bounds__(kWave) void k_stl_forward(StlArgs a) {
+// SPLIT: the latency layout of k_guidance_iter for scoring (small batches, the selected formula, controls as input): ten
+// wavefronts compute the geometry of two time steps each into LDS, wave 0 accumulates the formulas.  Bit-identical scores.
+constexpr int kSplitWaves = 10;             // two time steps per wave
+
+template <bool ALL3, bool STAGED, bool GIVEN, bool NORM = false, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_stl_forward(StlArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  static_assert(!SPLIT || (STAGED && !ALL3 && !GIVEN), "latency layout: staged tables, selected formula, controls");
   constexpr int NS = ALL3 ? kScratchFwd3 : kScratchFwd;
-  long row = (long)blockIdx.x * kWave + threadIdx.x;
+  const int lane = SPLIT ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
+  const int wq = SPLIT ? (int)(threadIdx.x / kWave) : 0;
+  long row = (long)blockIdx.x * kWave + lane;
   const f4* lanes;
   const float* nei;
   scene_tables<STAGED>(lds, NS, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes, nei);
-  if (row >= a.N) return;
-  const Scratch st = {lds + threadIdx.x, kWave};
+  const bool live = row < a.N;
+  if (!SPLIT && !live) return;
+  if (!live) row = a.N - 1;
+  const Scratch st = {lds + lane, kWave};
   const long b = row / a.rows_per_scene;
   const StlRow r = load_row<NORM>(a.stlp, a.hl, row);
   float best = -INFINITY;
@@ -102,6 +111,17 @@ __global__ __launch_bounds__(kWave) void k_stl_forward(StlArgs a) {
   for (int rep = rep_lo; rep < rep_hi; ++rep) {
     float o3[3];
     float score;
+    if constexpr (SPLIT) {
+      float* geo = lds + NS * kWave + stl_table_floats(a.K);
+      const DynSrc src(a.s0 + b * 4, a.controls + ((long)rep * a.N + row) * (2 * kT), 1.0f, 1.0f, a.env.dt);
+      if (rep > rep_lo) __syncthreads();   // wave 0 has read the previous candidate's geometry
+      if (live && r.mode < 3)
+        stl_geometry<false>(a.env, lanes + r.mode * kNseg, nei, a.K, src, (kT / kSplitWaves) * wq, (kT / kSplitWaves) * (wq + 1),
+                            geo + lane, kWave);
+      __syncthreads();
+      if (wq != 0 || !live) continue;
+      score = stl_eval<false, -1, NORM, true>(a.env, r, lanes, nei, a.K, src, st, 0, o3, nullptr, GeoPre{geo + lane, kWave});
+    } else
     if (GIVEN) {
       const GivenSrc src = {reinterpret_cast<const f4*>(a.states) + ((long)rep * a.N + row) * kT};
       score = stl_eval<ALL3, -1, NORM>(a.env, r, lanes, nei, a.K, src, st, 0, o3, nullptr);
@@ -121,6 +141,7 @@ __global__ __launch_bounds__(kWave) void k_stl_forward(StlArgs a) {
       best_rep = rep;
     }
   }
+  if (SPLIT && (wq != 0 || !live)) return;
   if (a.sel_controls && a.controls) {
     const f4* src = reinterpret_cast<const f4*>(a.controls + ((long)best_rep * a.N + row) * (2 * kT));
     f4* dst = reinterpret_cast<f4*>(a.sel_controls + row * (2 * kT));
@@ -241,16 +262,16 @@ struct GuideArgs {
 };
 
 // SPLIT (latency layout, small batches -- the closed-loop caller's 192 rows are three wavefronts on a 256-CU chip): the
-// workgroup is FOUR wavefronts over the same 64 rows.  Wave q first computes the geometry of time steps [5q, 5q + 5) of its
+// workgroup is kSplitWaves = 10 wavefronts over the same 64 rows.  Wave q first computes the geometry of time steps [2q, 2q + 2) of its
 // lane's row -- clearance, lane distance, heading term, the winners -- into LDS (stl_geometry: the forward sweep's own calls
 // on the same states; the few dynamics steps before 5q are regenerated); after one barrier wave 0 runs the sweep, the adjoint
 // and the update exactly as the one-wave kernel does, reading the geometry instead of computing it.  Same operations on the
-// same operands in the same order: bit-identical results, with three quarters of the forward geometry -- the bulk of the
-// sweep at K = 8 -- off the critical wavefront.
+// same operands in the same order: bit-identical results, with nine tenths of the geometry (the forward sweep's and the
+// adjoint's partials at the recorded winners) off the critical wavefront: 96 -> 45 us per launch at K = 8.
 constexpr int kGeoFloats = kGeoSlots * kT;   // per lane
 
 template <bool MULTI, bool STAGED, bool NORM = false, bool SPLIT = false>
-__global__ __launch_bounds__(SPLIT ? 4 * kWave : kWave) void k_guidance_iter(GuideArgs a) {
+__global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidance_iter(GuideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(!SPLIT || STAGED, "the latency layout stages its scene tables");
   const int lane = SPLIT ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(SPLIT ? 4 * kWave : kWave) void k_guidance_iter(Gui
     if (live && rq.mode < 3 && a.grad_scale * a.valid[row] != 0.0f)
       stl_geometry(a.env, lanes + rq.mode * kNseg, nei, a.K,
                    DynSrc(a.s0 + (row / a.rows_per_scene) * 4, a.mu + row * (2 * kT), a.wscale, a.ascale, a.env.dt),
-                   (kT / 4) * wq, (kT / 4) * (wq + 1), geo + lane, kWave);
+                   (kT / kSplitWaves) * wq, (kT / kSplitWaves) * (wq + 1), geo + lane, kWave);
     __syncthreads();
     if (wq != 0 || !live) return;
     pre = GeoPre{geo + lane, kWave};
@@ -861,8 +882,15 @@ extern "C" int pstl_stl_forward(const pstl_cfg* cfg, const float* s0, const floa
   else
     fn = scores3 ? (staged ? k_stl_forward<true, true, false> : k_stl_forward<true, false, false>)
                  : (staged ? k_stl_forward<false, true, false> : k_stl_forward<false, false, false>);
-  if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds)) return e;
-  hipLaunchKernelGGL(fn, grid, dim3(kWave), lds, as_stream(stream), a);
+  // few wavefronts (a small batch): the latency layout, where it is instantiated (staged tables, the selected formula, controls)
+  const bool split = staged && !scores3 && controls && !states && (long)grid.x * grid.y <= guidance_split_max_groups();
+  size_t lds_total = lds;
+  if (split) {
+    lds_total += (size_t)kGeoSlots * kT * kWave * sizeof(float);
+    fn = (cfg->flags & PSTL_FLAG_NORM_STL) ? k_stl_forward<false, true, false, true, true> : k_stl_forward<false, true, false, false, true>;
+  }
+  if (int e = allow_lds(reinterpret_cast<const void*>(fn), lds_total)) return e;
+  hipLaunchKernelGGL(fn, grid, dim3(split ? kSplitWaves * kWave : kWave), lds_total, as_stream(stream), a);
   if (select_after)
     hipLaunchKernelGGL(k_stl_select, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, as_stream(stream), a.N, reps,
                        (const float*)scores, controls, sel_controls, sel_scores, sel_idx);
@@ -961,7 +989,7 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
     a.iter = j;
     a.neg_step = adam_neg_step[j];
     a.bc2_sqrt = adam_bc2_sqrt[j];
-    hipLaunchKernelGGL(fn, grid, dim3(split ? 4 * kWave : kWave), lds_total, as_stream(stream), a);
+    hipLaunchKernelGGL(fn, grid, dim3(split ? kSplitWaves * kWave : kWave), lds_total, as_stream(stream), a);
     if (int e = launch_status()) return e;
   }
   return PSTL_OK;
