@@ -39,7 +39,7 @@ def test_latency_of_a_simulation_step_at_the_reference_settings(capsys):
     """The reference's closed-loop settings (nusc_sim.py: 64 samples x 3 modes = 192 rows, 100 diffusion steps, K = 8
     neighbours, maximize guidance on the last 10 steps, 5 candidates + RefineNet): wall-clock latency per simulation step
     with a device synchronisation on both sides, printed for the record (`pytest -s`, or the captured output of a failure)
-    and held to a generous bound -- the measured median on one MI355X is ~2.2 ms (round 2: 2.7)."""
+    and held to a generous bound -- the measured median on one MI355X is ~1.5 ms (round 2: 2.7)."""
     from pstl_diffusion_policy_amd.nusc_sim import closed_loop
     recs = closed_loop(golden_weights(), n_sim_steps=16, K=8, S=64, diffusion_steps=100, multi_cands=5, guidance=True,
                        guidance_before=10, guidance_lr=0.04, seed=1, verbose=False)

@@ -11,6 +11,6 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("total kernel ms %.2f = %.3f per simulation step (12 steps)" % (tot / 1e6, tot / 1e6 / 12))
-for r in rows[:8]:
+for r in rows[:26]:
     print("%-70s calls %5s avg %9.1f us" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3))
 P
