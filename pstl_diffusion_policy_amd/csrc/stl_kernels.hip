@@ -283,19 +283,20 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidanc
                        nei);
   GeoPre pre = {nullptr, 0};
   if (SPLIT) {
-    const bool live = row < a.N;
-    if (!live) row = a.N - 1;
+    const bool live0 = row < a.N;
+    if (!live0) row = a.N - 1;
     float* geo = lds + kScratchGrad * kWave + stl_table_floats(a.K);
     const StlRow rq = load_row<NORM>(a.stlp, a.hl, row);
-    if (live && rq.mode < 3 && a.grad_scale * a.valid[row] != 0.0f)
+    if (live0 && rq.mode < 3 && a.grad_scale * a.valid[row] != 0.0f)
       stl_geometry(a.env, lanes + rq.mode * kNseg, nei, a.K,
                    DynSrc(a.s0 + (row / a.rows_per_scene) * 4, a.mu + row * (2 * kT), a.wscale, a.ascale, a.env.dt),
                    (kT / kSplitWaves) * wq, (kT / kSplitWaves) * (wq + 1), geo + lane, kWave);
     __syncthreads();
-    if (wq != 0 || !live) return;
     pre = GeoPre{geo + lane, kWave};
+  } else if (row >= a.N) {
+    return;
   }
-  if (row >= a.N) return;
+  const bool live = !SPLIT || map_row(a.by_mode, a.rows_per_scene, lane) < a.N;   // (SPLIT: dead rows stay for the barriers)
   const Scratch st = {lds + lane, kWave};
   const long b = row / a.rows_per_scene;
   const StlRow r = load_row<NORM>(a.stlp, a.hl, row);
@@ -338,27 +339,56 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidanc
     *emit_v = c;
     return x;
   };
-  // mu[2t], mu[2t+1] are rewritten by emit(t) while the adjoint walks t = T-1 ... 0; the adjoint has already taken every
-  // value it still needs from earlier time steps only (and hands the current one to emit, so mu is not read here)
-  stl_eval_grad<NORM, SPLIT>(
-      a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
-      [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
-      [=, z4 = f4{0.0f, 0.0f, 0.0f, 0.0f}](int t, float gw, float ga, float w0, float a0) mutable {
-        // a noise quad covers two time steps (elements 4q .. 4q+3); emit() comes in the order t = T-1 ... 0, so the quad is
-        // drawn at the odd step and kept for the even one: one Philox draw per two time steps
-        if (a.rng && a.step > 1 && last && (t & 1)) {
-          float zz[4];
-          normal4(a.seed, a.row_offset + row, t >> 1, a.step, zz);
-          z4 = f4{zz[0], zz[1], zz[2], zz[3]};
-        }
-        const int o = (t & 1) * 2;
-        float ew = 0.0f, ea = 0.0f;
-        const float nw = update(2 * t, w0, gw, a.wscale, o ? z4.z : z4.x, &ew);
-        const float na = update(2 * t + 1, a0, ga, a.ascale, o ? z4.w : z4.y, &ea);
-        store_pair(mu + 2 * t, nw, na);                      // 8-byte gather stores: (w, a) of a step together
-        if (last && er) store_pair(er + 2 * t, ew, ea);
-      },
-      1, gs == 0.0f, pre);   // an invalid lane has zero loss weight: Adam sees exact zeros, only the noise is added
+  // the update of time step t: Adam on (w, a), and on the last iteration the noise (quad z4 of steps t | 1 and t & ~1) and emission
+  auto apply = [=](int t, float gw, float ga, float w0, float a0, const f4& z4) {
+    const int o = (t & 1) * 2;
+    float ew = 0.0f, ea = 0.0f;
+    const float nw = update(2 * t, w0, gw, a.wscale, o ? z4.z : z4.x, &ew);
+    const float na = update(2 * t + 1, a0, ga, a.ascale, o ? z4.w : z4.y, &ea);
+    store_pair(mu + 2 * t, nw, na);                      // 8-byte gather stores: (w, a) of a step together
+    if (last && er) store_pair(er + 2 * t, ew, ea);
+  };
+  if constexpr (SPLIT) {
+    // Wave 0 leaves every step's gradient and stored controls in LDS; after a barrier each wave updates its own two steps
+    // (= one noise quad): the elements are independent, so the ten waves share the Adam / Philox / emission work as well.
+    static_assert(kT == 2 * kSplitWaves, "a wave's two time steps are one noise quad");
+    float* upd = lds + kScratchGrad * kWave + stl_table_floats(a.K) + kGeoFloats * kWave + lane;
+    if (wq == 0 && live)
+      stl_eval_grad<NORM, true>(
+          a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
+          [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
+          [=](int t, float gw, float ga, float w0, float a0) {
+            upd[(4 * t + 0) * kWave] = gw, upd[(4 * t + 1) * kWave] = ga, upd[(4 * t + 2) * kWave] = w0, upd[(4 * t + 3) * kWave] = a0;
+          },
+          1, gs == 0.0f, pre);
+    __syncthreads();
+    if (!live) return;
+    f4 z4 = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.rng && a.step > 1 && last) {
+      float zz[4];
+      normal4(a.seed, a.row_offset + row, wq, a.step, zz);
+      z4 = f4{zz[0], zz[1], zz[2], zz[3]};
+    }
+    for (int t = 2 * wq + 1; t >= 2 * wq; --t)
+      apply(t, upd[(4 * t + 0) * kWave], upd[(4 * t + 1) * kWave], upd[(4 * t + 2) * kWave], upd[(4 * t + 3) * kWave], z4);
+  } else {
+    // mu[2t], mu[2t+1] are rewritten by emit(t) while the adjoint walks t = T-1 ... 0; the adjoint has already taken every
+    // value it still needs from earlier time steps only (and hands the current one to emit, so mu is not read here)
+    stl_eval_grad<NORM, false>(
+        a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
+        [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
+        [=, z4 = f4{0.0f, 0.0f, 0.0f, 0.0f}](int t, float gw, float ga, float w0, float a0) mutable {
+          // a noise quad covers two time steps (elements 4q .. 4q+3); emit() comes in the order t = T-1 ... 0, so the quad is
+          // drawn at the odd step and kept for the even one: one Philox draw per two time steps
+          if (a.rng && a.step > 1 && last && (t & 1)) {
+            float zz[4];
+            normal4(a.seed, a.row_offset + row, t >> 1, a.step, zz);
+            z4 = f4{zz[0], zz[1], zz[2], zz[3]};
+          }
+          apply(t, gw, ga, w0, a0, z4);
+        },
+        1, gs == 0.0f, pre);   // an invalid lane has zero loss weight: Adam sees exact zeros, only the noise is added
+  }
 }
 
 // ---- trajectory optimisation (nusc_train.py:1302-1325 with compute_trajopt_loss_lite :287-316) --------
@@ -980,7 +1010,7 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
   const bool split = staged && (long)grid.x <= guidance_split_max_groups();
   size_t lds_total = lds;
   if (split) {
-    lds_total += (size_t)kGeoFloats * kWave * sizeof(float);
+    lds_total += (size_t)(kGeoFloats + 4 * kT) * kWave * sizeof(float);   // the geometry and the per-step (gw, ga, w, a)
     if (cfg->flags & PSTL_FLAG_NORM_STL) fn = niters > 1 ? k_guidance_iter<true, true, true, true> : k_guidance_iter<false, true, true, true>;
     else fn = niters > 1 ? k_guidance_iter<true, true, false, true> : k_guidance_iter<false, true, false, true>;
   }
