@@ -492,6 +492,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // notes below); short tail blocks process phantom tiles whose rows are clamped on load and masked on store.
   // (XONCE: the pieces of a tile's image are made one more iteration ahead: >= 5.)
   if (G < (XONCE ? 5 : 4)) G = XONCE ? 5 : 4;
+  // (SPARSE with a single tile: its layer 1 always runs stand-alone -- layer 2's slot is empty then -- and splits its own
+  // input, so the pieces need not be made an iteration ahead: four slots, and no input split in the loop)
+  const bool solo = SPARSE && Gr == 1;
+  if (solo) G = 4;
   if (cont) G = a.tiles_per_group;   // every round walks all slots; tiles past the end are phantoms
   // ---- per-row constants and the initial state into the B-operand image ----
   // Four consecutive input columns k = 4j .. 4j+3 of one tile column sit in one 16-byte LDS slot of the B-operand image,
@@ -936,7 +940,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     PSTL_STAMP(0)
     if (UT && w == kStager && it + 3 < total && !(PSTL_ABL_SKIP & 32) && real(p3.tl)) stage_cst(p3, hbuf);
     if (cont && w == kStager && it >= 2 && it - 2 + G < total) stage_x(Pos{pm2.tl, pm2.n + 1});
-    if (!(PSTL_ABL_SKIP & 16) && real(p3.tl)) split_x(p3, (it + 1) & 1);      // pieces for the layer 1 woven into iteration it + 1
+    if (!(PSTL_ABL_SKIP & 16) && real(p3.tl) && !solo) split_x(p3, (it + 1) & 1);   // pieces for the layer 1 woven into iteration it + 1
     if (NOISE_SPLIT && (ABL == 0 || ABL >= 7)) {
       if (w >= NW / 2 && w < NW / 2 + NCW && !woven_noise && !(PSTL_ABL_SKIP & 2) && real(p0.tl)) {
         const int nt = tid - NT / 2;
