@@ -493,9 +493,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // (XONCE: the pieces of a tile's image are made one more iteration ahead: >= 5.)
   if (G < (XONCE ? 5 : 4)) G = XONCE ? 5 : 4;
   // (SPARSE with a single tile: its layer 1 always runs stand-alone -- layer 2's slot is empty then -- and splits its own
-  // input, so the pieces need not be made an iteration ahead: four slots, and no input split in the loop)
+  // input, so neither the pieces nor layer 1 itself need the distance the woven form takes: THREE slots per reverse step,
+  // layers 2 + 3 | epilogue | layer 1 of the next step (one tile-step ahead instead of two), no input split in the loop)
   const bool solo = SPARSE && Gr == 1;
-  if (solo) G = 4;
+  if (solo) G = 3;
   if (cont) G = a.tiles_per_group;   // every round walks all slots; tiles past the end are phantoms
   // ---- per-row constants and the initial state into the B-operand image ----
   // Four consecutive input columns k = 4j .. 4j+3 of one tile column sit in one 16-byte LDS slot of the B-operand image,
@@ -968,7 +969,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     PSTL_STAMP(2)
     // ---------------- layer 2: 256 -> 256 (B from LDS), layer 3: this wave's 16*OT features -> 48 ----------------
     if (SPARSE && BF && !real(p0.tl)) {   // an empty layer-2 slot: at most layer 1 of tile-step it + 2, stand-alone
-      if (real(p2.tl) && it + 2 < total) layer1(p2, hbuf == 0 ? 2 : hbuf - 1);
+      if (solo) {
+        if (real(p1.tl) && it + 1 < total) layer1(p1, hbuf == 2 ? 0 : hbuf + 1);   // (solo: one ahead, behind the epilogue)
+      } else if (real(p2.tl) && it + 2 < total) {
+        layer1(p2, hbuf == 0 ? 2 : hbuf - 1);
+      }
     } else {
     f32x4 acc[OT];
 #pragma unroll
