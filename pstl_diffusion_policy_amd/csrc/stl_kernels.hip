@@ -1007,7 +1007,9 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
     fn = niters > 1 ? (staged ? k_guidance_iter<true, true, true> : k_guidance_iter<true, false, true>)
                     : (staged ? k_guidance_iter<false, true, true> : k_guidance_iter<false, false, true>);
   // fewer wavefronts than CUs: the latency layout (four waves per 64 rows, the forward geometry split over them by time step)
-  const bool split = staged && (long)grid.x <= guidance_split_max_groups();
+  // (up to two groups per CU: the ten-wave workgroups then run in two rounds of ~40 us, against ~100 us for one round of lone
+  // wavefronts; beyond that the one-wave kernel's wavefronts start to share SIMDs and win)
+  const bool split = staged && (long)grid.x <= 2 * guidance_split_max_groups();
   size_t lds_total = lds;
   if (split) {
     lds_total += (size_t)(kGeoFloats + 4 * kT) * kWave * sizeof(float);   // the geometry and the per-step (gw, ga, w, a)
