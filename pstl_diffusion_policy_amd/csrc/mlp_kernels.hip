@@ -405,12 +405,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   // one iteration before layer 1 of that tile-step reads them (XONCE: all eight waves used to split the same 48 x 16 values)
   u32x4* xpb = reinterpret_cast<u32x4*>(zbuf + 2 * 192);
   constexpr bool XONCE = BF;
+#ifndef PSTL_ABL_NO_EMPTY_SLOT_FIX   // (tools/dbg: the state before the fix, to show that tests/ldspoison catches it)
   if constexpr (SPARSE) {
     // the layer 1 woven into an empty pipeline slot reads the piece buffer without anyone having written it for that slot
     // (with a single tile per workgroup: never): defined contents instead of whatever the LDS held.  (The first writer, the
     // prologue's split_x, comes after the next barrier; the constant-row ring is filled by the prologue for all three slots.)
     for (int i = threadIdx.x; i < 2 * 4 * 64; i += blockDim.x) xpb[i] = u32x4{0u, 0u, 0u, 0u};
   }
+#endif
   // (declaring the wave index uniform -- readfirstlane -- turns the role branches into scalar branches and was measured
   // 30 % slower: that form of the loop spills inside it)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1045,7 +1047,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           split_hidden(a1[0], a1[OT - 1], hh, hl2, 2);   // layer 1's output, in the shadow of layer 2's MFMAs
           // (SPARSE: the layer 1 woven into an EMPTY slot ran on whatever the piece buffer and the constant-row ring held --
           // possibly LDS never written in this launch; its result is never read, and it must not reach the domain guard)
+#ifndef PSTL_ABL_NO_EMPTY_SLOT_FIX
           if (SPARSE && !real(p2.tl)) ovf = ovf_before;
+#endif
           if constexpr (SAVE)
             if (it + 2 < total) save_hidden(a.h1_save, p2, a1);
         }

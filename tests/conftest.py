@@ -14,6 +14,42 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+_LDS_POISON = []
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_lds(request):
+    """Before every -m gpu test: every CU's LDS holds NaN patterns (tests/ldspoison/lds_poison.hip, built by
+    __graft_entry__.build()), so that a kernel reading LDS it never wrote fails its test every time instead of depending on
+    what the previous kernel left there.  The library is test infrastructure; when it is not built the fixture says so once."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    if not _LDS_POISON:
+        import ctypes
+        so = os.path.join(ROOT, "tests", "ldspoison", "liblds_poison.so")
+        try:
+            lib = ctypes.CDLL(so)
+            lib.lds_poison.restype = ctypes.c_int
+            lib.lds_poison.argtypes = [ctypes.c_void_p]
+            _LDS_POISON.append(lib)
+        except OSError:
+            import warnings
+            warnings.warn("tests/ldspoison/liblds_poison.so is not built (run __graft_entry__.build()): LDS not poisoned")
+            _LDS_POISON.append(None)
+    if _LDS_POISON[0] is not None:
+        import torch
+        if torch.cuda.is_available():
+            assert _LDS_POISON[0].lds_poison(ctypes_stream()) == 0
+    yield
+
+
+def ctypes_stream():
+    import ctypes
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 

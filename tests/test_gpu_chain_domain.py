@@ -145,3 +145,30 @@ def test_unknown_chain_waves_is_a_shape_error():
     with pytest.raises(RuntimeError, match="shape"):
         sm.sampling_region(SceneBatch(scene, 8, hp, dev), 6, torch.zeros(24, 40, device=dev),
                            torch.zeros(5, 24, 40, device=dev))
+
+
+@pytest.mark.parametrize("scenes", [1, 48])
+def test_empty_pipeline_slots_stay_out_of_the_domain_guard(scenes):
+    """Round 3 regression: in the latency layout of k_chain (small batches) the layer 1 woven into an EMPTY pipeline slot read
+    a piece buffer nobody had written for that slot.  Its result was never used -- but it passed through the domain guard, and
+    on a fresh box (LDS full of a previous tenant's data) one bench process in twenty ended with the overflow flag set.
+    tests/ldspoison fills every CU's LDS with large finite garbage (the fixture in conftest.py does it before every -m gpu
+    test; here once more right before the launch): the flag must stay clear, one tile per workgroup (192 rows) and three."""
+    import conftest
+    from pstl_diffusion_policy_amd.engine import PackedWeights, Sampler, SceneBatch
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    dev = torch.device("cuda:0")
+    hp = default_hparams()
+    w = PackedWeights(golden_weights(), dev)
+    sm = Sampler(w, hp)
+    scene = make_scene_batch(scenes, K=2, S=64, seed=3, stlp_mode="wide")
+    sb = SceneBatch(scene, 64, hp, dev)
+    _, base_p, _ = sm.encode(sb, need_rect=False)
+    x = torch.randn(sb.N, 40, device=dev)
+    torch.cuda.synchronize()
+    if conftest._LDS_POISON and conftest._LDS_POISON[0] is not None:
+        assert conftest._LDS_POISON[0].lds_poison(conftest.ctypes_stream()) == 0
+    sm.rollout(sb, base_p, x, None, 20, n_emit=0, seed=9)
+    torch.cuda.synchronize()
+    assert torch.isfinite(x).all()
+    assert not w.chain_overflowed(clear=True)

@@ -23,8 +23,15 @@ scene = {k: v.to(dev) for k, v in make_scene_batch(scenes, K=2, S=64, seed=1, st
 g = dict(enabled=True, before=10, niters=1, lr=0.01)
 ref = {}
 bad = diff = 0
+poison = None
+if os.environ.get("PSTL_POISON"):      # NaN patterns in every CU's LDS before each call (tests/ldspoison)
+    import ctypes
+    poison = ctypes.CDLL(os.path.join(ROOT, "tests", "ldspoison", "liblds_poison.so"))
+    poison.lds_poison.argtypes = [ctypes.c_void_p]
 for i in range(calls):
     seed = 11 + (i % 4)
+    if poison is not None:
+        assert poison.lds_poison(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
     sb = SceneBatch(scene, 64, hp, dev)
     out = sm.sampling_region(sb, 50, None, None, rect_head=True, multi_cands=5, guidance=g, seed=seed, want_scores3=False)
     torch.cuda.synchronize()
