@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "timing: a test that reports a latency (no poisoned allocations: their fills would be timed)")
 
 
 _LDS_POISON = []
@@ -41,6 +42,27 @@ def _poisoned_lds(request):
         import torch
         if torch.cuda.is_available():
             assert _LDS_POISON[0].lds_poison(ctypes_stream()) == 0
+    yield
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_empty(request, monkeypatch):
+    """The same for global memory: during a -m gpu test every floating-point device buffer that comes from torch.empty /
+    empty_like is born full of 2.7e36 (large finite, see lds_poison.hip for why not NaN), so that a kernel reading an output or
+    work buffer before it wrote it cannot hide behind the zeros a fresh allocation usually holds."""
+    if request.node.get_closest_marker("gpu") is None or request.node.get_closest_marker("timing") is not None:
+        yield
+        return
+    import torch
+    real_empty, real_empty_like = torch.empty, torch.empty_like
+
+    def poisoned(t):
+        if isinstance(t, torch.Tensor) and t.is_cuda and t.is_floating_point() and t.numel() > 0:
+            t.fill_(2.66e36)
+        return t
+
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: poisoned(real_empty(*a, **k)))
+    monkeypatch.setattr(torch, "empty_like", lambda *a, **k: poisoned(real_empty_like(*a, **k)))
     yield
 
 

@@ -35,6 +35,7 @@ def test_reference_command_line_runs(capsys):
         nusc_sim.main("--diffusion --rect_head --diverse_loss --test -P e7_ours --n_trials 1".split())
 
 
+@pytest.mark.timing
 def test_latency_of_a_simulation_step_at_the_reference_settings(capsys):
     """The reference's closed-loop settings (nusc_sim.py: 64 samples x 3 modes = 192 rows, 100 diffusion steps, K = 8
     neighbours, maximize guidance on the last 10 steps, 5 candidates + RefineNet): wall-clock latency per simulation step
