@@ -71,7 +71,7 @@ typedef struct pstl_cfg {
                               v_mfma_f32_16x16x32_f16 products per fp32 product, fp32 accumulate -- as close to
                               the reference as an fp32 fmaf chain in another summation order (0: batches with
                               fewer than five 16-row tiles per CU -- the closed-loop caller's 192 rows -- run
-                              the multi-step launch in a latency layout, 1..4 tiles per workgroup; 16: always
+                              their denoiser launches in a latency layout, 1..4 tiles per workgroup; 16: always
                               the throughput layout; the results are bit-identical); 8 or 4 = fp32
                               MFMA (v_mfma_f32_16x16x4_f32) with 8 / 4 waves per workgroup; 32 = policy_net
                               on bfloat16 pieces (2^-17 per operand), rect_net on fp32 MFMA.
