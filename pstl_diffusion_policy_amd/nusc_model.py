@@ -76,8 +76,13 @@ class Net(nn.Module):
 
     # ---- kernel-layout weights, re-packed whenever a parameter changed (load_state_dict, optimiser step) ----
     def packed(self):
-        ps = list(self.parameters())
-        key = (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
+        # (called a dozen times per batch by the mirror: the walk over the module tree is done once -- the Parameter objects
+        # stay the same under load_state_dict, optimiser steps and .cuda() --, and the key is a few attribute reads: in-place
+        # changes bump a parameter's version counter, which only ever grows, so their sum moves with any of them)
+        ps = self.__dict__.get("_plist")
+        if ps is None:
+            ps = self.__dict__["_plist"] = list(self.parameters())
+        key = (ps[0].device, sum(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr(), len(ps))
         if self._packed is None or key != self._packed_key:
             if not ps[0].is_cuda:
                 raise RuntimeError("Net must be on the GPU (net.cuda()) before the HIP path can run")
