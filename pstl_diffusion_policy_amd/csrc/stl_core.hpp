@@ -568,8 +568,8 @@ PSTL_HD float conj6(const float* v, int n, float tau) {  // softmin over n <= 6 
   return -((PSTL_LOG(s) + m) / tau);
 }
 
-// The geometry of the forward sweep, computed ahead (latency layout of the guidance kernel: four waves of a workgroup each
-// take five of the 20 time steps; the sweep itself then only reads): per time step the clearance, the lane distance and
+// The geometry of the sweeps, computed ahead (latency layout of the STL kernels: the waves of a workgroup each take a few of
+// the 20 time steps; the sweeps themselves then only read): per time step the clearance, the lane distance and
 // heading term, and the winners' record (lane segment | clearance winner << 8, carried as a bit pattern).
 //   slots 0-3  (forward sweep): clearance, lane distance, heading term 1 - cos, winners (segment | clearance winner << 8)
 //   slots 4-13 (adjoint): the clearance's partials (x, y, heading), the heading term as the adjoint's own evaluation yields

@@ -1006,7 +1006,7 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
   if (cfg->flags & PSTL_FLAG_NORM_STL)
     fn = niters > 1 ? (staged ? k_guidance_iter<true, true, true> : k_guidance_iter<true, false, true>)
                     : (staged ? k_guidance_iter<false, true, true> : k_guidance_iter<false, false, true>);
-  // fewer wavefronts than CUs: the latency layout (four waves per 64 rows, the forward geometry split over them by time step)
+  // few wavefronts: the latency layout (kSplitWaves waves per 64 rows, the geometry split over them by time step)
   // (up to two groups per CU: the ten-wave workgroups then run in two rounds of ~40 us, against ~100 us for one round of lone
   // wavefronts; beyond that the one-wave kernel's wavefronts start to share SIMDs and win)
   const bool split = staged && (long)grid.x <= 2 * guidance_split_max_groups();
