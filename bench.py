@@ -251,6 +251,10 @@ def main():
             sm_t.trace = sampler.trace
             loss, scores = RectTrainer(sm_t).train_step(sb, tparams, topt, steps, x_T=x_T, noise=z, seed=seed,
                                                         multi_cands=a.multi_cands, coeffs=coeffs, e7=e7, joint=a.joint)
+            if sm_t.chain_fallback and a.chain_waves in (0, 16):
+                # train_step reads the split-f16 domain flag before the optimiser consumes the gradients and repeats the step
+                # on the exact-fp32 kernels when it is set; a bench line must not silently mix the two arithmetics
+                raise FloatingPointError("bench: " + sm_t.chain_fallback)
             counts, _ = sm_t.metrics(sb, scores)
             return gather_final(counts, torch.zeros(12, dtype=torch.float64, device=dev))
         out = sampler.sampling_region(sb, steps, x_T, z, rect_head=rect_head,
@@ -294,8 +298,8 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    if not train:
-        sampler.check_chain_domain(fallback=False)     # a split-f16 launch that left its domain would have produced NaNs
+    if not train:      # (train workloads: checked inside every train_step, see one_step)
+        sampler.check_chain_domain(fallback=False)     # a split-f16 launch that left its domain leaves undefined results
     ms = [e0.elapsed_time(e1) for (e0, e1, _, _) in sampler.trace]
     nst, nrows = sampler.trace[0][2], sampler.trace[0][3]
     k_ms = float(np.mean(ms))

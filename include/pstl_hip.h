@@ -245,7 +245,10 @@ size_t pstl_train_work_floats(const pstl_cfg* cfg);
  * dw1 (256,271), db1 (256), dw2 (256,256), db2 (256), dw3 (40,256), db3 (40).  Gradients w.r.t. the scene encoders and
  * merge_net (needed only with --joint: the reference's optimiser holds rect_net.parameters() otherwise,
  * nusc_train.py:1230-1233) come from pstl_encoder_backward / pstl_merge_backward below, which continue from what this
- * call leaves in `work`.  work: pstl_train_work_floats(cfg) floats. */
+ * call leaves in `work`.  work: pstl_train_work_floats(cfg) floats.
+ * Arithmetic: the activation-gradient products (dH2, dH1) are split-bf16 MFMA products (2^-17 per operand, fp32 range) in
+ * every mode; dw2 likewise unless cfg->chain_waves is 8 or 4 (the exact-fp32 request), where it is an fp32-MFMA
+ * contraction; dw1, dw3 and the bias gradients are always fp32.  Against the reference's autograd: rtol 5e-3 (tested). */
 int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float* w2, const float* w3, const float* feature,
                          const float* stlp, const float* hl, const float* init_controls,
                          const float* pooled /* (bs,3,n_shards,40) from the forward call; null with PSTL_FLAG_NO_MERGE */,

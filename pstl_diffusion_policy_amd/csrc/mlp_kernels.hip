@@ -516,7 +516,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     long row = (tile0 + tl) * kTileRows + c;
     if (row >= a.N) row = a.N - 1;
     f32x4 v;
-    if (j < kCtrl / 4) {
+    if (SPARSE && tl >= Gr) {   // an empty pipeline slot: zeros, never the rows of tiles other workgroups own (and rewrite)
+      v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    } else if (j < kCtrl / 4) {
       if (REFINE) {
         v = *reinterpret_cast<const f32x4*>(a.init + row * kCtrl + 4 * j);
         if (a.pooled) {  // fused = init + pooled[scene][mode][shard]   (nusc_model.py:186-200)
@@ -911,9 +913,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); \
     __builtin_amdgcn_sched_barrier(0);                                   \
   }
+  // (SPARSE: empty slots get neither a stand-alone layer 1 nor pieces -- nothing reads them, and they stay out of the guard)
   layer1(p0, 0);
-  if (total > 1) layer1(p1, 1);
-  split_x(p2, 0);      // pieces for the layer 1 woven into iteration 0
+  if (total > 1 && real(p1.tl)) layer1(p1, 1);
+  if (real(p2.tl) && !solo) split_x(p2, 0);      // pieces for the layer 1 woven into iteration 0
   __syncthreads();
   // BF, in-kernel noise: waves 4..6 draw it INSIDE their layer-2 MFMA stream (branch-free, one basic block) instead of in
   // a phase of their own in front of it

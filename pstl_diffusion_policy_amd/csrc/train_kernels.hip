@@ -315,7 +315,6 @@ __global__ void k_reg_grad(long N, float weight, const float* rect, const float*
     dcontrols[i] += (weight * reg_out[1] / (float)(N * kCtrl)) * (2.0f * (rect[i] - init[i]));
 }
 
-// row-major C(m x n) = op(A) op(B) through column-major rocBLAS
 constexpr int kRedBlocks = 512;
 constexpr long kWtPackWords = 16L * 8 * 8 * 64;   // split-bf16 A operands of one transposed 256 x 256 weight matrix (k_dgrad)
 
@@ -904,7 +903,13 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
   if (int e = wgrad<3, 16, 1, 8>(N, dO, kCtrl, kCtrl, h2, kHid, kHid, slabs, dw3, kHid, st)) return e;  // dW3 = dO^T h2
   // layer 2: dH2 = (dO W3) * [h2 > 0], db2 = column sums of dH2
   if (int e = dgrad<2>(N, dO, kCtrl, kCtrl, w3, wpack, h2, dH2, part, db2, st)) return e;
-  if (int e = wgrad_bf<16, 16, 2, 4>(N, dH2, kHid, kHid, h1, kHid, kHid, slabs, dw2, kHid, st)) return e;  // dW2 = dH2^T h1
+  // dW2 = dH2^T h1: split-bf16 products (2^-17 per operand, HBM-bound) unless the caller asked for the exact-fp32 kernels
+  // (cfg->chain_waves 8 / 4, also what the host falls back to after a split-f16 domain overflow): then the fp32 MFMA form
+  if (cfg->chain_waves == 8 || cfg->chain_waves == 4) {
+    if (int e = wgrad<16, 16, 4, 2>(N, dH2, kHid, kHid, h1, kHid, kHid, slabs, dw2, kHid, st)) return e;
+  } else {
+    if (int e = wgrad_bf<16, 16, 2, 4>(N, dH2, kHid, kHid, h1, kHid, kHid, slabs, dw2, kHid, st)) return e;
+  }
   // layer 1: dH1 = (dH2 W2) * [h1 > 0], db1 = column sums of dH1
   if (int e = dgrad<8>(N, dH2, kHid, kHid, w2, wpack, h1, dH1, part, db1, st)) return e;
   hipLaunchKernelGGL(k_scene_sum, dim3(cfg->bs), dim3(256), 0, st, cfg->rows_per_scene, dH1, S);

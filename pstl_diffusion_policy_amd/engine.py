@@ -177,8 +177,9 @@ def guidance_triggered(i, steps, g):
 
 class Sampler:
     def __init__(self, weights, hp, chain_waves=None):
-        # chain_waves: arithmetic of the MLP chains (include/pstl_hip.h): 0 = denoiser on split-bf16 MFMA (default),
-        # 8 = exact fp32 MFMA.  Callers that go through the reference's CLI surface choose with PSTL_CHAIN_WAVES.
+        # chain_waves: arithmetic of the MLP chains (include/pstl_hip.h): 0 = both MLP chains on split-f16 MFMA products
+        # (default), 8 = exact fp32 MFMA, 32 = split-bf16.  Callers that go through the reference's CLI surface choose with
+        # PSTL_CHAIN_WAVES.
         if chain_waves is None:
             chain_waves = int(os.environ.get("PSTL_CHAIN_WAVES", "0"))
         self.w, self.hp, self.chain_waves = weights, hp, int(chain_waves)
@@ -718,24 +719,33 @@ class RectTrainer:
         sm = self.sm
         use_merge = (e7 is not None) if merge is None else bool(merge)
         names = self.joint_names(use_merge) if joint else self.NAMES
-        saved = None
-        if joint:
-            feature, base_p, base_r, saved = sm.encode(sb, need_rect=True, save=True)
-        else:
-            feature, base_p, base_r = sm.encode(sb, need_rect=True)
-        x = sm.fill_normal(sb, steps, steps, seed) if seed is not None else x_T.clone()
-        emit = sm.rollout(sb, base_p, x, noise, steps, n_emit=max(multi_cands, 1), clip=True, coeffs=coeffs, seed=seed)
-        r = sm.score(sb, emit[-multi_cands:].contiguous(), select=True)
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         if e7 is not None and world > 1:
             # loss_diversity is a mean over the groups of the GLOBAL batch: with equal shards every rank contributes 1/world
             # (loss_reg's mask_mean is normalised per shard; its weight --rect_reg_loss is 0 in every README command)
             e7 = dict(e7, diversity_weight=float(e7["diversity_weight"]) / world,
                       rect_reg_loss=float(e7.get("rect_reg_loss", 0.0)) / world)
-        loss, rect, scores, g = self.loss_and_grads(sb, feature, base_r, params["rect_net.2.weight"],
-                                                    params["rect_net.4.weight"], r["sel_controls"], r["sel_scores"], e7=e7,
-                                                    stl_weight=stl_weight, merge=merge, clip_rect=clip_rect,
-                                                    joint=dict(params=params, saved=saved) if joint else None)
+
+        def forward_backward():
+            saved = None
+            if joint:
+                feature, base_p, base_r, saved = sm.encode(sb, need_rect=True, save=True)
+            else:
+                feature, base_p, base_r = sm.encode(sb, need_rect=True)
+            x = sm.fill_normal(sb, steps, steps, seed) if seed is not None else x_T.clone()
+            emit = sm.rollout(sb, base_p, x, noise, steps, n_emit=max(multi_cands, 1), clip=True, coeffs=coeffs, seed=seed)
+            r = sm.score(sb, emit[-multi_cands:].contiguous(), select=True)
+            return self.loss_and_grads(sb, feature, base_r, params["rect_net.2.weight"], params["rect_net.4.weight"],
+                                       r["sel_controls"], r["sel_scores"], e7=e7, stl_weight=stl_weight, merge=merge,
+                                       clip_rect=clip_rect, joint=dict(params=params, saved=saved) if joint else None)
+
+        loss, rect, scores, g = forward_backward()
+        # Domain of the split-f16 chains (rollout AND the saved RefineNet forward), read BEFORE the gradients reach the
+        # optimiser: a layer input beyond the half range leaves plausible-looking garbage, not NaNs.  One 4-byte copy; the
+        # step is then repeated on the exact-fp32 kernels (same noise: supplied, or the same Philox seed) and the sampler stays
+        # there -- the caller sees `self.sm.chain_fallback` and a RuntimeWarning.
+        if sm.check_chain_domain():
+            loss, rect, scores, g = forward_backward()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             flat = torch.cat([g[k].reshape(-1) for k in names] + [loss.reshape(1)])
             if dist.get_backend(group) == "gloo":       # host tensors (ranks sharing a device in the tests); RCCL: in place

@@ -71,24 +71,41 @@ class Net(nn.Module):
         self._packed = None
         self._packed_key = None
         # arithmetic of the MLP chains (include/pstl_hip.h, cfg.chain_waves): None = PSTL_CHAIN_WAVES or the default
-        # (split-f16); set to 8 (exact fp32 MFMA) by the harness when a batch left the split-f16 domain
+        # (split-f16); set to 8 (exact fp32 MFMA) when a call left the split-f16 domain (check_domain)
         self.chain_waves = None
+        # Domain guard of the split-f16 chains (|layer input| < 4094; outside it the kernels leave plausible garbage, not NaNs,
+        # and set a sticky status word).  "eager": every forward / rect_forward / diffusion_rollout call reads that word before
+        # it returns (a 4-byte copy: one device synchronisation per call) and, when it is set, warns, repeats the call on the
+        # exact-fp32 kernels and stays there.  "deferred": the caller promises to call net.check_domain() where it
+        # synchronises anyway and to discard / repeat the work since the last check when it returns True (run_sampling_test
+        # does that around its timed region).
+        self.domain_check = "eager"
 
     # ---- kernel-layout weights, re-packed whenever a parameter changed (load_state_dict, optimiser step) ----
     def packed(self):
-        # (called a dozen times per batch by the mirror: the walk over the module tree is done once -- the Parameter objects
-        # stay the same under load_state_dict, optimiser steps and .cuda() --, and the key is a few attribute reads: in-place
-        # changes bump a parameter's version counter, which only ever grows, so their sum moves with any of them)
-        ps = self.__dict__.get("_plist")
-        if ps is None:
-            ps = self.__dict__["_plist"] = list(self.parameters())
-        key = (ps[0].device, sum(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr(), len(ps))
+        # (called a dozen times per batch by the mirror, so the key is cheap -- ~15 us: a direct walk over the six Sequentials'
+        # Linear layers instead of nn.Module.parameters() -- and complete: the identity of every storage (a replaced Parameter
+        # or sub-module, `p.data = t`, load_state_dict(assign=True), .cuda()) and every version counter (in-place changes:
+        # optimiser steps, load_state_dict's copy_) enter it.)
+        ps = list(self._iter_params())
+        key = (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
         if self._packed is None or key != self._packed_key:
             if not ps[0].is_cuda:
                 raise RuntimeError("Net must be on the GPU (net.cuda()) before the HIP path can run")
             self._packed = PackedWeights({k: v for k, v in self.state_dict().items()}, ps[0].device)
             self._packed_key = key
         return self._packed
+
+    def _iter_params(self):
+        """The live Parameter objects in parameters() order, read straight from the six Sequentials' Linear layers."""
+        for name in ("ego_encoder", "neighbor_encoder", "lane_encoder", "policy_net", "merge_net", "rect_net"):
+            seq = self._modules.get(name)
+            if seq is None:
+                continue
+            for layer in seq._modules.values():
+                for p in layer._parameters.values():
+                    if p is not None:
+                        yield p
 
     def chain_arith(self):
         """cfg.chain_waves for this net's weights: the requested arithmetic, or the exact-fp32 kernels when a chain weight is
@@ -103,6 +120,28 @@ class Net(nn.Module):
                               % (ffi.SPLIT_F16_WMAX, pw.chain_wmax["policy_net"], pw.chain_wmax["rect_net"]), RuntimeWarning)
             return 8
         return cw
+
+    def check_domain(self, fallback=True):
+        """Did a split-f16 launch since the last check see a layer input outside the half range?  False when all is well.
+        Otherwise every result since the last check is undefined: with fallback=True a RuntimeWarning is issued, the net is
+        switched to the exact-fp32 kernels for good (chain_waves = 8), the flag cleared and True returned -- the caller repeats
+        the work; with fallback=False a FloatingPointError is raised.  Synchronises (one 4-byte copy)."""
+        if self.chain_arith() not in (0, 16) or not self.packed().chain_overflowed(clear=True):
+            return False
+        why = "a layer input left the split-f16 domain |x| < 4094"
+        if not fallback:
+            raise FloatingPointError("pstl: " + why + "; set net.chain_waves = 8 (exact-fp32 kernels)")
+        warnings.warn("pstl: " + why + "; the call is repeated, and later ones run, on the exact-fp32 kernels "
+                      "(chain_waves = 8)", RuntimeWarning, stacklevel=3)
+        self.chain_waves = 8
+        return True
+
+    def _guarded(self, launch):
+        """launch(chain_waves) -> result, under the domain guard (see __init__)."""
+        out = launch(self.chain_arith())
+        if self.domain_check == "eager" and self.check_domain():
+            out = launch(8)
+        return out
 
     def hparams(self):
         a = self.args
@@ -159,20 +198,26 @@ class Net(nn.Module):
         info = self._bases_of(feature)
         pw = self.packed()
         dev = pw.device
-        x = ffi.f32(ext["noise"], dev).clone()
-        N = x.shape[0]
+        x_in = ffi.f32(ext["noise"], dev)
+        N = x_in.shape[0]
         t = int(ext["timestep"].reshape(-1)[0].item())
         steps = max(int(a.diffusion_steps), t + 1)
         stlp = ffi.f32(nn_input["stlp_dense"][:, 0], dev)
         hl = ffi.f32(ext["highlevel"].reshape(N), dev)
         rps = info["rows_per_scene"]
-        cfg = ffi.make_cfg(N // rps, rps, max(rps // 3, 1), 1, steps, self.hparams(), chain_waves=self.chain_arith())
         from .engine import diffusion_coeffs
         beta, alpha, alpha_hat = diffusion_coeffs(steps, dev)
-        ffi.check(ffi.lib().pstl_rollout(ctypes.byref(cfg), ffi.ptr(pw.packed), ffi.ptr(info["base_policy"]),
-                                         ffi.ptr(pw.tbias(steps)), ffi.ptr(stlp), ffi.ptr(hl), ffi.ptr(beta),
-                                         ffi.ptr(alpha), ffi.ptr(alpha_hat), ffi.ptr(None), t, t, 2, ffi.ptr(x),
-                                         ffi.ptr(None), 0, ffi.stream()), "rollout(eps)")
+
+        def launch(chain_waves):
+            x = x_in.clone()
+            cfg = ffi.make_cfg(N // rps, rps, max(rps // 3, 1), 1, steps, self.hparams(), chain_waves=chain_waves)
+            ffi.check(ffi.lib().pstl_rollout(ctypes.byref(cfg), ffi.ptr(pw.packed), ffi.ptr(info["base_policy"]),
+                                             ffi.ptr(pw.tbias(steps)), ffi.ptr(stlp), ffi.ptr(hl), ffi.ptr(beta),
+                                             ffi.ptr(alpha), ffi.ptr(alpha_hat), ffi.ptr(None), t, t, 2, ffi.ptr(x),
+                                             ffi.ptr(None), 0, ffi.stream()), "rollout(eps)")
+            return x
+
+        x = self._guarded(launch)
         controls = x.reshape(N, a.nt, 2)
         return (controls, feature) if get_feature else controls
 
@@ -186,18 +231,24 @@ class Net(nn.Module):
         rps = info["rows_per_scene"]
         diverse = bool(getattr(a, "diverse_loss", False)) and not getattr(a, "no_arch", False)
         flags = (0 if diverse else ffi.PSTL_FLAG_NO_MERGE) | (ffi.PSTL_FLAG_CLIP_RECT if getattr(a, "clip_rect", False) else 0)
-        cfg = ffi.make_cfg(N // rps, rps, rps // 3, 1, 2, self.hparams(), flags, chain_waves=self.chain_arith())
+        n_shards = int(self.hparams().get("n_shards", 4))
         if diverse and rps // 3 != a.n_randoms:
             raise ValueError("merge_net pooling needs sampling_size == n_randoms (reference nusc_model.py:187-196)")
         init = ffi.f32(init_controls.reshape(N, -1), dev)
-        pooled = torch.empty(N // rps, 3, cfg.n_shards, ffi.CTRL, dtype=torch.float32, device=dev) if diverse else None
+        pooled = torch.empty(N // rps, 3, n_shards, ffi.CTRL, dtype=torch.float32, device=dev) if diverse else None
         out = torch.empty(N, ffi.CTRL, dtype=torch.float32, device=dev)
         # converted copies get names: every argument is evaluated before the asynchronous launch, and an unnamed copy
         # would be freed (and its block handed to the next copy) before the kernel reads it
         stlp_c, hl_c, sc_c = ffi.f32(stlp_dense_feat, dev), ffi.f32(highlevel.reshape(N), dev), ffi.f32(scores.reshape(N), dev)
-        ffi.check(ffi.lib().pstl_refine(ctypes.byref(cfg), ffi.ptr(pw.packed), ffi.ptr(info["base_rect"]),
-                                        ffi.ptr(stlp_c), ffi.ptr(hl_c), ffi.ptr(init), ffi.ptr(sc_c), ffi.ptr(pooled),
-                                        ffi.ptr(out), ffi.stream()), "refine")
+
+        def launch(chain_waves):
+            cfg = ffi.make_cfg(N // rps, rps, rps // 3, 1, 2, self.hparams(), flags, chain_waves=chain_waves)
+            ffi.check(ffi.lib().pstl_refine(ctypes.byref(cfg), ffi.ptr(pw.packed), ffi.ptr(info["base_rect"]),
+                                            ffi.ptr(stlp_c), ffi.ptr(hl_c), ffi.ptr(init), ffi.ptr(sc_c), ffi.ptr(pooled),
+                                            ffi.ptr(out), ffi.stream()), "refine")
+            return out
+
+        out = self._guarded(launch)
         return out.reshape(N, a.nt, 2)
 
 

@@ -72,12 +72,29 @@ class SyntheticWorld:
         return float(d.min())
 
 
+def _plan(sm, obs, S, hp, dev, diffusion_steps, multi_cands, g, seed):
+    """One planning step: the sampling region on the one-scene batch, then the best lane-keeping sample.  Returns a host tensor
+    (first control (2), its score, the bits of the chain-domain status word)."""
+    sb = SceneBatch(obs, S, hp, dev)
+    out = sm.sampling_region(sb, diffusion_steps, None, None, rect_head=True, multi_cands=multi_cands, guidance=g,
+                             seed=seed, want_scores3=False)
+    # lane-keeping samples only (the reference sets the other two modes' scores to -10000 before its argmax, :676-677):
+    # the best of column 0, its first control and its score, selected on the device and brought back in ONE copy
+    keep = out["final_scores"].reshape(S, 3)[:, 0]
+    bi = torch.argmax(keep)
+    first = out["final_controls"].reshape(S, 3, ffi.T, 2)[:, 0, 0, :]     # (S,2): first control of every mode-0 sample
+    return torch.cat([first.index_select(0, bi.reshape(1)).reshape(2), keep.index_select(0, bi.reshape(1)),
+                      sm.w.status[2:3]]).cpu()
+
+
 def closed_loop(state_dict, n_sim_steps=20, K=8, S=64, diffusion_steps=100, multi_cands=5, guidance=True, guidance_before=10,
-                guidance_lr=0.04, seed=0, device="cuda:0", verbose=True):
-    """Runs the receding-horizon loop; returns per-step records (latency in seconds with device sync, score, state)."""
+                guidance_lr=0.04, seed=0, device="cuda:0", verbose=True, chain_waves=None):
+    """Runs the receding-horizon loop; returns per-step records (latency in seconds with device sync, score, state).
+    chain_waves: arithmetic of the MLP chains (None: PSTL_CHAIN_WAVES or the default split-f16 form; a step that leaves its
+    domain is planned again on the exact-fp32 kernels, with a RuntimeWarning, and the loop stays on them)."""
     dev = torch.device(device)
     hp = default_hparams()
-    sm = Sampler(PackedWeights(state_dict, dev), hp)
+    sm = Sampler(PackedWeights(state_dict, dev), hp, chain_waves=chain_waves)
     world = SyntheticWorld(K=K, seed=seed, dt=hp["dt"], nt=hp["nt"])
     g = dict(enabled=True, before=guidance_before, niters=1, lr=guidance_lr, maximize=True) if guidance else None
     records = []
@@ -85,15 +102,12 @@ def closed_loop(state_dict, n_sim_steps=20, K=8, S=64, diffusion_steps=100, mult
         obs = world.observation()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        sb = SceneBatch(obs, S, hp, dev)
-        out = sm.sampling_region(sb, diffusion_steps, None, None, rect_head=True, multi_cands=multi_cands, guidance=g,
-                                 seed=seed * 100003 + it, want_scores3=False)
-        # lane-keeping samples only (the reference sets the other two modes' scores to -10000 before its argmax, :676-677):
-        # the best of column 0, its first control and its score, selected on the device and brought back in ONE copy
-        keep = out["final_scores"].reshape(S, 3)[:, 0]
-        bi = torch.argmax(keep)
-        first = out["final_controls"].reshape(S, 3, ffi.T, 2)[:, 0, 0, :]     # (S,2): first control of every mode-0 sample
-        pick = torch.cat([first.index_select(0, bi.reshape(1)).reshape(2), keep.index_select(0, bi.reshape(1))]).cpu()
+        pick = _plan(sm, obs, S, hp, dev, diffusion_steps, multi_cands, g, seed * 100003 + it)
+        # The split-f16 domain flag rides in the same copy as the control (bit pattern of the packed buffer's status word 2):
+        # a layer input beyond the half range leaves plausible garbage, not NaNs, and this loop would drive the vehicle with it.
+        # The step is then planned again on the exact-fp32 kernels (same Philox seed), and so is every later one.
+        if pick[3:4].view(torch.int32).item() != 0 and sm.check_chain_domain():
+            pick = _plan(sm, obs, S, hp, dev, diffusion_steps, multi_cands, g, seed * 100003 + it)
         ctrl = pick[:2]
         lat = time.perf_counter() - t0
         world.step(ctrl)

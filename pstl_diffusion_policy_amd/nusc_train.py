@@ -432,13 +432,21 @@ def diffusion_rollout(noise, net, batch_cuda, highlevel_dense, feature, args, co
             guidance = dict(enabled=True, before=args.guidance_before, niters=args.guidance_niters,
                             lr=args.guidance_lr, reverse=args.guidance_reverse, sets=args.guidance_sets,
                             freq=args.guidance_freq, maximize=maximize)
-        sm = Sampler(net.packed(), net.hparams(), chain_waves=net.chain_arith())
         n_emit = steps if args.diff_full else 1
         if fastforward:
             emit = normalize_diff(x, n, args.nt, args.mul_w_max, args.mul_a_max, args.diffusion_clip).reshape(1, n, -1)
         else:
+            # domain guard of the split-f16 chain (Net.domain_check): in eager mode x_T is kept, so that a rollout that set the
+            # flag is repeated on the exact-fp32 kernels from the same x_T and the same noise (supplied, or the same Philox seed)
+            eager = net.domain_check == "eager" and net.chain_arith() in (0, 16)
+            x_T = x.clone() if eager else None
+            sm = Sampler(net.packed(), net.hparams(), chain_waves=net.chain_arith())
             emit = sm.rollout(sb, feature.pstl["base_policy"], x, zs, steps, n_emit=n_emit, clip=args.diffusion_clip,
                               guidance=guidance, coeffs=coeffs, seed=seed)
+            if eager and net.check_domain():
+                sm = Sampler(net.packed(), net.hparams(), chain_waves=net.chain_arith())
+                emit = sm.rollout(sb, feature.pstl["base_policy"], x_T, zs, steps, n_emit=n_emit, clip=args.diffusion_clip,
+                                  guidance=guidance, coeffs=coeffs, seed=seed)
     diffused_result = emit[-1].reshape(n, args.nt, 2)
     if args.diff_full:
         final_list = [e.reshape(n, args.nt, 2) for e in emit]
@@ -593,16 +601,17 @@ def run_sampling_test(stls_cac, data_loader, net, coeffs, args, result_queue=Non
             tttt2 = time.time()
             return nn_controls, scores, acc, scene_acc, sm, sb, tttt2 - tttt1
 
-        nn_controls, scores, acc, scene_acc, sm, sb, elapsed = timed_region()
-        # Domain of the default (split-f16) chain arithmetic, checked where the harness synchronises anyway: a layer input
-        # beyond the half range turns the state into NaN and sets the packed buffer's status word.  The batch is then run
-        # again on the exact-fp32 kernels, and so is everything after it.
-        if net.chain_arith() in (0, 16) and net.packed().chain_overflowed(clear=True):
-            import warnings
-            warnings.warn("pstl: a layer input left the split-f16 domain |x| < 4094 in batch %d; re-running it, and running the "
-                          "rest, on the exact-fp32 kernels (chain_waves = 8)" % bi, RuntimeWarning)
-            net.chain_waves = 8
-            nn_controls, scores, acc, scene_acc, sm, sb, elapsed = timed_region(first=False)
+        # Domain of the default (split-f16) chain arithmetic, checked ONCE per batch where the harness synchronises anyway
+        # (the per-call checks of Net.forward / rect_forward / diffusion_rollout are deferred for the timed region): a layer
+        # input beyond the half range leaves undefined results and sets the packed buffer's status word.  The batch is then
+        # run again on the exact-fp32 kernels, and so is everything after it (net.check_domain warns and switches).
+        mode, net.domain_check = net.domain_check, "deferred"
+        try:
+            nn_controls, scores, acc, scene_acc, sm, sb, elapsed = timed_region()
+            if net.check_domain():
+                nn_controls, scores, acc, scene_acc, sm, sb, elapsed = timed_region(first=False)
+        finally:
+            net.domain_check = mode
         md.update("acc", acc.item())
         md.update("scene_acc", scene_acc.item())
         md.update("time", elapsed)
@@ -733,6 +742,10 @@ def run_training(data_loader, net, coeffs, args):
                                          multi_cands=args.multi_cands or 1, coeffs=coeffs, e7=e7, stl_weight=args.stl_weight,
                                          merge=bool(args.diverse_loss and not args.no_arch), clip_rect=bool(args.clip_rect),
                                          joint=bool(args.joint))
+            if tr.sm.chain_fallback and net.chain_waves != 8:
+                # train_step found the split-f16 domain flag set (or a weight outside |w| < 63.9), repeated the step on the
+                # exact-fp32 kernels and warned; the run stays there: weights that grew past the domain rarely come back
+                net.chain_waves = 8
             counts, _ = tr.sm.metrics(sb, scores)
             acc, _ = acc_from_counts(counts)
             md.update("loss", float(loss))
