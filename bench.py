@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the DDPM-sampling + STL hot path on MI355X (contract: see the round prompt).
 
+The line also carries (single-GPU runs; skipped with --no_extras): "roofline.fp32_exact" (the same step on the exact-fp32
+MFMA chains), "also" (BASELINE configs 2, 3 and 5 -- e5, e7, e8_train -- three timed steps each, each with its own dominant-kernel
+roofline fraction; e8_train with the HBM rate of RefineNet's backward) and "sweep" (the headline workload at 192 ... 786 432 rows).
+
 A "step" is one pass of the timed region of the reference's sampling harness (nusc_train.py:957-1105) over one
 synthetic batch already resident in HBM: row constants, scene preparation, scene encoder, noise generation,
 `diffusion_steps-1` denoiser evaluations (+ STL guidance on the last `guidance_before` steps), candidate scoring +
@@ -46,7 +50,8 @@ def parse():
     p.add_argument("--noise", default="kernel", choices=["kernel", "torch"],
                    help="kernel: Philox noise drawn inside the HIP kernels; torch: torch.randn tensors (parity mode)")
     p.add_argument("--no_cpu_baseline", action="store_true")
-    p.add_argument("--cpu_scenes", type=int, default=24)
+    p.add_argument("--cpu_scenes", type=int, default=12)
+    p.add_argument("--no_extras", action="store_true", help="skip the fp32-exact leg, the 'also' workloads and the batch-size sweep")
     p.add_argument("--trajopt_iters", type=int, default=50, help="Adam iterations per step of the trajopt workload")
     return p.parse_args()
 
@@ -160,6 +165,152 @@ def spawn_ranks(a):
     return rc
 
 
+# algorithmic HBM bytes per row of RefineNet's backward (pstl_refine_backward): what must be read once -- the two saved
+# activations h1, h2 (2 x 256 floats), dcontrols / pre / init (3 x 40), hl | stlp (7) -- the 145 704 gradients it writes are noise
+BWD_BYTES_PER_ROW = 4 * (2 * 256 + 3 * 40 + 7)
+
+
+def chain_layout(n_rows, cus=256):
+    """Which layout pstl_rollout picks for a batch (csrc/mlp_kernels.hip: sparse_tiles_per_group / tiles_per_group)."""
+    n_tiles = (n_rows + 15) // 16
+    if n_tiles < 5 * cus:
+        return "latency (%d tile(s) per workgroup, empty pipeline slots)" % ((n_tiles + cus - 1) // cus)
+    return "throughput (%d tiles per workgroup)" % max(5, min(12, n_tiles // 256))
+
+
+class Job:
+    """One workload on one synthetic scene shard, resident in HBM: step() enqueues one pass of the timed region."""
+
+    def __init__(self, a, workload, bs, dev, rank, world, cpu_group, weights, hp, sd, chain_waves, joint=False):
+        from pstl_diffusion_policy_amd.engine import Sampler, diffusion_coeffs
+        from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+        self.a, self.workload, self.bs, self.dev, self.rank, self.world, self.cpu_group = a, workload, bs, dev, rank, world, cpu_group
+        self.hp, self.sd, self.chain_waves, self.joint = hp, sd, chain_waves, joint
+        self.rect_head = workload != "e5"
+        self.guidance = dict(enabled=True, before=10, niters=1, lr=0.01) if workload == "e7_guid" else None
+        self.train = workload in ("e8_train", "e7_train")   # one optimisation step of RefineNet (SURVEY 8f N1): config 5 / e7
+        self.e7 = dict(stl_weight=0.0, diversity_weight=1.0) if workload == "e7_train" else None
+        self.trajopt = workload == "trajopt"    # N4: the data-augmentation loop, trajopt_iters Adam iterations per step
+        self.S, self.steps = a.sampling_size, a.diffusion_steps
+        # every rank owns its own contiguous block of scenes (seeded by the global scene offset); no data-path collective
+        scene = make_scene_batch(bs, K=a.neighbors, S=self.S, seed=1000 + rank, invalid_lane_frac=0.2, stlp_mode="wide")
+        self.ids_host = float(sum(scene[k].sum().item() for k in ("curr_id", "left_id", "right_id")))   # from the CPU copy, as a
+        self.scene = {k: v.to(dev) for k, v in scene.items() if k not in ("pre_stlp", "tj_scores_prior")}   # data loader would
+        self.sampler = Sampler(weights, hp, chain_waves=chain_waves)
+        if self.train:
+            from pstl_diffusion_policy_amd.engine import RectTrainer
+            self.tnames = RectTrainer.joint_names(self.e7 is not None) if joint else RectTrainer.NAMES   # --joint: encoders (+ merge_net) too
+            self.tparams = {k: sd[k].to(dev).clone().requires_grad_() for k in self.tnames}
+            self.topt = torch.optim.Adam([self.tparams[k] for k in self.tnames], lr=3e-4)
+            self.sd_live = {k: (self.tparams[k] if k in self.tparams else v) for k, v in sd.items()}
+        self.coeffs = diffusion_coeffs(self.steps, dev)
+        self.N = bs * self.S * 3
+        self.gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        self.call = 0
+
+    def step(self):
+        from pstl_diffusion_policy_amd.engine import PackedWeights, RectTrainer, Sampler, SceneBatch
+        from pstl_diffusion_policy_amd.shard import gather_final, global_valid_stats
+        a, dev, N, S, steps, sampler = self.a, self.dev, self.N, self.S, self.steps, self.sampler
+        # global mean(valid) of the guidance loss (one tiny all-reduce; the shard split must not change results)
+        vsum, vrows = global_valid_stats(self.ids_host * S, N, torch.device("cpu") if (self.cpu_group or self.world == 1) else dev,
+                                         group=self.cpu_group)
+        sb = SceneBatch(self.scene, S, self.hp, dev, global_valid_sum=vsum, global_rows=vrows, row_offset=self.rank * N)
+        if a.noise == "torch":
+            x_T = torch.randn(N, 40, device=dev, generator=self.gen)
+            z = torch.randn(steps - 1, N, 40, device=dev, generator=self.gen)
+            seed = None
+        else:
+            x_T = z = None
+            self.call += 1
+            seed = 987654321 + self.call
+        if self.trajopt:
+            params = self.scene["params"].reshape(N, 40).clone()
+            sc, _ = sampler.trajopt(sb, params, a.trajopt_iters, 0.005, 0.01, 10.0, global_valid_sum=vsum, global_rows=vrows)
+            counts, _ = sampler.metrics(sb, sc)
+            return gather_final(counts, torch.zeros(12, dtype=torch.float64, device=dev))
+        if self.train:
+            sm_t = Sampler(PackedWeights(self.sd_live, dev), self.hp, chain_waves=self.chain_waves)   # weights changed: re-pack
+            sm_t.trace, sm_t.trace_bwd = sampler.trace, sampler.trace_bwd
+            loss, scores = RectTrainer(sm_t).train_step(sb, self.tparams, self.topt, steps, x_T=x_T, noise=z, seed=seed,
+                                                        multi_cands=a.multi_cands, coeffs=self.coeffs, e7=self.e7, joint=self.joint)
+            if sm_t.chain_fallback and self.chain_waves in (0, 16):
+                # train_step reads the split-f16 domain flag before the optimiser consumes the gradients and repeats the step
+                # on the exact-fp32 kernels when it is set; a bench line must not silently mix the two arithmetics
+                raise FloatingPointError("bench: " + sm_t.chain_fallback)
+            counts, _ = sm_t.metrics(sb, scores)
+            return gather_final(counts, torch.zeros(12, dtype=torch.float64, device=dev))
+        out = sampler.sampling_region(sb, steps, x_T, z, rect_head=self.rect_head,
+                                      multi_cands=a.multi_cands if self.rect_head else None, guidance=self.guidance,
+                                      coeffs=self.coeffs, want_scores3=False, seed=seed, diversity=True)
+        # the only exchange after the rollout: the final diversity / STL-satisfaction reduction -- 8 counters + 12
+        # diversity totals per rank in one RCCL all-gather over xGMI (when N > 1)
+        return gather_final(out["counts"], out["div_totals"])
+
+    def measure(self, steps, warmup, dist=None):
+        """`warmup` untimed steps, then exactly `steps` timed ones between barrier + synchronize on both sides; MAX over ranks."""
+        for _ in range(warmup):
+            self.step()
+        sm = self.sampler
+        sm.trace, sm.trace_stl, sm.trace_bwd = [], {}, ([] if self.train else None)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            counts, div_totals = self.step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        if not self.train and not self.trajopt:      # (train workloads: checked inside every train_step, see step())
+            sm.check_chain_domain(fallback=False)    # a split-f16 launch that left its domain leaves undefined results
+        res = {"dt": dt, "ms_per_step": dt / steps * 1e3, "value": self.world * self.N * steps / dt, "counts": counts,
+               "div_totals": div_totals, "steps": steps}
+        multi = [(e0.elapsed_time(e1), n, rows) for (e0, e1, n, rows) in (sm.trace or [])]
+        if multi:      # dominant kernel (k_chain, the multi-step denoiser launch): HIP events on the launch stream
+            nst, nrows = multi[0][1], multi[0][2]
+            k_ms = float(np.mean([m for m, n, _ in multi if n == nst]))
+            flop = float(nrows) * nst * F_STEP_MIN
+            res.update(kernel_ms=k_ms, kernel_steps=nst, flop=flop, achieved=flop / (k_ms * 1e-3) / 1e12)
+        # the STL kernels (one row per lane): row-evaluations/s and what that means against the HBM roofline.  Algorithmic
+        # bytes per row-evaluation in the scene-shared layout: 160 B controls + 16 B s0 + 24 B stlp + 4 B score + scene
+        # tables amortised over the 192 rows of a scene (SURVEY 8d) -- these kernels are VALU-bound, not HBM-bound.
+        K = self.a.neighbors
+        stl_bytes = 160 + 16 + 24 + 4 + (K * 20 * 7 * 4 + 540) / (3.0 * self.S)
+        stl_info = {}
+        for kind, evs in (sm.trace_stl or {}).items():
+            ms_k = sum(e0.elapsed_time(e1) for (e0, e1, _) in evs)
+            evals = sum(n for (_, _, n) in evs)
+            if ms_k > 0:
+                rate = evals / (ms_k * 1e-3)
+                stl_info[kind] = {"kernel": "k_guidance_iter (forward + adjoint + Adam)" if kind == "guidance" else "k_stl_forward",
+                                  "row_evals_per_s": rate, "ms_per_step": ms_k / steps,
+                                  "algorithmic_bytes_per_row_eval": stl_bytes * (2 if kind == "guidance" else 1),
+                                  "achieved_GBps": rate * stl_bytes * (2 if kind == "guidance" else 1) / 1e9,
+                                  "frac_of_hbm_peak": rate * stl_bytes * (2 if kind == "guidance" else 1) / 8e12}
+        res["stl_info"] = stl_info
+        if self.train and sm.trace_bwd:
+            b_ms = float(np.mean([e0.elapsed_time(e1) for (e0, e1, _) in sm.trace_bwd]))
+            gbps = self.N * BWD_BYTES_PER_ROW / (b_ms * 1e-3) / 1e9
+            res["backward"] = {"kernel": "pstl_refine_backward (head, dgrad x2, wgrad x4, column/scene sums)", "ms": b_ms,
+                               "algorithmic_bytes": self.N * BWD_BYTES_PER_ROW, "achieved_GBps": gbps, "peak_GBps": 8000.0,
+                               "frac_of_hbm_peak": gbps / 8000.0,
+                               "note": "algorithmic bytes = h1, h2, dcontrols, pre, init, hl|stlp read once (%d B/row)" % BWD_BYTES_PER_ROW}
+        sm.trace, sm.trace_stl, sm.trace_bwd = None, None, None
+        return res
+
+
+def chain_peak(chain_waves):
+    # split forms: three 16-bit MFMA products per fp32 product, so the roofline of the fp32 work they deliver is the
+    # dense 16-bit matrix peak / 3
+    return PEAK_BF16_MATRIX_TFLOPS / 3 if chain_waves in (0, 16, 32) else PEAK_FP32_MATRIX_TFLOPS
+
+
 def main():
     a = parse()
     if a.gpus < 1:
@@ -198,92 +349,21 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from pstl_diffusion_policy_amd.engine import (PackedWeights, SceneBatch, Sampler, acc_from_counts,
-                                                  diffusion_coeffs, diversity_from_totals)
+    from pstl_diffusion_policy_amd.engine import PackedWeights, acc_from_counts, diversity_from_totals
     from pstl_diffusion_policy_amd.nusc_model import init_state_dict
-    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    from pstl_diffusion_policy_amd.synthetic import default_hparams
 
     hp = default_hparams()
-    rect_head = a.workload != "e5"
-    guidance = dict(enabled=True, before=10, niters=1, lr=0.01) if a.workload == "e7_guid" else None
-    train = a.workload in ("e8_train", "e7_train")   # one optimisation step of RefineNet: config 5 / e7
-    e7 = dict(stl_weight=0.0, diversity_weight=1.0) if a.workload == "e7_train" else None
-    trajopt = a.workload == "trajopt"    # N4: the data-augmentation loop, trajopt_iters Adam iterations per step
     sd = init_state_dict(1007)     # random init as in the reference under seed 1007 (no checkpoints offline)
-    S, steps, bs = a.sampling_size, a.diffusion_steps, a.scenes
-    # every rank owns its own contiguous block of scenes (seeded by the global scene offset); no data-path collective
-    scene = make_scene_batch(bs, K=a.neighbors, S=S, seed=1000 + rank, invalid_lane_frac=0.2, stlp_mode="wide")
-    ids_host = float(sum(scene[k].sum().item() for k in ("curr_id", "left_id", "right_id")))   # from the CPU copy, as a
-    scene = {k: v.to(dev) for k, v in scene.items() if k not in ("pre_stlp", "tj_scores_prior")}   # data loader would
-    sampler = Sampler(PackedWeights(sd, dev), hp, chain_waves=a.chain_waves)
-    if train:
-        from pstl_diffusion_policy_amd.engine import RectTrainer
-        tnames = RectTrainer.joint_names(e7 is not None) if a.joint else RectTrainer.NAMES   # --joint: encoders (+ merge_net) too
-        tparams = {k: sd[k].to(dev).clone().requires_grad_() for k in tnames}
-        topt = torch.optim.Adam([tparams[k] for k in tnames], lr=3e-4)
-        sd_live = {k: (tparams[k] if k in tparams else v) for k, v in sd.items()}
-    coeffs = diffusion_coeffs(steps, dev)
-    N = bs * S * 3
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    from pstl_diffusion_policy_amd.shard import gather_final, global_valid_stats
-    call = [0]
+    weights = PackedWeights(sd, dev)
+    mk = lambda workload, bs, chain_waves=a.chain_waves: Job(a, workload, bs, dev, rank, world, cpu_group, weights, hp, sd,
+                                                             chain_waves, joint=a.joint)
+    job = mk(a.workload, a.scenes)
+    S, steps, bs, N = job.S, job.steps, a.scenes, job.N
+    rect_head, guidance, train, trajopt = job.rect_head, job.guidance, job.train, job.trajopt
+    m = job.measure(a.steps, a.warmup, dist if world > 1 else None)
+    dt, counts, div_totals = m["dt"], m["counts"], m["div_totals"]
 
-    def one_step():
-        # global mean(valid) of the guidance loss (one tiny all-reduce; the shard split must not change results)
-        vsum, vrows = global_valid_stats(ids_host * S, N, torch.device("cpu") if (cpu_group or world == 1) else dev,
-                                         group=cpu_group)
-        sb = SceneBatch(scene, S, hp, dev, global_valid_sum=vsum, global_rows=vrows, row_offset=rank * N)
-        if a.noise == "torch":
-            x_T = torch.randn(N, 40, device=dev, generator=gen)
-            z = torch.randn(steps - 1, N, 40, device=dev, generator=gen)
-            seed = None
-        else:
-            x_T = z = None
-            call[0] += 1
-            seed = 987654321 + call[0]
-        if trajopt:
-            params = scene["params"].reshape(N, 40).clone()
-            sc, _ = sampler.trajopt(sb, params, a.trajopt_iters, 0.005, 0.01, 10.0, global_valid_sum=vsum, global_rows=vrows)
-            counts, _ = sampler.metrics(sb, sc)
-            return gather_final(counts, torch.zeros(12, dtype=torch.float64, device=dev))
-        if train:
-            sm_t = Sampler(PackedWeights(sd_live, dev), hp, chain_waves=a.chain_waves)   # weights changed: re-pack
-            sm_t.trace = sampler.trace
-            loss, scores = RectTrainer(sm_t).train_step(sb, tparams, topt, steps, x_T=x_T, noise=z, seed=seed,
-                                                        multi_cands=a.multi_cands, coeffs=coeffs, e7=e7, joint=a.joint)
-            if sm_t.chain_fallback and a.chain_waves in (0, 16):
-                # train_step reads the split-f16 domain flag before the optimiser consumes the gradients and repeats the step
-                # on the exact-fp32 kernels when it is set; a bench line must not silently mix the two arithmetics
-                raise FloatingPointError("bench: " + sm_t.chain_fallback)
-            counts, _ = sm_t.metrics(sb, scores)
-            return gather_final(counts, torch.zeros(12, dtype=torch.float64, device=dev))
-        out = sampler.sampling_region(sb, steps, x_T, z, rect_head=rect_head,
-                                      multi_cands=a.multi_cands if rect_head else None, guidance=guidance, coeffs=coeffs,
-                                      want_scores3=False, seed=seed, diversity=True)
-        # the only exchange after the rollout: the final diversity / STL-satisfaction reduction -- 8 counters + 12
-        # diversity totals per rank in one RCCL all-gather over xGMI (when N > 1)
-        return gather_final(out["counts"], out["div_totals"])
-
-    for _ in range(a.warmup):
-        counts, div_totals = one_step()
-    sampler.trace = []
-    sampler.trace_stl = {}
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        counts, div_totals = one_step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-
-    # dominant kernel (k_chain, the multi-step denoiser launch): HIP events on the launch stream
     if trajopt:   # no denoiser in this workload: report row-iterations/s and stop
         if rank == 0:
             print(json.dumps({"metric": "traj-opt row-iterations/sec (STL forward + adjoint + Adam per row and iteration)",
@@ -298,86 +378,90 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    if not train:      # (train workloads: checked inside every train_step, see one_step)
-        sampler.check_chain_domain(fallback=False)     # a split-f16 launch that left its domain leaves undefined results
-    ms = [e0.elapsed_time(e1) for (e0, e1, _, _) in sampler.trace]
-    nst, nrows = sampler.trace[0][2], sampler.trace[0][3]
-    k_ms = float(np.mean(ms))
-    flop = float(nrows) * nst * F_STEP_MIN
-    achieved = flop / (k_ms * 1e-3) / 1e12
+    nst, k_ms, flop, achieved = m["kernel_steps"], m["kernel_ms"], m["flop"], m["achieved"]
     split_f16 = a.chain_waves in (0, 16)
     split_bf16 = a.chain_waves == 32
-    # split forms: three 16-bit MFMA products per fp32 product, so the roofline of the fp32 work they deliver is the
-    # dense 16-bit matrix peak / 3
-    peak = PEAK_BF16_MATRIX_TFLOPS / 3 if (split_f16 or split_bf16) else PEAK_FP32_MATRIX_TFLOPS
+    peak = chain_peak(a.chain_waves)
     dtype = ("f32 (MLP products formed from two f16 pieces per operand, 2^-23 per operand, 3 v_mfma_f32_16x16x32_f16 per f32 "
              "product, f32 accumulate; everything else plain f32)") if split_f16 else (
         "bf16x3 (two bf16 pieces per f32 operand, 2^-17 per operand, 3 bf16 MFMA products per f32 product, f32 accumulate; "
         "STL and rect_net in f32)") if split_bf16 else "f32"
     acc, sacc = acc_from_counts(counts)
-    # the STL kernels (one row per lane): row-evaluations/s and what that means against the HBM roofline.  Algorithmic
-    # bytes per row-evaluation in the scene-shared layout: 160 B controls + 16 B s0 + 24 B stlp + 4 B score + scene
-    # tables amortised over the 192 rows of a scene -- these kernels are VALU-bound, not HBM-bound.
-    K = a.neighbors
-    stl_bytes = 160 + 16 + 24 + 4 + (K * 20 * 7 * 4 + 540) / (3.0 * S)
-    stl_info = {}
-    for kind, evs in (sampler.trace_stl or {}).items():
-        ms_k = sum(e0.elapsed_time(e1) for (e0, e1, _) in evs)
-        evals = sum(n for (_, _, n) in evs)
-        if ms_k > 0:
-            rate = evals / (ms_k * 1e-3)
-            stl_info[kind] = {"kernel": "k_guidance_iter (forward + adjoint + Adam)" if kind == "guidance" else "k_stl_forward",
-                              "row_evals_per_s": rate, "ms_per_step": ms_k / a.steps,
-                              "algorithmic_bytes_per_row_eval": stl_bytes * (2 if kind == "guidance" else 1),
-                              "achieved_GBps": rate * stl_bytes * (2 if kind == "guidance" else 1) / 1e9,
-                              "frac_of_hbm_peak": rate * stl_bytes * (2 if kind == "guidance" else 1) / 8e12}
+    stl_info = m["stl_info"]
+    extras = world == 1 and not a.no_extras
     # Second opinion inside the same run: the same step with both MLP chains on the exact-fp32 MFMA
     # kernels (chain_waves 8: bit-for-bit a k-ordered fmaf chain), three timed steps after one warm-up, priced against the
     # dense fp32 matrix peak.
     fp32_exact = None
     sampler_exact = None
-    if world == 1 and not train and a.chain_waves != 8:
-        main_sampler = sampler
-        sampler_exact = Sampler(main_sampler.w, hp, chain_waves=8)
-        sampler = sampler_exact
-        one_step()
-        sampler_exact.trace = []
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            one_step()
-        torch.cuda.synchronize()
-        dt_x = (time.perf_counter() - t1) / 3
-        sampler = main_sampler
-        ms_x = float(np.mean([e0.elapsed_time(e1) for (e0, e1, _, _) in sampler_exact.trace]))
-        ach_x = float(sampler_exact.trace[0][3]) * sampler_exact.trace[0][2] * F_STEP_MIN / (ms_x * 1e-3) / 1e12
-        fp32_exact = {"chain_waves": 8, "steps": 3, "ms_per_step": dt_x * 1e3, "value": N / dt_x, "kernel_ms": ms_x,
-                      "achieved": ach_x, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach_x / PEAK_FP32_MATRIX_TFLOPS,
+    if extras and not train and a.chain_waves != 8:
+        jx = mk(a.workload, a.scenes, 8)
+        jx.scene, jx.ids_host = job.scene, job.ids_host
+        mx = jx.measure(3, 1)
+        sampler_exact = jx.sampler
+        fp32_exact = {"chain_waves": 8, "steps": 3, "ms_per_step": mx["ms_per_step"], "value": mx["value"],
+                      "kernel_ms": mx["kernel_ms"], "achieved": mx["achieved"], "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                      "frac": mx["achieved"] / PEAK_FP32_MATRIX_TFLOPS,
                       "note": "v_mfma_f32_16x16x4_f32 chains (exact f32), same step, same run"}
+    # BASELINE configs 2, 3 and 5 in the driver's own run: three timed steps each after one warm-up,
+    # same shard size, each with the roofline fraction of ITS dominant launch (the 49-step k_chain)
+    also = None
+    if extras:
+        also = {}
+        for wl in ("e5", "e7", "e8_train"):
+            if wl == a.workload:
+                continue
+            jw = mk(wl, a.scenes)
+            jw.scene, jw.ids_host = job.scene, job.ids_host
+            mw = jw.measure(3, 1)
+            rec = {"steps": 3, "ms_per_step": mw["ms_per_step"], "value": mw["value"], "unit": "trajectories/s",
+                   "stl_sat_rate": acc_from_counts(mw["counts"])[0],
+                   "roofline": {"bound": "mfma", "kernel": "k_chain (%d reverse steps per launch)" % mw["kernel_steps"],
+                                "kernel_ms": mw["kernel_ms"], "achieved": mw["achieved"], "peak": peak, "unit": "TFLOP/s",
+                                "frac": mw["achieved"] / peak}}
+            if "backward" in mw:
+                rec["backward"] = mw["backward"]
+            also[wl] = rec
+            del jw
+            torch.cuda.empty_cache()
+    # the headline workload at other batch sizes: 3 timed steps each after 2 warm-ups
+    sweep = None
+    if extras and not train:
+        sweep = []
+        for sbs in (1, 16, 128, 512):
+            if sbs >= a.scenes:
+                continue
+            js = mk(a.workload, sbs)
+            ms_ = js.measure(3, 2)
+            sweep.append({"rows": js.N, "ms_per_step": ms_["ms_per_step"], "value": ms_["value"], "layout": chain_layout(js.N)})
+        sweep.append({"rows": N, "ms_per_step": m["ms_per_step"], "value": m["value"], "layout": chain_layout(N)})
     # VALU-issue roofline of the one-row-per-lane STL kernels (they are instruction-issue-bound, not HBM-bound): vector
     # instructions per row-evaluation from the committed PMC pass (SQ_INSTS_VALU / rows of that launch) x the row-evaluation
     # rate measured live in this run x 4 issue cycles per wavefront instruction / (1024 SIMDs x the clock of the PMC run)
-    pmc_r3 = os.path.join(ROOT, "profiles", "r3", "pmc_summary.json")
-    if os.path.exists(pmc_r3):
-        pj = json.load(open(pmc_r3))
-        for kind, info in stl_info.items():
-            v = pj.get("stl_kernels", {}).get(kind)
-            if v and v.get("rows_per_launch") and v.get("K") == a.neighbors and v.get("clock_GHz"):
-                per_row = v["SQ_INSTS_VALU"] / v["rows_per_launch"]       # wavefront instructions per row-evaluation (1/64 each)
-                clk = float(v["clock_GHz"]) * 1e9
-                info["valu_wave_insts_per_row_eval"] = per_row
-                info["valu_issue_frac"] = per_row * info["row_evals_per_s"] * 4.0 / (1024.0 * clk)
-                info["valu_issue_frac_pmc_run"] = v.get("valu_issue_frac")
-                info["valu_issue_note"] = ("SQ_INSTS_VALU per row-evaluation (profiles/r3/pmc_summary.json) x live row-evaluations/s x 4 "
-                                           "cycles / (1024 SIMDs x %.2f GHz)" % (clk / 1e9))
+    pmc_path = None
+    for rnd in ("r4", "r3", "r2"):
+        cand = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
+        if os.path.exists(cand):
+            pmc_path = cand
+            break
+    pj = json.load(open(pmc_path)) if pmc_path else {}
+    for kind, info in stl_info.items():
+        v = pj.get("stl_kernels", {}).get(kind)
+        if v and v.get("rows_per_launch") and v.get("K") == a.neighbors and v.get("clock_GHz"):
+            per_row = v["SQ_INSTS_VALU"] / v["rows_per_launch"]       # wavefront instructions per row-evaluation (1/64 each)
+            clk = float(v["clock_GHz"]) * 1e9
+            info["valu_wave_insts_per_row_eval"] = per_row
+            info["valu_issue_frac"] = per_row * info["row_evals_per_s"] * 4.0 / (1024.0 * clk)
+            info["valu_issue_frac_pmc_run"] = v.get("valu_issue_frac")
+            info["valu_issue_note"] = ("SQ_INSTS_VALU per row-evaluation (%s) x live row-evaluations/s x 4 cycles / (1024 SIMDs x "
+                                       "%.2f GHz)" % (os.path.relpath(pmc_path, ROOT), clk / 1e9))
     # HBM bytes of that launch from the committed PMC passes (FETCH_SIZE/WRITE_SIZE cannot be read inside this process);
     # only quoted when this run is the configuration those passes were collected on
     traffic = None
-    pmc = pmc_r3 if os.path.exists(pmc_r3) else os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")
     is_default = (a.workload == "e7_guid" and bs == 4096 and S == 64 and a.neighbors == 2 and steps == 50
                   and a.noise == "kernel" and not a.chain_waves)
-    if is_default and os.path.exists(pmc):
-        traffic = json.load(open(pmc))["summary_dominant_kernel"]["hbm_bytes_per_launch_corrected"]
+    if is_default and pj.get("summary_dominant_kernel"):
+        traffic = pj["summary_dominant_kernel"]["hbm_bytes_per_launch_corrected"]
     line = None
     if rank == 0:
         line = {
@@ -403,15 +487,24 @@ def main():
                                        if (split_f16 or split_bf16) else "dense f32 MFMA peak"),
                          "matrix_pipe_frac_issued": (achieved * F_STEP_ISSUED_BF16 / F_STEP_MIN / PEAK_BF16_MATRIX_TFLOPS)
                                                     if (split_f16 or split_bf16) else achieved / peak,
-                         "traffic_source": "%s (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)" % os.path.relpath(pmc, ROOT)
+                         "traffic_source": "%s (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)" % os.path.relpath(pmc_path, ROOT)
                                            if traffic else None,
                          "fp32_exact": fp32_exact,
                          "kernel_ms": k_ms, "flop_per_launch": flop, "stl_kernels": stl_info,
+                         "whole_step_frac": ((steps - 1) * F_STEP_MIN + ((F_STEP_MIN + 7168) if rect_head else 0))
+                                            * float(N) / (dt / a.steps) / 1e12 / peak,
                          "note": "algorithmic FLOP = rows x steps x 172032 (hoisted layer-1 columns not counted); achieved "
-                                 "counts every f32 multiply-add once, whatever the kernel issues for it"},
+                                 "counts every f32 multiply-add once, whatever the kernel issues for it; whole_step_frac = (all "
+                                 "denoiser evaluations + RefineNet + merge_net, same minimal count) / ms_per_step / peak"},
         }
+        if "backward" in m:
+            line["roofline"]["backward"] = m["backward"]
+        if also is not None:
+            line["also"] = also
+        if sweep is not None:
+            line["sweep"] = sweep
         if not a.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
-            line["cpu_baseline"] = cpu_baseline(a, hp, sd, guidance, rect_head, None if (train or trajopt) else sampler, dev,
+            line["cpu_baseline"] = cpu_baseline(a, hp, sd, guidance, rect_head, None if (train or trajopt) else job.sampler, dev,
                                                 sampler_exact=sampler_exact)
         print(json.dumps(line), flush=True)
     if world > 1:

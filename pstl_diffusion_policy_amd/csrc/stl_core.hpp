@@ -38,11 +38,22 @@
 // computed with exact arithmetic afterwards); a different winner needs two pair sums within 1 ulp of each other
 #define PSTL_SQRT_RANK(x) __builtin_amdgcn_sqrtf(x)
 #define PSTL_SINCOS(x, s, c) sincosf((x), (s), (c))
+// Hardware forms (v_rcp_f32, v_sqrt_f32: 1 ulp; v_sin_f32 / v_cos_f32: ~1e-6 absolute) for quantities that only ever reach
+// a GRADIENT or an optimiser step -- the adjoint's partial derivatives and exponential weights, Adam's m / (sqrt(v) + eps) --
+// never a score, a satisfaction mask or a candidate choice: the forward sweeps do not use them.  The reference's autograd
+// gradients are matched to rtol 5e-3 (tests), these forms are good to ~1e-6; an IEEE division or square root is ~10-12
+// instructions here, the hardware form one (quarter rate).
+#define PSTL_RCP_ADJ(x) __builtin_amdgcn_rcpf(x)
+#define PSTL_SQRT_ADJ(x) __builtin_amdgcn_sqrtf(x)
+#define PSTL_SINCOS_ADJ(x, s, c) (*(s) = __sinf(x), *(c) = __cosf(x))
 #else
 #define PSTL_EXP(x) expf(x)
 #define PSTL_LOG(x) logf(x)
 #define PSTL_SQRT_RANK(x) sqrtf(x)
 #define PSTL_SINCOS(x, s, c) (*(s) = sinf(x), *(c) = cosf(x))
+#define PSTL_RCP_ADJ(x) (1.0f / (x))
+#define PSTL_SQRT_ADJ(x) sqrtf(x)
+#define PSTL_SINCOS_ADJ(x, s, c) (*(s) = sinf(x), *(c) = cosf(x))
 #endif
 
 namespace pstl {
@@ -157,6 +168,21 @@ PSTL_HD void prep_neighbor(const float* in, float* out) {
   out[11] = 0.0f;
 }
 
+// Prepared lane waypoint j of a 15-point lane: (x, y, heading, |w_j - w_{j+1}|) -- the length of the segment that starts
+// here (0 for the last point), computed with the very operations lane_eval used to spend per row and time step on it
+// (the segment is scene data: 20 x rows-per-scene evaluations shared one value).  `next` = waypoint j + 1 or null.
+PSTL_HD void prep_lane_point(const float* pt, const float* next, float* out) {
+  out[0] = pt[0];
+  out[1] = pt[1];
+  out[2] = pt[2];
+  float bl = 0.0f;
+  if (next) {
+    const float sx = pt[0] - next[0], sy = pt[1] - next[1];
+    bl = sqrtf(sx * sx + sy * sy);
+  }
+  out[3] = bl;
+}
+
 PSTL_HD StlEnv make_env(float tau, float dt, float ego_L, float ego_W) {
   StlEnv e;
   e.tau = tau;
@@ -226,29 +252,35 @@ PSTL_HD void lane_eval(const f4* lane, float px, float py, float pth, LaneHit& h
   h.jb = jb;
   const f4 p2 = lane[jb], p3 = lane[jb + 1];
   const float area = px * (p2.y - p3.y) + p2.x * (p3.y - py) + p3.x * (py - p2.y);
-  const float sx = p2.x - p3.x, sy = p2.y - p3.y;
-  const float bl = sqrtf(sx * sx + sy * sy);
+  const float bl = p2.w;   // |p2 - p3| = sqrtf(sx * sx + sy * sy), sx = p2.x - p3.x, sy = p2.y - p3.y: prep_lane_point
   const float qx = px - p2.x, qy = py - p2.y;
-  const float q2 = qx * qx + qy * qy;
-  const float l2 = sqrtf(fmaxf(q2, 1e-3f));
   const bool normal = (bl != 0.0f);
   const float cbl = fmaxf(bl, 1e-7f);
-  h.d = normal ? area / cbl : l2;
+  float q2 = 0.0f, l2 = 0.0f;
+  if (normal) {
+    h.d = area / cbl;
+  } else {   // a degenerate segment (an invalid lane's all-zero waypoints): the distance to the point itself
+    q2 = qx * qx + qy * qy;
+    l2 = sqrtf(fmaxf(q2, 1e-3f));
+    h.d = l2;
+  }
   const float du = p2.z - pth;
   float sdu = 0.0f, cdu;
   if (GRAD) {
-    PSTL_SINCOS(du, &sdu, &cdu);
+    PSTL_SINCOS_ADJ(du, &sdu, &cdu);   // (the adjoint's own evaluation of the heading term: it weights a gradient only)
   } else {
     cdu = cosf(du);
   }
   h.th = 1.0f - cdu;
   if (GRAD) {
     if (normal) {
-      h.dd_dx = (p2.y - p3.y) / cbl;
-      h.dd_dy = (p3.x - p2.x) / cbl;
+      const float r = PSTL_RCP_ADJ(cbl);
+      h.dd_dx = (p2.y - p3.y) * r;
+      h.dd_dy = (p3.x - p2.x) * r;
     } else if (q2 >= 1e-3f) {
-      h.dd_dx = qx / l2;
-      h.dd_dy = qy / l2;
+      const float r = PSTL_RCP_ADJ(l2);
+      h.dd_dx = qx * r;
+      h.dd_dy = qy * r;
     } else {
       h.dd_dx = 0.0f;
       h.dd_dy = 0.0f;
@@ -360,7 +392,7 @@ PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, f
       if (REC) win = ((unsigned)k << 4) | pair;
       if (GRAD) {
         const bool pass = (car >= -5.0f) && (car <= 20.0f) && (dist > 0.0f);
-        const float g = pass ? valid / dist : 0.0f;
+        const float g = pass ? valid * PSTL_RCP_ADJ(dist) : 0.0f;
         const float ddx = bdx * g, ddy = bdy * g;
         gx = ddx;
         gy = ddy;
@@ -400,7 +432,7 @@ PSTL_HD void clearance_from_winner(const StlEnv& env, const float* nei, int t, f
   const float clipped = fminf(fmaxf(car, -5.0f), 20.0f);
   h.dn = clipped * valid + (1.0f - valid) * 100.0f;
   const bool pass = (car >= -5.0f) && (car <= 20.0f) && (dist > 0.0f);
-  const float g = pass ? valid / dist : 0.0f;
+  const float g = pass ? valid * PSTL_RCP_ADJ(dist) : 0.0f;
   const float ddx = dx * g, ddy = dy * g;
   h.d_dx = ddx;
   h.d_dy = ddy;
@@ -834,7 +866,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     PSTL_NOUNROLL
     for (int k = 0; k < kFwin; ++k) {
       const float lb = st.at(LB + k), lt = st.at(LT + k);
-      const float qb = PSTL_EXP(-(lb / tau) * tau - Lfb), qt = PSTL_EXP(-(lt / tau) * tau - Lft);
+      const float qb = PSTL_EXP(-lb - Lfb), qt = PSTL_EXP(-lt - Lft);   // exp(tau g_k - Lf), g_k = -(L_k / tau): a gradient weight
       sb = (k == 0) ? qb : sb * PSTL_EXP(lb - lb_prev) + qb;
       sth = (k == 0) ? qt : sth * PSTL_EXP(lt - lt_prev) + qt;
       st.at(LB + k) = lb - PSTL_LOG(sb);
@@ -846,6 +878,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   // ---- adjoint, backwards in time -----------------------------------------------------------------------------
   float lx = 0.0f, ly = 0.0f, lth = 0.0f, lv = 0.0f;  // lambda_{t+1}
   const float dt = env.dt;
+  const float inv_thmax = PSTL_RCP_ADJ(r.thmax);   // (the heading predicate's divisor: here it only scales gradient weights)
   // The states are not stored per step: block by block (4 steps), they are re-derived from the block's checkpoint with the
   // forward sweep's own operations (bit-identical), kept in registers, and consumed in reverse order.  The controls a
   // block reads (steps < its last one) have not been rewritten yet by emit(), which has only reached later steps.
@@ -911,7 +944,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     } else {
       lane_eval<true>(lane, x, y, th, h, use_rec ? (int)rec_seg(rec, t) : -1);
     }
-    const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df), s3 = (r.thmax - h.th) / r.thmax;
+    const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df), s3 = (r.thmax - h.th) * inv_thmax;
     float gd, gsth;  // d score / d d_t , d score / d s3_t
     if (mode == 0) {
       gd = om[2] * PSTL_EXP(-s1 * tau - L1) - om[3] * PSTL_EXP(-s2 * tau - L2);
@@ -919,8 +952,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     } else {
       const float a1 = -s1 * tau, a2 = -s2 * tau;
       const float lp = lse2(a1, a2);
-      const float band = -(lp / tau);
-      const float ab = -band * tau, a3 = -s3 * tau;
+      const float ab = lp, a3 = -s3 * tau;   // (ab = -band tau with band = -(lp / tau))
       const int m = t < kFwin - 1 ? t : kFwin - 1;
       const float wb = PSTL_EXP(ab - st.at(LB + m));
       const float wt = PSTL_EXP(a3 - st.at(LT + m));
@@ -930,7 +962,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     if (NORM) gd = gd / r.df;
     gx += gd * h.dd_dx;
     gy += gd * h.dd_dy;
-    gth += gsth * (-1.0f / r.thmax) * h.dth_dth;
+    gth += gsth * (-inv_thmax) * h.dth_dth;
     // lambda_t = direct_t + J_t^T lambda_{t+1}
     const float nlth = gth + lth + lx * (-(v * s) * dt) + ly * ((v * c) * dt);
     const float nlv = gv + lv + lx * (c * dt) + ly * (s * dt);

@@ -309,6 +309,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidanc
   float* wm = MULTI ? a.work + row * (2 * kT) : nullptr;
   const float* zr = a.z ? a.z + row * (2 * kT) : nullptr;
   float* er = a.emit_out ? a.emit_out + row * (2 * kT) : nullptr;
+  const float inv_bc2 = 1.0f / a.bc2_sqrt;
   // one element of the Adam update; returns the value that goes back to mu (and, through *emit_v, to emit_out)
   auto update = [=](int e, float p0, float g, float nscale, float zdrawn, float* emit_v) -> float {
     // torch.optim.Adam, single-tensor path, betas (0.9, 0.999), eps 1e-8 (see oracle guidance_update)
@@ -319,8 +320,10 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidanc
     }
     m = m + 0.1f * (g - m);
     v = v * 0.999f + (0.001f * g) * g;
-    const float denom = sqrtf(v) / a.bc2_sqrt + 1e-8f;
-    float p = p0 + (a.neg_step * m) / denom;
+    // sqrt and both divisions in their hardware forms (1 ulp each: the step lr m / (sqrt(v) + eps) is at most lr, so the state
+    // moves by < 1e-8 against the IEEE forms; v_sqrt_f32 takes a denormal v as 0, where eps = 1e-8 decides anyway)
+    const float denom = PSTL_SQRT_ADJ(v) * inv_bc2 + 1e-8f;
+    float p = p0 + (a.neg_step * m) * PSTL_RCP_ADJ(denom);
     if (MULTI) {
       wm[e] = m;
       wm[plane + e] = v;
@@ -752,11 +755,7 @@ __global__ void k_prepare(long n_nei, long n_lane_pts, const float* nei, const f
   if (i < n_lane_pts) {  // i = (b*3 + m)*15 + j
     const long j = i % kNseg, bm = i / kNseg, m = bm % 3, b = bm / 3;
     const float* src = (m == 0 ? l0 : m == 1 ? l1 : l2) + (b * kNseg + j) * 3;
-    float* o = lane_prep + i * 4;
-    o[0] = src[0];
-    o[1] = src[1];
-    o[2] = src[2];
-    o[3] = 0.0f;
+    prep_lane_point(src, j + 1 < kNseg ? src + 3 : nullptr, lane_prep + i * 4);
   }
 }
 

@@ -193,6 +193,7 @@ class Sampler:
         self.trace = None
         # when set to a dict, STL launches append (start_event, end_event, row_evaluations) under "guidance" / "score"
         self.trace_stl = None
+        self.trace_bwd = None   # when set to a list, RectTrainer appends (start_event, end_event, n_rows) around pstl_refine_backward
         self.debug_buf = None   # diagnostic builds only (chain_waves 708): receives the kernel's cycle stamps
 
     def use_exact_fp32(self, why):
@@ -648,6 +649,11 @@ class RectTrainer:
                   "rect_net.4.weight": (ffi.CTRL, ffi.HID), "rect_net.4.bias": (ffi.CTRL,)}
         g = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in self.NAMES}
         w2c, w3c = ffi.f32(w2.detach(), dev), ffi.f32(w3.detach(), dev)   # named: a converted copy must outlive the launch
+        bev = None
+        if getattr(self.sm, "trace_bwd", None) is not None:   # bench.py: HIP events around RefineNet's backward (launch stream)
+            bev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), N)
+            bev[0].record()
+            self.sm.trace_bwd.append(bev)
         ffi.check(self.L.pstl_refine_backward(ctypes.byref(cfg), self.ctx, ffi.ptr(w2c),
                                               ffi.ptr(w3c), ffi.ptr(feature), ffi.ptr(sb.stlp),
                                               ffi.ptr(sb.hl), ffi.ptr(init_controls), ffi.ptr(pooled), ffi.ptr(prev_scores),
@@ -656,6 +662,8 @@ class RectTrainer:
                                               ffi.ptr(g["rect_net.2.weight"]), ffi.ptr(g["rect_net.2.bias"]),
                                               ffi.ptr(g["rect_net.4.weight"]), ffi.ptr(g["rect_net.4.bias"]),
                                               ffi.stream()), "refine_backward")
+        if bev is not None:
+            bev[1].record()
         if joint is not None:
             g.update(self._joint_grads(sb, cfg, work, joint["params"], joint["saved"], init_controls, merge))
         return loss, rect, scores, g

@@ -21,7 +21,7 @@ void hostsim_prepare(int bs, int K, const float* nei, const float* l0, const flo
       for (int j = 0; j < kNseg; ++j) {
         float* o = lane_prep + (((long)b * 3 + m) * kNseg + j) * 4;
         const float* in = ls[m] + ((long)b * kNseg + j) * 3;
-        o[0] = in[0], o[1] = in[1], o[2] = in[2], o[3] = 0.0f;
+        prep_lane_point(in, j + 1 < kNseg ? in + 3 : nullptr, o);
       }
 }
 

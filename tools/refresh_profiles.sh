@@ -4,7 +4,7 @@
 # bench lines of every workload, rocprofv3 kernel stats/trace of the default bench, three separate PMC passes
 # (FETCH_SIZE, WRITE_SIZE, SQ/GRBM) and their summary (tools/summarize_pmc.py).
 set -u
-r=${1:-r3}
+r=${1:-r4}
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/profiles_$r
 mkdir -p "$out"
@@ -23,13 +23,13 @@ b bench_e7_train_joint --workload e7_train --joint --no_cpu_baseline
 b bench_trajopt --workload trajopt --steps 3 --warmup 1
 b bench_big_shard --scenes 32768 --steps 3 --warmup 1 --no_cpu_baseline
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" --no_cpu_baseline > "$out/bench_default_under_rocprof.json" 2> "$out/stats.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_fp32" -o run -- python3 "$root/bench.py" --no_cpu_baseline --chain_waves 8 --steps 5 > "$out/bench_fp32_under_rocprof.json" 2> "$out/stats_fp32.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_train" -o run -- python3 "$root/bench.py" --no_cpu_baseline --workload e8_train --steps 5 > "$out/bench_e8_train_under_rocprof.json" 2> "$out/stats_train.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" --no_cpu_baseline --no_extras > "$out/bench_default_under_rocprof.json" 2> "$out/stats.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_fp32" -o run -- python3 "$root/bench.py" --no_cpu_baseline --no_extras --chain_waves 8 --steps 5 > "$out/bench_fp32_under_rocprof.json" 2> "$out/stats_fp32.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_train" -o run -- python3 "$root/bench.py" --no_cpu_baseline --no_extras --workload e8_train --steps 5 > "$out/bench_e8_train_under_rocprof.json" 2> "$out/stats_train.err"
 # (a fourth pass, "VALU": the vector-issue counters that show the one-row-per-lane STL kernels to be VALU-issue-bound)
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
   tag=$(echo $pass | cut -d' ' -f1 | sed 's/SQ_WAVE_CYCLES/SQ/; s/SQ_INSTS_VALU/VALU/')
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$out/pmc_$tag" -o run -- python3 "$root/bench.py" --no_cpu_baseline --steps 2 --warmup 1 > /dev/null 2> "$out/pmc_$tag.err"
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$out/pmc_$tag" -o run -- python3 "$root/bench.py" --no_cpu_baseline --no_extras --steps 2 --warmup 1 > /dev/null 2> "$out/pmc_$tag.err"
 done
 cd "$root"
 find "$out/stats" -name "*kernel_stats.csv" -exec cp {} "$out/bench_default_kernel_stats.csv" \;
