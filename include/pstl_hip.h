@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-#define PSTL_ABI_VERSION 3   /* 2: pstl_encode_scene takes a work buffer; --joint and --refinement entry points
-                                3: status block in the packed weight buffer (pstl_packed_status_offset) */
+#define PSTL_ABI_VERSION 4   /* 2: pstl_encode_scene takes a work buffer; --joint and --refinement entry points
+                                3: status block in the packed weight buffer (pstl_packed_status_offset)
+                                4: pstl_cfg.dyn -- run-time parameters in device memory (HIP-graph replay) */
 
 /* compile-time shape of the path (reference defaults: nt=20, n_segs=15, hiddens=[256,256], feat 7*32) */
 #define PSTL_T 20
@@ -57,6 +58,15 @@ enum {
                             /* 0.3), safe_factor = clip(dsafe, 0.3) in pstl_stl_forward / _backward / pstl_guidance_step; */
                             /* pstl_trajopt and pstl_refinement answer PSTL_ERR_SHAPE                                   */
 };
+
+/* Run-time parameters a caller may keep in DEVICE memory (pstl_cfg.dyn) instead of passing them by value: a sequence of
+ * launches captured once in a HIP graph can then be replayed with another noise seed / guidance-loss scale by writing
+ * these 16 bytes (the closed-loop caller does: one graph replay per simulation step, nusc_sim.py). */
+typedef struct pstl_dyn {
+  uint64_t seed;           /* replaces cfg.seed                                                            */
+  float grad_scale;        /* replaces the grad_scale argument of pstl_guidance_step                        */
+  float reserved;
+} pstl_dyn;
 
 typedef struct pstl_cfg {
   int32_t bs;              /* scenes in this shard                                        */
@@ -91,6 +101,8 @@ typedef struct pstl_cfg {
   uint64_t seed;           /* PSTL_FLAG_RNG: noise stream                                 */
   int64_t row_offset;      /* PSTL_FLAG_RNG: global index of this shard's first row, so that the noise of a row */
                            /* does not depend on how the batch is split over GPUs                                */
+  const pstl_dyn* dyn;     /* device pointer or NULL.  Non-null: pstl_fill_normal, pstl_rollout and pstl_guidance_step */
+                           /* read seed (and grad_scale) from it at kernel start and ignore the by-value ones           */
 } pstl_cfg;
 
 /* state_dict blobs of the reference Net (nusc_model.py:20-46; keys "<net>.{0,2,4}.{weight,bias}").

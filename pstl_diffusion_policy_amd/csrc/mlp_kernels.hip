@@ -249,6 +249,7 @@ struct ChainArgs {
   int tiles_per_group;   // 16-row tiles owned by one workgroup (4..kG)
   int rng;               // draw the noise in the kernel (seed, row_offset)
   unsigned long long seed;
+  const unsigned long long* seed_dev;   // cfg->dyn: the seed is read from device memory instead (HIP-graph replay)
   long row_offset;
   float* x_inout;        // (N,40)
   float* emit_out;       // (n_emit,N,40)
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
     }
   }
 
+  const unsigned long long seed = a.seed_dev ? uniform_u64(a.seed_dev) : a.seed;
   // split-f16 domain guard (see note_pieces): per-lane maximum of the hi pieces this lane made; tested once after the loop
   unsigned ovf = 0;
   if (F16 && tid == 0) {   // the weights themselves: max |w| as the packer recorded it (status words 0 = policy_net, 1 = rect_net)
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   const long tile0 = grp * a.tiles_per_group;
   auto t0 = [&](int n) { return cont ? ((long)blockIdx.x + (long)n * gridDim.x) * a.tiles_per_group : tile0; };
   int G = (int)((n_tiles - tile0) < a.tiles_per_group ? (n_tiles - tile0) : a.tiles_per_group);
-  // SPARSE (latency layout for small batches, tiles_per_group 1..4): the workgroup owns Gr < 5 tiles; the other slots of the
+  // SPARSE (latency layout for small batches, tiles_per_group 1..5): the workgroup owns Gr <= 5 tiles; the other slots of the
   // five-deep software pipeline are EMPTY rather than phantom tiles: an iteration does only the stages whose tile exists
   // (nothing at all -- just the barrier -- when neither layer 1's nor layer 2's position is a tile).  Same arithmetic per
   // row, so the same bits as the throughput layout.
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
       if (row < a.N) {
         if (a.rng) {
           float z[4];
-          normal4(a.seed, a.row_offset + row, et >> 4, i, z);
+          normal4(seed, a.row_offset + row, et >> 4, i, z);
           z4 = f32x4{z[0], z[1], z[2], z[3]};
         } else {
           const unsigned loff = (unsigned)((et & 15) * kCtrl + 4 * (et >> 4));
@@ -1060,7 +1062,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
           const int nt = tid - NT / 2;
           const int i = step_of(p0.n);
           float z[4];
-          normal4(a.seed, a.row_offset + (t0(p0.n) + p0.tl) * kTileRows + (nt & 15), nt >> 4, i, z);
+          normal4(seed, a.row_offset + (t0(p0.n) + p0.tl) * kTileRows + (nt & 15), nt >> 4, i, z);
           zv = i > 1 ? f32x4{z[0], z[1], z[2], z[3]} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
         ch = nh;
@@ -1656,9 +1658,10 @@ __global__ void k_merge_reduce(int nslabs, const float* slabs, float* dw0, float
   else db2[i - 3648] = acc;
 }
 
-__global__ void k_fill_normal(long N, unsigned long long seed, long row_offset, int step, float* out) {
+__global__ void k_fill_normal(long N, unsigned long long seed, const pstl_dyn* dyn, long row_offset, int step, float* out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (row, quad)
   if (i >= N * 10) return;
+  if (dyn) seed = uniform_u64(&dyn->seed);
   const long row = i / 10;
   const int quad = (int)(i % 10);
   float z[4];
@@ -1669,6 +1672,7 @@ __global__ void k_fill_normal(long N, unsigned long long seed, long row_offset, 
 // Tiles per workgroup: 12 (192 rows) when there is enough work for every CU; small batches (the closed-loop caller
 // runs 192 rows per simulation step, reference nusc_sim.py) are spread over more workgroups, down to the 5 tiles the
 // software pipeline needs, which cuts the latency of one reverse step from 12 to 5 tile-iterations.
+inline int cu_count();
 inline int tiles_per_group(long N) {
   const long n_tiles = (N + kTileRows - 1) / kTileRows;
   long g = n_tiles / 256;
@@ -1676,10 +1680,25 @@ inline int tiles_per_group(long N) {
   if (g > kG) g = kG;
   return (int)g;
 }
+// Multi-step launches (one workgroup per CU and round, every workgroup alive for the whole launch): the fewest rounds of
+// <= 12-tile workgroups, and the tiles spread evenly over rounds x CUs workgroups -- so that a batch just past a multiple
+// of 12 tiles per CU (3 200 tiles on 256 CUs: 267 twelve-tile groups = a second round for 11 workgroups, 24 tile-steps per
+// reverse step where 2 x 7 do) does not pay a whole extra round.  Results do not depend on the grouping (row-wise
+// arithmetic, noise keyed by the global row).
+inline int tiles_per_group_balanced(long N) {
+  const long n_tiles = (N + kTileRows - 1) / kTileRows;
+  const long cus = cu_count();
+  const long rounds = (n_tiles + cus * kG - 1) / (cus * kG);
+  long g = (n_tiles + cus * rounds - 1) / (cus * rounds);
+  if (g < 5) g = 5;
+  if (g > kG) g = kG;
+  return (int)g;
+}
 
-// The latency layout: fewer than five tiles per CU -> 1..4 tiles per workgroup, spread over as many CUs as there are tiles
-// (0 = enough work for the throughput layout).
-inline int cu_count();
+// The latency layout: fewer than five tiles per CU -> 1..5 tiles per workgroup, spread over as many CUs as there are tiles
+// (0 = enough work for the throughput layout).  (Five -- more than four but fewer than five tiles per CU -- fills every
+// pipeline slot with a real tile: the SPARSE instantiation then skips nothing, and unlike 5-tile groups of the throughput
+// layout it computes no phantom tiles; tests: test_latency_layout_equals_throughput_layout[100-64-6].)
 inline int sparse_tiles_per_group(long N) {
   const long n_tiles = (N + kTileRows - 1) / kTileRows;
   const long cus = cu_count();
@@ -1712,9 +1731,16 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)(PERSIST && n_groups > cu_count() ? cu_count() : n_groups));
   const size_t lds = chain_lds_bytes<NW>();
   auto fn = k_chain<NW, REFINE, ABL, UT, PT, PERSIST, SAVE, SPARSE>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-      hipSuccess)
-    return PSTL_ERR_LAUNCH;
+  // (once per instantiation and device: the attribute call costs host time on every launch of a latency-bound caller)
+  static int allowed_dev = -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return PSTL_ERR_LAUNCH;
+  if (allowed_dev != dev) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return PSTL_ERR_LAUNCH;
+    allowed_dev = dev;
+  }
   hipLaunchKernelGGL(fn, grid, dim3(NW * 64), lds, st, a);
   return launch_status();
 }
@@ -1750,6 +1776,12 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
     if constexpr (REFINE)
       if (a.h1_save && a.h2_save)   // training forward pass
         return ut ? launch_chain<8, true, 0, true, 2, false, true>(a, st) : launch_chain<8, true, 0, false, 2, false, true>(a, st);
+    if constexpr (!REFINE)
+      if (a.step_hi > a.step_lo) {   // multi-step: whole rounds of evenly sized workgroups
+        ChainArgs b = a;
+        b.tiles_per_group = tiles_per_group_balanced(a.N);
+        return ut ? launch_chain<8, false, 0, true, 2>(b, st) : launch_chain<8, false, 0, false, 2>(b, st);
+      }
     return ut ? launch_chain<8, REFINE, 0, true, 2>(a, st) : launch_chain<8, REFINE, 0, false, 2>(a, st);
   }
   if (chain_waves == 32) {
@@ -1880,7 +1912,7 @@ extern "C" int pstl_fill_normal(const pstl_cfg* cfg, int step, float* out, void*
   if (!out || step < 0) return PSTL_ERR_ARG;
   const long N = n_rows(cfg);
   hipLaunchKernelGGL(k_fill_normal, dim3((unsigned)((N * 10 + 255) / 256)), dim3(256), 0, as_stream(stream), N,
-                     (unsigned long long)cfg->seed, (long)cfg->row_offset, step, out);
+                     (unsigned long long)cfg->seed, cfg->dyn, (long)cfg->row_offset, step, out);
   return launch_status();
 }
 
@@ -2018,6 +2050,7 @@ extern "C" int pstl_rollout(const pstl_cfg* cfg, float* packed, const float* bas
   a.noise = noise;
   a.rng = (cfg->flags & PSTL_FLAG_RNG) ? 1 : 0;
   a.seed = cfg->seed;
+  a.seed_dev = cfg->dyn ? reinterpret_cast<const unsigned long long*>(&cfg->dyn->seed) : nullptr;
   a.row_offset = (long)cfg->row_offset;
   a.x_inout = x_inout;
   a.emit_out = emit_out;

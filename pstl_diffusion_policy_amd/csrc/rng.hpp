@@ -30,6 +30,18 @@ __host__ __device__ inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
   return c;
 }
 
+// A 64-bit / 32-bit run-time parameter kept in device memory (pstl_dyn, include/pstl_hip.h), read as a wave-UNIFORM value:
+// a plain load through a global pointer that may alias the kernel's stores is a vector load (the seed would sit in vector
+// registers and every Philox round key would be vector arithmetic); readfirstlane puts it where a by-value argument is.
+__device__ inline uint64_t uniform_u64(const void* p) {
+  const uint32_t* q = static_cast<const uint32_t*>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(q[0]), hi = __builtin_amdgcn_readfirstlane(q[1]);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ inline float uniform_f32(const void* p) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*static_cast<const uint32_t*>(p)));
+}
+
 // four independent N(0,1) values for (global row, quad = f0/4, step)
 // (contraction is switched off inside: the function is compiled into two translation units with different
 // -ffp-contract settings and must give the same bits in both)

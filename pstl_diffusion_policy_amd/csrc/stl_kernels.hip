@@ -255,6 +255,7 @@ struct GuideArgs {
   const float* z;   // (N,40) or null
   int rng, step;    // PSTL_FLAG_RNG: draw z for reverse step `step` in the kernel
   unsigned long long seed;
+  const pstl_dyn* dyn;   // cfg->dyn: seed and grad_scale are read from device memory instead (HIP-graph replay)
   long row_offset;
   float* mu;        // (N,40) in/out
   float* work;      // (3,N,40): m, v, anchor (niters > 1 only)
@@ -274,6 +275,8 @@ template <bool MULTI, bool STAGED, bool NORM = false, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidance_iter(GuideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(!SPLIT || STAGED, "the latency layout stages its scene tables");
+  const unsigned long long seed = a.dyn ? uniform_u64(&a.dyn->seed) : a.seed;
+  const float grad_scale = a.dyn ? uniform_f32(&a.dyn->grad_scale) : a.grad_scale;
   const int lane = SPLIT ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
   const int wq = SPLIT ? (int)(threadIdx.x / kWave) : 0;
   long row = map_row(a.by_mode, a.rows_per_scene, lane);
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidanc
     if (!live0) row = a.N - 1;
     float* geo = lds + kScratchGrad * kWave + stl_table_floats(a.K);
     const StlRow rq = load_row<NORM>(a.stlp, a.hl, row);
-    if (live0 && rq.mode < 3 && a.grad_scale * a.valid[row] != 0.0f)
+    if (live0 && rq.mode < 3 && grad_scale * a.valid[row] != 0.0f)
       stl_geometry(a.env, lanes + rq.mode * kNseg, nei, a.K,
                    DynSrc(a.s0 + (row / a.rows_per_scene) * 4, a.mu + row * (2 * kT), a.wscale, a.ascale, a.env.dt),
                    (kT / kSplitWaves) * wq, (kT / kSplitWaves) * (wq + 1), geo + lane, kWave);
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidanc
   const StlRow r = load_row<NORM>(a.stlp, a.hl, row);
   float* mu = a.mu + row * (2 * kT);
   const float vr = a.valid[row];
-  const float gs = a.grad_scale * vr;
+  const float gs = grad_scale * vr;
   const float thres = a.thres;
   const bool last = (a.iter == a.niters - 1);
   const long plane = a.N * (2 * kT);
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidanc
     f4 z4 = f4{0.0f, 0.0f, 0.0f, 0.0f};
     if (a.rng && a.step > 1 && last) {
       float zz[4];
-      normal4(a.seed, a.row_offset + row, wq, a.step, zz);
+      normal4(seed, a.row_offset + row, wq, a.step, zz);
       z4 = f4{zz[0], zz[1], zz[2], zz[3]};
     }
     for (int t = 2 * wq + 1; t >= 2 * wq; --t)
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidanc
           // drawn at the odd step and kept for the even one: one Philox draw per two time steps
           if (a.rng && a.step > 1 && last && (t & 1)) {
             float zz[4];
-            normal4(a.seed, a.row_offset + row, t >> 1, a.step, zz);
+            normal4(seed, a.row_offset + row, t >> 1, a.step, zz);
             z4 = f4{zz[0], zz[1], zz[2], zz[3]};
           }
           apply(t, gw, ga, w0, a0, z4);
@@ -832,8 +835,26 @@ static long guidance_split_max_groups() {
 
 static int allow_lds(const void* fn, size_t bytes) {
   if (bytes <= 48 * 1024) return PSTL_OK;
-  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? PSTL_OK
-                                                                                                        : PSTL_ERR_LAUNCH;
+  // (remembered per kernel and device: the largest size already allowed -- the attribute call costs host time per launch)
+  struct Seen {
+    const void* fn;
+    int dev;
+    size_t bytes;
+  };
+  static Seen seen[64];
+  static int n_seen = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return PSTL_ERR_LAUNCH;
+  for (int i = 0; i < n_seen; ++i)
+    if (seen[i].fn == fn && seen[i].dev == dev) {
+      if (seen[i].bytes >= bytes) return PSTL_OK;
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return PSTL_ERR_LAUNCH;
+      seen[i].bytes = bytes;
+      return PSTL_OK;
+    }
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return PSTL_ERR_LAUNCH;
+  if (n_seen < 64) seen[n_seen++] = Seen{fn, dev, bytes};
+  return PSTL_OK;
 }
 
 extern "C" int pstl_prepare_scene(const pstl_cfg* cfg, const float* neighbors_traj, const float* currlane,
@@ -992,6 +1013,7 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
   a.rng = (cfg->flags & PSTL_FLAG_RNG) ? 1 : 0;
   a.step = step;
   a.seed = cfg->seed;
+  a.dyn = cfg->dyn;
   a.row_offset = (long)cfg->row_offset;
   a.mu = mu_x_inout;
   a.work = work;

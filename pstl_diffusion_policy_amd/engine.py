@@ -101,9 +101,14 @@ class SceneBatch:
     (bs,15,3), {curr,left,right}_id (bs,1), and either stlp_modes (bs,3,6) or stlp_rows (N,6).
     """
 
-    def __init__(self, scene, S, hp, device, global_valid_sum=None, global_rows=None, row_offset=0):
+    def __init__(self, scene, S, hp, device, global_valid_sum=None, global_rows=None, row_offset=0, dyn=None):
+        """dyn: None, or a 4-float32 device tensor laid out as a pstl_dyn (include/pstl_hip.h): the kernels then read the noise
+        seed from its first 8 bytes and the guidance-loss scale from its third word -- which THIS constructor writes there, on
+        the device, from the lane ids (no host synchronisation) -- instead of taking them by value: the launches of a whole
+        planning step can be captured in a HIP graph and replayed with new inputs (nusc_sim.py)."""
         dev = torch.device(device)
         self.row_offset = int(row_offset)   # global index of the first row (in-kernel noise is keyed by global row)
+        self.dyn = dyn
         # A batch that arrives in host memory (the closed-loop caller builds one scene per simulation step) crosses PCIe as
         # ONE staged copy instead of one per tensor, and the guidance-loss scale is taken from the host copy of the lane ids:
         # no device synchronisation while the batch is set up.
@@ -146,11 +151,19 @@ class SceneBatch:
         ids3 = torch.stack(self.ids, dim=-1)                                                             # (bs,3)
         self.valid = ids3.reshape(self.bs, 1, 3).expand(self.bs, self.S, 3).reshape(self.N).contiguous()  # :751-752
         # scale of d loss / d score in the guidance loss mask_mean(relu(thres - score), valid) (nusc_train.py:23-27,619)
-        vsum = float(ids3.sum().item()) * self.S if global_valid_sum is None else float(global_valid_sum)
         rows = self.N if global_rows is None else int(global_rows)
-        mean_valid = np.float32(np.float32(vsum) / np.float32(rows))
-        c = np.float32(max(mean_valid, np.float32(1e-2)))
-        self.grad_scale = float(np.float32(np.float32(1.0) / c) / np.float32(rows))
+        if dyn is not None and global_valid_sum is None:
+            # the same float32 operations on the device, written into the parameter block the kernels read
+            c = torch.clamp((ids3.sum() * float(self.S)) / float(rows), min=1e-2)
+            dyn[2:3].copy_(((1.0 / c) / float(rows)).reshape(1))
+            self.grad_scale = 0.0     # (the by-value argument is ignored when cfg.dyn is set)
+        else:
+            vsum = float(ids3.sum().item()) * self.S if global_valid_sum is None else float(global_valid_sum)
+            mean_valid = np.float32(np.float32(vsum) / np.float32(rows))
+            c = np.float32(max(mean_valid, np.float32(1e-2)))
+            self.grad_scale = float(np.float32(np.float32(1.0) / c) / np.float32(rows))
+            if dyn is not None:
+                dyn[2:3].fill_(self.grad_scale)
         # prepared tables for the STL kernels
         self.nei_prep = torch.empty(self.bs, self.K, ffi.T, ffi.NEI_PREP, dtype=torch.float32, device=dev)
         self.lane_prep = torch.empty(self.bs, 3, ffi.NSEG, 4, dtype=torch.float32, device=dev)
@@ -160,7 +173,8 @@ class SceneBatch:
                                                ffi.ptr(self.lane_prep), ffi.stream()), "prepare_scene")
 
     def cfg(self, steps, flags=0, chain_waves=0, seed=0):
-        return ffi.make_cfg(self.bs, self.rps, self.S, self.K, steps, self.hp, flags, chain_waves, seed, self.row_offset)
+        return ffi.make_cfg(self.bs, self.rps, self.S, self.K, steps, self.hp, flags, chain_waves, seed, self.row_offset,
+                            dyn=self.dyn)
 
 
 def guidance_triggered(i, steps, g):
@@ -269,7 +283,13 @@ class Sampler:
         or seed != None: the kernels draw the noise themselves (Philox keyed by seed and global row).
         Returns emit (n_emit,N,40): the last n_emit entries of the reference's normalised diff_full list."""
         dev = sb.device
-        beta, alpha, alpha_hat = coeffs if coeffs is not None else diffusion_coeffs(steps, dev)
+        if coeffs is None:   # (kept per schedule: building it copies three host tensors to the device -- not capturable, not free)
+            ck = self.__dict__.setdefault("_coeffs", {})
+            if (int(steps), str(dev)) not in ck:
+                ck.clear()
+                ck[(int(steps), str(dev))] = diffusion_coeffs(steps, dev)
+            coeffs = ck[(int(steps), str(dev))]
+        beta, alpha, alpha_hat = coeffs
         # host copy of beta (sqrt(beta_i) is a by-value argument of the guidance launch); taking it from the device tensor
         # would block the host on the GPU at every rollout, so it is cached per schedule
         cache = self.__dict__.setdefault("_beta_host", {})

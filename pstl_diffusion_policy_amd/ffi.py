@@ -25,7 +25,7 @@ HID = 256
 FEAT = 224
 NEI_PREP = 12
 
-ABI_VERSION = 3      # include/pstl_hip.h PSTL_ABI_VERSION
+ABI_VERSION = 4      # include/pstl_hip.h PSTL_ABI_VERSION
 SPLIT_F16_WMAX = 63.9   # include/pstl_hip.h PSTL_SPLIT_F16_WMAX
 
 class PstlCfg(ctypes.Structure):
@@ -35,7 +35,7 @@ class PstlCfg(ctypes.Structure):
                 ("tau", ctypes.c_float), ("thres", ctypes.c_float), ("w_max", ctypes.c_float),
                 ("a_max", ctypes.c_float), ("dt", ctypes.c_float), ("ego_L", ctypes.c_float),
                 ("ego_W", ctypes.c_float), ("reserved_f", ctypes.c_float),
-                ("seed", ctypes.c_uint64), ("row_offset", ctypes.c_int64)]
+                ("seed", ctypes.c_uint64), ("row_offset", ctypes.c_int64), ("dyn", ctypes.c_void_p)]
 
 
 class Mlp3(ctypes.Structure):
@@ -140,14 +140,17 @@ def ptr(t, dtype=torch.float32):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def make_cfg(bs, rows_per_scene, S, K, steps, hp, flags=0, chain_waves=0, seed=0, row_offset=0):
+def make_cfg(bs, rows_per_scene, S, K, steps, hp, flags=0, chain_waves=0, seed=0, row_offset=0, dyn=None):
+    """dyn: None, or a 4-float32 device tensor holding a pstl_dyn (seed as two 32-bit words, grad_scale, 0): the kernels read
+    seed / grad_scale from it at run time (HIP-graph replay with new values, include/pstl_hip.h)."""
     if hp.get("norm_stl", False):     # --norm_stl travels with the hyper-parameters: every launch of the batch sees it
         flags = int(flags) | PSTL_FLAG_NORM_STL
     return PstlCfg(bs=int(bs), rows_per_scene=int(rows_per_scene), S=int(S), K=int(K), steps=int(steps),
                    n_shards=int(hp.get("n_shards", 4)), flags=int(flags), chain_waves=int(chain_waves),
                    tau=float(hp["smoothing_factor"]), thres=float(hp["stl_nn_thres"]), w_max=float(hp["mul_w_max"]),
                    a_max=float(hp["mul_a_max"]), dt=float(hp["dt"]), ego_L=float(hp["ego_L"]),
-                   ego_W=float(hp["ego_W"]), reserved_f=0.0, seed=int(seed) & (2 ** 64 - 1), row_offset=int(row_offset))
+                   ego_W=float(hp["ego_W"]), reserved_f=0.0, seed=int(seed) & (2 ** 64 - 1), row_offset=int(row_offset),
+                   dyn=None if dyn is None else ptr(dyn).value)
 
 
 def f32(x, device):

@@ -72,10 +72,14 @@ class SyntheticWorld:
         return float(d.min())
 
 
-def _plan(sm, obs, S, hp, dev, diffusion_steps, multi_cands, g, seed):
-    """One planning step: the sampling region on the one-scene batch, then the best lane-keeping sample.  Returns a host tensor
-    (first control (2), its score, the bits of the chain-domain status word)."""
-    sb = SceneBatch(obs, S, hp, dev)
+_SCENE_KEYS = ("ego_traj", "neighbors", "neighbors_traj", "currlane_wpts", "leftlane_wpts", "rightlane_wpts", "curr_id",
+               "left_id", "right_id", "stlp_modes")
+
+
+def _plan_device(sm, scene, S, hp, dev, diffusion_steps, multi_cands, g, seed, dyn=None):
+    """One planning step: the sampling region on the one-scene batch, then the best lane-keeping sample.  Returns a device
+    tensor (first control (2), its score, the bits of the chain-domain status word)."""
+    sb = SceneBatch(scene, S, hp, dev, dyn=dyn)
     out = sm.sampling_region(sb, diffusion_steps, None, None, rect_head=True, multi_cands=multi_cands, guidance=g,
                              seed=seed, want_scores3=False)
     # lane-keeping samples only (the reference sets the other two modes' scores to -10000 before its argmax, :676-677):
@@ -84,12 +88,77 @@ def _plan(sm, obs, S, hp, dev, diffusion_steps, multi_cands, g, seed):
     bi = torch.argmax(keep)
     first = out["final_controls"].reshape(S, 3, ffi.T, 2)[:, 0, 0, :]     # (S,2): first control of every mode-0 sample
     return torch.cat([first.index_select(0, bi.reshape(1)).reshape(2), keep.index_select(0, bi.reshape(1)),
-                      sm.w.status[2:3]]).cpu()
+                      sm.w.status[2:3]])
+
+
+def _plan(sm, obs, S, hp, dev, diffusion_steps, multi_cands, g, seed):
+    return _plan_device(sm, obs, S, hp, dev, diffusion_steps, multi_cands, g, seed).cpu()
+
+
+class GraphPlanner:
+    """The ~45 launches of one planning step captured ONCE in a HIP graph and replayed per simulation step.
+
+    What changes between simulation steps lives in one device buffer: the observation (every scene tensor, 16-byte slots) and
+    a pstl_dyn block (the noise seed; the guidance-loss scale is written there by the captured work itself, from the lane
+    ids).  The kernels read seed and scale from that block (cfg.dyn, ABI 4) instead of taking them by value, so a replay with
+    new inputs is: fill a pinned host mirror, ONE host-to-device copy, graph launch, ONE 16-byte copy back.  Same kernels, same
+    arguments, same order as the eager path: bit-identical results (tested)."""
+
+    def __init__(self, sm, obs, S, hp, dev, diffusion_steps, multi_cands, g):
+        self.sm, self.S, self.hp, self.dev = sm, S, hp, dev
+        self.args = (diffusion_steps, multi_cands, g)
+        self.layout, o = [], 0
+        for k in _SCENE_KEYS:
+            t = torch.as_tensor(obs[k])
+            self.layout.append((k, tuple(t.shape), o, t.numel()))
+            o += t.numel() + (-t.numel() % 4)
+        self.n_scene = o
+        self.host = torch.zeros(o + 4, dtype=torch.float32).pin_memory()
+        self.host_np = self.host.numpy()
+        self.inp = torch.zeros(o + 4, dtype=torch.float32, device=dev)
+        self.graph = None
+        self.capture(obs)
+
+    def _fill(self, obs, seed):
+        for k, shape, o, n in self.layout:
+            t = torch.as_tensor(obs[k])
+            if tuple(t.shape) != shape:
+                raise ValueError("observation tensor %s changed its shape (%s, captured %s)" % (k, tuple(t.shape), shape))
+            self.host[o:o + n] = t.reshape(-1).to(torch.float32)
+        seed = int(seed) & (2 ** 64 - 1)
+        self.host_np[self.n_scene:self.n_scene + 2].view("uint32")[:] = (seed & 0xffffffff, seed >> 32)
+
+    def _body(self):
+        scene = {k: self.inp[o:o + n].reshape(shape) for k, shape, o, n in self.layout}
+        steps, mc, g = self.args
+        return _plan_device(self.sm, scene, self.S, self.hp, self.dev, steps, mc, g, 0, dyn=self.inp[self.n_scene:])
+
+    def capture(self, obs):
+        """(Re-)captures the graph with the sampler's current arithmetic (after a domain fallback: the exact-fp32 kernels)."""
+        self._fill(obs, 0)
+        self.inp.copy_(self.host)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # eager warm-up on the capture stream: allocations, function attributes, caches
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._body()
+
+    def plan(self, obs, seed):
+        self._fill(obs, seed)
+        self.inp.copy_(self.host, non_blocking=True)
+        self.graph.replay()
+        return self.out.cpu()
 
 
 def closed_loop(state_dict, n_sim_steps=20, K=8, S=64, diffusion_steps=100, multi_cands=5, guidance=True, guidance_before=10,
-                guidance_lr=0.04, seed=0, device="cuda:0", verbose=True, chain_waves=None):
+                guidance_lr=0.04, seed=0, device="cuda:0", verbose=True, chain_waves=None, graph=True):
     """Runs the receding-horizon loop; returns per-step records (latency in seconds with device sync, score, state).
+    graph: replay one captured HIP graph per simulation step (GraphPlanner) instead of ~45 eager launches; same results.
     chain_waves: arithmetic of the MLP chains (None: PSTL_CHAIN_WAVES or the default split-f16 form; a step that leaves its
     domain is planned again on the exact-fp32 kernels, with a RuntimeWarning, and the loop stays on them)."""
     dev = torch.device(device)
@@ -98,16 +167,24 @@ def closed_loop(state_dict, n_sim_steps=20, K=8, S=64, diffusion_steps=100, mult
     world = SyntheticWorld(K=K, seed=seed, dt=hp["dt"], nt=hp["nt"])
     g = dict(enabled=True, before=guidance_before, niters=1, lr=guidance_lr, maximize=True) if guidance else None
     records = []
+    planner = GraphPlanner(sm, world.observation(), S, hp, dev, diffusion_steps, multi_cands, g) if graph else None
+    if planner is not None:
+        plan = planner.plan
+        sm.w.chain_overflowed(clear=True)      # (the capture's warm-up ran on a zero seed: whatever it flagged is re-detected)
+    else:
+        plan = lambda obs, sd: _plan(sm, obs, S, hp, dev, diffusion_steps, multi_cands, g, sd)
     for it in range(n_sim_steps):
         obs = world.observation()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pick = _plan(sm, obs, S, hp, dev, diffusion_steps, multi_cands, g, seed * 100003 + it)
+        pick = plan(obs, seed * 100003 + it)
         # The split-f16 domain flag rides in the same copy as the control (bit pattern of the packed buffer's status word 2):
         # a layer input beyond the half range leaves plausible garbage, not NaNs, and this loop would drive the vehicle with it.
         # The step is then planned again on the exact-fp32 kernels (same Philox seed), and so is every later one.
         if pick[3:4].view(torch.int32).item() != 0 and sm.check_chain_domain():
-            pick = _plan(sm, obs, S, hp, dev, diffusion_steps, multi_cands, g, seed * 100003 + it)
+            if planner is not None:
+                planner.capture(obs)           # the graph holds the old arithmetic's launches: captured again
+            pick = plan(obs, seed * 100003 + it)
         ctrl = pick[:2]
         lat = time.perf_counter() - t0
         world.step(ctrl)

@@ -23,6 +23,19 @@ def test_receding_horizon_loop_runs_and_is_reproducible():
     assert a[-1]["x"] > a[0]["x"]                      # the ego moves forward
 
 
+def test_graph_replay_equals_eager_launches():
+    """GraphPlanner: the launches of a planning step captured once and replayed with new observations and seeds (read by the
+    kernels from the device-resident pstl_dyn block) give, step for step, the very numbers the eager launches give."""
+    from pstl_diffusion_policy_amd.nusc_sim import closed_loop
+    sd = golden_weights()
+    kw = dict(n_sim_steps=5, K=8, diffusion_steps=30, guidance_before=6, seed=7, verbose=False)
+    a = closed_loop(sd, graph=True, **kw)
+    b = closed_loop(sd, graph=False, **kw)
+    for ra, rb in zip(a, b):
+        assert (ra["best_score"], ra["x"], ra["y"], ra["v"]) == (rb["best_score"], rb["x"], rb["y"], rb["v"])
+    assert len({r["best_score"] for r in a}) > 1      # the replays did see different inputs
+
+
 def test_reference_command_line_runs(capsys):
     """README command of the guided closed-loop run, through the mirror's main()."""
     from pstl_diffusion_policy_amd import nusc_sim

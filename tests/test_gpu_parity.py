@@ -396,11 +396,36 @@ def test_streamed_single_step_launches_equal_the_grouped_ones(dev, noise):
             assert torch.equal(a, b), k
 
 
+@pytest.mark.parametrize("bs", [112, 267])
+def test_balanced_workgroup_sizes_do_not_change_results(dev, bs):
+    """Multi-step denoiser launches spread a batch's tiles evenly over whole rounds of workgroups (tiles_per_group_balanced,
+    mlp_kernels.hip): 112 scenes = 1 344 tiles run as 224 six-tile workgroups (five-tile groups would need a second round for
+    13 of them), 267 scenes = 3 204 tiles as two rounds of seven-tile workgroups instead of 267 twelve-tile ones.  Row-wise
+    arithmetic, noise keyed by the global row: a 24-scene shard of the batch, evaluated alone in the latency layout, must
+    reproduce its rows bit for bit."""
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    S, steps = 64, 8
+    scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=2, S=S, seed=31, invalid_lane_frac=0.2, stlp_mode="wide").items()
+             if k not in ("params", "pre_stlp", "tj_scores_prior")}
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    kw = dict(rect_head=True, multi_cands=3, want_scores3=False, seed=5)
+    sb = SceneBatch(scene, S, hp, dev)
+    full = sm.sampling_region(sb, steps, None, None, **kw)
+    lo, hi = bs - 30, bs - 6
+    sub = {k: v[lo:hi].contiguous() for k, v in scene.items()}
+    r0, r1 = lo * S * 3, hi * S * 3
+    part = sm.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=r0), steps, None, None, **kw)
+    for k in ("final_controls", "final_scores", "sel_controls"):
+        assert torch.isfinite(full[k]).all() and torch.equal(part[k], full[k][r0:r1]), k
+
+
 @pytest.mark.parametrize("bs,S,steps", [(1, 64, 100), (3, 16, 12), (7, 32, 20), (40, 64, 9), (100, 64, 6)])
 @pytest.mark.parametrize("noise", ["kernel", "tensor"])
 def test_latency_layout_equals_throughput_layout(dev, bs, S, steps, noise):
     """`chain_waves = 0` runs the multi-step denoiser launch of a batch with fewer than five tiles per CU in the latency
-    layout (1..4 tiles per workgroup, empty pipeline slots skipped: SPARSE in mlp_kernels.hip); `chain_waves = 16` is the
+    layout (1..5 tiles per workgroup, empty pipeline slots skipped: SPARSE in mlp_kernels.hip); `chain_waves = 16` is the
     same arithmetic in the throughput layout whatever the size (what the bench's batch gets, and what every small fixture
     ran before round 3).  Same arithmetic per row, noise keyed by the global row: every output must agree bit for bit --
     192 rows (the closed loop's batch), 144 and 672 rows, 480 tiles (two per workgroup), 1200 tiles (five: nothing skipped)."""

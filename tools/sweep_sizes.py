@@ -25,6 +25,8 @@ def main():
     p.add_argument("--reps", type=int, default=5)
     p.add_argument("--chain_waves", type=int, default=0)
     p.add_argument("--detail", action="store_true")
+    p.add_argument("--diversity", action="store_true")
+    p.add_argument("--rollout_only", action="store_true", help="time only the multi-step denoiser launch (HIP events)")
     a = p.parse_args()
     from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler
     from pstl_diffusion_policy_amd.nusc_model import init_state_dict
@@ -43,8 +45,25 @@ def main():
             call[0] += 1
             sb = SceneBatch(scene, 64, hp, dev)
             return sm.sampling_region(sb, a.steps, None, None, rect_head=rect, multi_cands=a.multi_cands if rect else None,
-                                      guidance=guid, want_scores3=False, seed=1234 + call[0], n_rolls=a.n_rolls)
+                                      guidance=guid, want_scores3=False, seed=1234 + call[0], n_rolls=a.n_rolls,
+                                      diversity=a.diversity)
 
+        if a.rollout_only:
+            sb = SceneBatch(scene, 64, hp, dev)
+            _, base_p, _ = sm.encode(sb, need_rect=False)
+            x = torch.randn(sb.N, 40, device=dev)
+            sm.trace = []
+            for _ in range(a.reps + 1):
+                sm.rollout(sb, base_p, x, None, a.steps, n_emit=5, clip=True, seed=7)
+            torch.cuda.synchronize()
+            ms = [e0.elapsed_time(e1) for (e0, e1, n, _) in sm.trace][1:]
+            n_tiles = sb.N // 16
+            g = (n_tiles + 255) // 256 if n_tiles < 5 * 256 else max(5, min(12, n_tiles // 256))
+            rounds = -(-n_tiles // (g * 256)) if n_tiles >= 5 * 256 else 1
+            print(json.dumps(dict(rows=sb.N, tiles_per_group=g, rounds=rounds, chain_ms=sum(ms) / len(ms),
+                                  us_per_tile_step=1e3 * sum(ms) / len(ms) / ((a.steps - 1) * g * rounds))), flush=True)
+            sm.trace = None
+            continue
         for _ in range(2):
             step()
         sm.trace, sm.trace_stl = [], {}
