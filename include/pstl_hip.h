@@ -322,6 +322,13 @@ int pstl_diversity_loss(const pstl_cfg* cfg, const float* rect_controls, const f
 int pstl_reduce_metrics(const pstl_cfg* cfg, const float* scores, const float* valid /* (N,) */, uint64_t* counts,
                         uint8_t* sat_mask, void* stream);
 
+/* The closed-loop caller's choice (reference nusc_sim.py:677-683: the scores of modes 1 and 2 set to -10000, torch.argmax over
+ * the (S,3) scores of the ONE scene of the batch, that row's controls): out4[0..1] = the first (w, a) of the best lane-keeping
+ * sample, out4[2] = its score, out4[3] = the bit pattern of the chain-domain status word (packed_status = packed +
+ * pstl_packed_status_offset() + 2, or NULL), so that control and flag reach the host in one 16-byte copy.  cfg->bs must be 1. */
+int pstl_select_plan(const pstl_cfg* cfg, const float* scores /* (3*S,) */, const float* controls /* (3*S,40) */,
+                     const float* packed_status, float* out4, void* stream);
+
 /* ---- post-sampling diversity metrics (the numbers run_sampling_test prints after its timer) -------- */
 /* measure_diversity (nusc_api.py:817-875), measure_extra_diversity (nusc_api.py:894-936, compute_entropy
  * utils.py:388-417, compute_area nusc_api.py:878-891) and compute_ade_fde (nusc_train.py:877-887) for the final

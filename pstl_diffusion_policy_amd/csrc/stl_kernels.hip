@@ -172,6 +172,36 @@ __global__ void k_stl_select(long N, int reps, const float* scores, const float*
   sel_idx[row] = best_rep;
 }
 
+// The closed-loop caller's choice of the control to apply (reference nusc_sim.py:677-683: scores of modes 1, 2 set to -10000,
+// torch.argmax over the flattened (S,3) scores of ONE scene -- first maximum wins --, then that row's control sequence): the best
+// lane-keeping sample.  out[0..1] = its first (w, a), out[2] = its score, out[3] = the bit pattern of *status (the packed
+// weight buffer's chain-domain word, so that the flag reaches the host in the same 16-byte copy).  One wavefront.
+__global__ __launch_bounds__(kWave) void k_select_plan(int S, const float* scores /* (S,3) */, const float* controls /* (S*3,40) */,
+                                                       const unsigned* status, float* out) {
+  const int lane = threadIdx.x;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int s = lane; s < S; s += kWave) {
+    const float v = scores[3 * s];
+    if (bi == 0x7fffffff || v > best) best = v, bi = s;   // (ascending s within a lane: the first maximum stays)
+  }
+  // all -10000 columns lose to any finite mode-0 score; a NaN score never wins a ">" (torch.argmax would return it: the
+  // domain flag in out[3] is what reports such a batch)
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float ob = __shfl_xor(best, m, kWave);
+    const int oi = __shfl_xor(bi, m, kWave);
+    if (ob > best || (ob == best && oi < bi)) best = ob, bi = oi;
+  }
+  if (lane == 0) {
+    const float* c = controls + (long)(3 * bi) * (2 * kT);
+    out[0] = c[0];
+    out[1] = c[1];
+    out[2] = best;
+    out[3] = status ? __builtin_bit_cast(float, *status) : 0.0f;
+  }
+}
+
 // Row handled by this lane.  by_mode (scene-indexed rows r = (b*S + s)*3 + mode with S a multiple of 64): a wavefront
 // takes 64 samples of ONE (scene, mode) instead of 64 consecutive rows.  Rows of a (scene, mode) share their lane, their
 // validity and mostly their fate (satisfied or not), so whole wavefronts take the cheap exits of stl_eval_grad -- an
@@ -1175,6 +1205,16 @@ extern "C" int pstl_stl_signals(const pstl_cfg* cfg, const float* s0, const floa
   hipLaunchKernelGGL(k_stl_signals, dim3((unsigned)((N + kWave - 1) / kWave)), dim3(kWave), 0, as_stream(stream), N,
                      cfg->rows_per_scene, cfg->K, make_env(cfg->tau, cfg->dt, cfg->ego_L, cfg->ego_W), s0, controls, states,
                      nei_prep, lane_prep, signals);
+  return launch_status();
+}
+
+extern "C" int pstl_select_plan(const pstl_cfg* cfg, const float* scores, const float* controls, const float* packed_status,
+                                float* out4, void* stream) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!scores || !controls || !out4) return PSTL_ERR_ARG;
+  if (cfg->bs != 1 || cfg->rows_per_scene != 3 * cfg->S) return PSTL_ERR_SHAPE;   // the closed loop plans one scene at a time
+  hipLaunchKernelGGL(k_select_plan, dim3(1), dim3(kWave), 0, as_stream(stream), cfg->S, scores, controls,
+                     reinterpret_cast<const unsigned*>(packed_status), out4);
   return launch_status();
 }
 

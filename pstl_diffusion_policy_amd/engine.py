@@ -101,11 +101,13 @@ class SceneBatch:
     (bs,15,3), {curr,left,right}_id (bs,1), and either stlp_modes (bs,3,6) or stlp_rows (N,6).
     """
 
-    def __init__(self, scene, S, hp, device, global_valid_sum=None, global_rows=None, row_offset=0, dyn=None):
+    def __init__(self, scene, S, hp, device, global_valid_sum=None, global_rows=None, row_offset=0, dyn=None,
+                 scale_in_dyn=False):
         """dyn: None, or a 4-float32 device tensor laid out as a pstl_dyn (include/pstl_hip.h): the kernels then read the noise
         seed from its first 8 bytes and the guidance-loss scale from its third word -- which THIS constructor writes there, on
         the device, from the lane ids (no host synchronisation) -- instead of taking them by value: the launches of a whole
-        planning step can be captured in a HIP graph and replayed with new inputs (nusc_sim.py)."""
+        planning step can be captured in a HIP graph and replayed with new inputs (nusc_sim.py).  scale_in_dyn: the caller has
+        already put the scale there (SceneBatch.loss_scale of the host copy of the lane ids): nothing is computed here."""
         dev = torch.device(device)
         self.row_offset = int(row_offset)   # global index of the first row (in-kernel noise is keyed by global row)
         self.dyn = dyn
@@ -152,16 +154,16 @@ class SceneBatch:
         self.valid = ids3.reshape(self.bs, 1, 3).expand(self.bs, self.S, 3).reshape(self.N).contiguous()  # :751-752
         # scale of d loss / d score in the guidance loss mask_mean(relu(thres - score), valid) (nusc_train.py:23-27,619)
         rows = self.N if global_rows is None else int(global_rows)
-        if dyn is not None and global_valid_sum is None:
+        if dyn is not None and scale_in_dyn:
+            self.grad_scale = 0.0
+        elif dyn is not None and global_valid_sum is None:
             # the same float32 operations on the device, written into the parameter block the kernels read
             c = torch.clamp((ids3.sum() * float(self.S)) / float(rows), min=1e-2)
             dyn[2:3].copy_(((1.0 / c) / float(rows)).reshape(1))
             self.grad_scale = 0.0     # (the by-value argument is ignored when cfg.dyn is set)
         else:
             vsum = float(ids3.sum().item()) * self.S if global_valid_sum is None else float(global_valid_sum)
-            mean_valid = np.float32(np.float32(vsum) / np.float32(rows))
-            c = np.float32(max(mean_valid, np.float32(1e-2)))
-            self.grad_scale = float(np.float32(np.float32(1.0) / c) / np.float32(rows))
+            self.grad_scale = self.loss_scale(vsum, rows)
             if dyn is not None:
                 dyn[2:3].fill_(self.grad_scale)
         # prepared tables for the STL kernels
@@ -171,6 +173,14 @@ class SceneBatch:
         ffi.check(ffi.lib().pstl_prepare_scene(ctypes.byref(cfg), ffi.ptr(self.nei_traj), ffi.ptr(self.lanes[0]),
                                                ffi.ptr(self.lanes[1]), ffi.ptr(self.lanes[2]), ffi.ptr(self.nei_prep),
                                                ffi.ptr(self.lane_prep), ffi.stream()), "prepare_scene")
+
+    @staticmethod
+    def loss_scale(valid_sum, rows):
+        """d loss / d score of mask_mean(relu(thres - score), valid) per violated valid row: (1 / clip(mean(valid), 1e-2)) / rows,
+        in float32 as the reference computes it (nusc_train.py:23-27,619)."""
+        mean_valid = np.float32(np.float32(valid_sum) / np.float32(rows))
+        c = np.float32(max(mean_valid, np.float32(1e-2)))
+        return float(np.float32(np.float32(1.0) / c) / np.float32(rows))
 
     def cfg(self, steps, flags=0, chain_waves=0, seed=0):
         return ffi.make_cfg(self.bs, self.rps, self.S, self.K, steps, self.hp, flags, chain_waves, seed, self.row_offset,
@@ -409,6 +419,15 @@ class Sampler:
                                      ffi.ptr(out), ffi.stream()), "refine")
         return out
 
+    def select_plan(self, sb, scores, controls):
+        """The closed loop's choice (reference nusc_sim.py:677-683): device tensor (first w, first a, score, domain-flag bits) of
+        the best lane-keeping sample of the one scene in `sb`."""
+        out = torch.empty(4, dtype=torch.float32, device=sb.device)
+        cfg = sb.cfg(2)
+        ffi.check(self.L.pstl_select_plan(ctypes.byref(cfg), ffi.ptr(scores), ffi.ptr(controls), ffi.ptr(self.w.status[2:3]),
+                                          ffi.ptr(out), ffi.stream()), "select_plan")
+        return out
+
     def metrics(self, sb, scores, want_mask=False):
         """Integer numerators/denominators of acc and scene_acc (device tensor of 8 int64; no host sync here)."""
         counts = torch.empty(8, dtype=torch.int64, device=sb.device)
@@ -498,7 +517,7 @@ class Sampler:
     # ---- A12: the timed region ----
     def sampling_region(self, sb, steps, x_T, noise, rect_head=False, multi_cands=None, refinenet=True, guidance=None,
                         n_rolls=None, diverse=True, full_list=False, coeffs=None, want_scores3=True, seed=None,
-                        diversity=False, clip_rect=False, use_rect=True, refinement_iters=None):
+                        diversity=False, clip_rect=False, use_rect=True, refinement_iters=None, want_counts=True):
         """x_T (N,40) and noise (steps-1,N,40) supplied by the caller (parity), or seed != None: x_T and all noise are
         drawn by the kernels (x_T / noise arguments ignored)."""
         out = {}
@@ -537,8 +556,9 @@ class Sampler:
                 controls = self.refinement(sb, controls.contiguous(), emit, iters=int(refinement_iters))
                 out["refinement_controls"] = controls
         fin = self.score(sb, controls.reshape(1, sb.N, ffi.CTRL), all3=want_scores3)
-        counts, _ = self.metrics(sb, fin["scores"][0])
-        out.update(final_controls=controls, final_scores=fin["scores"][0], counts=counts)
+        out.update(final_controls=controls, final_scores=fin["scores"][0])
+        if want_counts:      # (the closed-loop caller only needs the best sample: three launches less per planning step)
+            out["counts"] = self.metrics(sb, fin["scores"][0])[0]
         if diversity:   # std / hull volume / entropies / area / ADE / FDE (the reference: on the CPU, after its timer)
             pm, ps, tot = self.diversity(sb, controls, fin["scores"][0])
             out.update(div_per_mode=pm, div_per_scene=ps, div_totals=tot)

@@ -72,6 +72,7 @@ SIGNATURES = [
     ("pstl_guidance_step", _I, [_C] + [_P] * 6 + [_F, _I, _P, _P, _F, _I] + [_P] * 5),
     ("pstl_refine", _I, [_C] + [_P] * 9),
     ("pstl_reduce_metrics", _I, [_C] + [_P] * 5),
+    ("pstl_select_plan", _I, [_C] + [_P] * 5),
     ("pstl_refine_train_forward", _I, [_C] + [_P] * 12),
     ("pstl_loss_grad", _I, [_C, _P, _P, _F, _P, _P, _P]),
     ("pstl_train_create", _I, [_P]),

@@ -77,18 +77,13 @@ _SCENE_KEYS = ("ego_traj", "neighbors", "neighbors_traj", "currlane_wpts", "left
 
 
 def _plan_device(sm, scene, S, hp, dev, diffusion_steps, multi_cands, g, seed, dyn=None):
-    """One planning step: the sampling region on the one-scene batch, then the best lane-keeping sample.  Returns a device
-    tensor (first control (2), its score, the bits of the chain-domain status word)."""
-    sb = SceneBatch(scene, S, hp, dev, dyn=dyn)
+    """One planning step: the sampling region on the one-scene batch, then the best lane-keeping sample (the reference sets the
+    other two modes' scores to -10000 before its argmax, nusc_sim.py:677-683).  Returns a device tensor (first control (2), its
+    score, the bits of the chain-domain status word): everything the loop needs comes back in ONE 16-byte copy."""
+    sb = SceneBatch(scene, S, hp, dev, dyn=dyn, scale_in_dyn=dyn is not None)
     out = sm.sampling_region(sb, diffusion_steps, None, None, rect_head=True, multi_cands=multi_cands, guidance=g,
-                             seed=seed, want_scores3=False)
-    # lane-keeping samples only (the reference sets the other two modes' scores to -10000 before its argmax, :676-677):
-    # the best of column 0, its first control and its score, selected on the device and brought back in ONE copy
-    keep = out["final_scores"].reshape(S, 3)[:, 0]
-    bi = torch.argmax(keep)
-    first = out["final_controls"].reshape(S, 3, ffi.T, 2)[:, 0, 0, :]     # (S,2): first control of every mode-0 sample
-    return torch.cat([first.index_select(0, bi.reshape(1)).reshape(2), keep.index_select(0, bi.reshape(1)),
-                      sm.w.status[2:3]])
+                             seed=seed, want_scores3=False, want_counts=False)
+    return sm.select_plan(sb, out["final_scores"], out["final_controls"])
 
 
 def _plan(sm, obs, S, hp, dev, diffusion_steps, multi_cands, g, seed):
@@ -99,8 +94,7 @@ class GraphPlanner:
     """The ~45 launches of one planning step captured ONCE in a HIP graph and replayed per simulation step.
 
     What changes between simulation steps lives in one device buffer: the observation (every scene tensor, 16-byte slots) and
-    a pstl_dyn block (the noise seed; the guidance-loss scale is written there by the captured work itself, from the lane
-    ids).  The kernels read seed and scale from that block (cfg.dyn, ABI 4) instead of taking them by value, so a replay with
+    a pstl_dyn block (the noise seed and the guidance-loss scale, computed on the host from the lane ids).  The kernels read seed and scale from that block (cfg.dyn, ABI 4) instead of taking them by value, so a replay with
     new inputs is: fill a pinned host mirror, ONE host-to-device copy, graph launch, ONE 16-byte copy back.  Same kernels, same
     arguments, same order as the eager path: bit-identical results (tested)."""
 
@@ -127,6 +121,9 @@ class GraphPlanner:
             self.host[o:o + n] = t.reshape(-1).to(torch.float32)
         seed = int(seed) & (2 ** 64 - 1)
         self.host_np[self.n_scene:self.n_scene + 2].view("uint32")[:] = (seed & 0xffffffff, seed >> 32)
+        # the guidance-loss scale from the host copy of the lane ids (what SceneBatch computes for an eager step)
+        vsum = float(sum(torch.as_tensor(obs[k]).to(torch.float32).sum() for k in ("curr_id", "left_id", "right_id"))) * self.S
+        self.host_np[self.n_scene + 2] = SceneBatch.loss_scale(vsum, 3 * self.S * int(torch.as_tensor(obs["curr_id"]).shape[0]))
 
     def _body(self):
         scene = {k: self.inp[o:o + n].reshape(shape) for k, shape, o, n in self.layout}
