@@ -53,6 +53,8 @@ enum {
   PSTL_FLAG_NO_MERGE = 8,   /* rect_forward without merge_net pooling (not diverse_loss / --no_arch)       */
   PSTL_FLAG_RNG = 16,       /* kernels draw the diffusion noise themselves (cfg.seed, cfg.row_offset); the  */
                             /* `noise` / `z` pointer arguments are then ignored                              */
+  PSTL_FLAG_KEEP_DH1 = 64,  /* pstl_refine_backward leaves dH1 (N,256) in its work buffer: pstl_encoder_backward follows      */
+                            /* (--joint).  Without it the one-pass layer kernels never write dH1 to memory.                 */
   PSTL_FLAG_NORM_STL = 32   /* --norm_stl (nusc_train.py:88-91,97-113): the speed, lane-distance and clearance       */
                             /* predicates divided by v_factor = clip(vmax - vmin, 0.3), d_factor = clip((dmax - dmin)*5, */
                             /* 0.3), safe_factor = clip(dsafe, 0.3) in pstl_stl_forward / _backward / pstl_guidance_step; */
@@ -260,8 +262,10 @@ size_t pstl_train_work_floats(const pstl_cfg* cfg);
  * nusc_train.py:1230-1233) come from pstl_encoder_backward / pstl_merge_backward below, which continue from what this
  * call leaves in `work`.  work: pstl_train_work_floats(cfg) floats.
  * Arithmetic: the activation-gradient products (dH2, dH1) are split-bf16 MFMA products (2^-17 per operand, fp32 range) in
- * every mode; dw2 likewise unless cfg->chain_waves is 8 or 4 (the exact-fp32 request), where it is an fp32-MFMA
- * contraction; dw1, dw3 and the bias gradients are always fp32.  Against the reference's autograd: rtol 5e-3 (tested). */
+ * every mode; the weight gradients dw1[:, 224:], dw2, dw3 likewise (each layer's two contractions share one pass over the
+ * saved activations) unless cfg->chain_waves is 8 or 4 (the exact-fp32 request) or rows_per_scene is not a multiple of 32,
+ * where they are fp32-MFMA contractions in launches of their own; dw1[:, :224] and the bias gradients are always fp32.
+ * Against the reference's autograd: rtol 5e-3 (tested).  pstl_encoder_backward needs PSTL_FLAG_KEEP_DH1 in cfg->flags. */
 int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float* w2, const float* w3, const float* feature,
                          const float* stlp, const float* hl, const float* init_controls,
                          const float* pooled /* (bs,3,n_shards,40) from the forward call; null with PSTL_FLAG_NO_MERGE */,

@@ -783,6 +783,353 @@ int dgrad(long N, const float* G, int ldg, int kvalid, const float* W, unsigned*
   return dgrad<NKB>(N, G, ldg, kvalid, W, kHid, kHid, wpack, H, out, kHid, partial, colsum, st);
 }
 
+// ---- RefineNet's backward, one pass per layer (round 4): every saved activation is read ONCE ---------------------------
+// Until round 3 each layer ran an activation-gradient launch (k_dgrad) AND a weight-gradient launch (k_wgrad*), each
+// streaming the same (N,256) activations from HBM: h2 and h1 were read twice, dH2 written once and read twice, dH1 written and
+// read twice (per-scene sums, dW1) -- 2.4 GB of the backward's ~5 GB at 786 432 rows.  Both contractions of a layer need the
+// same rows at the same time, so they share one pass:
+//   k_bwd_l2:  dH2 = (dO W3) * [h2 > 0]  +  db2 partials  +  dW3 = dO^T h2            (h2 read once: its mask quads ARE the operand)
+//   k_bwd_l1:  dH1 = (dH2 W2) * [h1 > 0] +  db1 partials  +  per-scene sums S  +  dW1[:, 224:] = dH1^T x47
+//              (dH1 never leaves the chip unless the encoders' backward follows: PSTL_FLAG_KEEP_DH1)
+// dW2 = dH2^T h1 stays a launch of its own (k_wgrad_bf): its 256 x 256 accumulators (128 registers per lane) do not fit beside
+// the register-stationary W2^T (128) of the activation gradient.
+// Scheme: k_dgrad's (transposed weights register-stationary as split-bf16 A operands, 16-row gradient tiles staged through
+// LDS as B operands, mask + column sums in the epilogue) on 32-row chunks = two tiles = ONE k-block of the weight-gradient
+// MFMAs, whose contraction index is the row.  A lane of the epilogue holds four consecutive features of one row; it writes
+// them (k_bwd_l2: the h2 quad it just used as mask) as bfloat16 hi / lo pieces into the operand layout of k_wgrad_bf
+// ([16-column tile][row / 8][column % 16][row % 8]) -- and the tiles a wave writes are exactly the tiles its own weight-
+// gradient MFMAs read (wave w owns features [32 w, 32 w + 32) in both roles), so that hand-over needs no barrier.  The small
+// second operand (dO^T: 48 x 32, x47: 32 x 48) is staged by all threads from the contiguous chunk.  Arithmetic: split-bf16
+// products (2^-17 per operand, fp32 range and accumulation) for both contractions; cfg->chain_waves 8 / 4 (exact request)
+// keeps the unfused launches with the fp32-MFMA weight gradients.  Deterministic: slabs and column-sum partials per
+// workgroup, added in a fixed order.
+constexpr int kFcRows = 32;
+__device__ __forceinline__ int wg_off(int col16, int row32) { return ((row32 >> 3) * 16 + col16) * 16 + (row32 & 7) * 2; }
+__device__ __forceinline__ void put_pieces(char* tile_hi, char* tile_lo, int col16, int row32, float v) {
+  const __bf16 hi = (__bf16)v;
+  const int o = wg_off(col16, row32);
+  *reinterpret_cast<__bf16*>(tile_hi + o) = hi;
+  *reinterpret_cast<__bf16*>(tile_lo + o) = (__bf16)(v - (float)hi);
+}
+
+constexpr size_t bwd_l2_lds() { return (size_t)2 * 2 * 2 * 2 * 64 * 16 + (size_t)2 * 3 * 2 * kWbTile + (size_t)16 * 2 * kWbTile; }
+constexpr size_t bwd_l1_lds() { return (size_t)2 * 2 * 8 * 2 * 64 * 16 + (size_t)2 * 3 * 2 * kWbTile + (size_t)16 * 2 * kWbTile; }
+
+// dH2 (N,256), partial [grid][256] (column sums of dH2), slabs [grid][48][256] (dW3 partials; rows 40..47 are zero)
+__global__ __launch_bounds__(512, 1) void k_bwd_l2(long N, const float* dO, const unsigned* Wp, const float* h2, float* dH2,
+                                                   float* partial, float* slabs) {
+  constexpr int NKB = 2;
+  extern __shared__ __attribute__((aligned(16))) char flds[];
+  u32x4* pieces = reinterpret_cast<u32x4*>(flds);                       // [buf][tile][kb][hi | lo][lane]
+  char* dot = flds + (size_t)2 * 2 * NKB * 2 * 64 * 16;                 // [buf][3 column tiles of dO][hi | lo]: dO^T, A operand
+  char* ht = dot + (size_t)2 * 3 * 2 * kWbTile;                         // [16 column tiles of h2][hi | lo]: B operand, wave-private
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  for (int i = tid; i < (int)(2 * 3 * 2 * kWbTile / 16); i += 512) reinterpret_cast<u32x4*>(dot)[i] = u32x4{0u, 0u, 0u, 0u};   // columns 40..47
+  bf16x8 wh[2][NKB], wl[2][NKB];
+  {
+    const u32x4* q4 = reinterpret_cast<const u32x4*>(Wp);
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const long blk = (long)(2 * w + ot) * NKB + kb;
+        wh[ot][kb] = __builtin_bit_cast(bf16x8, q4[(blk * 2 + 0) * 64 + lane]);
+        wl[ot][kb] = __builtin_bit_cast(bf16x8, q4[(blk * 2 + 1) * 64 + lane]);
+      }
+  }
+  const long n_chunks = (N + kFcRows - 1) / kFcRows;
+  const long per = (n_chunks + gridDim.x - 1) / gridDim.x;
+  const long c0 = blockIdx.x * per, c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
+  f32x4 rq[2];
+  float rd[3];
+  f32x4 hn[2][2];   // the chunk's h2 quads of this lane (mask and dW3 operand), fetched one chunk ahead like everything else
+  auto load_chunk = [&](long ch) {
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+      const long row = ch * kFcRows + tile * 16 + c;
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+        hn[tile][ot] = row < N ? *reinterpret_cast<const f32x4*>(h2 + row * kHid + 16 * (2 * w + ot) + 4 * g) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    rq[0] = rq[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (w < 2 * NKB) {   // waves 0..3: tile w >> 1, k-block w & 1 of the dO tile (the activation gradient's B operand)
+      const long row = ch * kFcRows + (w >> 1) * 16 + c;
+      if (row < N) {
+        const int k0 = 32 * (w & 1) + 4 * g;
+        if (k0 < kCtrl) rq[0] = *reinterpret_cast<const f32x4*>(dO + row * kCtrl + k0);
+        if (k0 + 16 < kCtrl) rq[1] = *reinterpret_cast<const f32x4*>(dO + row * kCtrl + k0 + 16);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {   // the chunk of dO once more, element-wise (contiguous: 1 280 floats), for dO^T
+      const int e = tid + 512 * u;
+      const long row = ch * kFcRows + e / kCtrl;
+      rd[u] = (e < kFcRows * kCtrl && row < N) ? dO[ch * kFcRows * kCtrl + e] : 0.0f;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    if (w < 2 * NKB) {
+      float hi[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hi[q] = (float)(__bf16)rq[0][q], hi[4 + q] = (float)(__bf16)rq[1][q];
+      u32x4* pb = pieces + ((size_t)(buf * 2 + (w >> 1)) * NKB + (w & 1)) * 2 * 64;
+      pb[lane] = u32x4{bf16_pair(hi[0], hi[1]), bf16_pair(hi[2], hi[3]), bf16_pair(hi[4], hi[5]), bf16_pair(hi[6], hi[7])};
+      pb[64 + lane] = u32x4{bf16_pair(rq[0][0] - hi[0], rq[0][1] - hi[1]), bf16_pair(rq[0][2] - hi[2], rq[0][3] - hi[3]),
+                            bf16_pair(rq[1][0] - hi[4], rq[1][1] - hi[5]), bf16_pair(rq[1][2] - hi[6], rq[1][3] - hi[7])};
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int e = tid + 512 * u;
+      if (e < kFcRows * kCtrl) {
+        const int row = e / kCtrl, col = e % kCtrl;
+        char* t = dot + (size_t)(buf * 3 + (col >> 4)) * 2 * kWbTile;
+        put_pieces(t, t + kWbTile, col & 15, row, rd[u]);
+      }
+    }
+  };
+  f32x4 wacc[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) wacc[a][0] = wacc[a][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 cs[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+  if (c0 < c1) {
+    load_chunk(c0);
+    __syncthreads();   // (the zero fill of dot)
+    store_chunk(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (long ch = c0; ch < c1; ++ch) {
+    f32x4 hc[2][2];
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) hc[tile][0] = hn[tile][0], hc[tile][1] = hn[tile][1];
+    if (ch + 1 < c1) load_chunk(ch + 1);          // in flight during the MFMAs below
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+      const long row = ch * kFcRows + tile * 16 + c;
+      const f32x4 hm[2] = {hc[tile][0], hc[tile][1]};
+      f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+      const u32x4* pb = pieces + (size_t)(buf * 2 + tile) * NKB * 2 * 64 + lane;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, pb[(2 * kb) * 64]), bl = __builtin_bit_cast(bf16x8, pb[(2 * kb + 1) * 64]);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ot][kb], bh, acc[ot], 0, 0, 0);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ot][kb], bh, acc[ot], 0, 0, 0);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ot][kb], bl, acc[ot], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = hm[ot][r] > 0.0f ? acc[ot][r] : 0.0f;
+        if (row < N) {
+          *reinterpret_cast<f32x4*>(dH2 + row * kHid + 16 * (2 * w + ot) + 4 * g) = o;
+          cs[ot] += o;
+        }
+        char* t = ht + (size_t)(2 * w + ot) * 2 * kWbTile;      // this wave's own operand tiles (rows past N: zeros)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) put_pieces(t, t + kWbTile, 4 * g + r, tile * 16 + c, hm[ot][r]);
+      }
+    }
+    // dW3 partials: (dO^T: 3 tiles of 16 columns) x (this wave's two 16-column tiles of h2), contraction over the 32 rows
+    wg_bf8 bh[2], bl[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      bh[b] = *reinterpret_cast<const wg_bf8*>(ht + (size_t)((2 * w + b) * 2 + 0) * kWbTile + lane * 16);
+      bl[b] = *reinterpret_cast<const wg_bf8*>(ht + (size_t)((2 * w + b) * 2 + 1) * kWbTile + lane * 16);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const wg_bf8 ah = *reinterpret_cast<const wg_bf8*>(dot + (size_t)((buf * 3 + a) * 2 + 0) * kWbTile + lane * 16);
+      const wg_bf8 al = *reinterpret_cast<const wg_bf8*>(dot + (size_t)((buf * 3 + a) * 2 + 1) * kWbTile + lane * 16);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[b], wacc[a][b], 0, 0, 0);
+        wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[b], wacc[a][b], 0, 0, 0);
+        wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[b], wacc[a][b], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < c1) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = cs[ot][r];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+      cs[ot][r] = v;
+    }
+    if (c == 0) *reinterpret_cast<f32x4*>(partial + (long)blockIdx.x * kHid + 16 * (2 * w + ot) + 4 * g) = cs[ot];
+  }
+  float* out = slabs + (long)blockIdx.x * 48 * kHid;      // accumulator tile: row f = 16 a + 4 (lane >> 4) + r, column 16 (2w + b) + (lane & 15)
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(16 * a + 4 * g + r) * kHid + 16 * (2 * w + b) + c] = wacc[a][b][r];
+}
+
+// Workgroup b owns the scenes [b * spw, (b + 1) * spw): rows_per_scene is a multiple of 32, so chunks never straddle a scene and
+// N = bs * rows_per_scene has no tail.  S (bs,256) per-scene sums of dH1, partial [grid][256] its column sums per workgroup,
+// slabs [grid][256][48] the partials of dH1^T x47 (column 47 is zero), dH1 (N,256) only with WRITE.
+template <bool WRITE>
+__global__ __launch_bounds__(512, 1) void k_bwd_l1(int bs, int rows_per_scene, int spw, const float* dH2, const unsigned* Wp,
+                                                   const float* h1, const float* x47, float* dH1, float* S, float* slabs) {
+  constexpr int NKB = 8;
+  extern __shared__ __attribute__((aligned(16))) char flds[];
+  u32x4* pieces = reinterpret_cast<u32x4*>(flds);                       // [buf][tile][kb][hi | lo][lane]
+  char* xt = flds + (size_t)2 * 2 * NKB * 2 * 64 * 16;                  // [buf][3 column tiles of x47][hi | lo]: B operand
+  char* at = xt + (size_t)2 * 3 * 2 * kWbTile;                          // [16 feature tiles of dH1][hi | lo]: dH1^T, wave-private
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  for (int i = tid; i < (int)(2 * 3 * 2 * kWbTile / 16); i += 512) reinterpret_cast<u32x4*>(xt)[i] = u32x4{0u, 0u, 0u, 0u};   // column 47
+  bf16x8 wh[2][NKB], wl[2][NKB];
+  {
+    const u32x4* q4 = reinterpret_cast<const u32x4*>(Wp);
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const long blk = (long)(2 * w + ot) * NKB + kb;
+        wh[ot][kb] = __builtin_bit_cast(bf16x8, q4[(blk * 2 + 0) * 64 + lane]);
+        wl[ot][kb] = __builtin_bit_cast(bf16x8, q4[(blk * 2 + 1) * 64 + lane]);
+      }
+  }
+  const int cps = rows_per_scene / kFcRows;          // chunks per scene
+  const long s0 = (long)blockIdx.x * spw, s1 = (s0 + spw < bs) ? s0 + spw : bs;
+  const long c0 = s0 * cps, c1 = s1 * cps;
+  f32x4 rq[2][2];
+  float rx[3];
+  auto load_chunk = [&](long ch) {   // wave w makes k-block w of both tiles (k_dgrad's staging)
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+      const long row = ch * kFcRows + tile * 16 + c;
+      const int k0 = 32 * w + 4 * g;
+      rq[tile][0] = *reinterpret_cast<const f32x4*>(dH2 + row * kHid + k0);
+      rq[tile][1] = *reinterpret_cast<const f32x4*>(dH2 + row * kHid + k0 + 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {   // the chunk of x47 (contiguous: 32 x 47 floats)
+      const int e = tid + 512 * u;
+      rx[u] = e < kFcRows * kX47 ? x47[ch * kFcRows * kX47 + e] : 0.0f;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+      float hi[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hi[q] = (float)(__bf16)rq[tile][0][q], hi[4 + q] = (float)(__bf16)rq[tile][1][q];
+      u32x4* pb = pieces + ((size_t)(buf * 2 + tile) * NKB + w) * 2 * 64;
+      pb[lane] = u32x4{bf16_pair(hi[0], hi[1]), bf16_pair(hi[2], hi[3]), bf16_pair(hi[4], hi[5]), bf16_pair(hi[6], hi[7])};
+      pb[64 + lane] = u32x4{bf16_pair(rq[tile][0][0] - hi[0], rq[tile][0][1] - hi[1]), bf16_pair(rq[tile][0][2] - hi[2], rq[tile][0][3] - hi[3]),
+                            bf16_pair(rq[tile][1][0] - hi[4], rq[tile][1][1] - hi[5]), bf16_pair(rq[tile][1][2] - hi[6], rq[tile][1][3] - hi[7])};
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int e = tid + 512 * u;
+      if (e < kFcRows * kX47) {
+        const int row = e / kX47, col = e % kX47;
+        char* t = xt + (size_t)(buf * 3 + (col >> 4)) * 2 * kWbTile;
+        put_pieces(t, t + kWbTile, col & 15, row, rx[u]);
+      }
+    }
+  };
+  f32x4 wacc[2][3];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) wacc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 css[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+  if (c0 < c1) {
+    load_chunk(c0);
+    __syncthreads();   // (the zero fill of xt)
+    store_chunk(0);
+  }
+  __syncthreads();
+  int buf = 0, in_scene = 0;
+  long scene = s0;
+  for (long ch = c0; ch < c1; ++ch) {
+    if (ch + 1 < c1) load_chunk(ch + 1);          // in flight during the MFMAs below
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+      const long row = ch * kFcRows + tile * 16 + c;
+      f32x4 hm[2];
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) hm[ot] = *reinterpret_cast<const f32x4*>(h1 + row * kHid + 16 * (2 * w + ot) + 4 * g);
+      f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+      const u32x4* pb = pieces + (size_t)(buf * 2 + tile) * NKB * 2 * 64 + lane;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, pb[(2 * kb) * 64]), bl = __builtin_bit_cast(bf16x8, pb[(2 * kb + 1) * 64]);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ot][kb], bh, acc[ot], 0, 0, 0);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ot][kb], bh, acc[ot], 0, 0, 0);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ot][kb], bl, acc[ot], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = hm[ot][r] > 0.0f ? acc[ot][r] : 0.0f;
+        if (WRITE) *reinterpret_cast<f32x4*>(dH1 + row * kHid + 16 * (2 * w + ot) + 4 * g) = o;
+        css[ot] += o;
+        char* t = at + (size_t)(2 * w + ot) * 2 * kWbTile;      // this wave's own operand tiles
+#pragma unroll
+        for (int r = 0; r < 4; ++r) put_pieces(t, t + kWbTile, 4 * g + r, tile * 16 + c, o[r]);
+      }
+    }
+    // dW1[:, 224:271] partials: (this wave's two 16-feature tiles of dH1^T) x (3 tiles of 16 columns of x47), over the 32 rows
+    // (operands fetched pair by pair: the register file is full of W2^T)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const wg_bf8 ah = *reinterpret_cast<const wg_bf8*>(at + (size_t)((2 * w + a) * 2 + 0) * kWbTile + lane * 16);
+      const wg_bf8 al = *reinterpret_cast<const wg_bf8*>(at + (size_t)((2 * w + a) * 2 + 1) * kWbTile + lane * 16);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const wg_bf8 bh = *reinterpret_cast<const wg_bf8*>(xt + (size_t)((buf * 3 + b) * 2 + 0) * kWbTile + lane * 16);
+        const wg_bf8 bl = *reinterpret_cast<const wg_bf8*>(xt + (size_t)((buf * 3 + b) * 2 + 1) * kWbTile + lane * 16);
+        wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, wacc[a][b], 0, 0, 0);
+        wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, wacc[a][b], 0, 0, 0);
+        wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, wacc[a][b], 0, 0, 0);
+      }
+    }
+    if (++in_scene == cps) {   // the scene is complete: its sums (16 row-lanes added in a fixed butterfly order)
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        f32x4 v = css[ot];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int m = 1; m < 16; m <<= 1) v[r] += __shfl_xor(v[r], m, 64);
+        if (c == 0) *reinterpret_cast<f32x4*>(S + scene * kHid + 16 * (2 * w + ot) + 4 * g) = v;
+        css[ot] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      in_scene = 0;
+      ++scene;
+    }
+    if (ch + 1 < c1) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* out = slabs + (long)blockIdx.x * kHid * 48;      // accumulator tile: row f = 16 (2w + a) + 4 (lane >> 4) + r, column 16 b + (lane & 15)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(16 * (2 * w + a) + 4 * g + r) * 48 + 16 * b + c] = wacc[a][b][r];
+}
+
 // ---- scene-encoder backward (training with --joint) -----------------------------------------------------------------
 // feature (bs,224) = [ego 32 | neighbour min 32 | mean 32 | max 32 | 3 lanes x 32] (nusc_model.py:82-93): route d feature
 // to the encoder outputs, tokens ordered [bs ego | bs*K neighbours | 3*bs lanes].  min / max send their gradient to the
@@ -900,12 +1247,53 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
   // layer 3
   hipLaunchKernelGGL(k_colsum40, dim3(nb), dim3(256), 0, st, N, dO, part);
   hipLaunchKernelGGL(k_colsum_final, dim3(kCtrl), dim3(64), 0, st, nb, kCtrl, part, db3);
+  const bool exact = cfg->chain_waves == 8 || cfg->chain_waves == 4;
+  if (!exact && cfg->rows_per_scene % kFcRows == 0) {
+    // one pass per layer (k_bwd_l2 / k_bwd_l1 above): each saved activation is read once
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      hipDeviceProp_t pr;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+                ? pr.multiProcessorCount : 256;
+      if (cus > kRedBlocks) cus = kRedBlocks;
+    }
+    const long n_chunks = (N + kFcRows - 1) / kFcRows;
+    const int nb2 = (int)(n_chunks < cus ? n_chunks : cus);
+    static bool lds_ok = false;
+    if (!lds_ok) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_l2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_l2_lds()) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_l1<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_l1_lds()) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_l1<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_l1_lds()) != hipSuccess)
+        return PSTL_ERR_LAUNCH;
+      lds_ok = true;
+    }
+    // layer 2 and dW3:  dH2 = (dO W3) * [h2 > 0], db2, dW3 = dO^T h2
+    hipLaunchKernelGGL(k_pack_wt_bf, dim3(16 * 2 * 2), dim3(256), 0, st, w3, kHid, kCtrl, kHid, 2, wpack);
+    hipLaunchKernelGGL(k_bwd_l2, dim3(nb2), dim3(512), bwd_l2_lds(), st, N, (const float*)dO, (const unsigned*)wpack, h2, dH2, part, slabs);
+    hipLaunchKernelGGL(k_colsum_final, dim3(kHid), dim3(64), 0, st, nb2, kHid, part, db2);
+    hipLaunchKernelGGL(k_slab_reduce, dim3((48 * kHid + 255) / 256), dim3(256), 0, st, nb2, 48, kHid, kCtrl, kHid, slabs, dw3, kHid);
+    if (int e = wgrad_bf<16, 16, 2, 4>(N, dH2, kHid, kHid, h1, kHid, kHid, slabs, dw2, kHid, st)) return e;  // dW2 = dH2^T h1
+    // layer 1:  dH1 = (dH2 W2) * [h1 > 0], db1, per-scene sums S, dW1[:, 224:] = dH1^T x47
+    const int spw = (cfg->bs + cus - 1) / cus;
+    const int nb1 = (cfg->bs + spw - 1) / spw;
+    hipLaunchKernelGGL(k_pack_wt_bf, dim3(16 * 8 * 2), dim3(256), 0, st, w2, kHid, kHid, kHid, 8, wpack);
+    if (cfg->flags & PSTL_FLAG_KEEP_DH1)
+      hipLaunchKernelGGL(k_bwd_l1<true>, dim3(nb1), dim3(512), bwd_l1_lds(), st, cfg->bs, cfg->rows_per_scene, spw, (const float*)dH2,
+                         (const unsigned*)wpack, h1, (const float*)x47, dH1, S, slabs);
+    else
+      hipLaunchKernelGGL(k_bwd_l1<false>, dim3(nb1), dim3(512), bwd_l1_lds(), st, cfg->bs, cfg->rows_per_scene, spw, (const float*)dH2,
+                         (const unsigned*)wpack, h1, (const float*)x47, dH1, S, slabs);
+    hipLaunchKernelGGL(k_colsum_final, dim3(kHid), dim3(64), 0, st, cfg->bs, kHid, (const float*)S, db1);   // db1 = the sum of the scenes' sums
+    hipLaunchKernelGGL(k_slab_reduce, dim3((kHid * 48 + 255) / 256), dim3(256), 0, st, nb1, kHid, 48, kHid, kX47, slabs, dw1 + kFeat, kIn);
+    if (int e = launch_status()) return e;
+  } else {
   if (int e = wgrad<3, 16, 1, 8>(N, dO, kCtrl, kCtrl, h2, kHid, kHid, slabs, dw3, kHid, st)) return e;  // dW3 = dO^T h2
   // layer 2: dH2 = (dO W3) * [h2 > 0], db2 = column sums of dH2
   if (int e = dgrad<2>(N, dO, kCtrl, kCtrl, w3, wpack, h2, dH2, part, db2, st)) return e;
-  // dW2 = dH2^T h1: split-bf16 products (2^-17 per operand, HBM-bound) unless the caller asked for the exact-fp32 kernels
-  // (cfg->chain_waves 8 / 4, also what the host falls back to after a split-f16 domain overflow): then the fp32 MFMA form
-  if (cfg->chain_waves == 8 || cfg->chain_waves == 4) {
+  // dW2 = dH2^T h1: the exact-fp32 request (cfg->chain_waves 8 / 4, also what the host falls back to after a split-f16 domain
+  // overflow) keeps every weight gradient on the fp32 MFMA form
+  if (exact) {
     if (int e = wgrad<16, 16, 4, 2>(N, dH2, kHid, kHid, h1, kHid, kHid, slabs, dw2, kHid, st)) return e;
   } else {
     if (int e = wgrad_bf<16, 16, 2, 4>(N, dH2, kHid, kHid, h1, kHid, kHid, slabs, dw2, kHid, st)) return e;
@@ -913,9 +1301,10 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
   // layer 1: dH1 = (dH2 W2) * [h1 > 0], db1 = column sums of dH1
   if (int e = dgrad<8>(N, dH2, kHid, kHid, w2, wpack, h1, dH1, part, db1, st)) return e;
   hipLaunchKernelGGL(k_scene_sum, dim3(cfg->bs), dim3(256), 0, st, cfg->rows_per_scene, dH1, S);
+  if (int e = wgrad<16, 3, 8, 1>(N, dH1, kHid, kHid, x47, kX47, kX47, slabs, dw1 + kFeat, kIn, st)) return e;
+  }
   // the 224 scene-constant input columns: dW1[:, :224] = S^T feature (contraction over the scenes)
   if (int e = wgrad<16, 14, 4, 2>(cfg->bs, S, kHid, kHid, feature, kFeat, kFeat, slabs, dw1, kIn, st)) return e;
-  if (int e = wgrad<16, 3, 8, 1>(N, dH1, kHid, kHid, x47, kX47, kX47, slabs, dw1 + kFeat, kIn, st)) return e;
   return launch_status();
 }
 

@@ -641,7 +641,9 @@ class RectTrainer:
         N = sb.N
         objective_e7 = e7 is not None
         merge = objective_e7 if merge is None else bool(merge)
-        cfg = sb.cfg(2, 0 if merge else ffi.PSTL_FLAG_NO_MERGE, self.sm.chain_waves)
+        # (KEEP_DH1: the encoders' backward continues from dH1 in pstl_refine_backward's work buffer; otherwise it is never written)
+        cfg = sb.cfg(2, (0 if merge else ffi.PSTL_FLAG_NO_MERGE) | (ffi.PSTL_FLAG_KEEP_DH1 if joint is not None else 0),
+                     self.sm.chain_waves)
         cfg_fwd = sb.cfg(2, (0 if merge else ffi.PSTL_FLAG_NO_MERGE) | (ffi.PSTL_FLAG_CLIP_RECT if clip_rect else 0),
                          self.sm.chain_waves)
         h1 = torch.empty(N, ffi.HID, dtype=torch.float32, device=dev)

@@ -17,6 +17,7 @@ PSTL_FLAG_CLIP_RECT = 4
 PSTL_FLAG_NO_MERGE = 8
 PSTL_FLAG_RNG = 16
 PSTL_FLAG_NORM_STL = 32
+PSTL_FLAG_KEEP_DH1 = 64
 
 T = 20
 NSEG = 15

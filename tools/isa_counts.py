@@ -31,17 +31,15 @@ def main():
         c = collections.Counter(ins)
         valu = sum(v for k, v in c.items() if k.startswith("v_"))
         trans = sum(v for k, v in c.items() if re.match(r"v_(exp|log|rcp|rsq|sqrt|sin|cos)_", k))
-        meta = {}
-        for l in lines[j:j + 400]:
-            mm = re.match(r"\s*\.(vgpr_count|sgpr_count|private_segment_fixed_size|agpr_count):\s*(\d+)", l)
-            if mm:
-                meta[mm.group(1)] = int(mm.group(2))
-        # the kernel descriptor's directives live in the .amdhsa_kernel block after the code
-        txt = "\n".join(lines[j:j + 200])
-        vg = re.search(r"\.amdhsa_next_free_vgpr (\d+)", txt)
-        sc = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", txt)
-        print("%6d valu %6d trans %4d nop %4d vgpr %4s scratch %4s  %s" % (
-            len(ins), valu, trans, c.get("s_nop", 0), vg.group(1) if vg else "?", sc.group(1) if sc else "?", dn[:100]))
+        # the compiler's resource summary follows the kernel descriptor ("; NumVgprs: 21" ...)
+        txt = "\n".join(body)
+        vg = re.search(r"; NumVgprs: (\d+)", txt)
+        ag = re.search(r"; NumAgprs: (\d+)", txt)
+        sc = re.search(r"; ScratchSize: (\d+)", txt)
+        oc = re.search(r"; Occupancy: (\d+)", txt)
+        print("%6d valu %6d trans %4d nop %4d vgpr %4s agpr %3s scratch %4s occ %s  %s" % (
+            len(ins), valu, trans, c.get("s_nop", 0), vg.group(1) if vg else "?", ag.group(1) if ag else "?",
+            sc.group(1) if sc else "?", oc.group(1) if oc else "?", dn[:100]))
 
 
 if __name__ == "__main__":
