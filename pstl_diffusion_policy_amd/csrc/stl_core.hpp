@@ -38,14 +38,13 @@
 // computed with exact arithmetic afterwards); a different winner needs two pair sums within 1 ulp of each other
 #define PSTL_SQRT_RANK(x) __builtin_amdgcn_sqrtf(x)
 #define PSTL_SINCOS(x, s, c) sincosf((x), (s), (c))
-// Hardware forms (v_rcp_f32, v_sqrt_f32: 1 ulp; v_sin_f32 / v_cos_f32: ~1e-6 absolute) for quantities that only ever reach
-// a GRADIENT or an optimiser step -- the adjoint's partial derivatives and exponential weights, Adam's m / (sqrt(v) + eps) --
-// never a score, a satisfaction mask or a candidate choice: the forward sweeps do not use them.  The reference's autograd
-// gradients are matched to rtol 5e-3 (tests), these forms are good to ~1e-6; an IEEE division or square root is ~10-12
+// Hardware forms (v_rcp_f32, v_sqrt_f32: 1 ulp) for quantities that only ever SCALE a gradient or an optimiser step -- the
+// adjoint's partial derivatives, Adam's m / (sqrt(v) + eps) -- never a score, a satisfaction mask, a candidate choice or the
+// argument of a soft-min exponential (those are multiplied by tau = 100: see the note at kGeoSlots): the forward sweeps do not
+// use them.  The reference's autograd gradients are matched to rtol 5e-3 (tests); an IEEE division or square root is ~10-12
 // instructions here, the hardware form one (quarter rate).
 #define PSTL_RCP_ADJ(x) __builtin_amdgcn_rcpf(x)
 #define PSTL_SQRT_ADJ(x) __builtin_amdgcn_sqrtf(x)
-#define PSTL_SINCOS_ADJ(x, s, c) (*(s) = __sinf(x), *(c) = __cosf(x))
 #else
 #define PSTL_EXP(x) expf(x)
 #define PSTL_LOG(x) logf(x)
@@ -53,7 +52,6 @@
 #define PSTL_SINCOS(x, s, c) (*(s) = sinf(x), *(c) = cosf(x))
 #define PSTL_RCP_ADJ(x) (1.0f / (x))
 #define PSTL_SQRT_ADJ(x) sqrtf(x)
-#define PSTL_SINCOS_ADJ(x, s, c) (*(s) = sinf(x), *(c) = cosf(x))
 #endif
 
 namespace pstl {
@@ -265,13 +263,24 @@ PSTL_HD void lane_eval(const f4* lane, float px, float py, float pth, LaneHit& h
     h.d = l2;
   }
   const float du = p2.z - pth;
-  float sdu = 0.0f, cdu;
+  float sdu = 0.0f, cdu = 1.0f;
   if (GRAD) {
-    PSTL_SINCOS_ADJ(du, &sdu, &cdu);   // (the adjoint's own evaluation of the heading term: it weights a gradient only)
+    // The adjoint's own evaluation of the heading term.  It feeds a soft-min exponent (tau (thmax - h.th) / thmax), so it has to
+    // be good to ~1e-7 -- the hardware v_cos_f32 is not -- but not bit-equal to the forward sweep's cosf: for the heading errors
+    // that occur (|du| <= pi/4) the Taylor polynomials of 1 - cos and sin, truncated below 3e-8, in ~15 instructions instead
+    // of sincosf's ~45; beyond that the library call.
+    if (fabsf(du) <= 0.78f) {
+      const float x2 = du * du;
+      h.th = x2 * (0.5f - x2 * (0x1.555556p-5f - x2 * (0x1.6c16c2p-10f - x2 * 0x1.a01a02p-16f)));
+      sdu = du * (1.0f - x2 * (0x1.555556p-3f - x2 * (0x1.111112p-7f - x2 * 0x1.a01a02p-13f)));
+    } else {
+      PSTL_SINCOS(du, &sdu, &cdu);
+      h.th = 1.0f - cdu;
+    }
   } else {
     cdu = cosf(du);
+    h.th = 1.0f - cdu;
   }
-  h.th = 1.0f - cdu;
   if (GRAD) {
     if (normal) {
       const float r = PSTL_RCP_ADJ(cbl);
@@ -604,9 +613,17 @@ PSTL_HD float conj6(const float* v, int n, float tau) {  // softmin over n <= 6 
 // the 20 time steps; the sweeps themselves then only read): per time step the clearance, the lane distance and
 // heading term, and the winners' record (lane segment | clearance winner << 8, carried as a bit pattern).
 //   slots 0-3  (forward sweep): clearance, lane distance, heading term 1 - cos, winners (segment | clearance winner << 8)
-//   slots 4-13 (adjoint): the clearance's partials (x, y, heading), the heading term as the adjoint's own evaluation yields
-//                         it and the lane distance's partials (x, y) and the heading term's, then v, cos, sin of the state
-constexpr int kGeoSlots = 14;
+//   slots 4-15 (adjoint): the clearance's partials (x, y, heading), the heading term as the adjoint's own evaluation yields
+//                         it and the lane distance's partials (x, y) and the heading term's, then v, cos, sin of the ADJOINT's
+//                         state, and the clearance and lane distance as the adjoint's own evaluation yields them
+// The adjoint's state is the forward sweep's, bit for bit: stl_eval_grad re-derives the states of a 4-step block from the
+// block's checkpoint with the forward sweep's own operations, the exact sincosf included.  (Round 4 tried the hardware
+// v_sin_f32 / v_cos_f32 there -- the adjoint only reaches a gradient -- and the reference's autograd gradients were missed:
+// a position that is 1e-5 m off moves a soft-min exponent by tau * 1e-5 = 1e-3, i.e. the per-step weights by 0.1 % against
+// normalisers the forward sweep computed at the exact states; test_stl_backward_matches_reference_autograd[stl_mixed] failed
+// its 5e-3.  The divisions, square roots and the heading term's sin / cos of the adjoint are another matter: they scale a
+// partial derivative, not an exponent.)
+constexpr int kGeoSlots = 16;
 struct GeoPre {
   const float* p;   // element (t, c) of this lane at p[(kGeoSlots t + c) * stride]
   int stride;
@@ -634,6 +651,7 @@ PSTL_HD void stl_geometry(const StlEnv& env, const f4* sel_lane, const float* ne
   for (int t = 0; t < t1; ++t) {
     float x, y, th, v, c, s;
     src.get(t, x, y, th, v, c, s);
+    const float ca = c, sa = s, xt = x, yt = y;   // (the adjoint's state IS the forward sweep's: see the note at kGeoSlots)
     if (t < t0) continue;
     float* o = out + (kGeoSlots * t) * stride;
     ClearHit ch;
@@ -646,10 +664,10 @@ PSTL_HD void stl_geometry(const StlEnv& env, const f4* sel_lane, const float* ne
     if (!ADJ) continue;
     o[3 * stride] = geo_float((unsigned)h.jb | (ch.win << 8));
     ClearHit cg;
-    if (use_rec) clearance_from_winner(env, nei, t, x, y, c, s, ch.win, cg);
-    else clearance_eval<true>(env, nei, K, t, x, y, c, s, cg);
+    if (use_rec) clearance_from_winner(env, nei, t, xt, yt, ca, sa, ch.win, cg);
+    else clearance_eval<true>(env, nei, K, t, xt, yt, ca, sa, cg);
     LaneHit hg;
-    lane_eval<true>(sel_lane, x, y, th, hg, use_rec ? h.jb : -1);
+    lane_eval<true>(sel_lane, xt, yt, th, hg, use_rec ? h.jb : -1);
     o[4 * stride] = cg.d_dx;
     o[5 * stride] = cg.d_dy;
     o[6 * stride] = cg.d_dth;
@@ -658,8 +676,10 @@ PSTL_HD void stl_geometry(const StlEnv& env, const f4* sel_lane, const float* ne
     o[9 * stride] = hg.dd_dy;
     o[10 * stride] = hg.dth_dth;
     o[11 * stride] = v;
-    o[12 * stride] = c;
-    o[13 * stride] = s;
+    o[12 * stride] = ca;
+    o[13 * stride] = sa;
+    o[14 * stride] = cg.dn;
+    o[15 * stride] = hg.d;
   }
 }
 
@@ -893,7 +913,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
       PSTL_UNROLL
       for (int i = 0; i < kCkStride; ++i) {
         float c, s;
-        PSTL_SINCOS(th, &s, &c);
+        PSTL_SINCOS(th, &s, &c);   // (exact: see the note at kGeoSlots)
         bx[i] = x, by[i] = y, bth[i] = th, bv[i] = v, bc[i] = c, bs[i] = s;
         if (i + 1 < kCkStride) {
           float wr, ar;
@@ -926,8 +946,8 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     gv = o_v1 * PSTL_EXP(-over<NORM>(v - r.vmin, r.vf) * tau - Lv1) - o_v2 * PSTL_EXP(-over<NORM>(-v + r.vmax, r.vf) * tau - Lv2);
     if (NORM) gv = gv / r.vf;
     ClearHit ch;
-    if (PRE) {   // (the clearance itself: the winner's operations repeated on the same operands give the forward sweep's value)
-      ch.dn = pre.at(t, 0), ch.d_dx = pre.at(t, 4), ch.d_dy = pre.at(t, 5), ch.d_dth = pre.at(t, 6);
+    if (PRE) {
+      ch.dn = pre.at(t, 14), ch.d_dx = pre.at(t, 4), ch.d_dy = pre.at(t, 5), ch.d_dth = pre.at(t, 6);
     } else if (use_rec) {
       clearance_from_winner(env, nei, t, x, y, c, s, rec_win(rec, t), ch);
     } else {
@@ -940,7 +960,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     gth = gs * ch.d_dth;
     LaneHit h;
     if (PRE) {
-      h.d = pre.at(t, 1), h.th = pre.at(t, 7), h.dd_dx = pre.at(t, 8), h.dd_dy = pre.at(t, 9), h.dth_dth = pre.at(t, 10);
+      h.d = pre.at(t, 15), h.th = pre.at(t, 7), h.dd_dx = pre.at(t, 8), h.dd_dy = pre.at(t, 9), h.dth_dth = pre.at(t, 10);
     } else {
       lane_eval<true>(lane, x, y, th, h, use_rec ? (int)rec_seg(rec, t) : -1);
     }
