@@ -119,11 +119,17 @@ def test_bench_starts_its_own_ranks():
     assert one.returncode == 0, one.stderr[-2000:]
     l1 = json.loads(one.stdout.strip().splitlines()[-1])
     assert l1["n_gpus"] == 1
+    # the single-GPU line carries the driver-observed extras: the exact-fp32 leg, configs 2 / 3 / 5 and the batch-size sweep
+    assert l1["roofline"]["fp32_exact"]["chain_waves"] == 8 and 0.0 < l1["roofline"]["whole_step_frac"] < 1.0
+    assert sorted(l1["also"]) == ["e5", "e7", "e8_train"]
+    assert all(v["ms_per_step"] > 0 and 0.0 < v["roofline"]["frac"] < 1.0 for v in l1["also"].values())
+    assert l1["also"]["e8_train"]["backward"]["achieved_GBps"] > 0
+    assert [s["rows"] for s in l1["sweep"]] == [192, 3072, 48 * 192] and all(s["value"] > 0 for s in l1["sweep"])
     ndev = torch.cuda.device_count()
     two = _bench(["--gpus", "2"] + small, None if ndev >= 2 else {"PSTL_BENCH_BACKEND": "gloo"})
     assert two.returncode == 0, two.stderr[-2000:]
     l2 = json.loads(two.stdout.strip().splitlines()[-1])
-    assert l2["n_gpus"] == 2 and l2["scaling"] == "weak"
+    assert l2["n_gpus"] == 2 and l2["scaling"] == "weak" and "also" not in l2 and "sweep" not in l2
     assert l2["config"]["rows_per_gpu"] == l1["config"]["rows_per_gpu"]
     assert abs(l2["stl_sat_rate"] - l1["stl_sat_rate"]) < 0.2
     if ndev < 2:
