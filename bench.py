@@ -247,6 +247,18 @@ class Job:
         # diversity totals per rank in one RCCL all-gather over xGMI (when N > 1)
         return gather_final(out["counts"], out["div_totals"])
 
+    def measure_best(self, steps, warmup, repeats):
+        """measure() `repeats` times (warm-up once); the repetition with the smallest wall time.  For the secondary blocks of
+        the line ("also", "sweep": a few short steps each), where one descheduling of this process on a shared host would
+        otherwise be a third of the measurement; the headline is never measured this way."""
+        best = None
+        for r in range(repeats):
+            m = self.measure(steps, warmup if r == 0 else 0)
+            if best is None or m["dt"] < best["dt"]:
+                best = m
+        best["timing"] = "best of %d x %d steps" % (repeats, steps)
+        return best
+
     def measure(self, steps, warmup, dist=None):
         """`warmup` untimed steps, then exactly `steps` timed ones between barrier + synchronize on both sides; MAX over ranks."""
         for _ in range(warmup):
@@ -413,8 +425,8 @@ def main():
                 continue
             jw = mk(wl, a.scenes)
             jw.scene, jw.ids_host = job.scene, job.ids_host
-            mw = jw.measure(3, 2)
-            rec = {"steps": 3, "ms_per_step": mw["ms_per_step"], "value": mw["value"], "unit": "trajectories/s",
+            mw = jw.measure_best(3, 2, 2)
+            rec = {"steps": 3, "timing": mw["timing"], "ms_per_step": mw["ms_per_step"], "value": mw["value"], "unit": "trajectories/s",
                    "stl_sat_rate": acc_from_counts(mw["counts"])[0],
                    "roofline": {"bound": "mfma", "kernel": "k_chain (%d reverse steps per launch)" % mw["kernel_steps"],
                                 "kernel_ms": mw["kernel_ms"], "achieved": mw["achieved"], "peak": peak, "unit": "TFLOP/s",
@@ -424,7 +436,7 @@ def main():
             also[wl] = rec
             del jw
             torch.cuda.empty_cache()
-    # the headline workload at other batch sizes: 3 timed steps each after 2 warm-ups
+    # the headline workload at other batch sizes: best of 3 x 3 timed steps each after 2 warm-ups
     sweep = None
     if extras and not train:
         sweep = []
@@ -432,9 +444,11 @@ def main():
             if sbs >= a.scenes:
                 continue
             js = mk(a.workload, sbs)
-            ms_ = js.measure(3, 2)
-            sweep.append({"rows": js.N, "ms_per_step": ms_["ms_per_step"], "value": ms_["value"], "layout": chain_layout(js.N)})
-        sweep.append({"rows": N, "ms_per_step": m["ms_per_step"], "value": m["value"], "layout": chain_layout(N)})
+            ms_ = js.measure_best(3, 2, 3)
+            sweep.append({"rows": js.N, "ms_per_step": ms_["ms_per_step"], "value": ms_["value"], "layout": chain_layout(js.N),
+                          "timing": ms_["timing"]})
+        sweep.append({"rows": N, "ms_per_step": m["ms_per_step"], "value": m["value"], "layout": chain_layout(N),
+                      "timing": "the headline measurement (%d steps)" % a.steps})
     # VALU-issue roofline of the one-row-per-lane STL kernels (they are instruction-issue-bound, not HBM-bound): vector
     # instructions per row-evaluation from the committed PMC pass (SQ_INSTS_VALU / rows of that launch) x the row-evaluation
     # rate measured live in this run x 4 issue cycles per wavefront instruction / (1024 SIMDs x the clock of the PMC run)
