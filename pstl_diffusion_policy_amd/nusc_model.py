@@ -87,14 +87,17 @@ class Net(nn.Module):
         # Linear layers instead of nn.Module.parameters() -- and complete: the identity of every storage (a replaced Parameter
         # or sub-module, `p.data = t`, load_state_dict(assign=True), .cuda()) and every version counter (in-place changes:
         # optimiser steps, load_state_dict's copy_) enter it.)
-        ps = list(self._iter_params())
-        key = (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
+        ps, key = self._pack_key()
         if self._packed is None or key != self._packed_key:
             if not ps[0].is_cuda:
                 raise RuntimeError("Net must be on the GPU (net.cuda()) before the HIP path can run")
             self._packed = PackedWeights({k: v for k, v in self.state_dict().items()}, ps[0].device)
             self._packed_key = key
         return self._packed
+
+    def _pack_key(self):
+        ps = list(self._iter_params())
+        return ps, (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
 
     def _iter_params(self):
         """The live Parameter objects in parameters() order, read straight from the six Sequentials' Linear layers."""

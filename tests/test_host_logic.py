@@ -163,3 +163,40 @@ def test_bench_refuses_to_measure_fewer_ranks_than_asked_for():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "launcher started 1 rank" in r.stderr
+
+
+def test_packed_weight_key_sees_every_way_a_parameter_can_change():
+    """Net.packed() must re-pack when ANY parameter changes -- in place (optimiser step, load_state_dict's copy_),
+    by `p.data = t` on a middle parameter, by replacing a Parameter or a sub-module, by load_state_dict(assign=True).  The key
+    it compares is checked here on the CPU (the packing itself needs the GPU)."""
+    import types
+
+    import torch
+    from pstl_diffusion_policy_amd.nusc_model import Net
+    args = types.SimpleNamespace(diffusion=True, hiddens=[256, 256], nt=20, n_segs=15, rect_head=True, diverse_loss=True,
+                                 no_arch=False, diverse_fuse_type="add", rect_hiddens=[256, 256], use_init_hint=False)
+    net = Net(args)
+    ps, k0 = net._pack_key()
+    assert [id(p) for p in ps] == [id(p) for p in net.parameters()]      # the direct walk IS parameters(), in order
+    assert net._pack_key()[1] == k0                                      # stable while nothing changes
+    keys = [k0]
+
+    def changed():
+        k = net._pack_key()[1]
+        assert k not in keys
+        keys.append(k)
+
+    with torch.no_grad():
+        net.policy_net[2].weight.add_(1.0)                               # in place (an optimiser step)
+    changed()
+    net.policy_net[2].bias.data = torch.zeros(256)                       # p.data = t on a middle parameter
+    changed()
+    net.merge_net[0].weight = torch.nn.Parameter(torch.zeros(32, 40))    # a replaced Parameter
+    changed()
+    net.rect_net = Net(args).rect_net                                    # a replaced sub-module
+    changed()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, assign=True)                                 # storages swapped wholesale
+    changed()
+    net.load_state_dict({k: v + 1 for k, v in sd.items()})               # the usual copy_ into the existing storages
+    changed()
