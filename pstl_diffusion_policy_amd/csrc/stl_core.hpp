@@ -613,9 +613,9 @@ PSTL_HD float conj6(const float* v, int n, float tau) {  // softmin over n <= 6 
 // the 20 time steps; the sweeps themselves then only read): per time step the clearance, the lane distance and
 // heading term, and the winners' record (lane segment | clearance winner << 8, carried as a bit pattern).
 //   slots 0-3  (forward sweep): clearance, lane distance, heading term 1 - cos, winners (segment | clearance winner << 8)
-//   slots 4-15 (adjoint): the clearance's partials (x, y, heading), the heading term as the adjoint's own evaluation yields
-//                         it and the lane distance's partials (x, y) and the heading term's, then v, cos, sin of the ADJOINT's
-//                         state, and the clearance and lane distance as the adjoint's own evaluation yields them
+//   slots 4-13 (adjoint): the clearance's partials (x, y, heading), the heading term as the adjoint's own evaluation yields
+//                         it and the lane distance's partials (x, y) and the heading term's, then v (slot 11: written for the
+//                         forward sweep too), cos, sin of the state
 // The adjoint's state is the forward sweep's, bit for bit: stl_eval_grad re-derives the states of a 4-step block from the
 // block's checkpoint with the forward sweep's own operations, the exact sincosf included.  (Round 4 tried the hardware
 // v_sin_f32 / v_cos_f32 there -- the adjoint only reaches a gradient -- and the reference's autograd gradients were missed:
@@ -623,7 +623,7 @@ PSTL_HD float conj6(const float* v, int n, float tau) {  // softmin over n <= 6 
 // normalisers the forward sweep computed at the exact states; test_stl_backward_matches_reference_autograd[stl_mixed] failed
 // its 5e-3.  The divisions, square roots and the heading term's sin / cos of the adjoint are another matter: they scale a
 // partial derivative, not an exponent.)
-constexpr int kGeoSlots = 16;
+constexpr int kGeoSlots = 14;
 struct GeoPre {
   const float* p;   // element (t, c) of this lane at p[(kGeoSlots t + c) * stride]
   int stride;
@@ -651,7 +651,6 @@ PSTL_HD void stl_geometry(const StlEnv& env, const f4* sel_lane, const float* ne
   for (int t = 0; t < t1; ++t) {
     float x, y, th, v, c, s;
     src.get(t, x, y, th, v, c, s);
-    const float ca = c, sa = s, xt = x, yt = y;   // (the adjoint's state IS the forward sweep's: see the note at kGeoSlots)
     if (t < t0) continue;
     float* o = out + (kGeoSlots * t) * stride;
     ClearHit ch;
@@ -661,13 +660,14 @@ PSTL_HD void stl_geometry(const StlEnv& env, const f4* sel_lane, const float* ne
     o[0 * stride] = ch.dn;
     o[1 * stride] = h.d;
     o[2 * stride] = h.th;
+    o[11 * stride] = v;      // (the sweeps read the speed here instead of running the dynamics -- 20 sincosf -- once more)
     if (!ADJ) continue;
     o[3 * stride] = geo_float((unsigned)h.jb | (ch.win << 8));
     ClearHit cg;
-    if (use_rec) clearance_from_winner(env, nei, t, xt, yt, ca, sa, ch.win, cg);
-    else clearance_eval<true>(env, nei, K, t, xt, yt, ca, sa, cg);
+    if (use_rec) clearance_from_winner(env, nei, t, x, y, c, s, ch.win, cg);
+    else clearance_eval<true>(env, nei, K, t, x, y, c, s, cg);
     LaneHit hg;
-    lane_eval<true>(sel_lane, xt, yt, th, hg, use_rec ? h.jb : -1);
+    lane_eval<true>(sel_lane, x, y, th, hg, use_rec ? h.jb : -1);
     o[4 * stride] = cg.d_dx;
     o[5 * stride] = cg.d_dy;
     o[6 * stride] = cg.d_dth;
@@ -675,11 +675,8 @@ PSTL_HD void stl_geometry(const StlEnv& env, const f4* sel_lane, const float* ne
     o[8 * stride] = hg.dd_dx;
     o[9 * stride] = hg.dd_dy;
     o[10 * stride] = hg.dth_dth;
-    o[11 * stride] = v;
-    o[12 * stride] = ca;
-    o[13 * stride] = sa;
-    o[14 * stride] = cg.dn;
-    o[15 * stride] = hg.d;
+    o[12 * stride] = c;
+    o[13 * stride] = s;
   }
 }
 
@@ -714,9 +711,10 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
   const f4* sel_lane = lanes + (mode < 3 ? mode : 0) * kNseg;
   PSTL_NOUNROLL
   for (int t = 0; t < kT; ++t) {
-    float x, y, th, v, c, s;
-    src.get(t, x, y, th, v, c, s);
-    if (XY >= 0 && (t & (kCkStride - 1)) == 0) {   // state checkpoints for the adjoint (every 4th step)
+    float x = 0.0f, y = 0.0f, th = 0.0f, v, c = 1.0f, s = 0.0f;
+    if (PRE) v = pre.at(t, 11);   // (everything else of the state went into the precomputed geometry; the adjoint reads v, cos, sin there too)
+    else src.get(t, x, y, th, v, c, s);
+    if (!PRE && XY >= 0 && (t & (kCkStride - 1)) == 0) {   // state checkpoints for the adjoint (every 4th step)
       const int k = t / kCkStride;
       st.at(XY + k) = x;
       st.at(XY + kCk + k) = y;
@@ -745,10 +743,14 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
     {
       const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df);
       const float a3 = -((r.thmax - h.th) / r.thmax) * tau;
-      g1.add(-s1 * tau);
-      g2.add(-s2 * tau);
-      g3.add(a3);
-      if (!ALL3) R1.step(tau, t, s1, s2, a3, st, tab);
+      // (the selected formula only: lane keeping reads the three "always" terms, the lane changes the two "reach" terms;
+      // the kernels that map a wavefront to ONE (scene, mode) take one side of each branch as a whole)
+      if (ALL3 || mode == 0) {
+        g1.add(-s1 * tau);
+        g2.add(-s2 * tau);
+        g3.add(a3);
+      }
+      if (!ALL3 && (mode == 1 || mode == 2)) R1.step(tau, t, s1, s2, a3, st, tab);
     }
     if (ALL3) {
       lane_eval<false>(lanes + kNseg, x, y, th, h);
@@ -947,7 +949,9 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     if (NORM) gv = gv / r.vf;
     ClearHit ch;
     if (PRE) {
-      ch.dn = pre.at(t, 14), ch.d_dx = pre.at(t, 4), ch.d_dy = pre.at(t, 5), ch.d_dth = pre.at(t, 6);
+      // (the clearance and the lane distance themselves: the adjoint's evaluation repeats the forward sweep's operations on
+      // the same operands, so the forward sweep's slots hold its values)
+      ch.dn = pre.at(t, 0), ch.d_dx = pre.at(t, 4), ch.d_dy = pre.at(t, 5), ch.d_dth = pre.at(t, 6);
     } else if (use_rec) {
       clearance_from_winner(env, nei, t, x, y, c, s, rec_win(rec, t), ch);
     } else {
@@ -960,7 +964,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     gth = gs * ch.d_dth;
     LaneHit h;
     if (PRE) {
-      h.d = pre.at(t, 15), h.th = pre.at(t, 7), h.dd_dx = pre.at(t, 8), h.dd_dy = pre.at(t, 9), h.dth_dth = pre.at(t, 10);
+      h.d = pre.at(t, 1), h.th = pre.at(t, 7), h.dd_dx = pre.at(t, 8), h.dd_dy = pre.at(t, 9), h.dth_dth = pre.at(t, 10);
     } else {
       lane_eval<true>(lane, x, y, th, h, use_rec ? (int)rec_seg(rec, t) : -1);
     }

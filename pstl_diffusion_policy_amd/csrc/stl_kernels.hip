@@ -35,6 +35,7 @@ struct StlArgs {
   float* sel_scores;
   int32_t* sel_idx;
   int rep_split;          // small batches: blockIdx.y is the rep (one candidate per wavefront, k_stl_select picks afterwards)
+  int by_mode;            // a wavefront takes 64 samples of ONE (scene, mode) (map_row): the formula branches are wave-uniform
 };
 
 template <bool NORM = false>
@@ -84,6 +85,25 @@ inline size_t stl_lds_bytes(int n_scratch, int K, bool staged) {
   return ((size_t)n_scratch * kWave + (staged ? (size_t)(3 * kNseg + 3) * 4 + (size_t)K * kT * kNeiPrep : 0)) * sizeof(float);
 }
 
+// Row handled by this lane.  by_mode (scene-indexed rows r = (b*S + s)*3 + mode with S a multiple of 64): a wavefront
+// takes 64 samples of ONE (scene, mode) instead of 64 consecutive rows.  Rows of a (scene, mode) share their lane, their
+// validity and mostly their fate (satisfied or not), so whole wavefronts take the cheap exits of stl_eval_grad -- an
+// invalid lane skips both sweeps, a satisfied row the adjoint -- instead of idling beside the lanes that cannot.
+// The workgroup -> scene map is unchanged (blockIdx.x * 64 / rows_per_scene), which is what scene_tables relies on.
+__device__ __forceinline__ long map_row(int by_mode, int rows_per_scene, int lane = -1) {
+  const long blk = blockIdx.x;
+  if (lane < 0) lane = threadIdx.x;
+  if (!by_mode) return blk * kWave + lane;
+  const int gps = rows_per_scene / kWave;   // workgroups per scene = 3 * (S / 64)
+  const long b = blk / gps;
+  const int g = (int)(blk % gps);
+  const int mode = g % 3, chunk = g / 3, S = rows_per_scene / 3;
+  return (b * S + chunk * kWave + lane) * 3 + mode;
+}
+static bool rows_by_mode(const pstl_cfg* cfg, bool staged) {
+  return staged && cfg->rows_per_scene == 3 * cfg->S && cfg->S % kWave == 0;
+}
+
 // SPLIT: the latency layout of k_guidance_iter for scoring (small batches, the selected formula, controls as input): ten
 // wavefronts compute the geometry of two time steps each into LDS, wave 0 accumulates the formulas.  Bit-identical scores.
 constexpr int kSplitWaves = 10;             // two time steps per wave
@@ -95,7 +115,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_stl_for
   constexpr int NS = ALL3 ? kScratchFwd3 : kScratchFwd;
   const int lane = SPLIT ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
   const int wq = SPLIT ? (int)(threadIdx.x / kWave) : 0;
-  long row = (long)blockIdx.x * kWave + lane;
+  long row = SPLIT ? (long)blockIdx.x * kWave + lane : map_row(a.by_mode, a.rows_per_scene, lane);
   const f4* lanes;
   const float* nei;
   scene_tables<STAGED>(lds, NS, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes, nei);
@@ -202,24 +222,6 @@ __global__ __launch_bounds__(kWave) void k_select_plan(int S, const float* score
   }
 }
 
-// Row handled by this lane.  by_mode (scene-indexed rows r = (b*S + s)*3 + mode with S a multiple of 64): a wavefront
-// takes 64 samples of ONE (scene, mode) instead of 64 consecutive rows.  Rows of a (scene, mode) share their lane, their
-// validity and mostly their fate (satisfied or not), so whole wavefronts take the cheap exits of stl_eval_grad -- an
-// invalid lane skips both sweeps, a satisfied row the adjoint -- instead of idling beside the lanes that cannot.
-// The workgroup -> scene map is unchanged (blockIdx.x * 64 / rows_per_scene), which is what scene_tables relies on.
-__device__ __forceinline__ long map_row(int by_mode, int rows_per_scene, int lane = -1) {
-  const long blk = blockIdx.x;
-  if (lane < 0) lane = threadIdx.x;
-  if (!by_mode) return blk * kWave + lane;
-  const int gps = rows_per_scene / kWave;   // workgroups per scene = 3 * (S / 64)
-  const long b = blk / gps;
-  const int g = (int)(blk % gps);
-  const int mode = g % 3, chunk = g / 3, S = rows_per_scene / 3;
-  return (b * S + chunk * kWave + lane) * 3 + mode;
-}
-static bool rows_by_mode(const pstl_cfg* cfg, bool staged) {
-  return staged && cfg->rows_per_scene == 3 * cfg->S && cfg->S % kWave == 0;
-}
 
 struct GradArgs {
   long N;
@@ -947,6 +949,9 @@ extern "C" int pstl_stl_forward(const pstl_cfg* cfg, const float* s0, const floa
     if (select_after) a.sel_controls = nullptr;
   }
   const bool staged = scene_staged(cfg);
+  // (the selected-formula kernel gains from wavefronts of one (scene, mode): its formula branches become wave-uniform; the
+  // all-three kernel evaluates everything for every row anyway)
+  a.by_mode = (!scores3 && rows_by_mode(cfg, staged)) ? 1 : 0;
   const size_t lds = stl_lds_bytes(scores3 ? kScratchFwd3 : kScratchFwd, cfg->K, staged);
   void (*fn)(StlArgs);
   if (cfg->flags & PSTL_FLAG_NORM_STL) {
