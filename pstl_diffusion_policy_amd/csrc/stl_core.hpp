@@ -67,6 +67,7 @@ constexpr int kScratchFwd3 = 4 * kFwin;      // all three formulas (left and rig
 constexpr int kCkStride = 4;                     // state checkpoints every 4 steps (the adjoint re-derives blocks of 4 states)
 constexpr int kCk = kT / kCkStride;               // 5 checkpoints of (x, y, th, v)
 constexpr int kScratchGrad = 4 * kCk + 2 * kFwin;
+constexpr int kScratchGradPre = 2 * kFwin;        // ... with the precomputed geometry (PRE): no checkpoints
 
 struct alignas(16) f4 {
   float x, y, z, w;
@@ -612,10 +613,12 @@ PSTL_HD float conj6(const float* v, int n, float tau) {  // softmin over n <= 6 
 // The geometry of the sweeps, computed ahead (latency layout of the STL kernels: the waves of a workgroup each take a few of
 // the 20 time steps; the sweeps themselves then only read): per time step the clearance, the lane distance and
 // heading term, and the winners' record (lane segment | clearance winner << 8, carried as a bit pattern).
-//   slots 0-3  (forward sweep): clearance, lane distance, heading term 1 - cos, winners (segment | clearance winner << 8)
-//   slots 4-13 (adjoint): the clearance's partials (x, y, heading), the heading term as the adjoint's own evaluation yields
-//                         it and the lane distance's partials (x, y) and the heading term's, then v (slot 11: written for the
-//                         forward sweep too), cos, sin of the state
+//   slots 0-3   (forward sweep): clearance, lane distance, heading term 1 - cos, speed
+//   slots 4-12  (adjoint): the clearance's partials (x, y, heading), the heading term as the adjoint's own evaluation yields
+//                          it and the lane distance's partials (x, y) and the heading term's, then cos, sin of the heading
+// (The winners of the hard minima stay inside stl_geometry: the adjoint's partials are evaluated right there.)  The adjoint of
+// step t is the last reader of step t's slots, which lets the guidance kernel park the update of step t - 1 in slots 4-7 of
+// step t (k_guidance_iter, SPLIT) instead of in a buffer of its own.
 // The adjoint's state is the forward sweep's, bit for bit: stl_eval_grad re-derives the states of a 4-step block from the
 // block's checkpoint with the forward sweep's own operations, the exact sincosf included.  (Round 4 tried the hardware
 // v_sin_f32 / v_cos_f32 there -- the adjoint only reaches a gradient -- and the reference's autograd gradients were missed:
@@ -623,7 +626,7 @@ PSTL_HD float conj6(const float* v, int n, float tau) {  // softmin over n <= 6 
 // normalisers the forward sweep computed at the exact states; test_stl_backward_matches_reference_autograd[stl_mixed] failed
 // its 5e-3.  The divisions, square roots and the heading term's sin / cos of the adjoint are another matter: they scale a
 // partial derivative, not an exponent.)
-constexpr int kGeoSlots = 14;
+constexpr int kGeoSlots = 13;
 struct GeoPre {
   const float* p;   // element (t, c) of this lane at p[(kGeoSlots t + c) * stride]
   int stride;
@@ -660,9 +663,8 @@ PSTL_HD void stl_geometry(const StlEnv& env, const f4* sel_lane, const float* ne
     o[0 * stride] = ch.dn;
     o[1 * stride] = h.d;
     o[2 * stride] = h.th;
-    o[11 * stride] = v;      // (the sweeps read the speed here instead of running the dynamics -- 20 sincosf -- once more)
+    o[3 * stride] = v;      // (the sweeps read the speed here instead of running the dynamics -- 20 sincosf -- once more)
     if (!ADJ) continue;
-    o[3 * stride] = geo_float((unsigned)h.jb | (ch.win << 8));
     ClearHit cg;
     if (use_rec) clearance_from_winner(env, nei, t, x, y, c, s, ch.win, cg);
     else clearance_eval<true>(env, nei, K, t, x, y, c, s, cg);
@@ -675,8 +677,8 @@ PSTL_HD void stl_geometry(const StlEnv& env, const f4* sel_lane, const float* ne
     o[8 * stride] = hg.dd_dx;
     o[9 * stride] = hg.dd_dy;
     o[10 * stride] = hg.dth_dth;
-    o[12 * stride] = c;
-    o[13 * stride] = s;
+    o[11 * stride] = c;
+    o[12 * stride] = s;
   }
 }
 
@@ -712,7 +714,7 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
   PSTL_NOUNROLL
   for (int t = 0; t < kT; ++t) {
     float x = 0.0f, y = 0.0f, th = 0.0f, v, c = 1.0f, s = 0.0f;
-    if (PRE) v = pre.at(t, 11);   // (everything else of the state went into the precomputed geometry; the adjoint reads v, cos, sin there too)
+    if (PRE) v = pre.at(t, 3);   // (everything else of the state went into the precomputed geometry; the adjoint reads v, cos, sin there too)
     else src.get(t, x, y, th, v, c, s);
     if (!PRE && XY >= 0 && (t & (kCkStride - 1)) == 0) {   // state checkpoints for the adjoint (every 4th step)
       const int k = t / kCkStride;
@@ -729,17 +731,12 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
       ch.dn = pre.at(t, 0);
       h.d = pre.at(t, 1);
       h.th = pre.at(t, 2);
-      if (REC) {
-        const unsigned bits = geo_bits(pre.at(t, 3));
-        h.jb = (int)(bits & 255u);
-        ch.win = bits >> 8;
-      }
     } else {
       clearance_eval<false, REC>(env, nei, K, t, x, y, c, s, ch);
     }
     gsafe.add(-over<NORM>(ch.dn - r.dsafe, r.sf) * tau);
     if (!PRE) lane_eval<false>(ALL3 ? lanes : sel_lane, x, y, th, h);
-    if (REC) rec_put(rec, t, (unsigned)h.jb, ch.win);
+    if (REC && !PRE) rec_put(rec, t, (unsigned)h.jb, ch.win);   // (PRE: the adjoint's partials are precomputed too, nobody reads the record)
     {
       const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df);
       const float a3 = -((r.thmax - h.th) / r.thmax) * tau;
@@ -842,7 +839,8 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     return 1.0f;
   }
   const f4* lane = lanes + mode * kNseg;
-  const int CKP = 0, LB = 4 * kCk, LT = 4 * kCk + kFwin;
+  // scratch: [checkpoints 4 x 5 | suffix tables 2 x 10]; with the precomputed geometry there are no checkpoints: the tables only
+  const int CKP = 0, LB = PRE ? 0 : 4 * kCk, LT = LB + kFwin;
   // ---- forward sweep ------------------------------------------------------------------------------------------
   FwdOut fo;
   Rec rec;
@@ -938,7 +936,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     if (t == 0) break;
     float x = 0.0f, y = 0.0f, th = 0.0f, v, c, s;
     if (PRE) {
-      v = pre.at(t, 11), c = pre.at(t, 12), s = pre.at(t, 13);
+      v = pre.at(t, 3), c = pre.at(t, 11), s = pre.at(t, 12);
     } else {
       x = pick4(bx, i), y = pick4(by, i), th = pick4(bth, i), v = pick4(bv, i), c = pick4(bc, i), s = pick4(bs, i);
     }

@@ -303,8 +303,9 @@ struct GuideArgs {
 // adjoint's partials at the recorded winners) off the critical wavefront: 96 -> 45 us per launch at K = 8.
 constexpr int kGeoFloats = kGeoSlots * kT;   // per lane
 
+// (SPLIT: two ten-wave workgroups per CU -- 74 KB of LDS each at K = 2 -- need five wavefronts per SIMD: <= 96 registers)
 template <bool MULTI, bool STAGED, bool NORM = false, bool SPLIT = false>
-__global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidance_iter(GuideArgs a) {
+__global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1) void k_guidance_iter(GuideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(!SPLIT || STAGED, "the latency layout stages its scene tables");
   const unsigned long long seed = a.dyn ? uniform_u64(&a.dyn->seed) : a.seed;
@@ -314,13 +315,13 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidanc
   long row = map_row(a.by_mode, a.rows_per_scene, lane);
   const f4* lanes;
   const float* nei;
-  scene_tables<STAGED>(lds, kScratchGrad, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes,
-                       nei);
+  constexpr int NS = SPLIT ? kScratchGradPre : kScratchGrad;
+  scene_tables<STAGED>(lds, NS, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes, nei);
   GeoPre pre = {nullptr, 0};
   if (SPLIT) {
     const bool live0 = row < a.N;
     if (!live0) row = a.N - 1;
-    float* geo = lds + kScratchGrad * kWave + stl_table_floats(a.K);
+    float* geo = lds + NS * kWave + stl_table_floats(a.K);
     const StlRow rq = load_row<NORM>(a.stlp, a.hl, row);
     if (live0 && rq.mode < 3 && grad_scale * a.valid[row] != 0.0f)
       stl_geometry(a.env, lanes + rq.mode * kNseg, nei, a.K,
@@ -390,13 +391,17 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidanc
     // Wave 0 leaves every step's gradient and stored controls in LDS; after a barrier each wave updates its own two steps
     // (= one noise quad): the elements are independent, so the ten waves share the Adam / Philox / emission work as well.
     static_assert(kT == 2 * kSplitWaves, "a wave's two time steps are one noise quad");
-    float* upd = lds + kScratchGrad * kWave + stl_table_floats(a.K) + kGeoFloats * kWave + lane;
+    // The adjoint of step t + 1 is the last reader of that step's geometry, and emit(t) comes right after it: (gw, ga, w, a) of
+    // step t are parked in slots 4-7 of step t + 1 (step 19's -- emitted before the adjoint starts -- in step 0's, whose adjoint
+    // slots nobody reads).  No buffer of its own: the workgroup stays under 80 KB and two fit a CU.
+    float* geo_l = lds + NS * kWave + stl_table_floats(a.K) + lane;
+    auto upd_at = [=](int t, int j) -> float* { return geo_l + (kGeoSlots * (t + 1 == kT ? 0 : t + 1) + 4 + j) * kWave; };
     if (wq == 0 && live)
       stl_eval_grad<NORM, true>(
           a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
           [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
           [=](int t, float gw, float ga, float w0, float a0) {
-            upd[(4 * t + 0) * kWave] = gw, upd[(4 * t + 1) * kWave] = ga, upd[(4 * t + 2) * kWave] = w0, upd[(4 * t + 3) * kWave] = a0;
+            *upd_at(t, 0) = gw, *upd_at(t, 1) = ga, *upd_at(t, 2) = w0, *upd_at(t, 3) = a0;
           },
           1, gs == 0.0f, pre);
     __syncthreads();
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_guidanc
       z4 = f4{zz[0], zz[1], zz[2], zz[3]};
     }
     for (int t = 2 * wq + 1; t >= 2 * wq; --t)
-      apply(t, upd[(4 * t + 0) * kWave], upd[(4 * t + 1) * kWave], upd[(4 * t + 2) * kWave], upd[(4 * t + 3) * kWave], z4);
+      apply(t, *upd_at(t, 0), *upd_at(t, 1), *upd_at(t, 2), *upd_at(t, 3), z4);
   } else {
     // mu[2t], mu[2t+1] are rewritten by emit(t) while the adjoint walks t = T-1 ... 0; the adjoint has already taken every
     // value it still needs from earlier time steps only (and hands the current one to emit, so mu is not read here)
@@ -1068,7 +1073,7 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
   const bool split = staged && (long)grid.x <= 2 * guidance_split_max_groups();
   size_t lds_total = lds;
   if (split) {
-    lds_total += (size_t)(kGeoFloats + 4 * kT) * kWave * sizeof(float);   // the geometry and the per-step (gw, ga, w, a)
+    lds_total = stl_lds_bytes(kScratchGradPre, cfg->K, true) + (size_t)kGeoFloats * kWave * sizeof(float);   // + the geometry
     if (cfg->flags & PSTL_FLAG_NORM_STL) fn = niters > 1 ? k_guidance_iter<true, true, true, true> : k_guidance_iter<false, true, true, true>;
     else fn = niters > 1 ? k_guidance_iter<true, true, false, true> : k_guidance_iter<false, true, false, true>;
   }
