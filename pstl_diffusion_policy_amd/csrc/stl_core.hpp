@@ -930,7 +930,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
         }
       }
     }
-  PSTL_NOUNROLL
+  PSTL_UNROLL   // (unrolled: the block's register arrays are then indexed by constants -- 24 selects per step otherwise)
   for (int i = kCkStride - 1; i >= 0; --i) {
     const int t = blk * kCkStride + i;
     if (t == 0) break;
