@@ -813,7 +813,7 @@ __device__ __forceinline__ void put_pieces(char* tile_hi, char* tile_lo, int col
 }
 
 constexpr size_t bwd_l2_lds() { return (size_t)2 * 2 * 2 * 2 * 64 * 16 + (size_t)2 * 3 * 2 * kWbTile + (size_t)16 * 2 * kWbTile; }
-constexpr size_t bwd_l1_lds() { return (size_t)2 * 2 * 8 * 2 * 64 * 16 + (size_t)2 * 3 * 2 * kWbTile + (size_t)16 * 2 * kWbTile; }
+constexpr size_t bwd_l1_lds() { return (size_t)2 * 8 * 2 * 64 * 16 + (size_t)2 * 3 * 2 * kWbTile + (size_t)16 * 2 * kWbTile; }
 
 // dH2 (N,256), partial [grid][256] (column sums of dH2), slabs [grid][48][256] (dW3 partials; rows 40..47 are zero)
 __global__ __launch_bounds__(512, 1) void k_bwd_l2(long N, const float* dO, const unsigned* Wp, const float* h2, float* dH2,
@@ -984,8 +984,8 @@ __global__ __launch_bounds__(512, 1) void k_bwd_l1(int bs, int rows_per_scene, i
                                                    const float* h1, const float* x47, float* dH1, float* S, float* slabs) {
   constexpr int NKB = 8;
   extern __shared__ __attribute__((aligned(16))) char flds[];
-  u32x4* pieces = reinterpret_cast<u32x4*>(flds);                       // [buf][tile][kb][hi | lo][lane]
-  char* xt = flds + (size_t)2 * 2 * NKB * 2 * 64 * 16;                  // [buf][3 column tiles of x47][hi | lo]: B operand
+  u32x4* pieces = reinterpret_cast<u32x4*>(flds);                       // [buf][kb][hi | lo][lane]: ONE 16-row tile per buffer
+  char* xt = flds + (size_t)2 * NKB * 2 * 64 * 16;                      // [buf][3 column tiles of x47][hi | lo]: B operand, per chunk
   char* at = xt + (size_t)2 * 3 * 2 * kWbTile;                          // [16 feature tiles of dH1][hi | lo]: dH1^T, wave-private
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -1002,42 +1002,45 @@ __global__ __launch_bounds__(512, 1) void k_bwd_l1(int bs, int rows_per_scene, i
         wl[ot][kb] = __builtin_bit_cast(bf16x8, q4[(blk * 2 + 1) * 64 + lane]);
       }
   }
-  const int cps = rows_per_scene / kFcRows;          // chunks per scene
+  // The pass is pipelined by 16-row TILE (the activation gradient's unit): while tile T is in the matrix pipe, the dH2 quads AND
+  // the h1 mask quads of tile T + 1 are in flight -- fetched at the top of a tile's own iteration, the mask cost one HBM round
+  // trip per tile (2.5 us: the whole kernel's pace).  The weight gradient runs after every second tile (32 rows = one k-block).
+  const int tps = rows_per_scene / 16;               // tiles per scene (even)
   const long s0 = (long)blockIdx.x * spw, s1 = (s0 + spw < bs) ? s0 + spw : bs;
-  const long c0 = s0 * cps, c1 = s1 * cps;
-  f32x4 rq[2][2];
+  const long t0 = s0 * tps, t1 = s1 * tps;
+  f32x4 rq[2], hn[2];
   float rx[3];
-  auto load_chunk = [&](long ch) {   // wave w makes k-block w of both tiles (k_dgrad's staging)
+  auto load_tile = [&](long t) {   // wave w makes k-block w of the tile (k_dgrad's staging) and fetches its own mask quads
+    const long row = t * 16 + c;
+    const int k0 = 32 * w + 4 * g;
+    rq[0] = *reinterpret_cast<const f32x4*>(dH2 + row * kHid + k0);
+    rq[1] = *reinterpret_cast<const f32x4*>(dH2 + row * kHid + k0 + 16);
 #pragma unroll
-    for (int tile = 0; tile < 2; ++tile) {
-      const long row = ch * kFcRows + tile * 16 + c;
-      const int k0 = 32 * w + 4 * g;
-      rq[tile][0] = *reinterpret_cast<const f32x4*>(dH2 + row * kHid + k0);
-      rq[tile][1] = *reinterpret_cast<const f32x4*>(dH2 + row * kHid + k0 + 16);
-    }
+    for (int ot = 0; ot < 2; ++ot) hn[ot] = *reinterpret_cast<const f32x4*>(h1 + row * kHid + 16 * (2 * w + ot) + 4 * g);
+  };
+  auto store_tile = [&](int buf) {
+    float hi[8];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {   // the chunk of x47 (contiguous: 32 x 47 floats)
+    for (int q = 0; q < 4; ++q) hi[q] = (float)(__bf16)rq[0][q], hi[4 + q] = (float)(__bf16)rq[1][q];
+    u32x4* pb = pieces + ((size_t)buf * NKB + w) * 2 * 64;
+    pb[lane] = u32x4{bf16_pair(hi[0], hi[1]), bf16_pair(hi[2], hi[3]), bf16_pair(hi[4], hi[5]), bf16_pair(hi[6], hi[7])};
+    pb[64 + lane] = u32x4{bf16_pair(rq[0][0] - hi[0], rq[0][1] - hi[1]), bf16_pair(rq[0][2] - hi[2], rq[0][3] - hi[3]),
+                          bf16_pair(rq[1][0] - hi[4], rq[1][1] - hi[5]), bf16_pair(rq[1][2] - hi[6], rq[1][3] - hi[7])};
+  };
+  auto load_x = [&](long ch) {   // the chunk of x47 (contiguous: 32 x 47 floats)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
       const int e = tid + 512 * u;
       rx[u] = e < kFcRows * kX47 ? x47[ch * kFcRows * kX47 + e] : 0.0f;
     }
   };
-  auto store_chunk = [&](int buf) {
-#pragma unroll
-    for (int tile = 0; tile < 2; ++tile) {
-      float hi[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) hi[q] = (float)(__bf16)rq[tile][0][q], hi[4 + q] = (float)(__bf16)rq[tile][1][q];
-      u32x4* pb = pieces + ((size_t)(buf * 2 + tile) * NKB + w) * 2 * 64;
-      pb[lane] = u32x4{bf16_pair(hi[0], hi[1]), bf16_pair(hi[2], hi[3]), bf16_pair(hi[4], hi[5]), bf16_pair(hi[6], hi[7])};
-      pb[64 + lane] = u32x4{bf16_pair(rq[tile][0][0] - hi[0], rq[tile][0][1] - hi[1]), bf16_pair(rq[tile][0][2] - hi[2], rq[tile][0][3] - hi[3]),
-                            bf16_pair(rq[tile][1][0] - hi[4], rq[tile][1][1] - hi[5]), bf16_pair(rq[tile][1][2] - hi[6], rq[tile][1][3] - hi[7])};
-    }
+  auto store_x = [&](int xbuf) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int e = tid + 512 * u;
       if (e < kFcRows * kX47) {
         const int row = e / kX47, col = e % kX47;
-        char* t = xt + (size_t)(buf * 3 + (col >> 4)) * 2 * kWbTile;
+        char* t = xt + (size_t)(xbuf * 3 + (col >> 4)) * 2 * kWbTile;
         put_pieces(t, t + kWbTile, col & 15, row, rx[u]);
       }
     }
@@ -1048,62 +1051,67 @@ __global__ __launch_bounds__(512, 1) void k_bwd_l1(int bs, int rows_per_scene, i
 #pragma unroll
     for (int b = 0; b < 3; ++b) wacc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   f32x4 css[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
-  if (c0 < c1) {
-    load_chunk(c0);
+  if (t0 < t1) {
+    load_tile(t0);
+    load_x(t0 / 2);
     __syncthreads();   // (the zero fill of xt)
-    store_chunk(0);
+    store_tile(0);
+    store_x(0);
   }
   __syncthreads();
-  int buf = 0, in_scene = 0;
+  int buf = 0, xbuf = 0, in_scene = 0;
   long scene = s0;
-  for (long ch = c0; ch < c1; ++ch) {
-    if (ch + 1 < c1) load_chunk(ch + 1);          // in flight during the MFMAs below
+  for (long t = t0; t < t1; ++t) {
+    const int half = (int)(t & 1);            // which half of the 32-row chunk (t0 is even)
+    const f32x4 hm[2] = {hn[0], hn[1]};
+    if (t + 1 < t1) load_tile(t + 1);         // dH2 and mask quads of the next tile: in flight during the MFMAs below
+    if (half == 0 && t + 2 < t1) load_x(t / 2 + 1);
+    const long row = t * 16 + c;
+    f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+    const u32x4* pb = pieces + (size_t)buf * NKB * 2 * 64 + lane;
 #pragma unroll
-    for (int tile = 0; tile < 2; ++tile) {
-      const long row = ch * kFcRows + tile * 16 + c;
-      f32x4 hm[2];
+    for (int kb = 0; kb < NKB; ++kb) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, pb[(2 * kb) * 64]), bl = __builtin_bit_cast(bf16x8, pb[(2 * kb + 1) * 64]);
 #pragma unroll
-      for (int ot = 0; ot < 2; ++ot) hm[ot] = *reinterpret_cast<const f32x4*>(h1 + row * kHid + 16 * (2 * w + ot) + 4 * g);
-      f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
-      const u32x4* pb = pieces + (size_t)(buf * 2 + tile) * NKB * 2 * 64 + lane;
+      for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ot][kb], bh, acc[ot], 0, 0, 0);
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, pb[(2 * kb) * 64]), bl = __builtin_bit_cast(bf16x8, pb[(2 * kb + 1) * 64]);
+      for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ot][kb], bh, acc[ot], 0, 0, 0);
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ot][kb], bh, acc[ot], 0, 0, 0);
+      for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ot][kb], bl, acc[ot], 0, 0, 0);
+    }
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ot][kb], bh, acc[ot], 0, 0, 0);
+    for (int ot = 0; ot < 2; ++ot) {
+      f32x4 o;
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ot][kb], bl, acc[ot], 0, 0, 0);
+      for (int r = 0; r < 4; ++r) o[r] = hm[ot][r] > 0.0f ? acc[ot][r] : 0.0f;
+      if (WRITE) *reinterpret_cast<f32x4*>(dH1 + row * kHid + 16 * (2 * w + ot) + 4 * g) = o;
+      css[ot] += o;
+      char* tl = at + (size_t)(2 * w + ot) * 2 * kWbTile;      // this wave's own operand tiles
+#pragma unroll
+      for (int r = 0; r < 4; ++r) put_pieces(tl, tl + kWbTile, 4 * g + r, half * 16 + c, o[r]);
+    }
+    if (half == 1) {
+      // dW1[:, 224:271] partials: (this wave's two 16-feature tiles of dH1^T) x (3 tiles of 16 columns of x47), over the 32 rows
+      // (operands fetched pair by pair: the register file is full of W2^T)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const wg_bf8 ah = *reinterpret_cast<const wg_bf8*>(at + (size_t)((2 * w + a) * 2 + 0) * kWbTile + lane * 16);
+        const wg_bf8 al = *reinterpret_cast<const wg_bf8*>(at + (size_t)((2 * w + a) * 2 + 1) * kWbTile + lane * 16);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const wg_bf8 bh = *reinterpret_cast<const wg_bf8*>(xt + (size_t)((xbuf * 3 + b) * 2 + 0) * kWbTile + lane * 16);
+          const wg_bf8 bl = *reinterpret_cast<const wg_bf8*>(xt + (size_t)((xbuf * 3 + b) * 2 + 1) * kWbTile + lane * 16);
+          wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, wacc[a][b], 0, 0, 0);
+          wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, wacc[a][b], 0, 0, 0);
+          wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, wacc[a][b], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int ot = 0; ot < 2; ++ot) {
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = hm[ot][r] > 0.0f ? acc[ot][r] : 0.0f;
-        if (WRITE) *reinterpret_cast<f32x4*>(dH1 + row * kHid + 16 * (2 * w + ot) + 4 * g) = o;
-        css[ot] += o;
-        char* t = at + (size_t)(2 * w + ot) * 2 * kWbTile;      // this wave's own operand tiles
-#pragma unroll
-        for (int r = 0; r < 4; ++r) put_pieces(t, t + kWbTile, 4 * g + r, tile * 16 + c, o[r]);
+      if (t + 1 < t1) {   // the next chunk's x47 (loaded a tile ago); the other buffer's last readers are two barriers back
+        store_x(xbuf ^ 1);
+        xbuf ^= 1;
       }
     }
-    // dW1[:, 224:271] partials: (this wave's two 16-feature tiles of dH1^T) x (3 tiles of 16 columns of x47), over the 32 rows
-    // (operands fetched pair by pair: the register file is full of W2^T)
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const wg_bf8 ah = *reinterpret_cast<const wg_bf8*>(at + (size_t)((2 * w + a) * 2 + 0) * kWbTile + lane * 16);
-      const wg_bf8 al = *reinterpret_cast<const wg_bf8*>(at + (size_t)((2 * w + a) * 2 + 1) * kWbTile + lane * 16);
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        const wg_bf8 bh = *reinterpret_cast<const wg_bf8*>(xt + (size_t)((buf * 3 + b) * 2 + 0) * kWbTile + lane * 16);
-        const wg_bf8 bl = *reinterpret_cast<const wg_bf8*>(xt + (size_t)((buf * 3 + b) * 2 + 1) * kWbTile + lane * 16);
-        wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, wacc[a][b], 0, 0, 0);
-        wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, wacc[a][b], 0, 0, 0);
-        wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, wacc[a][b], 0, 0, 0);
-      }
-    }
-    if (++in_scene == cps) {   // the scene is complete: its sums (16 row-lanes added in a fixed butterfly order)
+    if (++in_scene == tps) {   // the scene is complete: its sums (16 row-lanes added in a fixed butterfly order)
 #pragma unroll
       for (int ot = 0; ot < 2; ++ot) {
         f32x4 v = css[ot];
@@ -1117,7 +1125,7 @@ __global__ __launch_bounds__(512, 1) void k_bwd_l1(int bs, int rows_per_scene, i
       in_scene = 0;
       ++scene;
     }
-    if (ch + 1 < c1) store_chunk(buf ^ 1);
+    if (t + 1 < t1) store_tile(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
