@@ -87,3 +87,29 @@ def test_latency_of_a_simulation_step_at_the_reference_settings(capsys):
         print("\nclosed loop: median %.2f ms, worst %.2f ms per simulation step (192 rows, 100 steps, K=8, guidance)" % (med, worst))
     assert all(math.isfinite(r["best_score"]) for r in recs)
     assert med < 2.0, med      # twice the measured median (0.97-0.99 ms with the HIP-graph replay; round 3: 1.3, round 2: 2.7)
+
+
+def test_parameters_in_device_memory_equal_parameters_by_value():
+    """ABI 4 (pstl_cfg.dyn): noise seed and guidance-loss scale read by the kernels from a 16-byte device block give, bit for
+    bit, what the by-value arguments give -- x_T, a guided rollout and its candidates, in the throughput layout (672 scenes) and
+    in the latency layout (2 scenes)."""
+    import numpy as np
+    from pstl_diffusion_policy_amd.engine import PackedWeights, Sampler, SceneBatch
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    dev = torch.device("cuda:0")
+    hp = default_hparams()
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    guid = dict(enabled=True, before=3, niters=1, lr=0.01)
+    for bs in (2, 112):
+        scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=3, S=64, seed=8, invalid_lane_frac=0.2, stlp_mode="wide").items()
+                 if k not in ("params", "pre_stlp", "tj_scores_prior")}
+        seed = 0x1234567890abcdef
+        ref = sm.sampling_region(SceneBatch(scene, 64, hp, dev), 8, None, None, rect_head=True, multi_cands=3, guidance=guid,
+                                 seed=seed, want_scores3=False)
+        dyn = torch.zeros(4, dtype=torch.float32, device=dev)
+        dyn[:2] = torch.from_numpy(np.array([seed & 0xffffffff, seed >> 32], dtype=np.uint32).view(np.float32)).to(dev)
+        sb = SceneBatch(scene, 64, hp, dev, dyn=dyn)          # writes the loss scale into dyn[2] on the device
+        got = sm.sampling_region(sb, 8, None, None, rect_head=True, multi_cands=3, guidance=guid, seed=1, want_scores3=False)
+        for k in ("final_controls", "final_scores", "sel_controls", "cand_scores"):
+            assert torch.equal(got[k], ref[k]), (bs, k)
+        assert torch.isfinite(got["final_controls"]).all()
