@@ -3,7 +3,8 @@
 
 The line also carries (single-GPU runs; skipped with --no_extras): "roofline.fp32_exact" (the same step on the exact-fp32
 MFMA chains), "also" (BASELINE configs 2, 3 and 5 -- e5, e7, e8_train -- three timed steps each, each with its own dominant-kernel
-roofline fraction; e8_train with the HBM rate of RefineNet's backward) and "sweep" (the headline workload at 192 ... 786 432 rows).
+roofline fraction; e8_train with the HBM rate of RefineNet's backward), "sweep" (the headline workload at 192 ... 786 432 rows)
+and "paper_metric" (md["time"] of the reference's two README command lines through the CLI mirror).
 
 A "step" is one pass of the timed region of the reference's sampling harness (nusc_train.py:957-1105) over one
 synthetic batch already resident in HBM: row constants, scene preparation, scene encoder, noise generation,
@@ -317,6 +318,34 @@ class Job:
         return res
 
 
+def paper_metric(batches=8):
+    """The paper's own metric inside the driver's run (missing #2): md["time"] of run_sampling_test -- the wall time of
+    the region reference nusc_train.py:957-1105 per batch of 128 scenes x 64 x 3 = 24 576 rows at 100 diffusion steps and 8
+    neighbours, device synchronised on both sides -- for the README command lines "Ours" and "Ours+guidance" (reference
+    README.md:114,120) through the CLI mirror (pstl_diffusion_policy_amd.nusc_train.main) with in-kernel noise, on synthetic
+    scenes with random-init weights; median over the batches after the first.  Context, not target: the paper's numbers are
+    from an unspecified NVIDIA GPU on real nuScenes data, and the reference's timer does not synchronise the device."""
+    import contextlib
+    import io
+    import statistics
+    from pstl_diffusion_policy_amd import nusc_train as nt
+    common = ["-e", "e7_ours", "--diffusion", "--stl_weight", "0.0", "--load_stlp", "--rect_head", "--flex", "--diverse_loss",
+              "--test", "-P", "e7_ours", "--run_sampling_test", "--skip_nusc_load", "--viz_correct", "--allow_random_init",
+              "--kernel_noise", "--n_trials", str(batches - 1)]
+    configs = {"ours": (common + ["--multi_cands", "5"], 0.174),
+               "ours_guidance": (common + ["--multi_cands", "10", "--guidance", "--guidance_before", "10", "--guidance_niters", "1",
+                                           "--guidance_lr", "0.01", "--n_rolls", "3", "--other"], 0.786)}
+    out = {"rows_per_batch": 128 * 64 * 3, "batches": batches, "through": "nusc_train.main (the reference's CLI surface), --kernel_noise"}
+    for name, (argv, paper_s) in configs.items():
+        with contextlib.redirect_stdout(io.StringIO()):
+            md = nt.main(argv)
+        t = md.hist["time"]
+        med = statistics.median(t[1:] if len(t) > 1 else t)
+        out[name] = {"time_ms_median": med * 1e3, "trajectories_per_s": out["rows_per_batch"] / med, "stl_sat_rate": md("acc"),
+                     "paper_time_ms": paper_s * 1e3}
+    return out
+
+
 def chain_peak(chain_waves):
     # split forms: three 16-bit MFMA products per fp32 product, so the roofline of the fp32 work they deliver is the
     # dense 16-bit matrix peak / 3
@@ -517,6 +546,8 @@ def main():
             line["also"] = also
         if sweep is not None:
             line["sweep"] = sweep
+        if extras and a.workload == "e7_guid" and not a.chain_waves:
+            line["paper_metric"] = paper_metric()
         if not a.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
             line["cpu_baseline"] = cpu_baseline(a, hp, sd, guidance, rect_head, None if (train or trajopt) else job.sampler, dev,
                                                 sampler_exact=sampler_exact)

@@ -125,6 +125,7 @@ def test_bench_starts_its_own_ranks():
     assert all(v["ms_per_step"] > 0 and 0.0 < v["roofline"]["frac"] < 1.0 for v in l1["also"].values())
     assert l1["also"]["e8_train"]["backward"]["achieved_GBps"] > 0
     assert [s["rows"] for s in l1["sweep"]] == [192, 3072, 48 * 192] and all(s["value"] > 0 for s in l1["sweep"])
+    assert l1["paper_metric"]["ours"]["time_ms_median"] > 0 and l1["paper_metric"]["ours_guidance"]["paper_time_ms"] == 786.0
     ndev = torch.cuda.device_count()
     two = _bench(["--gpus", "2"] + small, None if ndev >= 2 else {"PSTL_BENCH_BACKEND": "gloo"})
     assert two.returncode == 0, two.stderr[-2000:]
