@@ -53,6 +53,7 @@ def parse():
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_scenes", type=int, default=12)
     p.add_argument("--no_extras", action="store_true", help="skip the fp32-exact leg, the 'also' workloads and the batch-size sweep")
+    p.add_argument("--no_graph", action="store_true", help="small batches: eager launches instead of one HIP-graph replay per step")
     p.add_argument("--trajopt_iters", type=int, default=50, help="Adam iterations per step of the trajopt workload")
     return p.parse_args()
 
@@ -169,6 +170,7 @@ def spawn_ranks(a):
 # algorithmic HBM bytes per row of RefineNet's backward (pstl_refine_backward): what must be read once -- the two saved
 # activations h1, h2 (2 x 256 floats), dcontrols / pre / init (3 x 40), hl | stlp (7) -- the 145 704 gradients it writes are noise
 BWD_BYTES_PER_ROW = 4 * (2 * 256 + 3 * 40 + 7)
+GRAPH_MAX_ROWS = 98304      # batches up to this many rows per GPU replay a captured HIP graph per step (see Job)
 
 
 def chain_layout(n_rows, cus=256):
@@ -208,6 +210,13 @@ class Job:
         self.N = bs * self.S * 3
         self.gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         self.call = 0
+        # Launch-bound sizes (a step is ~75 launches; below ~100 k rows most of them are 5-40 us): the step's launch sequence is
+        # captured once in a HIP graph and replayed, the per-step seed travelling through a pstl_dyn block in device memory
+        # (engine.GraphCapture; same kernels, same arguments, same results as the eager launches).  Single-GPU, in-kernel noise,
+        # sampling workloads only; --no_graph measures the eager launches.
+        self.use_graph = (world == 1 and not a.no_graph and a.noise == "kernel" and not self.train and not self.trajopt
+                          and self.N <= GRAPH_MAX_ROWS)
+        self.graph = None
 
     def step(self):
         from pstl_diffusion_policy_amd.engine import PackedWeights, RectTrainer, Sampler, SceneBatch
@@ -225,6 +234,23 @@ class Job:
             x_T = z = None
             self.call += 1
             seed = 987654321 + self.call
+        if self.use_graph:
+            if self.graph is None:
+                from pstl_diffusion_policy_amd.engine import DynBlock, GraphCapture
+                self.dyn = DynBlock(dev)
+                self.dyn.set(seed, SceneBatch.loss_scale(vsum, vrows))
+
+                def body():
+                    sbg = SceneBatch(self.scene, S, self.hp, dev, global_valid_sum=vsum, global_rows=vrows, row_offset=self.rank * N,
+                                     dyn=self.dyn.dev, scale_in_dyn=True)
+                    o = sampler.sampling_region(sbg, steps, None, None, rect_head=self.rect_head,
+                                                multi_cands=a.multi_cands if self.rect_head else None, guidance=self.guidance,
+                                                coeffs=self.coeffs, want_scores3=False, seed=0, diversity=True)
+                    return o["counts"], o["div_totals"]
+
+                self.graph = GraphCapture(body)
+            self.dyn.set(seed)
+            return self.graph.replay()
         if self.trajopt:
             params = self.scene["params"].reshape(N, 40).clone()
             sc, _ = sampler.trajopt(sb, params, a.trajopt_iters, 0.005, 0.01, 10.0, global_valid_sum=vsum, global_rows=vrows)
@@ -265,7 +291,12 @@ class Job:
         for _ in range(warmup):
             self.step()
         sm = self.sampler
-        sm.trace, sm.trace_stl, sm.trace_bwd = [], {}, ([] if self.train else None)
+        if self.use_graph and self.graph is None:
+            self.step()          # (the capture itself: never inside the timed region)
+        # per-kernel HIP events are recorded by the eager launches only (events cannot be timed inside a graph): a graph-replaying
+        # job takes its kernel timings from one extra eager step AFTER the timed ones
+        if not self.use_graph:
+            sm.trace, sm.trace_stl, sm.trace_bwd = [], {}, ([] if self.train else None)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -280,6 +311,12 @@ class Job:
             tmax = torch.tensor([dt], dtype=torch.float64, device=self.dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
+        if self.use_graph:
+            self.use_graph = False
+            sm.trace, sm.trace_stl = [], {}
+            self.step()
+            torch.cuda.synchronize()
+            self.use_graph = True
         if not self.train and not self.trajopt:      # (train workloads: checked inside every train_step, see step())
             sm.check_chain_domain(fallback=False)    # a split-f16 launch that left its domain leaves undefined results
         res = {"dt": dt, "ms_per_step": dt / steps * 1e3, "value": self.world * self.N * steps / dt, "counts": counts,
@@ -296,13 +333,14 @@ class Job:
         K = self.a.neighbors
         stl_bytes = 160 + 16 + 24 + 4 + (K * 20 * 7 * 4 + 540) / (3.0 * self.S)
         stl_info = {}
+        traced_steps = 1 if self.use_graph else steps
         for kind, evs in (sm.trace_stl or {}).items():
             ms_k = sum(e0.elapsed_time(e1) for (e0, e1, _) in evs)
             evals = sum(n for (_, _, n) in evs)
             if ms_k > 0:
                 rate = evals / (ms_k * 1e-3)
                 stl_info[kind] = {"kernel": "k_guidance_iter (forward + adjoint + Adam)" if kind == "guidance" else "k_stl_forward",
-                                  "row_evals_per_s": rate, "ms_per_step": ms_k / steps,
+                                  "row_evals_per_s": rate, "ms_per_step": ms_k / traced_steps,
                                   "algorithmic_bytes_per_row_eval": stl_bytes * (2 if kind == "guidance" else 1),
                                   "achieved_GBps": rate * stl_bytes * (2 if kind == "guidance" else 1) / 1e9,
                                   "frac_of_hbm_peak": rate * stl_bytes * (2 if kind == "guidance" else 1) / 8e12}
@@ -475,8 +513,9 @@ def main():
             js = mk(a.workload, sbs)
             ms_ = js.measure_best(3, 2, 3)
             sweep.append({"rows": js.N, "ms_per_step": ms_["ms_per_step"], "value": ms_["value"], "layout": chain_layout(js.N),
-                          "timing": ms_["timing"]})
+                          "launches": "one HIP-graph replay per step" if js.use_graph else "eager", "timing": ms_["timing"]})
         sweep.append({"rows": N, "ms_per_step": m["ms_per_step"], "value": m["value"], "layout": chain_layout(N),
+                      "launches": "one HIP-graph replay per step" if job.use_graph else "eager",
                       "timing": "the headline measurement (%d steps)" % a.steps})
     # VALU-issue roofline of the one-row-per-lane STL kernels (they are instruction-issue-bound, not HBM-bound): vector
     # instructions per row-evaluation from the committed PMC pass (SQ_INSTS_VALU / rows of that launch) x the row-evaluation

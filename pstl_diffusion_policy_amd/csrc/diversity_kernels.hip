@@ -395,6 +395,11 @@ __global__ __launch_bounds__(256) void k_diversity_totals(int bs, const double* 
 
 using namespace pstl;
 
+static __global__ void k_fill_words(int n, unsigned v, unsigned* p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 extern "C" int pstl_diversity(const pstl_cfg* cfg, const float* s0, const float* gt_traj, int gt_stride,
                               const float* controls, const float* scores, const float* valid, const float* alphas,
                               double* per_mode, float* per_scene, double* totals, void* stream) {
@@ -403,8 +408,9 @@ extern "C" int pstl_diversity(const pstl_cfg* cfg, const float* s0, const float*
     return PSTL_ERR_ARG;
   if (cfg->rows_per_scene != 3 * cfg->S || cfg->S > kWave) return PSTL_ERR_SHAPE;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(per_scene), 0x7f800000, (size_t)cfg->bs * 2, st) != hipSuccess)
-    return PSTL_ERR_LAUNCH;
+  // (+inf for the atomicMin of ADE / FDE -- by a kernel, not a memset node: memset nodes did not replay under HIP-graph capture)
+  hipLaunchKernelGGL(k_fill_words, dim3((unsigned)((cfg->bs * 2 + 255) / 256)), dim3(256), 0, st, cfg->bs * 2, 0x7f800000u,
+                     reinterpret_cast<unsigned*>(per_scene));
   DivArgs a;
   a.bs = cfg->bs;
   a.S = cfg->S;

@@ -799,6 +799,13 @@ __global__ void k_prepare(long n_nei, long n_lane_pts, const float* nei, const f
   }
 }
 
+// (a kernel, not hipMemsetAsync: under stream capture -- the closed loop's and bench.py's HIP graphs -- the memset node of this
+// ROCm did not zero its 64 bytes on replay, and the counters accumulated on top of the previous replay's)
+__global__ void k_zero_words(int n, unsigned* p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
 // grid-stride row counts; one pair of 64-bit atomics per workgroup (a few hundred in total instead of one per wave on
 // two addresses).  Integer counts are order-independent, so the result is reproducible bit for bit.
 __global__ __launch_bounds__(256) void k_metrics_rows(long N, const float* scores, const float* valid,
@@ -1191,7 +1198,8 @@ extern "C" int pstl_refinement(const pstl_cfg* cfg, const float* s0, const float
     int* ints = reinterpret_cast<int*>(work + (size_t)kMixPlanes * blocks * kWave);
     a.mix_count = ints;
     a.mix_list = ints + ((cfg->bs + 63) / 64) * 64;
-    if (hipMemsetAsync(a.mix_count, 0, (size_t)cfg->bs * sizeof(int), st) != hipSuccess) return PSTL_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((cfg->bs + 255) / 256)), dim3(256), 0, st, (int)cfg->bs,
+                       reinterpret_cast<unsigned*>(a.mix_count));
     const size_t lds_sel = stl_lds_bytes(kScratchFwd, cfg->K, true);
     if (int e = allow_lds(reinterpret_cast<const void*>(k_mix_select<true>), lds_sel)) return e;
     hipLaunchKernelGGL(k_mix_select<true>, dim3(blocks), dim3(kWave), lds_sel, st, a);
@@ -1235,7 +1243,7 @@ extern "C" int pstl_reduce_metrics(const pstl_cfg* cfg, const float* scores, con
   if (cfg->rows_per_scene != 3 * cfg->S) return PSTL_ERR_SHAPE;
   const long N = n_rows(cfg);
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(counts, 0, 8 * sizeof(uint64_t), st) != hipSuccess) return PSTL_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, st, 16, reinterpret_cast<unsigned*>(counts));
   auto* c = reinterpret_cast<unsigned long long*>(counts);
   const long nb = (N + 255) / 256;
   hipLaunchKernelGGL(k_metrics_rows, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, st, N, scores, valid, c,

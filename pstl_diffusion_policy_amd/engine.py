@@ -567,6 +567,47 @@ class Sampler:
         return out
 
 
+class GraphCapture:
+    """`body()` -- a fixed sequence of launches on fixed device buffers -- captured ONCE in a HIP graph and replayed: for
+    launch-bound callers (small batches: the closed loop's 192 rows are ~50 launches of 5-40 us).  What changes between replays
+    must live in device memory the body reads: inputs in static buffers, the noise seed and the guidance-loss scale in a
+    pstl_dyn block (`SceneBatch(..., dyn=...)`, ABI 4).  The library's launches go to the capturing stream like any other work
+    (ffi.stream() is torch's current stream); tensors the body allocates come from the graph's private pool and stay valid --
+    `out` is what the last replay produced.  Same kernels, same arguments, same order as the eager calls: identical results."""
+
+    def __init__(self, body, warmup=2):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):      # eager warm-up on a side stream: allocations, function attributes, host-side caches
+            for _ in range(warmup):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = body()
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+
+class DynBlock:
+    """A pstl_dyn in device memory with a pinned host mirror: set(seed[, grad_scale]) queues ONE 16-byte copy on the current stream."""
+
+    def __init__(self, device):
+        self.host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        self.host_np = self.host.numpy()
+        self.dev = torch.zeros(4, dtype=torch.float32, device=device)
+
+    def set(self, seed, grad_scale=None):
+        seed = int(seed) & (2 ** 64 - 1)
+        self.host_np[0:2].view("uint32")[:] = (seed & 0xffffffff, seed >> 32)
+        if grad_scale is not None:
+            self.host_np[2] = grad_scale
+        self.dev.copy_(self.host, non_blocking=True)
+
+
 def diversity_from_totals(totals, nt=ffi.T):
     """The reference's printed diversity numbers from the 12 additive totals of pstl_diversity (sums over shards add)."""
     t = [float(v) for v in (totals.tolist() if hasattr(totals, "tolist") else totals)]

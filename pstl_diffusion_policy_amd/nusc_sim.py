@@ -15,7 +15,7 @@ import time
 import torch
 
 from . import ffi
-from .engine import PackedWeights, Sampler, SceneBatch
+from .engine import GraphCapture, PackedWeights, Sampler, SceneBatch
 from .synthetic import default_hparams, make_scene_batch
 
 FIXED_STLP = (1.0, 9.0, -3.0, 2.0, 0.1, 0.2)   # vmin, vmax, dmin, dmax, dsafe, thmax (reference nusc_sim.py:467-472)
@@ -134,22 +134,12 @@ class GraphPlanner:
         """(Re-)captures the graph with the sampler's current arithmetic (after a domain fallback: the exact-fp32 kernels)."""
         self._fill(obs, 0)
         self.inp.copy_(self.host)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):          # eager warm-up on the capture stream: allocations, function attributes, caches
-            for _ in range(2):
-                self._body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = self._body()
+        self.graph = GraphCapture(self._body)
 
     def plan(self, obs, seed):
         self._fill(obs, seed)
         self.inp.copy_(self.host, non_blocking=True)
-        self.graph.replay()
-        return self.out.cpu()
+        return self.graph.replay().cpu()
 
 
 def closed_loop(state_dict, n_sim_steps=20, K=8, S=64, diffusion_steps=100, multi_cands=5, guidance=True, guidance_before=10,

@@ -113,3 +113,38 @@ def test_parameters_in_device_memory_equal_parameters_by_value():
         for k in ("final_controls", "final_scores", "sel_controls", "cand_scores"):
             assert torch.equal(got[k], ref[k]), (bs, k)
         assert torch.isfinite(got["final_controls"]).all()
+
+
+def test_graph_replay_of_the_whole_region_equals_eager_including_counters():
+    """engine.GraphCapture over the complete sampling region (what bench.py replays for batches up to 98 304 rows): three
+    replays with different seeds against eager calls -- controls, scores, the satisfaction COUNTERS and the diversity totals.
+    (Round 4: the counters were zeroed by hipMemsetAsync, whose graph node did not replay: from the second replay on they
+    accumulated on top of the previous values.  They are zeroed by a kernel now; the ADE / FDE minima likewise.)"""
+    from pstl_diffusion_policy_amd.engine import DynBlock, GraphCapture, PackedWeights, Sampler, SceneBatch
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    dev = torch.device("cuda:0")
+    hp = default_hparams()
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    bs, S, steps = 12, 64, 12
+    scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=2, S=S, seed=1000, invalid_lane_frac=0.2, stlp_mode="wide").items()
+             if k not in ("params", "pre_stlp", "tj_scores_prior")}
+    guid = dict(enabled=True, before=4, niters=1, lr=0.01)
+    N = bs * S * 3
+    vsum = float(sum(scene[k].sum().item() for k in ("curr_id", "left_id", "right_id"))) * S
+    kw = dict(rect_head=True, multi_cands=3, guidance=guid, want_scores3=False, diversity=True)
+    dyn = DynBlock(dev)
+    dyn.set(0, SceneBatch.loss_scale(vsum, N))
+
+    def body():
+        sb = SceneBatch(scene, S, hp, dev, global_valid_sum=vsum, global_rows=N, dyn=dyn.dev, scale_in_dyn=True)
+        o = sm.sampling_region(sb, steps, None, None, seed=0, **kw)
+        return o["counts"], o["div_totals"], o["final_controls"], o["final_scores"]
+
+    g = GraphCapture(body)
+    for seed in (5, 6, 5):
+        dyn.set(seed)
+        got = [t.clone() for t in g.replay()]
+        ref = sm.sampling_region(SceneBatch(scene, S, hp, dev, global_valid_sum=vsum, global_rows=N), steps, None, None, seed=seed, **kw)
+        for a, k in zip(got, ("counts", "div_totals", "final_controls", "final_scores")):
+            assert torch.equal(a, ref[k]), (seed, k)
+        assert 0 < int(got[0][0]) <= int(got[0][1]) <= N
