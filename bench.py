@@ -257,7 +257,14 @@ class Job:
             counts, _ = sampler.metrics(sb, sc)
             return gather_final(counts, torch.zeros(12, dtype=torch.float64, device=dev))
         if self.train:
-            sm_t = Sampler(PackedWeights(self.sd_live, dev), self.hp, chain_waves=self.chain_waves)   # weights changed: re-pack
+            # the optimiser changed the trained tensors: their networks are packed again, in place (rect_net only without
+            # --joint); max |w| is not read back -- the kernels compare it themselves and train_step reads the domain word
+            if getattr(self, "pw_train", None) is None:
+                self.pw_train = PackedWeights(self.sd_live, dev)
+            else:
+                nets = {k.split(".")[0] for k in self.tnames}
+                self.pw_train.update({k: v for k, v in self.sd_live.items() if k.split(".")[0] in nets}, read_status=False)
+            sm_t = Sampler(self.pw_train, self.hp, chain_waves=self.chain_waves)
             sm_t.trace, sm_t.trace_bwd = sampler.trace, sampler.trace_bwd
             loss, scores = RectTrainer(sm_t).train_step(sb, self.tparams, self.topt, steps, x_T=x_T, noise=z, seed=seed,
                                                         multi_cands=a.multi_cands, coeffs=self.coeffs, e7=self.e7, joint=self.joint)

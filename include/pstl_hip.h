@@ -145,6 +145,10 @@ size_t pstl_packed_status_offset(void);
 /* Re-lays the state_dict out for the kernels (MFMA operand order, transposed encoder matrices).
  * Replaces: Net.load_state_dict + the implicit layout of nn.Linear (nusc_train.py:1213-1215). */
 int pstl_pack_weights(const pstl_weight_ptrs* w, float* packed, void* stream);
+/* The same for the networks an optimiser step changed: packs again, IN PLACE, the networks whose six pointers are all non-null
+ * in `w`, leaves the others as they are (RefineNet training without --joint changes rect_net only: 15 launches instead of 75
+ * per step).  The max |w| status word of a re-packed chain is recomputed; the sticky domain word 2 is left alone. */
+int pstl_repack_weights(const pstl_weight_ptrs* w, float* packed, void* stream);
 /* tbias[t][h] = sum_k W1[h][264+k] * pe(t)[k] for t in [0,steps): the timestep embedding folded into a layer-1
  * bias.  Replaces Net.pos_encoding (nusc_model.py:48-53) + its 32 columns of policy_net layer 1. */
 int pstl_time_bias(const float* packed, int steps, float* tbias /* (steps,256) */, void* stream);

@@ -1876,16 +1876,16 @@ static int pack_chain(const pstl_mlp3& m, int in, int kext_mode, bool with_time,
   return launch_status();
 }
 
-extern "C" int pstl_pack_weights(const pstl_weight_ptrs* w, float* packed, void* stream) {
-  if (!w || !packed) return PSTL_ERR_ARG;
-  if (!mlp_ok(w->ego_encoder) || !mlp_ok(w->neighbor_encoder) || !mlp_ok(w->lane_encoder) || !mlp_ok(w->policy_net))
-    return PSTL_ERR_ARG;
-  hipStream_t st = as_stream(stream);
+// partial = false: the whole buffer (zeroed first; the four networks every checkpoint has are required).
+// partial = true:  only the networks whose six pointers are all there are packed again, in place (an optimiser step changed
+//                  them); the max |w| word of a re-packed chain is recomputed, the sticky domain word is left alone.
+static int pack_impl(const pstl_weight_ptrs* w, float* packed, hipStream_t st, bool partial) {
   const PackLayout L = make_layout();
-  if (hipMemsetAsync(packed, 0, L.total * sizeof(float), st) != hipSuccess) return PSTL_ERR_LAUNCH;
+  if (!partial && hipMemsetAsync(packed, 0, L.total * sizeof(float), st) != hipSuccess) return PSTL_ERR_LAUNCH;
   const pstl_mlp3* encs[3] = {&w->ego_encoder, &w->neighbor_encoder, &w->lane_encoder};
   for (int e = 0; e < 3; ++e) {   // fp32 MFMA A operands (k_enc_gemm)
     const pstl_mlp3& m = *encs[e];
+    if (!mlp_ok(m)) continue;
     const EncOff& o = L.enc[e];
     hipLaunchKernelGGL(k_pack_a, dim3(16 * enc_k16(e)), dim3(256), 0, st, m.w0, enc_in(e), kHid, 16, enc_k16(e), 0,
                        packed + o.a0, enc_in(e));
@@ -1896,15 +1896,35 @@ extern "C" int pstl_pack_weights(const pstl_weight_ptrs* w, float* packed, void*
     hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, st, m.b2, 32, 32, packed + o.b2);
     if (int err = launch_status()) return err;
   }
-  unsigned* status = reinterpret_cast<unsigned*>(packed + L.status);   // (zeroed by the memset above)
-  if (int err = pack_chain(w->policy_net, 303, 1, true, L.pol, packed, status + 0, st)) return err;
-  if (mlp_ok(w->rect_net))
+  unsigned* status = reinterpret_cast<unsigned*>(packed + L.status);   // (zeroed by the memset above when !partial)
+  auto zero_word = [&](int i) {   // (k_copy with no source elements writes the padding value: 0)
+    hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, st, (const float*)packed, 0, 1, packed + L.status + i);
+  };
+  if (mlp_ok(w->policy_net)) {
+    if (partial) zero_word(0);
+    if (int err = pack_chain(w->policy_net, 303, 1, true, L.pol, packed, status + 0, st)) return err;
+  }
+  if (mlp_ok(w->rect_net)) {
+    if (partial) zero_word(1);
     if (int err = pack_chain(w->rect_net, 271, 2, false, L.rect, packed, status + 1, st)) return err;
+  }
   if (mlp_ok(w->merge_net)) {
     const long off6[6] = {L.mrg.w0t, L.mrg.b0, L.mrg.w1t, L.mrg.b1, L.mrg.w2t, L.mrg.b2};
     if (int err = pack_mlp_t(w->merge_net, 40, 32, 40, off6, packed, st)) return err;
   }
   return PSTL_OK;
+}
+
+extern "C" int pstl_pack_weights(const pstl_weight_ptrs* w, float* packed, void* stream) {
+  if (!w || !packed) return PSTL_ERR_ARG;
+  if (!mlp_ok(w->ego_encoder) || !mlp_ok(w->neighbor_encoder) || !mlp_ok(w->lane_encoder) || !mlp_ok(w->policy_net))
+    return PSTL_ERR_ARG;
+  return pack_impl(w, packed, as_stream(stream), false);
+}
+
+extern "C" int pstl_repack_weights(const pstl_weight_ptrs* w, float* packed, void* stream) {
+  if (!w || !packed) return PSTL_ERR_ARG;
+  return pack_impl(w, packed, as_stream(stream), true);
 }
 
 extern "C" int pstl_fill_normal(const pstl_cfg* cfg, int step, float* out, void* stream) {

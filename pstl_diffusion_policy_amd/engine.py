@@ -34,6 +34,19 @@ class PackedWeights:
     def __init__(self, state_dict, device):
         self.device = torch.device(device)
         L = ffi.lib()
+        wp, keep = self._pointers(state_dict)
+        self.has_rect = "rect_net.0.weight" in state_dict
+        self.has_merge = "merge_net.0.weight" in state_dict
+        self.packed = torch.empty(L.pstl_packed_weight_floats(), dtype=torch.float32, device=self.device)
+        ffi.check(L.pstl_pack_weights(ctypes.byref(wp), ffi.ptr(self.packed), ffi.stream()), "pack_weights")
+        so = int(L.pstl_packed_status_offset())
+        self.status = self.packed[so:so + 16]
+        self._tbias = {}
+        self._read_status()
+        del keep
+
+    def _pointers(self, state_dict):
+        """WeightPtrs of the networks `state_dict` holds completely (six tensors each) + the converted copies to keep alive."""
         keep = {}
         wp = ffi.WeightPtrs()
         for name in MLP_NAMES:
@@ -48,21 +61,35 @@ class PackedWeights:
                         t = ffi.f32(t.detach(), self.device)
                         keep[key] = t
                         setattr(m, field, t.data_ptr())
+            have = sum(1 for f, _ in m._fields_ if getattr(m, f))
+            if have not in (0, 6):
+                raise ValueError("state_dict holds %d of the 6 tensors of %s: a network is packed whole" % (have, name))
             setattr(wp, name, m)
-        self.has_rect = "rect_net.0.weight" in state_dict
-        self.has_merge = "merge_net.0.weight" in state_dict
-        self.packed = torch.empty(L.pstl_packed_weight_floats(), dtype=torch.float32, device=self.device)
-        ffi.check(L.pstl_pack_weights(ctypes.byref(wp), ffi.ptr(self.packed), ffi.stream()), "pack_weights")
+        return wp, keep
+
+    def _read_status(self):
         # Status block of the packed buffer (include/pstl_hip.h, pstl_packed_status_offset): max |w| of the weights the MLP
-        # chains carry as half pieces, per network.  Reading it is the synchronisation this constructor needs anyway (the
-        # source blobs in `keep` may be freed after it).
-        so = int(L.pstl_packed_status_offset())
-        self.status = self.packed[so:so + 16]
+        # chains carry as half pieces, per network.  Reading it is a synchronisation (after which converted source blobs may go).
         wmax = [float(v) for v in self.status[:2].cpu()]
         self.chain_wmax = dict(policy_net=wmax[0], rect_net=wmax[1])
         # domain of the default (split-f16) chain arithmetic: |w| < 63.9 (NaN compares false)
         self.split_f16_ok = all(m < ffi.SPLIT_F16_WMAX for m in wmax)
-        self._tbias = {}
+
+    def update(self, state_dict, read_status=True):
+        """Packs again, in place, the networks `state_dict` holds completely (an optimiser step changed them; the others stay):
+        RefineNet training changes rect_net only -- 15 launches instead of the 75 of a full pack.  read_status=False skips the
+        synchronising read of max |w|: the kernels compare the recorded maximum themselves and set the domain word, which a
+        caller that checks it anyway (RectTrainer.train_step) then sees."""
+        wp, keep = self._pointers(state_dict)
+        ffi.check(ffi.lib().pstl_repack_weights(ctypes.byref(wp), ffi.ptr(self.packed), ffi.stream()), "repack_weights")
+        if any(k.startswith("policy_net.") for k in state_dict):
+            self._tbias = {}
+        if read_status:
+            self._read_status()
+        else:
+            self.chain_wmax, self.split_f16_ok = None, True
+            self._keep = keep      # (no synchronisation here: the converted copies live until the next update)
+        return self
 
     def chain_overflowed(self, clear=False):
         """True when a launch on the split-f16 arithmetic since the last clear left a non-finite state: a layer input was

@@ -60,6 +60,7 @@ SIGNATURES = [
     ("pstl_packed_weight_floats", _Z, []),
     ("pstl_packed_status_offset", _Z, []),
     ("pstl_pack_weights", _I, [ctypes.POINTER(WeightPtrs), _P, _P]),
+    ("pstl_repack_weights", _I, [ctypes.POINTER(WeightPtrs), _P, _P]),
     ("pstl_time_bias", _I, [_P, _I, _P, _P]),
     ("pstl_fill_normal", _I, [_C, _I, _P, _P]),
     ("pstl_prepare_scene", _I, [_C] + [_P] * 7),

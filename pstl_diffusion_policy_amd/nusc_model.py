@@ -91,24 +91,29 @@ class Net(nn.Module):
         if self._packed is None or key != self._packed_key:
             if not ps[0].is_cuda:
                 raise RuntimeError("Net must be on the GPU (net.cuda()) before the HIP path can run")
-            self._packed = PackedWeights({k: v for k, v in self.state_dict().items()}, ps[0].device)
+            old = self._packed_key
+            if self._packed is not None and old[0] == key[0] and [n for n, _ in old[1]] == [n for n, _ in key[1]]:
+                # the same networks on the same device: only those a parameter of which changed are packed again, in place
+                # (an optimiser over rect_net.parameters() touches one of the six)
+                changed = {n for (n, sub), (_, sub0) in zip(key[1], old[1]) if sub != sub0}
+                self._packed.update({k: v for k, v in self.state_dict().items() if k.split(".")[0] in changed})
+            else:
+                self._packed = PackedWeights({k: v for k, v in self.state_dict().items()}, ps[0].device)
             self._packed_key = key
         return self._packed
 
     def _pack_key(self):
-        ps = list(self._iter_params())
-        return ps, (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
-
-    def _iter_params(self):
-        """The live Parameter objects in parameters() order, read straight from the six Sequentials' Linear layers."""
+        """(parameters in parameters() order, key): the key holds, per network, the version counter and the storage of every
+        parameter -- whatever way a parameter changes, its network's entry changes."""
+        ps, nets = [], []
         for name in ("ego_encoder", "neighbor_encoder", "lane_encoder", "policy_net", "merge_net", "rect_net"):
             seq = self._modules.get(name)
             if seq is None:
                 continue
-            for layer in seq._modules.values():
-                for p in layer._parameters.values():
-                    if p is not None:
-                        yield p
+            mine = [p for layer in seq._modules.values() for p in layer._parameters.values() if p is not None]
+            ps += mine
+            nets.append((name, (tuple(p._version for p in mine), tuple(p.data_ptr() for p in mine))))
+        return ps, (ps[0].device, tuple(nets))
 
     def chain_arith(self):
         """cfg.chain_waves for this net's weights: the requested arithmetic, or the exact-fp32 kernels when a chain weight is
