@@ -1068,7 +1068,10 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
   const dim3 grid((unsigned)((a.N + kWave - 1) / kWave));
   const bool staged = scene_staged(cfg);
   a.by_mode = rows_by_mode(cfg, staged) ? 1 : 0;
-  const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged);
+#ifndef PSTL_DBG_LDS_PAD
+#define PSTL_DBG_LDS_PAD 0   // (timing builds of tools/dbg/ab.sh: fewer resident wavefronts)
+#endif
+  const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged) + PSTL_DBG_LDS_PAD;
   void (*fn)(GuideArgs) = niters > 1 ? (staged ? k_guidance_iter<true, true> : k_guidance_iter<true, false>)
                                      : (staged ? k_guidance_iter<false, true> : k_guidance_iter<false, false>);
   if (cfg->flags & PSTL_FLAG_NORM_STL)
