@@ -381,11 +381,15 @@ def paper_metric(batches=8):
                "ours_guidance": (common + ["--multi_cands", "10", "--guidance", "--guidance_before", "10", "--guidance_niters", "1",
                                            "--guidance_lr", "0.01", "--n_rolls", "3", "--other"], 0.786)}
     out = {"rows_per_batch": 128 * 64 * 3, "batches": batches, "through": "nusc_train.main (the reference's CLI surface), --kernel_noise"}
+    out["timing"] = "median over the batches after the first, the better of two runs of the command line"
     for name, (argv, paper_s) in configs.items():
-        with contextlib.redirect_stdout(io.StringIO()):
-            md = nt.main(argv)
-        t = md.hist["time"]
-        med = statistics.median(t[1:] if len(t) > 1 else t)
+        med = None
+        for _ in range(2):   # (md["time"] includes the host: one busy spell of a shared box -- seen once: 68 ms -- must not become the figure)
+            with contextlib.redirect_stdout(io.StringIO()):
+                md = nt.main(argv)
+            t = md.hist["time"]
+            m = statistics.median(t[1:] if len(t) > 1 else t)
+            med = m if med is None else min(med, m)
         out[name] = {"time_ms_median": med * 1e3, "trajectories_per_s": out["rows_per_batch"] / med, "stl_sat_rate": md("acc"),
                      "paper_time_ms": paper_s * 1e3}
     return out
