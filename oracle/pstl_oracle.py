@@ -14,8 +14,6 @@ Each function cites the reference lines it restates.  Inputs are scene-indexed (
 3 modes; row r = (b*S + s)*3 + mode, reference nusc_train.py:20,724-754) and are expanded to rows here.
 Weights are a dict with the reference's state_dict keys (numpy or torch float32).
 """
-import math
-
 import numpy as np
 import torch
 

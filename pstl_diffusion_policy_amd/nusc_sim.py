@@ -14,7 +14,6 @@ import time
 
 import torch
 
-from . import ffi
 from .engine import GraphCapture, PackedWeights, Sampler, SceneBatch
 from .synthetic import default_hparams, make_scene_batch
 
