@@ -646,39 +646,45 @@ PSTL_HD float geo_float(unsigned u) {
 // dynamics are a handful of operations per step).  The very calls of stl_eval_rec<false, ., true, .>: same values, bit for bit.
 // ... and of stl_eval_grad's adjoint for the same step (the partials at the recorded winners; K > kRecMaxK: ranked again).
 // ADJ = false: the forward values only (slots 0-2; value-only callers -- scoring -- run clearance_eval without the record).
+// one step of the geometry, written to the slots of step t (o = its slot 0)
+template <bool ADJ = true>
+PSTL_HD void stl_geometry_step(const StlEnv& env, const f4* sel_lane, const float* nei, int K, int t, float x, float y, float th,
+                               float v, float c, float s, float* o, int stride) {
+  const bool use_rec = K <= kRecMaxK;
+  ClearHit ch;
+  clearance_eval<false, ADJ>(env, nei, K, t, x, y, c, s, ch);
+  LaneHit h;
+  lane_eval<false>(sel_lane, x, y, th, h);
+  o[0 * stride] = ch.dn;
+  o[1 * stride] = h.d;
+  o[2 * stride] = h.th;
+  o[3 * stride] = v;      // (the sweeps read the speed here instead of running the dynamics -- 20 sincosf -- once more)
+  if (!ADJ) return;
+  ClearHit cg;
+  if (use_rec) clearance_from_winner(env, nei, t, x, y, c, s, ch.win, cg);
+  else clearance_eval<true>(env, nei, K, t, x, y, c, s, cg);
+  LaneHit hg;
+  lane_eval<true>(sel_lane, x, y, th, hg, use_rec ? h.jb : -1);
+  o[4 * stride] = cg.d_dx;
+  o[5 * stride] = cg.d_dy;
+  o[6 * stride] = cg.d_dth;
+  o[7 * stride] = hg.th;
+  o[8 * stride] = hg.dd_dx;
+  o[9 * stride] = hg.dd_dy;
+  o[10 * stride] = hg.dth_dth;
+  o[11 * stride] = c;
+  o[12 * stride] = s;
+}
+
 template <bool ADJ = true, class Src>
 PSTL_HD void stl_geometry(const StlEnv& env, const f4* sel_lane, const float* nei, int K, Src src, int t0, int t1, float* out,
                           int stride) {
-  const bool use_rec = K <= kRecMaxK;
   PSTL_NOUNROLL
   for (int t = 0; t < t1; ++t) {
     float x, y, th, v, c, s;
     src.get(t, x, y, th, v, c, s);
     if (t < t0) continue;
-    float* o = out + (kGeoSlots * t) * stride;
-    ClearHit ch;
-    clearance_eval<false, ADJ>(env, nei, K, t, x, y, c, s, ch);
-    LaneHit h;
-    lane_eval<false>(sel_lane, x, y, th, h);
-    o[0 * stride] = ch.dn;
-    o[1 * stride] = h.d;
-    o[2 * stride] = h.th;
-    o[3 * stride] = v;      // (the sweeps read the speed here instead of running the dynamics -- 20 sincosf -- once more)
-    if (!ADJ) continue;
-    ClearHit cg;
-    if (use_rec) clearance_from_winner(env, nei, t, x, y, c, s, ch.win, cg);
-    else clearance_eval<true>(env, nei, K, t, x, y, c, s, cg);
-    LaneHit hg;
-    lane_eval<true>(sel_lane, x, y, th, hg, use_rec ? h.jb : -1);
-    o[4 * stride] = cg.d_dx;
-    o[5 * stride] = cg.d_dy;
-    o[6 * stride] = cg.d_dth;
-    o[7 * stride] = hg.th;
-    o[8 * stride] = hg.dd_dx;
-    o[9 * stride] = hg.dd_dy;
-    o[10 * stride] = hg.dth_dth;
-    o[11 * stride] = c;
-    o[12 * stride] = s;
+    stl_geometry_step<ADJ>(env, sel_lane, nei, K, t, x, y, th, v, c, s, out + (kGeoSlots * t) * stride, stride);
   }
 }
 
@@ -692,12 +698,11 @@ struct FwdOut {  // what the adjoint needs from the forward sweep
 //   XY != -1    : additionally parks the state of every 4th step at scratch[XY ...] (x, y, th, v; 5 each)  (adjoint)
 //   REC         : records the winners of the hard minima (lane segment, neighbour, circle pair) per step in `rec`
 //                 (for the adjoint; !ALL3)
-//   PRE         : the geometry of every step was computed ahead (stl_geometry): read from `pre` instead   (REC, !ALL3)
-template <bool ALL3, int XY, bool REC, bool NORM, class Src, bool PRE = false>
+// (The latency layout, whose waves compute the geometry of every step ahead, has sweeps of its own: stl_pre_chain, adj_pre_*.)
+template <bool ALL3, int XY, bool REC, bool NORM, class Src>
 PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Src src, Scratch st,
-                           int tab, float* out3, FwdOut* fo, Rec& rec, GeoPre pre = GeoPre{nullptr, 0}) {
+                           int tab, float* out3, FwdOut* fo, Rec& rec) {
   static_assert(!(ALL3 && REC), "winners are recorded for the selected formula only");
-  static_assert(!PRE || !ALL3, "the precomputed geometry is that of the selected formula");
   const float tau = env.tau;
   Lse gv1, gv2, gsafe, g1, g2, g3;
   gv1.init();
@@ -713,10 +718,9 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
   const f4* sel_lane = lanes + (mode < 3 ? mode : 0) * kNseg;
   PSTL_NOUNROLL
   for (int t = 0; t < kT; ++t) {
-    float x = 0.0f, y = 0.0f, th = 0.0f, v, c = 1.0f, s = 0.0f;
-    if (PRE) v = pre.at(t, 3);   // (everything else of the state went into the precomputed geometry; the adjoint reads v, cos, sin there too)
-    else src.get(t, x, y, th, v, c, s);
-    if (!PRE && XY >= 0 && (t & (kCkStride - 1)) == 0) {   // state checkpoints for the adjoint (every 4th step)
+    float x, y, th, v, c, s;
+    src.get(t, x, y, th, v, c, s);
+    if (XY >= 0 && (t & (kCkStride - 1)) == 0) {   // state checkpoints for the adjoint (every 4th step)
       const int k = t / kCkStride;
       st.at(XY + k) = x;
       st.at(XY + kCk + k) = y;
@@ -727,16 +731,10 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
     gv2.add(-over<NORM>(-v + r.vmax, r.vf) * tau);
     ClearHit ch;
     LaneHit h;
-    if (PRE) {
-      ch.dn = pre.at(t, 0);
-      h.d = pre.at(t, 1);
-      h.th = pre.at(t, 2);
-    } else {
-      clearance_eval<false, REC>(env, nei, K, t, x, y, c, s, ch);
-    }
+    clearance_eval<false, REC>(env, nei, K, t, x, y, c, s, ch);
     gsafe.add(-over<NORM>(ch.dn - r.dsafe, r.sf) * tau);
-    if (!PRE) lane_eval<false>(ALL3 ? lanes : sel_lane, x, y, th, h);
-    if (REC && !PRE) rec_put(rec, t, (unsigned)h.jb, ch.win);   // (PRE: the adjoint's partials are precomputed too, nobody reads the record)
+    lane_eval<false>(ALL3 ? lanes : sel_lane, x, y, th, h);
+    if (REC) rec_put(rec, t, (unsigned)h.jb, ch.win);
     {
       const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df);
       const float a3 = -((r.thmax - h.th) / r.thmax) * tau;
@@ -798,11 +796,11 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
   return score;
 }
 
-template <bool ALL3, int XY, bool NORM = false, bool PRE = false, class Src>
+template <bool ALL3, int XY, bool NORM = false, class Src>
 PSTL_HD float stl_eval(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, Src src, Scratch st,
-                       int tab, float* out3, FwdOut* fo, GeoPre pre = GeoPre{nullptr, 0}) {
+                       int tab, float* out3, FwdOut* fo) {
   Rec none;
-  return stl_eval_rec<ALL3, XY, false, NORM, Src, PRE>(env, r, lanes, nei, K, src, st, tab, out3, fo, none, pre);
+  return stl_eval_rec<ALL3, XY, false, NORM, Src>(env, r, lanes, nei, K, src, st, tab, out3, fo, none);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -821,34 +819,51 @@ PSTL_HD float pick4(const float (&a)[kCkStride], int i) {   // register array, d
   return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
 }
 
-template <bool NORM = false, bool PRE = false, class DScoreFn, class EmitFn>
-PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, const float* s0,
-                            const float* u, Scratch st, float wscale, float ascale, DScoreFn dscore_fn, EmitFn emit,
-                            long us = 1, bool inert = false, GeoPre pre = GeoPre{nullptr, 0}) {
-  const float tau = env.tau;
-  const int mode = r.mode;
-  // inert: the caller knows that this row's score cannot reach the result (its loss weight is zero -- an invalid lane):
-  // every gradient is exactly zero, so neither sweep is needed (the returned score is then meaningless).
-  if (mode >= 3 || inert) {
-    PSTL_NOUNROLL
-    for (int t = kT - 1; t >= 0; --t) {   // emit() is always called for t = T-1 ... 0, in that order
-      float w, a;
-      ctrl_pair(u, us, t, w, a);
-      emit(t, 0.0f, 0.0f, w, a);
-    }
-    return 1.0f;
+// What the adjoint takes over from the forward sweep besides the scratch (checkpoints and suffix tables): 17 registers.
+// (k_guidance_iter's two-launch form hands both through device memory: the rows whose loss is active are compacted between
+// the sweeps, stl_kernels.hip.)
+struct AdjState {
+  FwdOut fo;
+  Rec rec;
+};
+
+// emit() is always called for t = T-1 ... 0, in that order; a row without gradient hands it exact zeros
+template <class EmitFn>
+PSTL_HD void stl_grad_zero(const float* u, long us, EmitFn emit) {
+  PSTL_NOUNROLL
+  for (int t = kT - 1; t >= 0; --t) {
+    float w, a;
+    ctrl_pair(u, us, t, w, a);
+    emit(t, 0.0f, 0.0f, w, a);
   }
-  const f4* lane = lanes + mode * kNseg;
-  // scratch: [checkpoints 4 x 5 | suffix tables 2 x 10]; with the precomputed geometry there are no checkpoints: the tables only
-  const int CKP = 0, LB = PRE ? 0 : 4 * kCk, LT = LB + kFwin;
-  // ---- forward sweep ------------------------------------------------------------------------------------------
+}
+
+// scratch: [checkpoints 4 x 5 | suffix tables 2 x 10]
+template <bool NORM = false>
+PSTL_HD float stl_grad_forward(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, const float* s0,
+                               const float* u, Scratch st, float wscale, float ascale, long us, AdjState& S) {
+  const int LB = 4 * kCk;
   FwdOut fo;
   Rec rec;
   rec_clear(rec);
+  const float score = stl_eval_rec<false, 0, true, NORM, DynSrc>(env, r, lanes, nei, K, DynSrc(s0, u, wscale, ascale, env.dt, us), st,
+                                                                 LB, nullptr, &fo, rec);
+  S.fo = fo;
+  S.rec = rec;
+  return score;
+}
+
+template <bool NORM = false, class EmitFn>
+PSTL_HD void stl_grad_adjoint(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, const float* u,
+                              Scratch st, float wscale, float ascale, long us, const AdjState& S, float dscore_in, EmitFn emit) {
+  const float tau = env.tau;
+  const int mode = r.mode;
+  const f4* lane = lanes + mode * kNseg;
+  const int CKP = 0, LB = 4 * kCk, LT = LB + kFwin;
   const bool use_rec = K <= kRecMaxK;   // uniform; with more neighbours the record is written but not trusted
-  const float score = stl_eval_rec<false, 0, true, NORM, DynSrc, PRE>(env, r, lanes, nei, K, DynSrc(s0, u, wscale, ascale, env.dt, us),
-                                                                      st, LB, nullptr, &fo, rec, pre);
-  const float Lv1 = fo.Lv1, Lv2 = fo.Lv2, Ls = fo.Ls, L1 = fo.L1, L2 = fo.L2, L3 = fo.L3, Lfb = fo.Lfb, Lft = fo.Lft;
+  const Rec rec = S.rec;
+  const float score = S.fo.score;
+  const float Lv1 = S.fo.Lv1, Lv2 = S.fo.Lv2, Ls = S.fo.Ls, L1 = S.fo.L1, L2 = S.fo.L2, L3 = S.fo.L3, Lfb = S.fo.Lfb, Lft = S.fo.Lft;
   float V[6];
   int n;
   if (mode == 0) {
@@ -859,16 +874,6 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     n = 5;
   }
   const float Lout = -score * tau;  // logsumexp of (-V_i tau)
-  const float dscore_in = dscore_fn(score);
-  if (dscore_in == 0.0f) {   // e.g. a hinge loss on a satisfied row: the adjoint would produce exact zeros
-    PSTL_NOUNROLL
-    for (int t = kT - 1; t >= 0; --t) {
-      float w, a;
-      ctrl_pair(u, us, t, w, a);
-      emit(t, 0.0f, 0.0f, w, a);
-    }
-    return score;
-  }
   float om[6];
   PSTL_UNROLL
   for (int i = 0; i < 6; ++i) om[i] = i < n ? PSTL_EXP(-V[i] * tau - Lout) * dscore_in : 0.0f;  // d score / d V_i
@@ -906,7 +911,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   for (int blk = kCk - 1; blk >= 0; --blk) {
     float bx[kCkStride], by[kCkStride], bth[kCkStride], bv[kCkStride], bc[kCkStride], bs[kCkStride];
     float bw[kCkStride], ba[kCkStride];   // stored controls of steps 4blk-1, 4blk, 4blk+1, 4blk+2: the ones emit() is called for
-    if (!PRE) {
+    {
       float x = st.at(CKP + blk), y = st.at(CKP + kCk + blk), th = st.at(CKP + 2 * kCk + blk), v = st.at(CKP + 3 * kCk + blk);
       CtrlReader rd(u, us);
       if (blk > 0) ctrl_pair(u, us, blk * kCkStride - 1, bw[0], ba[0]);
@@ -934,23 +939,14 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   for (int i = kCkStride - 1; i >= 0; --i) {
     const int t = blk * kCkStride + i;
     if (t == 0) break;
-    float x = 0.0f, y = 0.0f, th = 0.0f, v, c, s;
-    if (PRE) {
-      v = pre.at(t, 3), c = pre.at(t, 11), s = pre.at(t, 12);
-    } else {
-      x = pick4(bx, i), y = pick4(by, i), th = pick4(bth, i), v = pick4(bv, i), c = pick4(bc, i), s = pick4(bs, i);
-    }
+    const float x = pick4(bx, i), y = pick4(by, i), th = pick4(bth, i), v = pick4(bv, i), c = pick4(bc, i), s = pick4(bs, i);
     // direct partials of the score w.r.t. state t
     float gx, gy, gth, gv;
     // (--norm_stl: the predicates are a / f; the chain rule adds the factor 1 / f, as autograd's division does)
     gv = o_v1 * PSTL_EXP(-over<NORM>(v - r.vmin, r.vf) * tau - Lv1) - o_v2 * PSTL_EXP(-over<NORM>(-v + r.vmax, r.vf) * tau - Lv2);
     if (NORM) gv = gv / r.vf;
     ClearHit ch;
-    if (PRE) {
-      // (the clearance and the lane distance themselves: the adjoint's evaluation repeats the forward sweep's operations on
-      // the same operands, so the forward sweep's slots hold its values)
-      ch.dn = pre.at(t, 0), ch.d_dx = pre.at(t, 4), ch.d_dy = pre.at(t, 5), ch.d_dth = pre.at(t, 6);
-    } else if (use_rec) {
+    if (use_rec) {
       clearance_from_winner(env, nei, t, x, y, c, s, rec_win(rec, t), ch);
     } else {
       clearance_eval<true>(env, nei, K, t, x, y, c, s, ch);
@@ -961,11 +957,7 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     gy = gs * ch.d_dy;
     gth = gs * ch.d_dth;
     LaneHit h;
-    if (PRE) {
-      h.d = pre.at(t, 1), h.th = pre.at(t, 7), h.dd_dx = pre.at(t, 8), h.dd_dy = pre.at(t, 9), h.dth_dth = pre.at(t, 10);
-    } else {
-      lane_eval<true>(lane, x, y, th, h, use_rec ? (int)rec_seg(rec, t) : -1);
-    }
+    lane_eval<true>(lane, x, y, th, h, use_rec ? (int)rec_seg(rec, t) : -1);
     const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df), s3 = (r.thmax - h.th) * inv_thmax;
     float gd, gsth;  // d score / d d_t , d score / d s3_t
     if (mode == 0) {
@@ -993,15 +985,242 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
     lth = nlth;
     lv = nlv;
     // state_t = f(state_{t-1}, u_{t-1}):  th_t = th_{t-1} + w dt ; v_t = v_{t-1} + a dt
-    if (PRE) {
-      float w0, a0;
-      ctrl_pair(u, us, t - 1, w0, a0);   // (not yet rewritten: emit() has only reached later steps)
-      emit(t - 1, lth * dt * wscale, lv * dt * ascale, w0, a0);
+    emit(t - 1, lth * dt * wscale, lv * dt * ascale, pick4(bw, i), pick4(ba, i));
+  }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Both sweeps over precomputed geometry, in parts (latency layout of k_guidance_iter).  What one wavefront used to walk in
+// 20 + 19 dependent steps -- six running log-sum-exps forwards, ~110 instructions of soft-min weights and partial
+// derivatives per step backwards, then the costate -- splits into
+//   (0) the forward sweep's chains, which share nothing but their inputs: four wavefronts take one group each;
+//   (1) the score and the weights of the formula's terms, once per row;
+//   (2) the direct partials of the score with respect to the state of step t, which need nothing of the other steps: the
+//       waves of the workgroup take two steps each;
+//   (3) the costate recursion, ~20 instructions per step.
+// The expressions are stl_eval_rec's and stl_grad_adjoint's, operation for operation, each chain in its own order: same bits.
+// Scratch layout of the precomputed-geometry form: suffix tables LB = 0, LT = kFwin.
+// ---------------------------------------------------------------------------------------------------------------
+struct AdjCtx {   // 12 words per row
+  float Lv1, Lv2, Ls, L1, L2, L3;   // (lane changes: L1 = Lfb, L3 = Lft, L2 unused)
+  float om[6];
+};
+
+// part 0, chain group `which` of a row of mode 0, 1 or 2: 0 = speed (o0 = Lv1, o1 = Lv2), 1 = clearance (o0 = Ls),
+// 2 = lane distance (mode 0: o0 = L1, o1 = L2; lane changes: the band -- o0 = Lfb, table LB left as the adjoint's Lambda_m),
+// 3 = heading (mode 0: o0 = L3; lane changes: o0 = Lft, table LT).  (The Lambda recurrence is the adjoint's; with LAMBDA it
+// runs for every row, its result unread when the row has no gradient.)
+struct ChainOut {
+  float o0, o1;
+};
+template <bool NORM = false, bool LAMBDA = true>
+PSTL_HD ChainOut stl_pre_chain(int which, const StlEnv& env, const StlRow& r, GeoPre pre, Scratch st) {
+  const float tau = env.tau;
+  const int mode = r.mode;
+  float o0 = 0.0f, o1 = 0.0f;
+  if (which == 0) {
+    Lse gv1, gv2;
+    gv1.init();
+    gv2.init();
+    PSTL_NOUNROLL
+    for (int t = 0; t < kT; ++t) {
+      const float v = pre.at(t, 3);
+      gv1.add(-over<NORM>(v - r.vmin, r.vf) * tau);
+      gv2.add(-over<NORM>(-v + r.vmax, r.vf) * tau);
+    }
+    o0 = gv1.value(), o1 = gv2.value();
+  } else if (which == 1) {
+    Lse gsafe;
+    gsafe.init();
+    PSTL_NOUNROLL
+    for (int t = 0; t < kT; ++t) gsafe.add(-over<NORM>(pre.at(t, 0) - r.dsafe, r.sf) * tau);
+    o0 = gsafe.value();
+  } else if (mode == 0) {
+    if (which == 2) {
+      Lse g1, g2;
+      g1.init();
+      g2.init();
+      PSTL_NOUNROLL
+      for (int t = 0; t < kT; ++t) {
+        const float d = pre.at(t, 1);
+        const float s1 = over<NORM>(d - r.dmin, r.df), s2 = over<NORM>(-d + r.dmax, r.df);
+        g1.add(-s1 * tau);
+        g2.add(-s2 * tau);
+      }
+      o0 = g1.value(), o1 = g2.value();
     } else {
-      emit(t - 1, lth * dt * wscale, lv * dt * ascale, pick4(bw, i), pick4(ba, i));
+      Lse g3;
+      g3.init();
+      PSTL_NOUNROLL
+      for (int t = 0; t < kT; ++t) g3.add(-((r.thmax - pre.at(t, 2)) / r.thmax) * tau);
+      o0 = g3.value();
+    }
+  } else {
+    // one half of ReachAcc (the band or the heading term): first kFwin values parked, the tail as one running log-sum-exp,
+    // the suffix scan, the outer soft-max, then the adjoint's Lambda recurrence over the same table
+    const int base = which == 2 ? 0 : kFwin;
+    Lse tail, f;
+    tail.init();
+    f.init();
+    // (the values of the 20 steps are independent of one another: made in two unrolled batches of ten, so that their
+    // exp / log latencies overlap, then fed to the table and the running tail in the sweep's order)
+    PSTL_UNROLL
+    for (int half = 0; half < 2; ++half) {
+      float av[kFwin];
+      PSTL_UNROLL
+      for (int k = 0; k < kFwin; ++k) {
+        const int t = half * kFwin + k;
+        if (which == 2) {
+          const float d = pre.at(t, 1);
+          const float s1 = over<NORM>(d - r.dmin, r.df), s2 = over<NORM>(-d + r.dmax, r.df);
+          const float band = -(lse2(-s1 * tau, -s2 * tau) / tau);
+          av[k] = -band * tau;
+        } else {
+          av[k] = -((r.thmax - pre.at(t, 2)) / r.thmax) * tau;
+        }
+      }
+      PSTL_UNROLL
+      for (int k = 0; k < kFwin; ++k) {
+        if (half == 0) st.at(base + k) = av[k];
+        else tail.add(av[k]);
+      }
+    }
+    PSTL_NOUNROLL
+    for (int k = kFwin - 1; k >= 0; --k) {
+      tail.add(st.at(base + k));
+      const float l = tail.value();
+      st.at(base + k) = l;
+      f.add(-(l / tau) * tau);
+    }
+    const float Lf = f.value();
+    o0 = Lf;
+    if (!LAMBDA) return ChainOut{o0, o1};   // (value-only callers: scoring)
+    float sb = 0.0f, l_prev = 0.0f;
+    PSTL_NOUNROLL
+    for (int k = 0; k < kFwin; ++k) {
+      const float l = st.at(base + k);
+      const float q = PSTL_EXP(-l - Lf);
+      sb = (k == 0) ? q : sb * PSTL_EXP(l - l_prev) + q;
+      st.at(base + k) = l - PSTL_LOG(sb);
+      l_prev = l;
     }
   }
+  return ChainOut{o0, o1};
+}
+
+// part 1: the score from the chains' values (stl_eval_rec's tail) and d score / d V_i times the loss's derivative
+// (dscore_fn(score), 0 = no gradient: om is not written then); returns the score
+template <class DScoreFn>
+PSTL_HD float adj_pre_weights(const StlEnv& env, int mode, AdjCtx& C, DScoreFn dscore_fn, float& dscore_in) {
+  const float tau = env.tau;
+  const float Lv1 = C.Lv1, Lv2 = C.Lv2, Ls = C.Ls;
+  const float Vv1 = -(Lv1 / tau), Vv2 = -(Lv2 / tau), Vs = -(Ls / tau);
+  float V[6];
+  int n;
+  float score;
+  if (mode == 0) {
+    const float v6[6] = {Vv1, Vv2, -(C.L1 / tau), -(C.L2 / tau), -(C.L3 / tau), Vs};
+    score = conj6(v6, 6, tau);
+    V[0] = -(Lv1 / tau), V[1] = -(Lv2 / tau), V[2] = -(C.L1 / tau), V[3] = -(C.L2 / tau), V[4] = -(C.L3 / tau), V[5] = -(Ls / tau);
+    n = 6;
+  } else {
+    const float Lfb = C.L1, Lft = C.L3;
+    const float v1[5] = {Vv1, Vv2, Lfb / tau, Lft / tau, Vs};
+    score = conj6(v1, 5, tau);
+    V[0] = -(Lv1 / tau), V[1] = -(Lv2 / tau), V[2] = Lfb / tau, V[3] = Lft / tau, V[4] = -(Ls / tau);
+    n = 5;
   }
+  dscore_in = dscore_fn(score);
+  if (dscore_in == 0.0f) return score;
+  const float Lout = -score * tau;
+  PSTL_UNROLL
+  for (int i = 0; i < 6; ++i) C.om[i] = i < n ? PSTL_EXP(-V[i] * tau - Lout) * dscore_in : 0.0f;
+  return score;
+}
+
+// part 2: direct partials of the score with respect to (x, y, heading, speed) of step t >= 1, from the geometry slots of that step
+template <bool NORM = false>
+PSTL_HD void adj_pre_direct(const StlEnv& env, const StlRow& r, const AdjCtx& C, GeoPre pre, Scratch st, int t, float& gx,
+                            float& gy, float& gth, float& gv) {
+  const float tau = env.tau;
+  const int mode = r.mode;
+  const int LB = 0, LT = kFwin;
+  const float inv_thmax = PSTL_RCP_ADJ(r.thmax);
+  const float o_v1 = C.om[0], o_v2 = C.om[1], o_s = (mode == 0) ? C.om[5] : C.om[4];
+  const float v = pre.at(t, 3);
+  gv = o_v1 * PSTL_EXP(-over<NORM>(v - r.vmin, r.vf) * tau - C.Lv1) - o_v2 * PSTL_EXP(-over<NORM>(-v + r.vmax, r.vf) * tau - C.Lv2);
+  if (NORM) gv = gv / r.vf;
+  ClearHit ch;
+  ch.dn = pre.at(t, 0), ch.d_dx = pre.at(t, 4), ch.d_dy = pre.at(t, 5), ch.d_dth = pre.at(t, 6);
+  float gs = o_s * PSTL_EXP(-over<NORM>(ch.dn - r.dsafe, r.sf) * tau - C.Ls);
+  if (NORM) gs = gs / r.sf;
+  gx = gs * ch.d_dx;
+  gy = gs * ch.d_dy;
+  gth = gs * ch.d_dth;
+  LaneHit h;
+  h.d = pre.at(t, 1), h.th = pre.at(t, 7), h.dd_dx = pre.at(t, 8), h.dd_dy = pre.at(t, 9), h.dth_dth = pre.at(t, 10);
+  const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df), s3 = (r.thmax - h.th) * inv_thmax;
+  float gd, gsth;
+  if (mode == 0) {
+    gd = C.om[2] * PSTL_EXP(-s1 * tau - C.L1) - C.om[3] * PSTL_EXP(-s2 * tau - C.L2);
+    gsth = C.om[4] * PSTL_EXP(-s3 * tau - C.L3);
+  } else {
+    const float a1 = -s1 * tau, a2 = -s2 * tau;
+    const float lp = lse2(a1, a2);
+    const float ab = lp, a3 = -s3 * tau;
+    const int m = t < kFwin - 1 ? t : kFwin - 1;
+    const float wb = PSTL_EXP(ab - st.at(LB + m));
+    const float wt = PSTL_EXP(a3 - st.at(LT + m));
+    gd = C.om[2] * wb * (PSTL_EXP(a1 - lp) - PSTL_EXP(a2 - lp));
+    gsth = C.om[3] * wt;
+  }
+  if (NORM) gd = gd / r.df;
+  gx += gd * h.dd_dx;
+  gy += gd * h.dd_dy;
+  gth += gsth * (-inv_thmax) * h.dth_dth;
+}
+
+// part 3: lambda_t = direct_t + J_t^T lambda_{t+1}, t = T-1 ... 1; direct(t, gx, gy, gth, gv) hands back part 2's values,
+// emit(t, gw, ga) takes the gradient with respect to the control pair of step t, t = T-1 ... 0
+template <class DirectFn, class EmitFn>
+PSTL_HD void adj_pre_costate(const StlEnv& env, GeoPre pre, float wscale, float ascale, DirectFn direct, EmitFn emit) {
+  const float dt = env.dt;
+  emit(kT - 1, 0.0f, 0.0f);  // the last control never reaches a scored state
+  float lx = 0.0f, ly = 0.0f, lth = 0.0f, lv = 0.0f;
+  PSTL_NOUNROLL
+  for (int t = kT - 1; t >= 1; --t) {
+    const float v = pre.at(t, 3), c = pre.at(t, 11), s = pre.at(t, 12);
+    float gx, gy, gth, gv;
+    direct(t, gx, gy, gth, gv);
+    const float nlth = gth + lth + lx * (-(v * s) * dt) + ly * ((v * c) * dt);
+    const float nlv = gv + lv + lx * (c * dt) + ly * (s * dt);
+    lx = gx + lx;
+    ly = gy + ly;
+    lth = nlth;
+    lv = nlv;
+    emit(t - 1, lth * dt * wscale, lv * dt * ascale);
+  }
+}
+
+template <bool NORM = false, class DScoreFn, class EmitFn>
+PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, const float* s0,
+                            const float* u, Scratch st, float wscale, float ascale, DScoreFn dscore_fn, EmitFn emit,
+                            long us = 1, bool inert = false) {
+  // inert: the caller knows that this row's score cannot reach the result (its loss weight is zero -- an invalid lane):
+  // every gradient is exactly zero, so neither sweep is needed (the returned score is then meaningless).
+  if (r.mode >= 3 || inert) {
+    stl_grad_zero(u, us, emit);
+    return 1.0f;
+  }
+  AdjState S;
+  const float score = stl_grad_forward<NORM>(env, r, lanes, nei, K, s0, u, st, wscale, ascale, us, S);
+  const float dscore_in = dscore_fn(score);
+  if (dscore_in == 0.0f) {   // e.g. a hinge loss on a satisfied row: the adjoint would produce exact zeros
+    stl_grad_zero(u, us, emit);
+    return score;
+  }
+  stl_grad_adjoint<NORM>(env, r, lanes, nei, K, u, st, wscale, ascale, us, S, dscore_in, emit);
   return score;
 }
 

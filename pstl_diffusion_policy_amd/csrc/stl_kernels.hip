@@ -139,8 +139,26 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_stl_for
         stl_geometry<false>(a.env, lanes + r.mode * kNseg, nei, a.K, src, (kT / kSplitWaves) * wq, (kT / kSplitWaves) * (wq + 1),
                             geo + lane, kWave);
       __syncthreads();
+      // the forward sweep's chains on waves 0-3, one group each, then wave 0 combines them (stl_core.hpp, stl_pre_chain: as in
+      // the guidance kernel's latency layout; their values travel through slots 4-9 of step 0, which value-only geometry leaves alone)
+      float* g0 = geo + lane;
+      if (wq < 4 && live && r.mode < 3) {
+        const ChainOut co = stl_pre_chain<NORM, false>(wq, a.env, r, GeoPre{g0, kWave}, st);
+        if (wq == 0) g0[4 * kWave] = co.o0, g0[5 * kWave] = co.o1;
+        else if (wq == 1) g0[6 * kWave] = co.o0;
+        else if (wq == 2) g0[7 * kWave] = co.o0, g0[8 * kWave] = co.o1;
+        else g0[9 * kWave] = co.o0;
+      }
+      __syncthreads();
       if (wq != 0 || !live) continue;
-      score = stl_eval<false, -1, NORM, true>(a.env, r, lanes, nei, a.K, src, st, 0, o3, nullptr, GeoPre{geo + lane, kWave});
+      o3[0] = o3[1] = o3[2] = 0.0f;
+      score = 1.0f;   // (an outlier mode scores the constant 1: nusc_train.py:150-151)
+      if (r.mode < 3) {
+        AdjCtx C;
+        C.Lv1 = g0[4 * kWave], C.Lv2 = g0[5 * kWave], C.Ls = g0[6 * kWave], C.L1 = g0[7 * kWave], C.L2 = g0[8 * kWave], C.L3 = g0[9 * kWave];
+        float unused;
+        score = adj_pre_weights(a.env, r.mode, C, [](float) { return 0.0f; }, unused);
+      }
     } else
     if (GIVEN) {
       const GivenSrc src = {reinterpret_cast<const f4*>(a.states) + ((long)rep * a.N + row) * kT};
@@ -391,20 +409,79 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
     // Wave 0 leaves every step's gradient and stored controls in LDS; after a barrier each wave updates its own two steps
     // (= one noise quad): the elements are independent, so the ten waves share the Adam / Philox / emission work as well.
     static_assert(kT == 2 * kSplitWaves, "a wave's two time steps are one noise quad");
-    // The adjoint of step t + 1 is the last reader of that step's geometry, and emit(t) comes right after it: (gw, ga, w, a) of
-    // step t are parked in slots 4-7 of step t + 1 (step 19's -- emitted before the adjoint starts -- in step 0's, whose adjoint
-    // slots nobody reads).  No buffer of its own: the workgroup stays under 80 KB and two fit a CU.
+    // After the geometry both sweeps run in parts (stl_core.hpp, stl_pre_chain / adj_pre_*), a barrier between them:
+    //   (0) waves 0-3 each walk one group of the forward sweep's running log-sum-exps over the 20 steps (speed | clearance |
+    //       lane distance or band | heading), the lane changes' suffix tables included;
+    //   (1) wave 0 combines them into the score, the hinge and the weights of the formula's terms;
+    //   (2) every wave computes the direct partials of its own two time steps (~110 instructions per step that used to sit on
+    //       wave 0's serial path);
+    //   (3) wave 0 runs the costate recursion (~20 per step) and leaves every step's gradient in LDS;
+    //   (4) every wave updates its own two steps (= one noise quad; the stored controls it reads itself).
+    // Measured per launch at 192 rows, K = 2, before the split: geometry 14 us, forward sweep 11, adjoint 10, update 2.
+    // No buffer of its own for any of it (the workgroup stays under 80 KB and two fit a CU) -- all in slots nobody reads any more:
+    //   the chains' values (Lv1, Lv2, Ls, L1 | Lfb, L2, L3 | Lft): slots 4-9 of step 0 (adjoint slots; step 0 has no adjoint);
+    //   the six weights: slots 0-3, 10, 11 of step 0 (the chains have read step 0's forward values); slot 12: 1 = the row
+    //   has no gradient (satisfied, invalid or an outlier mode);
+    //   direct partials (gx, gy, gth, gv) of step t: slots 4-7 of step t, over the clearance partials they were made from;
+    //   gradient (gw, ga) of step t: slots 0, 1 of step t (forward values part 2 has consumed).
     float* geo_l = lds + NS * kWave + stl_table_floats(a.K) + lane;
-    auto upd_at = [=](int t, int j) -> float* { return geo_l + (kGeoSlots * (t + 1 == kT ? 0 : t + 1) + 4 + j) * kWave; };
-    if (wq == 0 && live)
-      stl_eval_grad<NORM, true>(
-          a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
-          [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
-          [=](int t, float gw, float ga, float w0, float a0) {
-            *upd_at(t, 0) = gw, *upd_at(t, 1) = ga, *upd_at(t, 2) = w0, *upd_at(t, 3) = a0;
-          },
-          1, gs == 0.0f, pre);
+    auto slot = [=](int t, int c) -> float* { return geo_l + (kGeoSlots * t + c) * kWave; };
+#ifndef PSTL_DBG_GEXIT
+#define PSTL_DBG_GEXIT 0   // (timing builds: leave after the geometry / part 0 / 1 / 2 / 3)
+#endif
+    if (PSTL_DBG_GEXIT == 1) return;
+    const bool act = live && r.mode < 3 && gs != 0.0f;   // (an invalid lane has zero loss weight: neither sweep is needed)
+    if (wq < 4 && act) {
+      const ChainOut co = stl_pre_chain<NORM>(wq, a.env, r, pre, st);
+      if (wq == 0) *slot(0, 4) = co.o0, *slot(0, 5) = co.o1;
+      else if (wq == 1) *slot(0, 6) = co.o0;
+      else if (wq == 2) *slot(0, 7) = co.o0, *slot(0, 8) = co.o1;
+      else *slot(0, 9) = co.o0;
+    }
     __syncthreads();
+    if (PSTL_DBG_GEXIT == 2) return;
+    auto load_ctx = [=](AdjCtx& C) {
+      C.Lv1 = *slot(0, 4), C.Lv2 = *slot(0, 5), C.Ls = *slot(0, 6), C.L1 = *slot(0, 7), C.L2 = *slot(0, 8), C.L3 = *slot(0, 9);
+    };
+    bool dead = true;
+    if (wq == 0) {
+      if (act) {
+        AdjCtx C;
+        load_ctx(C);
+        float dsc;
+        adj_pre_weights(a.env, r.mode, C, [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; }, dsc);
+        if (dsc != 0.0f) {
+          *slot(0, 0) = C.om[0], *slot(0, 1) = C.om[1], *slot(0, 2) = C.om[2], *slot(0, 3) = C.om[3], *slot(0, 10) = C.om[4],
+          *slot(0, 11) = C.om[5];
+          dead = false;
+        }
+      }
+      *slot(0, 12) = dead ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (PSTL_DBG_GEXIT == 3) return;
+    const bool has_grad = live && *slot(0, 12) == 0.0f;
+    if (has_grad) {
+      AdjCtx C;
+      load_ctx(C);
+      C.om[0] = *slot(0, 0), C.om[1] = *slot(0, 1), C.om[2] = *slot(0, 2), C.om[3] = *slot(0, 3), C.om[4] = *slot(0, 10),
+      C.om[5] = *slot(0, 11);
+      PSTL_NOUNROLL
+      for (int t = 2 * wq + 1; t >= 2 * wq && t >= 1; --t) {
+        float gx, gy, gth, gv;
+        adj_pre_direct<NORM>(a.env, r, C, pre, st, t, gx, gy, gth, gv);
+        *slot(t, 4) = gx, *slot(t, 5) = gy, *slot(t, 6) = gth, *slot(t, 7) = gv;
+      }
+    }
+    __syncthreads();
+    if (PSTL_DBG_GEXIT == 4) return;
+    if (wq == 0 && has_grad)
+      adj_pre_costate(
+          a.env, pre, a.wscale, a.ascale,
+          [=](int t, float& gx, float& gy, float& gth, float& gv) { gx = *slot(t, 4), gy = *slot(t, 5), gth = *slot(t, 6), gv = *slot(t, 7); },
+          [=](int t, float gw, float ga) { *slot(t, 0) = gw, *slot(t, 1) = ga; });
+    __syncthreads();
+    if (PSTL_DBG_GEXIT == 5) return;
     if (!live) return;
     f4 z4 = f4{0.0f, 0.0f, 0.0f, 0.0f};
     if (a.rng && a.step > 1 && last) {
@@ -412,12 +489,15 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
       normal4(seed, a.row_offset + row, wq, a.step, zz);
       z4 = f4{zz[0], zz[1], zz[2], zz[3]};
     }
-    for (int t = 2 * wq + 1; t >= 2 * wq; --t)
-      apply(t, *upd_at(t, 0), *upd_at(t, 1), *upd_at(t, 2), *upd_at(t, 3), z4);
+    for (int t = 2 * wq + 1; t >= 2 * wq; --t) {
+      float w0, a0;
+      ctrl_pair(mu, 1, t, w0, a0);   // (the stored controls of this wave's own steps; nobody else reads or rewrites them)
+      apply(t, has_grad ? *slot(t, 0) : 0.0f, has_grad ? *slot(t, 1) : 0.0f, w0, a0, z4);
+    }
   } else {
     // mu[2t], mu[2t+1] are rewritten by emit(t) while the adjoint walks t = T-1 ... 0; the adjoint has already taken every
     // value it still needs from earlier time steps only (and hands the current one to emit, so mu is not read here)
-    stl_eval_grad<NORM, false>(
+    stl_eval_grad<NORM>(
         a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
         [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
         [=, z4 = f4{0.0f, 0.0f, 0.0f, 0.0f}](int t, float gw, float ga, float w0, float a0) mutable {
@@ -430,7 +510,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
           }
           apply(t, gw, ga, w0, a0, z4);
         },
-        1, gs == 0.0f, pre);   // an invalid lane has zero loss weight: Adam sees exact zeros, only the noise is added
+        1, gs == 0.0f);   // an invalid lane has zero loss weight: Adam sees exact zeros, only the noise is added
   }
 }
 
