@@ -341,6 +341,10 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
     if (!live0) row = a.N - 1;
     float* geo = lds + NS * kWave + stl_table_floats(a.K);
     const StlRow rq = load_row<NORM>(a.stlp, a.hl, row);
+#ifndef PSTL_DBG_GEXIT
+#define PSTL_DBG_GEXIT 0   // (timing builds: leave before / after the geometry / part 0 / 1 / 2 / 3)
+#endif
+    if (PSTL_DBG_GEXIT == 9) return;
     if (live0 && rq.mode < 3 && grad_scale * a.valid[row] != 0.0f)
       stl_geometry(a.env, lanes + rq.mode * kNseg, nei, a.K,
                    DynSrc(a.s0 + (row / a.rows_per_scene) * 4, a.mu + row * (2 * kT), a.wscale, a.ascale, a.env.dt),
@@ -426,9 +430,6 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
     //   gradient (gw, ga) of step t: slots 0, 1 of step t (forward values part 2 has consumed).
     float* geo_l = lds + NS * kWave + stl_table_floats(a.K) + lane;
     auto slot = [=](int t, int c) -> float* { return geo_l + (kGeoSlots * t + c) * kWave; };
-#ifndef PSTL_DBG_GEXIT
-#define PSTL_DBG_GEXIT 0   // (timing builds: leave after the geometry / part 0 / 1 / 2 / 3)
-#endif
     if (PSTL_DBG_GEXIT == 1) return;
     const bool act = live && r.mode < 3 && gs != 0.0f;   // (an invalid lane has zero loss weight: neither sweep is needed)
     if (wq < 4 && act) {
