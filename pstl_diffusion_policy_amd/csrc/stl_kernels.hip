@@ -105,7 +105,8 @@ static bool rows_by_mode(const pstl_cfg* cfg, bool staged) {
 }
 
 // SPLIT: the latency layout of k_guidance_iter for scoring (small batches, the selected formula, controls as input): ten
-// wavefronts compute the geometry of two time steps each into LDS, wave 0 accumulates the formulas.  Bit-identical scores.
+// wavefronts compute the geometry of two time steps each into LDS, waves 0-3 walk one group of the forward sweep's running
+// log-sum-exps each (stl_pre_chain), wave 0 combines them into the score.  Bit-identical scores.
 constexpr int kSplitWaves = 10;             // two time steps per wave
 
 template <bool ALL3, bool STAGED, bool GIVEN, bool NORM = false, bool SPLIT = false>
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_stl_for
     if constexpr (SPLIT) {
       float* geo = lds + NS * kWave + stl_table_floats(a.K);
       const DynSrc src(a.s0 + b * 4, a.controls + ((long)rep * a.N + row) * (2 * kT), 1.0f, 1.0f, a.env.dt);
-      if (rep > rep_lo) __syncthreads();   // wave 0 has read the previous candidate's geometry
+      if (rep > rep_lo) __syncthreads();   // the chains have read the previous candidate's geometry, wave 0 their values
       if (live && r.mode < 3)
         stl_geometry<false>(a.env, lanes + r.mode * kNseg, nei, a.K, src, (kT / kSplitWaves) * wq, (kT / kSplitWaves) * (wq + 1),
                             geo + lane, kWave);
@@ -315,10 +316,11 @@ struct GuideArgs {
 // SPLIT (latency layout, small batches -- the closed-loop caller's 192 rows are three wavefronts on a 256-CU chip): the
 // workgroup is kSplitWaves = 10 wavefronts over the same 64 rows.  Wave q first computes the geometry of time steps [2q, 2q + 2) of its
 // lane's row -- clearance, lane distance, heading term, the winners -- into LDS (stl_geometry: the forward sweep's own calls
-// on the same states; the few dynamics steps before 5q are regenerated); after one barrier wave 0 runs the sweep, the adjoint
-// and the update exactly as the one-wave kernel does, reading the geometry instead of computing it.  Same operations on the
-// same operands in the same order: bit-identical results, with nine tenths of the geometry (the forward sweep's and the
-// adjoint's partials at the recorded winners) off the critical wavefront: 96 -> 45 us per launch at K = 8.
+// on the same states; the dynamics steps before 2q are regenerated).  The sweeps then read where the one-wave kernel computes
+// and are themselves shared out (parts 0-4 below: the forward sweep's chains on four waves, the adjoint's direct partials and
+// the update two steps per wave, only the score and the costate recursion on wave 0).  Same operations on the same operands,
+// every chain in its own order: bit-identical results.  Per launch at K = 8: 96 us (one wave) -> 38 (geometry shared, round 3)
+// -> 25 (sweeps shared, round 4).
 constexpr int kGeoFloats = kGeoSlots * kT;   // per lane
 
 // (SPLIT: two ten-wave workgroups per CU -- 74 KB of LDS each at K = 2 -- need five wavefronts per SIMD: <= 96 registers)
