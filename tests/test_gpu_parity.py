@@ -449,6 +449,38 @@ def test_latency_layout_equals_throughput_layout(dev, bs, S, steps, noise):
     assert torch.equal(outs[0]["counts"], outs[1]["counts"])
 
 
+@pytest.mark.parametrize("K,niters,maximize,norm", [(2, 1, False, False), (8, 1, True, False), (3, 2, False, False),
+                                                    (2, 1, False, True), (15, 1, False, False), (1, 3, True, True)])
+def test_stl_latency_layout_equals_one_wave_layout(dev, K, niters, maximize, norm):
+    """The STL kernels' latency layout (ten wavefronts per 64 rows: geometry two steps per wave, the forward sweep's chains
+    on four waves, the adjoint's direct partials two steps per wave, costate recursion and score on wave 0; stl_core.hpp
+    stl_pre_chain / adj_pre_*) against the one-wave kernels that run the fused sweeps: a 200-scene batch is 600 groups of 64
+    rows (one wave each), its 20-scene shard 60 groups (the latency layout, in the four-candidate scoring launch too: 240
+    workgroups) -- every row of the shard must come out bit for bit, through guided steps with one or several Adam iterations, the maximize loss (every row active), --norm_stl, and
+    K beyond the winners' record (15 > kRecMaxK: the adjoint ranks again)."""
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = dict(_hp())
+    if norm:
+        hp["norm_stl"] = True
+    bs, S, steps = 200, 64, 9
+    scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=K, S=S, seed=41 + K, invalid_lane_frac=0.2, stlp_mode="wide").items()
+             if k not in ("params", "pre_stlp", "tj_scores_prior")}
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp, chain_waves=16)   # (the MLP chains in ONE layout for both sizes)
+    guid = dict(enabled=True, before=5, niters=niters, lr=0.02, maximize=maximize)
+    kw = dict(rect_head=True, multi_cands=4, guidance=guid, want_scores3=False, seed=13)
+    N = bs * S * 3
+    vsum = float(sum(scene[k].sum().item() for k in ("curr_id", "left_id", "right_id"))) * S
+    full = sm.sampling_region(SceneBatch(scene, S, hp, dev), steps, None, None, **kw)
+    lo, hi = 130, 150
+    sub = {k: v[lo:hi].contiguous() for k, v in scene.items()}
+    r0, r1 = lo * S * 3, hi * S * 3
+    part = sm.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=r0, global_valid_sum=vsum, global_rows=N), steps, None, None, **kw)
+    for k in ("final_controls", "final_scores", "sel_controls", "cand_scores"):
+        a, b = part[k], (full[k][:, r0:r1] if k == "cand_scores" else full[k][r0:r1])
+        assert torch.isfinite(a).all() and torch.equal(a, b), k
+
+
 def test_stl_masks_at_scale_match_reference(dev):
     """6144 rows (32 scenes x the reference's sampling_size 64 x 3 modes; LDS-staged scene tables): the three formula
     scores and the satisfaction mask against the reference's own compute_stl_dense, plus the loss gradient."""
