@@ -37,7 +37,7 @@ def main():
                                         ffi.ptr(sb.hl), ffi.ptr(beta), ffi.ptr(alpha), ffi.ptr(alpha_hat), ffi.ptr(None), i, i,
                                         mu_only, ffi.ptr(x), ffi.ptr(dbg), 0, ffi.stream()), "rollout")
         res = {}
-        for mu_only in (1, 0):
+        for mu_only in [int(v) for v in os.environ.get("MU_ORDER", "1,0").split(",")]:
             for _ in range(3):
                 launch(20, mu_only)
             evs = []
