@@ -107,19 +107,31 @@ __device__ __forceinline__ bool lex_less(float ax, float ay, float bx, float by)
 #ifndef PSTL_DIV_SKIP
 #define PSTL_DIV_SKIP 0   // timing-only ablations (tools/dbg): 1 std, 2 hull, 4 | 32 hull scan (32 keeps the sort), 8 entropies, 16 occupancy
 #endif
-__global__ __launch_bounds__(kWave) void k_diversity(DivArgs a) {
+// SPLIT (small batches: a (scene, mode) is ONE wavefront, a chain of ~30 k dependent instructions -- 130 us whatever the batch):
+// the workgroup is kDivWaves = 10 wavefronts over the same 64 samples; every wave rolls the trajectories out (cheap), wave q
+// sorts and scans the hulls of time steps 2q, 2q + 1, the chains'
+// shoelace sums meet in LDS in the lane order the single wave has them, and wave 0 finishes (std, entropies, occupancy) while
+// the others have left.  Same operations, same summation orders: the same bits.
+constexpr int kDivWaves = 10;
+template <bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? kDivWaves * kWave : kWave) void k_diversity(DivArgs a) {
   __shared__ float2 s_pts[kT][kWave];          // satisfied samples' points per time step, sorted (x, then y)
   __shared__ uint8_t s_stack[2 * kT][kWave];   // chain stacks (indices into s_pts[t])
   __shared__ unsigned s_occ[kHistWords];
   __shared__ float s_al[kEntBins + 1];
+  __shared__ double s_sh[2 * kT];              // SPLIT: the shoelace sum of chain (t, lower | upper)
+  static_assert(!SPLIT || kT == 2 * kDivWaves, "two time steps per wave");
 
-  const int lane = threadIdx.x;
+  const int lane = SPLIT ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
+  const int wq = SPLIT ? (int)(threadIdx.x / kWave) : 0;
   const int b = blockIdx.x / 3, mode = blockIdx.x % 3;
   const int S = a.S;
   const bool live = lane < S;
   const long row = ((long)b * S + (live ? lane : 0)) * 3 + mode;
-  if (lane <= kEntBins) s_al[lane] = a.alphas[lane];
-  for (int i = lane; i < kHistWords; i += kWave) s_occ[i] = 0u;
+  if (wq == 0) {
+    if (lane <= kEntBins) s_al[lane] = a.alphas[lane];
+    for (int i = lane; i < kHistWords; i += kWave) s_occ[i] = 0u;
+  }
 
   const float score = a.scores[row];
   const bool rvalid = a.valid[row] > 0.0f;
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(kWave) void k_diversity(DivArgs a) {
     th = th + u[2 * t] * a.dt;
     v = v + u[2 * t + 1] * a.dt;
   }
-  {
+  if (wq == 0) {
     const float ade = wave_min(live ? err_sum / (float)kT : INFINITY);
     const float fde = wave_min(live ? err_last : INFINITY);
     if (lane == 0) {   // non-negative floats order like their bit patterns; min is order-independent => reproducible
@@ -169,6 +181,7 @@ __global__ __launch_bounds__(kWave) void k_diversity(DivArgs a) {
   // ---- masked std over the satisfied samples, mean over the 40 position features (nusc_api.py:824-831) ----------
   // variance of feature f lands in lane f, so that a single sqrt serves all 40 features
   double std_acc = 0.0;
+  auto masked_std = [&]() {
   if (n_sat > 0 && !(PSTL_DIV_SKIP & 1)) {
     const double inv = 1.0 / (double)n_sat;
     double var = 0.0;
@@ -182,12 +195,15 @@ __global__ __launch_bounds__(kWave) void k_diversity(DivArgs a) {
     }
     std_acc = wave_sum(lane < 2 * kT ? sqrt(fmax(var, 0.0)) : 0.0) / (double)(2 * kT);
   }
+  };
+  if (!SPLIT) masked_std();   // (SPLIT: after the hulls, so that the other waves do not wait for wave 0 at the hull's barrier)
 
   // ---- per-step convex-hull area of the satisfied samples (nusc_api.py:838-865) --------------------------------
   double vol = 0.0;
   if (mode_valid && n_sat >= 3 && !(PSTL_DIV_SKIP & 2)) {
 #pragma unroll
     for (int t = 0; t < kT; ++t) {
+      if (SPLIT && (t >> 1) != wq) continue;   // (wave-uniform; the register arrays keep their constant indices)
       // bitonic sort across the 64 lanes, key (x, y); unsatisfied samples carry +inf and end up behind the others
       float px = sat ? xr[t] : INFINITY, py = sat ? yr[t] : INFINITY;
 #pragma unroll
@@ -210,11 +226,12 @@ __global__ __launch_bounds__(kWave) void k_diversity(DivArgs a) {
     __syncthreads();
     double sh = 0.0;
     if (PSTL_DIV_SKIP & 32) sh = (double)s_pts[lane % kT][lane].x;   // (keeps the sort alive when the scan is ablated)
-    if (lane < 2 * kT && !(PSTL_DIV_SKIP & (4 | 32))) {
-      const int t = lane >> 1;
-      const bool upper = lane & 1;
+    const int chain = SPLIT ? 4 * wq + lane : lane;          // (t, lower | upper): the single wave's lane
+    if ((SPLIT ? lane < 4 : lane < 2 * kT) && !(PSTL_DIV_SKIP & (4 | 32))) {
+      const int t = chain >> 1;
+      const bool upper = chain & 1;
       const float2* P = s_pts[t];
-      uint8_t* stk = s_stack[lane];
+      uint8_t* stk = s_stack[chain];
       const float2 org = P[0];
       // the two topmost stack entries live in registers: o (below), p (top); k = stack size
       int k = 0;
@@ -242,7 +259,16 @@ __global__ __launch_bounds__(kWave) void k_diversity(DivArgs a) {
         prev = cur;
       }
     }
+    if (SPLIT) {
+      if (lane < 4) s_sh[chain] = sh;
+      __syncthreads();
+      sh = lane < 2 * kT ? s_sh[lane] : 0.0;
+    }
     vol = 0.5 * wave_sum(sh);
+  }
+  if (SPLIT) {
+    if (wq != 0) return;   // (the remaining barriers are wave 0's alone: a barrier counts the waves that have not ended)
+    masked_std();
   }
 
   // ---- entropies (nusc_api.py:906-926): 41 histograms (scores, w_t, a_t), six at a time over the wavefront --------
@@ -400,6 +426,17 @@ static __global__ void k_fill_words(int n, unsigned v, unsigned* p) {
   if (i < n) p[i] = v;
 }
 
+static long div_cu_count() {
+  static long n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+            ? p.multiProcessorCount : 256;
+  }
+  return n;
+}
+
 extern "C" int pstl_diversity(const pstl_cfg* cfg, const float* s0, const float* gt_traj, int gt_stride,
                               const float* controls, const float* scores, const float* valid, const float* alphas,
                               double* per_mode, float* per_scene, double* totals, void* stream) {
@@ -426,7 +463,12 @@ extern "C" int pstl_diversity(const pstl_cfg* cfg, const float* s0, const float*
   a.alphas = alphas;
   a.per_mode = per_mode;
   a.per_scene = per_scene;
-  hipLaunchKernelGGL(k_diversity, dim3((unsigned)cfg->bs * 3), dim3(kWave), 0, st, a);
+  // few (scene, mode) pairs: ten waves each (one workgroup per CU at ~165 registers: one round of them, 99 us against the 130 us
+  // of the single-wave chain; with two rounds -- 24 576 rows -- the single waves win)
+  if ((long)cfg->bs * 3 <= div_cu_count())
+    hipLaunchKernelGGL(k_diversity<true>, dim3((unsigned)cfg->bs * 3), dim3(kDivWaves * kWave), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_diversity<false>, dim3((unsigned)cfg->bs * 3), dim3(kWave), 0, st, a);
   if (totals)
     hipLaunchKernelGGL(k_diversity_totals, dim3(1), dim3(256), 0, st, cfg->bs, per_mode, per_scene, totals);
   return launch_status();

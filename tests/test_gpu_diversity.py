@@ -117,3 +117,27 @@ def test_diversity_is_reproducible_and_shard_additive(dev):
     t1 = _run(dev, scene["ego_traj"][h:], lv[h:], ctrl[rows:], scores[rows:], S)
     np.testing.assert_array_equal(np.concatenate([t0[0], t1[0]]), a[0])
     np.testing.assert_allclose(t0[2] + t1[2], a[2], rtol=1e-12)
+
+
+@pytest.mark.parametrize("S", [64, 24])
+def test_ten_wave_layout_equals_single_wave_layout(dev, S):
+    """Few (scene, mode) pairs run ten wavefronts each (k_diversity<true>: the twenty hulls two per wave), many run one: a batch of
+    200 scenes (600 pairs: one wave each) against its first 30 scenes evaluated alone (90 pairs: ten waves) -- the eight numbers
+    of every (scene, mode) and ADE / FDE of every scene bit for bit."""
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    bs = 200
+    scene = make_scene_batch(bs, K=2, S=S, seed=17, invalid_lane_frac=0.2)
+    g = torch.Generator().manual_seed(9)
+    N = bs * S * 3
+    ctrl = (torch.randn(N, 20, 2, generator=g) * 0.25 + torch.randn(N, 1, 2, generator=g) * 0.15).clamp(-1, 1)
+    ctrl = ctrl * torch.tensor([hp["mul_w_max"], hp["mul_a_max"]])
+    scores = torch.randn(N, generator=g) * 0.3 + 0.1
+    lv = torch.cat([scene["curr_id"], scene["left_id"], scene["right_id"]], dim=-1)
+    full = _run(dev, scene["ego_traj"], lv, ctrl, scores, S)
+    h = 30
+    rows = h * S * 3
+    part = _run(dev, scene["ego_traj"][:h], lv[:h], ctrl[:rows], scores[:rows], S)
+    np.testing.assert_array_equal(part[0], full[0][:h])
+    np.testing.assert_array_equal(part[1], full[1][:h])
+    assert np.isfinite(part[0]).all() and (part[0][:, :, 1] > 0).any()
