@@ -10,7 +10,7 @@ from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batc
 
 dev = torch.device("cuda:0")
 hp = default_hparams()
-bs, S, K = 4096, 64, 2
+bs, S, K = int(os.environ.get("DIV_BS", "4096")), 64, 2
 w = PackedWeights(init_state_dict(1007), dev)
 scene = make_scene_batch(bs, K=K, S=S, seed=3, stlp_mode="wide")
 scene = {k: v.to(dev) for k, v in scene.items() if k not in ("pre_stlp", "tj_scores_prior")}
