@@ -81,6 +81,55 @@ static void stl_grad_t(int N, int rows_per_scene, int K, float tau, float dt, fl
   }
 }
 
+// The same through the parts of the latency layout (stl_geometry -> stl_pre_chain x 4 -> adj_pre_weights -> adj_pre_direct per
+// step -> adj_pre_costate), walked one after the other as the ten wavefronts of a workgroup do between their barriers.
+template <bool NORM>
+static void stl_grad_parts_t(int N, int rows_per_scene, int K, float tau, float dt, float ego_L, float ego_W, const float* s0,
+                             const float* controls, float wscale, float ascale, const float* nei_prep, const float* lane_prep,
+                             const float* stlp, const float* hl, const float* dscore, int relu_mode, float thres, float gscale,
+                             const float* valid, float* scores, float* dcontrols) {
+  StlEnv env = make_env(tau, dt, ego_L, ego_W);
+  std::vector<float> scratch(kScratchGradPre), geo((size_t)kGeoSlots * kT);
+  for (int r = 0; r < N; ++r) {
+    const int b = r / rows_per_scene;
+    StlRow row = {stlp[r * 6 + 0], stlp[r * 6 + 1], stlp[r * 6 + 2], stlp[r * 6 + 3], stlp[r * 6 + 4], stlp[r * 6 + 5],
+                  (int)hl[r]};
+    if (NORM) norm_factors(row);
+    Scratch st = {scratch.data(), 1};
+    const f4* lanes = reinterpret_cast<const f4*>(lane_prep + (long)b * 3 * kNseg * 4);
+    const float* nei = nei_prep + (long)b * K * kT * kNeiPrep;
+    const float* u = controls + (long)r * 40;
+    float* out = dcontrols + (long)r * 40;
+    const float ds = dscore ? dscore[r] : 1.0f;
+    const float vr = valid ? valid[r] : 1.0f;
+    auto dfn = [=](float score) { return relu_mode ? ((thres - score > 0.0f) ? -(gscale * vr) : 0.0f) : ds; };
+    for (int i = 0; i < 40; ++i) out[i] = 0.0f;
+    if (row.mode >= 3) {
+      scores[r] = 1.0f;
+      continue;
+    }
+    for (int q = 0; q < 10; ++q)   // the geometry, two steps per "wave" (each regenerates the states up to its own steps)
+      stl_geometry(env, lanes + row.mode * kNseg, nei, K, DynSrc(s0 + b * 4, u, wscale, ascale, dt), 2 * q, 2 * q + 2, geo.data(), 1);
+    const GeoPre pre = {geo.data(), 1};
+    AdjCtx C;
+    const ChainOut c0 = stl_pre_chain<NORM>(0, env, row, pre, st), c1 = stl_pre_chain<NORM>(1, env, row, pre, st),
+                   c2 = stl_pre_chain<NORM>(2, env, row, pre, st), c3 = stl_pre_chain<NORM>(3, env, row, pre, st);
+    C.Lv1 = c0.o0, C.Lv2 = c0.o1, C.Ls = c1.o0, C.L1 = c2.o0, C.L2 = c2.o1, C.L3 = c3.o0;
+    float dsc;
+    scores[r] = adj_pre_weights(env, row.mode, C, dfn, dsc);
+    if (dsc == 0.0f) continue;
+    float part[kT][4];
+    for (int t = kT - 1; t >= 1; --t) adj_pre_direct<NORM>(env, row, C, pre, st, t, part[t][0], part[t][1], part[t][2], part[t][3]);
+    adj_pre_costate(
+        env, pre, wscale, ascale,
+        [&](int t, float& gx, float& gy, float& gth, float& gv) { gx = part[t][0], gy = part[t][1], gth = part[t][2], gv = part[t][3]; },
+        [=](int t, float gw, float ga) {
+          out[2 * t] = gw;
+          out[2 * t + 1] = ga;
+        });
+  }
+}
+
 extern "C" {
 #define FWD_ARGS int N, int rows_per_scene, int K, float tau, float dt, float ego_L, float ego_W, const float* s0,            \
                  const float* controls, const float* nei_prep, const float* lane_prep, const float* stlp, const float* hl,      \
@@ -96,4 +145,6 @@ void hostsim_stl_forward_norm(FWD_ARGS) { stl_forward_t<true>(FWD_PASS); }
                   dscore, relu_mode, thres, gscale, valid, scores, dcontrols
 void hostsim_stl_grad(GRAD_ARGS) { stl_grad_t<false>(GRAD_PASS); }
 void hostsim_stl_grad_norm(GRAD_ARGS) { stl_grad_t<true>(GRAD_PASS); }
+void hostsim_stl_grad_parts(GRAD_ARGS) { stl_grad_parts_t<false>(GRAD_PASS); }
+void hostsim_stl_grad_parts_norm(GRAD_ARGS) { stl_grad_parts_t<true>(GRAD_PASS); }
 }

@@ -4,6 +4,7 @@
 // high-level mode including the outlier constant, tiny and huge controls, forward (all three formulas / selected)
 // and the adjoint.  Exit code 0 = no report.
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include <vector>
@@ -64,6 +65,32 @@ int main() {
         if (!(a3 == a1) || !(a1 == ag) || (mode == 3 && a1 != 1.0f)) {
           fprintf(stderr, "inconsistent scores K=%d rep=%d mode=%d: %g %g %g\n", K, rep, mode, a3, a1, ag);
           return 2;
+        }
+        if (mode < 3) {   // the same row through the parts of the latency layout: same score, same gradient, bit for bit
+          std::vector<float> geo((size_t)kGeoSlots * kT), scp(kScratchGradPre);
+          for (int q = 0; q < 10; ++q)
+            stl_geometry(env, lanes.data() + mode * kNseg, nei_prep.data(), K, DynSrc(s0, u, 1.0f, 1.0f, 0.5f), 2 * q, 2 * q + 2,
+                         geo.data(), 1);
+          const GeoPre pre = {geo.data(), 1};
+          const Scratch sp = {scp.data(), 1};
+          AdjCtx C;
+          const ChainOut c0 = stl_pre_chain(0, env, r, pre, sp), c1 = stl_pre_chain(1, env, r, pre, sp),
+                         c2 = stl_pre_chain(2, env, r, pre, sp), c3 = stl_pre_chain(3, env, r, pre, sp);
+          C.Lv1 = c0.o0, C.Lv2 = c0.o1, C.Ls = c1.o0, C.L1 = c2.o0, C.L2 = c2.o1, C.L3 = c3.o0;
+          float dsc, dp[2 * kT], part[kT][4];
+          const float ap = adj_pre_weights(env, mode, C, [](float) { return 1.0f; }, dsc);
+          for (int t = kT - 1; t >= 1; --t) adj_pre_direct(env, r, C, pre, sp, t, part[t][0], part[t][1], part[t][2], part[t][3]);
+          adj_pre_costate(
+              env, pre, 1.0f, 1.0f,
+              [&](int t, float& gx, float& gy, float& gth, float& gv) { gx = part[t][0], gy = part[t][1], gth = part[t][2], gv = part[t][3]; },
+              [&](int t, float gw, float ga) {
+                dp[2 * t] = gw;
+                dp[2 * t + 1] = ga;
+              });
+          if (!(ap == ag) || memcmp(dp, du, sizeof(dp)) != 0) {
+            fprintf(stderr, "the parts disagree with the fused sweeps K=%d rep=%d mode=%d: %g %g\n", K, rep, mode, ap, ag);
+            return 4;
+          }
         }
         for (int i = 0; i < 2 * kT; ++i)
           if (!(du[i] == du[i])) {

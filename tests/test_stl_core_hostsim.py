@@ -60,12 +60,13 @@ class HostRows:
                                     _ptr(self.hl), int(all3), _ptr(scores), _ptr(s3))
         return scores, s3
 
-    def grad(self, controls, wscale=1.0, ascale=1.0, dscore=None, relu=False, thres=0.0, gscale=0.0, valid=None):
+    def grad(self, controls, wscale=1.0, ascale=1.0, dscore=None, relu=False, thres=0.0, gscale=0.0, valid=None, parts=False):
+        """parts: through the parts of the latency layout (stl_pre_chain / adj_pre_*) instead of the fused sweeps"""
         c = np.ascontiguousarray(controls.reshape(self.N, 40), dtype=np.float32)
         scores = np.zeros(self.N, np.float32)
         g = np.zeros((self.N, 40), np.float32)
         hp = self.hp
-        fn = self.hs.hostsim_stl_grad_norm if hp.get("norm_stl") else self.hs.hostsim_stl_grad
+        fn = getattr(self.hs, "hostsim_stl_grad" + ("_parts" if parts else "") + ("_norm" if hp.get("norm_stl") else ""))
         fn(self.N, 3 * self.S, self.K, ctypes.c_float(hp["smoothing_factor"]),
                                  ctypes.c_float(hp["dt"]), ctypes.c_float(hp["ego_L"]), ctypes.c_float(hp["ego_W"]),
                                  _ptr(self.s0), _ptr(c), ctypes.c_float(wscale), ctypes.c_float(ascale),
@@ -154,3 +155,25 @@ def test_adjoint_vs_oracle_autograd_on_fresh_scenes(hs):
     ref = gref.numpy().reshape(-1, 40)
     sc_ = np.abs(ref).max(axis=1, keepdims=True) + 1e-20
     np.testing.assert_allclose(gmine / sc_, ref / sc_, rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("name,norm", [("stl_mixed", False), ("stl_norm", True), ("stl_big", False)])
+def test_parts_of_the_latency_layout_equal_the_fused_sweeps(hs, name, norm):
+    """stl_pre_chain x 4 -> adj_pre_weights -> adj_pre_direct per step -> adj_pre_costate over stl_geometry's slots (what the ten
+    wavefronts of the STL kernels' latency layout run between their barriers) against stl_eval_grad's fused sweeps: the same
+    operations on the same operands, every chain in its own order -- scores and gradients bit for bit, for a plain upstream
+    gradient and for the guidance hinge (which leaves satisfied rows without one)."""
+    d = load_golden(name)
+    bs, S, K, seed = [int(v) for v in d["meta"]]
+    hp = dict(default_hparams(), norm_stl=True) if norm else default_hparams()
+    rows = HostRows(hs, scene_from_golden(d), S, hp)
+    n = min(rows.N, 1536)
+    ctrl = d["controls"].reshape(rows.N, 40)
+    for kw in (dict(), dict(relu=True, thres=0.05, gscale=0.25, wscale=0.5, ascale=5.0)):
+        c = ctrl / np.array([kw.get("wscale", 1.0), kw.get("ascale", 1.0)] * 20, np.float32)
+        sa, ga = rows.grad(c, **kw)
+        sb, gb = rows.grad(c, parts=True, **kw)
+        mode3 = rows.hl >= 3
+        np.testing.assert_array_equal(sa[~mode3][:n], sb[~mode3][:n])
+        np.testing.assert_array_equal(ga[:n], gb[:n])
+        assert np.isfinite(ga).all() and np.abs(ga).max() > 0
