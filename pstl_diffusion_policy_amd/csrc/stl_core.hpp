@@ -612,13 +612,14 @@ PSTL_HD float conj6(const float* v, int n, float tau) {  // softmin over n <= 6 
 
 // The geometry of the sweeps, computed ahead (latency layout of the STL kernels: the waves of a workgroup each take a few of
 // the 20 time steps; the sweeps themselves then only read): per time step the clearance, the lane distance and
-// heading term, and the winners' record (lane segment | clearance winner << 8, carried as a bit pattern).
+// heading term.
 //   slots 0-3   (forward sweep): clearance, lane distance, heading term 1 - cos, speed
 //   slots 4-12  (adjoint): the clearance's partials (x, y, heading), the heading term as the adjoint's own evaluation yields
 //                          it and the lane distance's partials (x, y) and the heading term's, then cos, sin of the heading
-// (The winners of the hard minima stay inside stl_geometry: the adjoint's partials are evaluated right there.)  The adjoint of
-// step t is the last reader of step t's slots, which lets the guidance kernel park the update of step t - 1 in slots 4-7 of
-// step t (k_guidance_iter, SPLIT) instead of in a buffer of its own.
+// (The winners of the hard minima stay inside stl_geometry: the adjoint's partials are evaluated right there.)  Every slot has
+// one reader, and the stage that has read it writes its own result over it (k_guidance_iter, SPLIT: the chains' values and the
+// weights in step 0's slots, the direct partials over the clearance partials, the gradients over the forward values) -- no
+// buffer of its own for any hand-over between the stages.
 // The adjoint's state is the forward sweep's, bit for bit: stl_eval_grad re-derives the states of a 4-step block from the
 // block's checkpoint with the forward sweep's own operations, the exact sincosf included.  (Round 4 tried the hardware
 // v_sin_f32 / v_cos_f32 there -- the adjoint only reaches a gradient -- and the reference's autograd gradients were missed:
