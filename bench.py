@@ -268,7 +268,7 @@ class Job:
             sm_t.trace, sm_t.trace_bwd = sampler.trace, sampler.trace_bwd
             loss, scores = RectTrainer(sm_t).train_step(sb, self.tparams, self.topt, steps, x_T=x_T, noise=z, seed=seed,
                                                         multi_cands=a.multi_cands, coeffs=self.coeffs, e7=self.e7, joint=self.joint)
-            if sm_t.chain_fallback and self.chain_waves in (0, 16):
+            if sm_t.chain_fallback and self.chain_waves in (0, 16, 2):
                 # train_step reads the split-f16 domain flag before the optimiser consumes the gradients and repeats the step
                 # on the exact-fp32 kernels when it is set; a bench line must not silently mix the two arithmetics
                 raise FloatingPointError("bench: " + sm_t.chain_fallback)
@@ -469,7 +469,7 @@ def main():
             dist.destroy_process_group()
         return
     nst, k_ms, flop, achieved = m["kernel_steps"], m["kernel_ms"], m["flop"], m["achieved"]
-    split_f16 = a.chain_waves in (0, 16)
+    split_f16 = a.chain_waves in (0, 16, 2)
     split_bf16 = a.chain_waves == 32
     peak = chain_peak(a.chain_waves)
     dtype = ("f32 (MLP products formed from two f16 pieces per operand, 2^-23 per operand, 3 v_mfma_f32_16x16x32_f16 per f32 "

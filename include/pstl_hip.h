@@ -84,10 +84,14 @@ typedef struct pstl_cfg {
                               the reference as an fp32 fmaf chain in another summation order (0: batches with
                               fewer than five 16-row tiles per CU -- the closed-loop caller's 192 rows -- run
                               their denoiser launches in a latency layout, 1..4 tiles per workgroup; 16: always
-                              the throughput layout; the results are bit-identical); 8 or 4 = fp32
+                              the throughput layout; the results are bit-identical; 0 also hands the multi-step
+                              denoiser launches of batches that fill whole rounds of 256-row workgroups -- >= 65 536
+                              rows on 256 CUs -- to the row-stationary kernel k_chain2: same arithmetic and domain,
+                              another summation order; 2: k_chain2 for every launch it can take whatever the batch
+                              size, the other launches as 16); 8 or 4 = fp32
                               MFMA (v_mfma_f32_16x16x4_f32) with 8 / 4 waves per workgroup; 32 = policy_net
                               on bfloat16 pieces (2^-17 per operand), rect_net on fp32 MFMA.
-                              DOMAIN of 0 / 16: the pieces are halves of 2^10 w and 2^4 x, so the chain weights must
+                              DOMAIN of 0 / 16 / 2: the pieces are halves of 2^10 w and 2^4 x, so the chain weights must
                               satisfy |w| < PSTL_SPLIT_F16_WMAX and every layer input |x| < 4094; outside it the
                               results are undefined (an overflowed piece is an infinity: NaNs where it reaches the
                               output, but max(NaN, 0) = 0 inside a ReLU) and the status block of the packed buffer

@@ -16,6 +16,9 @@ UNITS = [("stl_kernels.hip", ["-ffp-contract=off", "-Xarch_device", "-mllvm=-mis
          # mlp_kernels: top-down pre-RA list scheduling follows the hand-laid order of the chain kernel's fused block more
          # closely (multi-step launch -1.4 %, single-step -1.9 %, nothing else in the unit changes)
          ("mlp_kernels.hip", ["-Xarch_device", "-mllvm=-misched-prera-direction=topdown"]), ("train_kernels.hip", []),
+         # chain2_kernels: one wave per SIMD with all 512 registers; the accumulation half holds the resident layer-1 output
+         # (MFMA B operands), so the accumulators go to the architectural half ("VGPR form")
+         ("chain2_kernels.hip", ["-Xarch_device", "-mllvm=-amdgpu-mfma-vgpr-form"]),
          ("diversity_kernels.hip", ["-ffp-contract=off"]), ("stl_program.hip", ["-ffp-contract=off"])]
 LINK_LIBS = []   # no vendor BLAS: every kernel of the library is in csrc/
 

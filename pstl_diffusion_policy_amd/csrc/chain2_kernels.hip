@@ -1,0 +1,685 @@
+// chain2_kernels.hip -- k_chain2: the multi-step denoiser launch (policy_net, reverse diffusion A3-A5) with the ROWS
+// stationary and the WEIGHTS streamed.  Same arithmetic as k_chain's default form (mlp_kernels.hip: every fp32 operand as
+// two IEEE-half pieces, three v_mfma_f32_16x16x32_f16 products per fp32 product, fp32 accumulation), other dataflow:
+//
+//  * One workgroup = 4 waves, one per SIMD (up to 512 registers each), owns 256 rows for ALL reverse steps of the launch.
+//    A wave owns 64 rows (four 16-row tiles) and all 256 hidden features.  The ReLU'd, split layer-1 output of its rows --
+//    8 k-blocks x 4 row tiles x (hi | lo) = 256 registers -- stays in the accumulation half of its register file as the B
+//    operands of layer 2; a layer's accumulators, ReLU'd and split, ARE the next layer's B operands (the permuted-k
+//    hand-over of k_chain), so no activation crosses LDS and no barrier sits between the layers.  Layer 2 is walked in 8
+//    chunks of 32 output features; a finished chunk is one k-block of layer 3; layer 3's output (+ the DDPM update) is, in
+//    the same lane layout, the next step's layer-1 input.  x never leaves the wave.
+//  * The 368 KB of split weights stream L2 -> LDS by LDS-DMA (1 KB per wave-instruction = one (tile, k-block, piece) block of
+//    the packed buffer) through a ring of three 22 KB slots, 20 phases per tile-step (4 of layer 1, 16 of layers 2 + 3), ONE
+//    barrier per phase placed in the middle of it.  Every A operand is read once per wave and feeds 12 MFMAs.
+//  * The instruction stream is laid out by hand: one slot = one MFMA + what goes into its shadow, closed by
+//    sched_barrier(0) (the compiler allocates registers, counts LDS waits and pads hazards; left to choose the order it
+//    puts a chunk's ~170 conversion instructions in front of the MFMAs they should hide under).
+//
+// Reference: nusc_model.py:97-180 (Net.forward, diffusion branch), nusc_train.py:557-587,628-655 (diffusion_rollout).
+// Built with -mllvm -amdgpu-mfma-vgpr-form (accumulators in the architectural half: the accumulation half is full).
+#include <type_traits>
+#include <utility>
+
+#include "chain_args.hpp"
+#include "pstl_common.hpp"
+#include "rng.hpp"
+
+namespace pstl {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int uw4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int RT = 4;                      // 16-row tiles per wave
+constexpr int kWgRows = 4 * 16 * RT;       // 256 rows per workgroup
+constexpr int kCtrl2 = 40, kHid2 = 256;
+constexpr int kSlotBytes = 22 * 1024, kRing = 3;
+constexpr int kMaxScn = 7;                 // scenes a workgroup's 256 rows may touch (rows_per_scene >= 48)
+// LDS carve (bytes)
+constexpr int kOffXq = kRing * kSlotBytes;                   // [4 waves][RT][3][64] f32x4: the state x, lane-private
+constexpr int kOffCrow = kOffXq + 4 * RT * 3 * 64 * 16;      // [kMaxScn][256] (base[scene] + tbias[step]) x kAcc
+constexpr int kOffBrow = kOffCrow + kMaxScn * 1024;          // [kMaxScn][256] base[scene]
+constexpr int kOffB2 = kOffBrow + kMaxScn * 1024;            // [256] b2 x kAcc
+constexpr int kOffB3 = kOffB2 + 1024;                        // [48]  b3 x kAcc
+constexpr int kOffCoef = kOffB3 + 192;                       // [kMaxLaunchSteps][4] kk, a, sb, 0
+constexpr int kLdsBytes = kOffCoef + kMaxLaunchSteps * 16;
+
+constexpr float kSX = kSplitX, kSW = kSplitW, kAcc = kSX * kSW, kInvSW = 1.0f / kSW, kInvAcc = 1.0f / kAcc;
+
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+// Timing-only ablations (tools/dbg/build_variants2.sh + time_variants.py; the results are garbage): bits 1 noise steps,
+// 2 layer-1 conversions + pins, 4 layer-2 conversions, 8 epilogue, 16 LDS-DMA, 32 phase barriers, 64 the tail's conversion,
+// 128 the domain guard's running maximum, 256 layer 1 altogether, 512 layer 3
+#ifndef PSTL_C2_ABL
+#define PSTL_C2_ABL 0
+#endif
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).  Every index is a
+// constant expression by construction (a run-time loop the unroller gives up on puts the arrays it indexes in scratch).
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+template <int I>
+using Ic = std::integral_constant<int, I>;
+
+// one 1 KB LDS-DMA piece: lane l moves 16 bytes from sbase + voff to LDS byte address lds_dst + 16 l.  Issued from inline
+// assembly: invisible to the compiler's wait-count pass (a tracked LDS-DMA puts s_waitcnt vmcnt(0) in front of the wave's
+// next ds_read), waited for by the vmcnt(0) in front of each phase barrier.
+__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
+  if (PSTL_C2_ABL & 16) return;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// domain guard of the split-f16 arithmetic (see note_pieces in mlp_kernels.hip): running v_pk_max_u16 of the hi pieces
+// (as an asm statement: written as a max() chain the optimiser re-associates it and sinks the whole chain behind the
+// phases, keeping -- spilling -- every hi word until then)
+__device__ __forceinline__ void note_word(unsigned& ovf, unsigned w) {
+  if (PSTL_C2_ABL & 128) return;
+  asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(ovf) : "v"(w));
+}
+__device__ __forceinline__ bool pieces_overflowed(unsigned ovf) { return (ovf & 0xffffu) >= 0x7c00u || (ovf >> 16) >= 0x7c00u; }
+// A value the optimiser must take as it comes at this point: stops it from hoisting `uniform pointer + lane offset` out of the
+// step loop as per-lane 64-bit pointers (twelve of them were spilled and reloaded from scratch in every epilogue, each reload a
+// memory round trip in a wave that has nothing else to issue)
+__device__ __forceinline__ unsigned here(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ float clip_keep_nan(float v, float m) { return v < -m ? -m : (v > m ? m : v); }
+
+// Phases of a tile-step and what their ring slot holds (1 KB pieces; piece kq*4 + t*2 + hl is the A operand of tile t,
+// piece hl of the phase's k-block kq):
+//   P0..P3   layer 1, phase q: chunks 2q, 2q+1 (kq = 2 cl + kb); P0 also carries W3's k-block 7 (pieces 16..21) for the
+//            tail of the step before
+//   P4+2c    layers 2/3, chunk c, k-blocks 0..3; for c >= 1 also W3's k-block c-1 (pieces 16..21)
+//   P5+2c    chunk c, k-blocks 4..7
+template <bool RNG>
+__global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, col = lane & 15;
+  constexpr int NM = 6 * RT;          // MFMAs per k-block
+  constexpr int NCONV = 32 * RT;      // conversion micro-steps per chunk (4 RT pairs x 8)
+  constexpr int kLead = 4;            // slots between an LDS read of a constant part and the MFMA that takes it as C
+  const long wg_row0 = (long)blockIdx.x * kWgRows;
+  const long row0 = wg_row0 + (long)w * (16 * RT);           // first row of this wave
+  const int nsteps = a.step_hi - a.step_lo + 1;
+
+  float* crow = reinterpret_cast<float*>(smem + kOffCrow);
+  float* brow = reinterpret_cast<float*>(smem + kOffBrow);
+  float* b2s = reinterpret_cast<float*>(smem + kOffB2);
+  float* b3s = reinterpret_cast<float*>(smem + kOffB3);
+  f32x4* coef = reinterpret_cast<f32x4*>(smem + kOffCoef);
+  f32x4* xq = reinterpret_cast<f32x4*>(smem + kOffXq) + (w * RT * 3) * 64 + lane;   // [rt][j] at (rt*3 + j)*64
+
+  // ---- scenes of this workgroup's rows; per-row-tile scene slot (a 16-row tile lies in one scene: rows_per_scene % 16 == 0) ----
+  const long last_row = a.N - 1;
+  const long scene_first = wg_row0 / a.rows_per_scene;
+  int scn[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    long r = row0 + 16 * rt;
+    if (r > last_row) r = last_row;
+    scn[rt] = (int)(r / a.rows_per_scene - scene_first);
+  }
+
+  // ---- tables ----
+  {
+    b2s[tid] = a.packed[a.off.b2 + tid] * kAcc;
+    if (tid < 48) b3s[tid] = a.packed[a.off.b3 + tid] * kAcc;
+    if (tid < nsteps) {   // reverse-step coefficients (nusc_train.py:580-587): x' = a x + sb z - kk (eps_net + b3),  a = (1 - c1) / sqrt(alpha)
+      const int i = a.step_hi - tid;
+      const float al = a.alpha[i], ah = a.alpha_hat[i], be = a.beta[i];
+      const float c1 = (1.0f - al) / sqrtf(1.0f - ah), inv_sa = 1.0f / sqrtf(al);
+      const float kk = inv_sa * c1;
+      const bool noisy = i > 1 && (RNG || a.noise);   // the reference adds zeros at the last step
+      coef[tid] = f32x4{kk, inv_sa - kk, noisy ? sqrtf(be) : 0.0f, 0.0f};
+    }
+    const long nscn_rows = (wg_row0 + kWgRows - 1 > last_row ? last_row : wg_row0 + kWgRows - 1);
+    const int nscn = (int)(nscn_rows / a.rows_per_scene - scene_first) + 1;
+    for (int s = 0; s < kMaxScn; ++s) {
+      const int ss = s < nscn ? s : nscn - 1;
+      const float bvv = a.base[(scene_first + ss) * kHid2 + tid];
+      brow[s * 256 + tid] = bvv;
+      crow[s * 256 + tid] = (bvv + a.tbias[(long)a.step_hi * kHid2 + tid]) * kAcc;
+    }
+  }
+  const unsigned long long seed = a.seed_dev ? uniform_u64(a.seed_dev) : a.seed;
+  unsigned ovf = 0;
+  if (tid == 0 && blockIdx.x == 0) {   // the weights themselves: max |w| as the packer recorded it (status word 0 = policy_net)
+    const float wm = reinterpret_cast<const float*>(a.status)[-2];
+    if (!(wm < PSTL_SPLIT_F16_WMAX)) atomicOr(a.status, 1u);
+  }
+
+  // ---- state ----
+  f16x8 bh[8][RT], bl[8][RT];         // h1 pieces: B operands of layer 2 (accumulation registers)
+  f16x8 xh[2][RT], xl[2][RT];         // x pieces: B operands of layer 1
+  f32x4 acc3[3][RT];
+  f32x4 accA[2][RT], accB[2][RT];     // chunk accumulators (layer 1 and layer 2), even / odd chunk
+  unsigned phw[RT][4], plw[RT][4];    // pieces of the finished chunk, as packed words
+  f16x8 ah[2], al[2], nh[2], nl[2];   // A operands of the current / the next k-block
+  f16x8 w3h[2], w3l[2];               // layer 3's A operands, double buffered over j
+  f32x4 bv[2];                        // layer-2 bias of the chunk that starts next
+  f32x4 cst[2 * RT];                  // layer-1 constant parts (scene + timestep) on their way: read kLead slots ahead of the MFMA that starts from them
+  f32x4 b3v[3];
+  f32x2 cm[2], cf[2];                 // conversion state of the two pairs in flight
+  unsigned chw[2];
+
+  // pieces of four (scaled) values pairs -> words
+  auto split_quad2 = [&](const f32x4& u, const f32x4& v, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      hi[i] = (_Float16)u[i];
+      hi[4 + i] = (_Float16)v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lo[i] = (_Float16)(u[i] - (float)hi[i]);
+      lo[4 + i] = (_Float16)(v[i] - (float)hi[4 + i]);
+    }
+    const uw4 hw = __builtin_bit_cast(uw4, hi);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) note_word(ovf, hw[r] & 0x7fff7fffu);
+  };
+  // the layer-1 B operands of row tile rt from its state quads (x 16): k-block 0 = output tiles j = 0, 1; k-block 1 = tile
+  // j = 2 (x 32..39 | hl | stlp) and zeros
+  auto make_x_pieces = [&](int rt, const f32x4& q0, const f32x4& q1, const f32x4& q2) {
+    split_quad2(q0 * kSX, q1 * kSX, xh[0][rt], xl[0][rt]);
+    split_quad2(q2 * kSX, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, xh[1][rt], xl[1][rt]);
+  };
+
+  // ---- the initial state: lane (g, col) of row tile rt holds columns 16 j + 4 g .. + 3 of row 16 rt + col ----
+  const bool own2 = g < 2;            // tile j = 2: lanes g < 2 hold x 32..39, lanes g >= 2 the row constants hl | stlp | 0
+  {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      long r = row0 + 16 * rt + col;
+      if (r > last_row) r = last_row;
+      const float* xr = a.x_inout + r * kCtrl2;
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(xr + 4 * g);
+      const f32x4 q1 = *reinterpret_cast<const f32x4*>(xr + 16 + 4 * g);
+      f32x4 q2;
+      if (own2) {
+        q2 = *reinterpret_cast<const f32x4*>(xr + 32 + 4 * g);
+      } else {
+        const float* sp = a.stlp + r * 6;
+        q2 = g == 2 ? f32x4{a.hl[r], sp[0], sp[1], sp[2]} : f32x4{sp[3], sp[4], sp[5], 0.0f};
+      }
+      xq[(rt * 3 + 0) * 64] = q0;
+      xq[(rt * 3 + 1) * 64] = q1;
+      xq[(rt * 3 + 2) * 64] = q2;
+      make_x_pieces(rt, q0, q1, q2);
+      if (a.n_emit >= a.steps && a.step_hi == a.steps - 1 && row0 + 16 * rt + col <= last_row) {   // x_T is entry 0 of the full list
+        const f32x4 sc = f32x4{a.w_max, a.a_max, a.w_max, a.a_max};
+        float* er = a.emit_out + ((long)(a.n_emit - a.steps) * a.N + r) * kCtrl2;
+        f32x4 v0 = q0 * sc, v1 = q1 * sc, v2 = q2 * sc;
+        if (a.clip) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v0[e] = clip_keep_nan(v0[e], sc[e]), v1[e] = clip_keep_nan(v1[e], sc[e]), v2[e] = clip_keep_nan(v2[e], sc[e]);
+        }
+        *reinterpret_cast<f32x4*>(er + 4 * g) = v0;
+        *reinterpret_cast<f32x4*>(er + 16 + 4 * g) = v1;
+        if (own2) *reinterpret_cast<f32x4*>(er + 32 + 4 * g) = v2;
+      }
+    }
+  }
+
+  // ---- the weight stream ----
+  const unsigned* w1p = reinterpret_cast<const unsigned*>(a.packed + a.off.w1xh);
+  const unsigned* w2p = reinterpret_cast<const unsigned*>(a.packed + a.off.w2h);
+  const unsigned* w3p = reinterpret_cast<const unsigned*>(a.packed + a.off.w3h);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  // piece k (0..5) of this wave's share (pieces w, w + 4, ...) of a phase; KIND 0: layer-1 phase q = c; 1 / 2: first /
+  // second half of layer-2 chunk c.  k >= 4: the W3 k-block that rides with the phase (c3)
+  auto issue_piece = [&](auto kind_tag, int c, int c3, int k, unsigned slot_byte) {
+    constexpr int KIND = decltype(kind_tag)::value;
+    if (k < 4) {
+      const int qq = 4 * k + w;
+      const int kq = qq >> 2, t = (qq >> 1) & 1, hl = qq & 1;
+      if constexpr (KIND == 0) {   // kq = 2 cl + kb; tile 2 (2 q + cl) + t of W1 [16 T][2 kb][hi | lo]
+        const long blk = ((long)(2 * (2 * c + (kq >> 1)) + t) * 2 + (kq & 1)) * 2 + hl;
+        dma16(w1p + blk * 256, lane16, slot_byte + (unsigned)qq * 1024u);
+      } else {                     // tile 2 c + t, k-block 4 half + kq of W2 [16 T][8 kb][hi | lo]
+        const long blk = ((long)(2 * c + t) * 8 + 4 * (KIND - 1) + kq) * 2 + hl;
+        dma16(w2p + blk * 256, lane16, slot_byte + (unsigned)qq * 1024u);
+      }
+    } else {   // (branch-free: waves 2 and 3 issue pieces 2 and 3 a second time -- same bytes to the same place)
+      const int q0 = 4 * (k - 4) + w;
+      const int qq = q0 < 6 ? q0 : q0 - 4;
+      const int j = qq >> 1, hl = qq & 1;
+      const long blk = ((long)(j * 8 + c3) * 2 + hl);
+      dma16(w3p + blk * 256, lane16, slot_byte + 16384u + (unsigned)qq * 1024u);
+    }
+  };
+
+  // prologue: phases P0 and P1 of the first tile-step
+  static_for<6>([&](auto k) { issue_piece(Ic<0>{}, 0, 7, decltype(k)::value, 0u); });
+  static_for<4>([&](auto k) { issue_piece(Ic<0>{}, 1, 0, decltype(k)::value, (unsigned)kSlotBytes); });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  unsigned s_cur = 0u, s_nxt = (unsigned)kSlotBytes, s_nn = 2u * (unsigned)kSlotBytes;   // slots of phases p, p + 1, p + 2
+  const uw4* lbase = reinterpret_cast<const uw4*>(smem) + lane;
+  auto rdA = [&](unsigned slot_byte, int piece) { return __builtin_bit_cast(f16x8, lbase[(slot_byte >> 4) + piece * 64]); };
+  auto rd_bias = [&](int c, int t) { return *reinterpret_cast<const f32x4*>(b2s + 16 * (2 * c + t) + 4 * g); };
+  auto rd_cst = [&](int c1, int t, int rt) { return *reinterpret_cast<const f32x4*>(crow + scn[rt] * 256 + 16 * (2 * c1 + t) + 4 * g); };
+
+#pragma unroll
+  for (int t = 0; t < 2; ++t) ah[t] = rdA(s_cur, t * 2), al[t] = rdA(s_cur, t * 2 + 1);
+#pragma unroll
+  for (int u = 0; u < kLead; ++u) cst[u] = rd_cst(0, u / RT, u % RT);
+
+  // ReLU + split of the finished chunk's accumulators S into the packed pieces, as 8 single-instruction steps per pair of
+  // values, two pairs in flight: step i = 16 grp + 2 stage + which
+  auto conv_step = [&](auto& S, auto i_tag) {
+    constexpr int i = decltype(i_tag)::value;
+    constexpr int which = i & 1, stage = (i >> 1) & 7, p = 2 * (i >> 4) + which;   // pair p = 4 rt + q
+    constexpr int rt = p >> 2, q = p & 3, t = q >> 1, e = (q & 1) * 2, word = 2 * t + (q & 1);
+    if constexpr (stage == 0) {
+      const float v0 = S[t][rt][e];   // (a copy: __builtin_bit_cast of a vector ELEMENT lvalue reads element 0)
+      cm[which][0] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v0), 0));
+    } else if constexpr (stage == 1) {
+      const float v1 = S[t][rt][e + 1];
+      cm[which][1] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v1), 0));
+    } else if constexpr (stage == 2) {
+      cm[which] *= kInvSW;
+    } else if constexpr (stage == 3) {
+      chw[which] = __builtin_bit_cast(unsigned, __builtin_convertvector(cm[which], f16x2));
+      phw[rt][word] = chw[which];
+    } else if constexpr (stage == 4) {
+      cf[which][0] = (float)__builtin_bit_cast(f16x2, chw[which])[0];
+    } else if constexpr (stage == 5) {
+      cf[which][1] = (float)__builtin_bit_cast(f16x2, chw[which])[1];
+      note_word(ovf, chw[which]);
+    } else if constexpr (stage == 6) {
+      cf[which] = cm[which] - cf[which];
+    } else {
+      plw[rt][word] = __builtin_bit_cast(unsigned, __builtin_convertvector(cf[which], f16x2));
+    }
+  };
+  auto pieces_h = [&](int rt) { return __builtin_bit_cast(f16x8, uw4{phw[rt][0], phw[rt][1], phw[rt][2], phw[rt][3]}); };
+  auto pieces_l = [&](int rt) { return __builtin_bit_cast(f16x8, uw4{plw[rt][0], plw[rt][1], plw[rt][2], plw[rt][3]}); };
+  // the finished pieces of row tile rt become k-block KB of layer 2's B operand, in the accumulation half of the register file
+  auto pin_h1 = [&](auto kb_tag, auto rt_tag, auto hl_tag) {
+    constexpr int KB = decltype(kb_tag)::value, rt = decltype(rt_tag)::value, HL = decltype(hl_tag)::value;
+    if constexpr (HL == 0) {
+      bh[KB][rt] = pieces_h(rt);
+      asm volatile("" : "+a"(bh[KB][rt]));
+    } else {
+      bl[KB][rt] = pieces_l(rt);
+      asm volatile("" : "+a"(bl[KB][rt]));
+    }
+  };
+  // conversion of a layer-1 chunk in NS steps per slot, and its pieces pinned as soon as a row tile's eight words are done
+  // (slot = 0 .. of the shadow the conversion runs in)
+  auto conv_h1_slot = [&](auto& S, auto kb_tag, auto slot_tag, auto ns_tag) {
+    constexpr int slot = decltype(slot_tag)::value, NS = decltype(ns_tag)::value;
+    static_for<NS>([&](auto u) {
+      constexpr int i = slot * NS + decltype(u)::value;
+      if constexpr (i < NCONV) conv_step(S, Ic<i>{});
+    });
+    // row tile rt is complete after step 32 (rt + 1) - 1, i.e. in slot (32 (rt + 1) - 1) / NS; pin hi and lo in the two slots after
+    static_for<RT>([&](auto rt_tag) {
+      constexpr int rt = decltype(rt_tag)::value;
+      constexpr int done = (32 * (rt + 1) - 1) / NS;
+      if constexpr (slot == done + 1) pin_h1(kb_tag, rt_tag, Ic<0>{});
+      if constexpr (slot == done + 2) pin_h1(kb_tag, rt_tag, Ic<1>{});
+    });
+  };
+
+  // ---- in-kernel noise (RNG): Philox4x32-10 + Box-Muller of rng.hpp (normal4: same operations, same bits), and
+  // Q = a x + sb z written over x in the wave's LDS image, as single-instruction-sized steps that ride in the shadow of the
+  // MFMAs of the second halves of layer 2's chunks (no conversion runs there): 64 steps per quad, 1.5 quads per phase; the
+  // two phases of chunk pair p do the three quads j = 0, 1, 2 of row tile p.
+  unsigned qx = 0, qy = 0, qz = 0, qw = 0, qtx = 0;
+  unsigned long long qp0 = 0, qp1 = 0;
+  float qu0 = 0.0f, qu1 = 0.0f, qu2 = 0.0f, qu3 = 0.0f, qr0 = 0.0f, qr1 = 0.0f;
+  f32x4 qxv = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, qzv = qxv;
+  float n_ca = 0.0f, n_sb = 0.0f;     // this step's a and sb
+  int n_step = 0;
+  auto noise_sub = [&](int rt, auto j_tag, auto sub_tag) {
+#pragma clang fp contract(off)
+    constexpr int j = decltype(j_tag)::value, sub = decltype(sub_tag)::value;
+    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    const float k32 = 2.3283064365386963e-10f, c2 = -1.3862943611198906f;
+    if constexpr (sub == 0) {
+      const unsigned ln = here((unsigned)lane);
+      unsigned r = (unsigned)row0 + 16u * (unsigned)rt + (ln & 15u);   // (N < 2^31: checked by the host)
+      if (r > (unsigned)last_row) r = (unsigned)last_row;
+      const unsigned long long e = ((unsigned long long)a.row_offset + r) * 10u + (unsigned long long)(4 * j + (int)(ln >> 4));
+      qx = (unsigned)e, qy = (unsigned)(e >> 32), qz = (unsigned)n_step, qw = 0x5053544Cu;
+      qxv = xq[(rt * 3 + j) * 64];
+    } else if constexpr (sub <= 40) {
+      constexpr int r = (sub - 1) >> 2, ph = (sub - 1) & 3;
+      const unsigned k0 = (unsigned)seed + (unsigned)r * W0, k1 = (unsigned)(seed >> 32) + (unsigned)r * W1;
+      if constexpr (ph == 0) qp0 = (unsigned long long)M0 * qx;
+      else if constexpr (ph == 1) qp1 = (unsigned long long)M1 * qz;
+      else if constexpr (ph == 2) qtx = (unsigned)(qp1 >> 32) ^ qy ^ k0;
+      else {
+        qz = (unsigned)(qp0 >> 32) ^ qw ^ k1;
+        qx = qtx, qy = (unsigned)qp1, qw = (unsigned)qp0;
+      }
+    } else if constexpr (sub == 41) {
+      qu0 = ((float)qx + 1.0f) * k32;
+    } else if constexpr (sub == 42) {
+      qu1 = (float)qy * k32;
+    } else if constexpr (sub == 43) {
+      qu2 = ((float)qz + 1.0f) * k32;
+    } else if constexpr (sub == 44) {
+      qu3 = (float)qw * k32;
+    } else if constexpr (sub == 45) {
+      qr0 = __builtin_amdgcn_sqrtf(c2 * __builtin_amdgcn_logf(qu0));
+    } else if constexpr (sub == 46) {
+      qr1 = __builtin_amdgcn_sqrtf(c2 * __builtin_amdgcn_logf(qu2));
+    } else if constexpr (sub == 47) {
+      qzv[0] = qr0 * __builtin_amdgcn_cosf(qu1);
+      qzv[1] = qr0 * __builtin_amdgcn_sinf(qu1);
+    } else if constexpr (sub == 48) {
+      qzv[2] = qr1 * __builtin_amdgcn_cosf(qu3);
+      qzv[3] = qr1 * __builtin_amdgcn_sinf(qu3);
+    } else if constexpr (sub == 49) {
+      const float lsb = (j < 2 || own2) ? n_sb : 0.0f;
+      qzv *= lsb;
+    } else if constexpr (sub == 50) {
+      const float la = (j < 2 || own2) ? n_ca : 1.0f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qzv[e] = __builtin_fmaf(la, qxv[e], qzv[e]);
+    } else if constexpr (sub == 51) {
+      xq[(rt * 3 + j) * 64] = qzv;
+    }
+  };
+  // slot s (0..95) of the second-half phase of chunk 2 p (EVEN) / 2 p + 1 (odd)
+  auto noise_slot = [&](int p, auto odd_tag, auto s_tag) {
+    constexpr int s = decltype(s_tag)::value;
+    constexpr bool ODD = decltype(odd_tag)::value;
+    if constexpr (RNG && !(PSTL_C2_ABL & 1)) {
+      if constexpr (!ODD) {
+        if constexpr (s < 64) noise_sub(p, Ic<0>{}, Ic<s>{});
+        else noise_sub(p, Ic<1>{}, Ic<s - 64>{});
+      } else {
+        if constexpr (s < 32) noise_sub(p, Ic<1>{}, Ic<s + 32>{});
+        else noise_sub(p, Ic<2>{}, Ic<s - 32>{});
+      }
+    }
+  };
+
+  // one k-block of layer 3: the pieces of a finished chunk against its W3 blocks (pieces 16..21 of `slot`; the first pair
+  // w3h[0] / w3l[0] was read by the caller).  FIRST: the accumulators start from the bias.
+  auto layer3 = [&](unsigned slot, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    static_for<9 * RT>([&](auto m_tag) {
+      constexpr int m = decltype(m_tag)::value;
+      constexpr int j = m / (3 * RT), pr = (m / RT) % 3, rt = m % RT;
+      const f16x8 wa = pr == 1 ? w3l[j & 1] : w3h[j & 1];
+      const f16x8 pb = pr == 2 ? pieces_l(rt) : pieces_h(rt);
+      if constexpr (FIRST && pr == 0) acc3[j][rt] = mfma(wa, pb, b3v[j]);
+      else acc3[j][rt] = mfma(wa, pb, acc3[j][rt]);
+      if constexpr (j < 2 && pr == 0 && rt == 0) w3h[(j + 1) & 1] = rdA(slot, 16 + (j + 1) * 2);
+      if constexpr (j < 2 && pr == 0 && rt == 1) w3l[(j + 1) & 1] = rdA(slot, 16 + (j + 1) * 2 + 1);
+      FENCE();
+    });
+  };
+
+  // what every phase has in common: slot (kq, m) after its MFMA -- A operands of the next k-block, the DMA of the phase
+  // after next in the third k-block, the barrier after the second
+  auto common_fill = [&](auto kq_tag, auto m_tag, auto kind_tag, auto np_tag, int c_issue, int c3_issue) {
+    constexpr int kq = decltype(kq_tag)::value, m = decltype(m_tag)::value, NP = decltype(np_tag)::value;
+    if constexpr (m < 4) {   // (kq == 3: the next phase's first k-block; its slot was published by this phase's barrier)
+      const unsigned sl = kq < 3 ? s_cur : s_nxt;
+      constexpr int pc = (kq < 3 ? (kq + 1) * 4 : 0) + m;
+      if constexpr (m & 1) nl[m >> 1] = rdA(sl, pc);
+      else nh[m >> 1] = rdA(sl, pc);
+    }
+    constexpr int DS = (NM - 2) / 6;
+    if constexpr (kq == 2 && m >= 2 && (m - 2) % DS == 0 && (m - 2) / DS < NP) issue_piece(kind_tag, c_issue, c3_issue, (m - 2) / DS, s_nn);
+  };
+  auto end_kq = [&](auto kq_tag, auto&& mid) {
+    constexpr int kq = decltype(kq_tag)::value;
+    if constexpr (kq == 1) {
+      // every wave's share of phase p + 1 has landed (issued a whole phase ago), every wave is done with phase p - 1
+      if (PSTL_C2_ABL & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      FENCE();
+      mid();   // (nothing of this wave is in flight here: a compiler-counted global load consumed now waits for nothing)
+      FENCE();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) ah[t] = nh[t], al[t] = nl[t];
+  };
+  auto rotate = [&] {
+    const unsigned t_ = s_cur;
+    s_cur = s_nxt, s_nxt = s_nn, s_nn = t_;
+  };
+
+  // ---- a layer-1 phase: chunks 2 Q (accumulators D0) and 2 Q + 1 (D1); the chunk before each is converted in its shadow
+  // (S0: the chunk before 2 Q -- none when Q == 0; D0 under the second chunk).  Issues phase p + 2 (kind, c_issue).
+  auto l1_phase = [&](auto q_tag, auto& D0, auto& D1, auto kind_tag, auto np_tag, int c_issue, int c3_issue) {
+    constexpr int Q = decltype(q_tag)::value;
+    FENCE();
+    static_for<4>([&](auto kq_tag) {
+      constexpr int kq = decltype(kq_tag)::value;
+      constexpr int cl = kq >> 1, kb = kq & 1, c1 = 2 * Q + cl;
+      static_for<NM>([&](auto m_tag) {
+        constexpr int m = decltype(m_tag)::value;
+        constexpr int pr = m / (2 * RT), t = (m / RT) % 2, rt = m % RT;
+        const f16x8 wa = pr == 1 ? al[t] : ah[t];
+        const f16x8 xb = pr == 2 ? xl[kb][rt] : xh[kb][rt];
+        auto& D = cl == 0 ? D0 : D1;
+        if constexpr (kb == 0 && pr == 0) D[t][rt] = mfma(wa, xb, cst[m]);   // starts from the scene / timestep part (m = t RT + rt)
+        else D[t][rt] = mfma(wa, xb, D[t][rt]);
+        common_fill(kq_tag, m_tag, kind_tag, np_tag, c_issue, c3_issue);
+        // the constant parts of the chunk's first 2 RT MFMAs, kLead slots ahead: the last kLead slots of the chunk before
+        // (k-block 1) fetch 0 .. kLead-1, slot m of k-block 0 fetches m + kLead
+        if constexpr (kb == 1 && m >= NM - kLead && c1 < 7) cst[m - (NM - kLead)] = rd_cst(c1 + 1, (m - (NM - kLead)) / RT, (m - (NM - kLead)) % RT);
+        if constexpr (kb == 0 && m + kLead < 2 * RT) cst[m + kLead] = rd_cst(c1, (m + kLead) / RT, (m + kLead) % RT);
+        // conversion of the chunk before this one: 3 steps per slot over this chunk's two k-blocks
+        if constexpr (c1 > 0 && !(PSTL_C2_ABL & 2)) {
+          auto& S = cl == 0 ? D1 : D0;
+          conv_h1_slot(S, Ic<c1 - 1>{}, Ic<kb * NM + m>{}, Ic<3>{});
+        }
+        FENCE();
+      });
+      end_kq(kq_tag, [] {});
+    });
+    rotate();
+  };
+
+  // ---- a layer-2 phase on D (chunk c, half HALF).  CONV 1: the layer-2 chunk before (S) is converted in its shadow and its
+  // layer 3 follows the fourth k-block; CONV 2: S is layer 1's last chunk (pieces -> k-block 7 of h1).
+  auto l2_phase = [&](auto& D, auto& S, auto half_tag, auto conv_tag, auto l3first_tag, auto kind_tag, auto np_tag, int c_issue,
+                      int c3_issue, int c_bias, auto&& mid, auto&& slot_fn) {
+    constexpr int HALF = decltype(half_tag)::value;
+    constexpr int CONV = decltype(conv_tag)::value;
+    FENCE();
+    static_for<4>([&](auto kq_tag) {
+      constexpr int kq = decltype(kq_tag)::value;
+      constexpr int kb = 4 * HALF + kq;
+      static_for<NM>([&](auto m_tag) {
+        constexpr int m = decltype(m_tag)::value;
+        constexpr int pr = m / (2 * RT), t = (m / RT) % 2, rt = m % RT;
+        const f16x8 wa = pr == 1 ? al[t] : ah[t];
+        const f16x8 xb = pr == 2 ? bl[kb][rt] : bh[kb][rt];
+        if constexpr (HALF == 0 && kq == 0 && pr == 0) D[t][rt] = mfma(wa, xb, bv[t]);   // the chunk starts from its bias
+        else D[t][rt] = mfma(wa, xb, D[t][rt]);
+        common_fill(kq_tag, m_tag, kind_tag, np_tag, c_issue, c3_issue);
+        if constexpr (CONV == 1 && !(PSTL_C2_ABL & 4)) {
+          constexpr int i0 = 2 * (kq * NM + m);
+          if constexpr (i0 < NCONV) conv_step(S, Ic<i0>{});
+          if constexpr (i0 + 1 < NCONV) conv_step(S, Ic<i0 + 1>{});
+        }
+        if constexpr (CONV == 2 && !(PSTL_C2_ABL & 2)) conv_h1_slot(S, Ic<7>{}, Ic<kq * NM + m>{}, Ic<2>{});
+        if constexpr (HALF == 1 && kq == 3 && (m == 4 || m == 5)) bv[m - 4] = rd_bias(c_bias, m - 4);   // bias of the next chunk
+        if constexpr (CONV == 1 && kq == 3 && m == 6) w3h[0] = rdA(s_cur, 16);
+        if constexpr (CONV == 1 && kq == 3 && m == 7) w3l[0] = rdA(s_cur, 17);
+        slot_fn(Ic<kq * NM + m>{});
+        FENCE();
+      });
+      end_kq(kq_tag, mid);
+    });
+    if constexpr (CONV == 1 && !(PSTL_C2_ABL & 512)) layer3(s_cur, l3first_tag);
+    rotate();
+  };
+  using Yes = std::true_type;
+  using No = std::false_type;
+
+  const f32x4 sc = f32x4{a.w_max, a.a_max, a.w_max, a.a_max};
+#pragma unroll 1
+  for (int n = 0; n < nsteps; ++n) {
+    const int i = a.step_hi - n;
+    const f32x4 cf4 = coef[n];
+    const float kk = cf4[0], ca = cf4[1], sb = cf4[2];
+    n_ca = ca, n_sb = sb, n_step = i;
+    // the timestep row of the NEXT step, on its way while this one computes
+    float tb_next = 0.0f;
+    if (n + 1 < nsteps) tb_next = a.tbias[(long)(i - 1) * kHid2 + tid];
+    auto none = [] {};
+    auto noslot = [](auto) {};
+    // the constant rows of the next step, written right behind the barrier of B(0): every wave is past layer 1's reads of
+    // this step's rows (two barriers ago), the next reads come after the barriers of the remaining phases
+    auto write_crow = [&] {
+      if (n + 1 < nsteps) {
+#pragma unroll
+        for (int s = 0; s < kMaxScn; ++s) crow[s * 256 + tid] = (brow[s * 256 + tid] + tb_next) * kAcc;
+      }
+    };
+
+    // ---- layer 1: 47 -> 256 (four phases), its pieces into the accumulation registers ----
+    if (PSTL_C2_ABL & 256) {
+      rotate(), rotate(), rotate(), rotate();
+    } else {
+    l1_phase(Ic<0>{}, accA, accB, Ic<0>{}, Ic<4>{}, 2, 0);          // issues P2
+    l1_phase(Ic<1>{}, accA, accB, Ic<0>{}, Ic<4>{}, 3, 0);          // issues P3
+    l1_phase(Ic<2>{}, accA, accB, Ic<1>{}, Ic<4>{}, 0, 0);          // issues A(0)
+    l1_phase(Ic<3>{}, accA, accB, Ic<2>{}, Ic<4>{}, 0, 0);          // issues B(0)
+    }
+    // ---- layers 2 + 3 ----
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bv[t] = rd_bias(0, t);
+    l2_phase(accA, accB, Ic<0>{}, Ic<2>{}, No{}, Ic<1>{}, Ic<6>{}, 1, 0, 0, none, noslot);    // A(0): converts layer 1's chunk 7; issues A(1) + W3[0]
+    l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 1, 0, 1, write_crow, [&](auto s_) { noise_slot(0, No{}, s_); });    // B(0); issues B(1)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) b3v[j] = *reinterpret_cast<const f32x4*>(b3s + 16 * j + 4 * g);
+    l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, Yes{}, Ic<1>{}, Ic<6>{}, 2, 1, 0, none, noslot);   // A(1): layer 3 of chunk 0
+    l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 2, 0, 2, none, [&](auto s_) { noise_slot(0, Yes{}, s_); });
+#pragma unroll 1
+    for (int cc = 2; cc < 6; cc += 2) {
+      l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, No{}, Ic<1>{}, Ic<6>{}, cc + 1, cc, 0, none, noslot);
+      l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, cc + 1, 0, cc + 1, none, [&](auto s_) { noise_slot(cc >> 1, No{}, s_); });
+      l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, No{}, Ic<1>{}, Ic<6>{}, cc + 2, cc + 1, 0, none, noslot);
+      l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, cc + 2, 0, cc + 2, none, [&](auto s_) { noise_slot(cc >> 1, Yes{}, s_); });
+    }
+    l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, No{}, Ic<1>{}, Ic<6>{}, 7, 6, 0, none, noslot);    // A(6); issues A(7) + W3[6]
+    l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 7, 0, 7, none, [&](auto s_) { noise_slot(3, No{}, s_); });
+    l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, No{}, Ic<0>{}, Ic<6>{}, 0, 7, 0, none, noslot);    // A(7); issues P0 of the next step + W3[7]
+    l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, No{}, Ic<0>{}, Ic<4>{}, 1, 0, 0, none, [&](auto s_) { noise_slot(3, Yes{}, s_); });    // B(7); issues P1 of the next step
+    // tail: layer 3 of chunk 7.  Its W3 blocks sit in the slot of the NEXT tile-step's first phase (s_cur now): landed and
+    // published by the barrier in the middle of the phase just finished.
+    w3h[0] = rdA(s_cur, 16);
+    w3l[0] = rdA(s_cur, 17);
+    if (!(PSTL_C2_ABL & 64)) static_for<NCONV>([&](auto i_tag) { conv_step(accB, i_tag); });
+    FENCE();
+    layer3(s_cur, No{});
+
+    // ---- epilogue: eps = layer 3 + b3 (already in the accumulators); x' = a x + sb z - kk eps; candidates; next pieces ----
+    const bool emit = i <= a.n_emit, last = i == a.step_lo;
+    {
+    // (global addresses = uniform pointer of the tile's first row + a 32-bit lane offset, re-derived here: see here())
+    const unsigned ln = here((unsigned)lane);
+    const unsigned lc = ln & 15u, lg = ln >> 4;
+#pragma unroll
+    for (int rt = 0; rt < ((PSTL_C2_ABL & 8) ? 0 : RT); ++rt) {
+      const unsigned trow0 = (unsigned)row0 + 16u * (unsigned)rt;     // uniform
+      const bool in = trow0 + lc <= (unsigned)last_row;
+      f32x4 xn[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const bool upd = j < 2 || own2;
+        const float lkk = upd ? kk : 0.0f;
+        const f32x4 o = acc3[j][rt] * kInvAcc;
+        const unsigned loff = lc * (unsigned)kCtrl2 + (unsigned)(16 * j) + 4u * lg;
+        f32x4 qv;
+        if constexpr (RNG) {
+          qv = xq[(rt * 3 + j) * 64];   // Q = a x + sb z, made in the shadow of layer 2
+        } else {
+          const f32x4 x = xq[(rt * 3 + j) * 64];
+          f32x4 z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          if (sb != 0.0f && upd && in)
+            z = *reinterpret_cast<const f32x4*>((a.noise + ((long)(a.steps - 1 - i) * a.N + trow0) * kCtrl2) + loff);
+          const float la = upd ? ca : 1.0f, lsb = upd ? sb : 0.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) qv[e] = __builtin_fmaf(la, x[e], lsb * z[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xn[j][e] = __builtin_fmaf(-lkk, o[e], qv[e]);
+        xq[(rt * 3 + j) * 64] = xn[j];
+        if (upd && in) {
+          if (last) {
+            *reinterpret_cast<f32x4*>((a.x_inout + (long)trow0 * kCtrl2) + loff) = xn[j];
+            if (!(fabsf((xn[j][0] + xn[j][1]) + (xn[j][2] + xn[j][3])) <= 3.0e38f)) atomicOr(a.status, 1u);
+          }
+          if (emit) {
+            f32x4 v = xn[j] * sc;
+            if (a.clip) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = clip_keep_nan(v[e], sc[e]);
+            }
+            *reinterpret_cast<f32x4*>((a.emit_out + ((long)(a.n_emit - i) * a.N + trow0) * kCtrl2) + loff) = v;
+          }
+        }
+      }
+      make_x_pieces(rt, xn[0], xn[1], xn[2]);
+    }
+    }
+    // the first chunk's constant part for the next step (its rows were written above, two or more barriers ago)
+#pragma unroll
+    for (int u = 0; u < kLead; ++u) cst[u] = rd_cst(0, u / RT, u % RT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last step's look-ahead DMA
+  if (pieces_overflowed(ovf)) atomicOr(a.status, 1u);   // a layer input left |x| < 4094 somewhere in this launch
+}
+
+}  // namespace
+
+bool chain2_eligible(const ChainArgs& a) {
+  if (a.mu_only || a.step_hi <= a.step_lo) return false;            // multi-step segments only
+  if (a.h1_save || a.h2_save || a.pre_save || a.init) return false;  // policy_net inference only
+  if (a.rows_per_scene % 16 != 0 || a.rows_per_scene < 48) return false;
+  if (a.step_hi - a.step_lo + 1 > kMaxLaunchSteps) return false;
+  return true;
+}
+
+template <bool RNG>
+static int launch_chain2_t(const ChainArgs& a, hipStream_t st) {
+  const long n_wg = (a.N + kWgRows - 1) / kWgRows;
+  static int allowed_dev = -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return PSTL_ERR_LAUNCH;
+  if (allowed_dev != dev) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<RNG>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) !=
+        hipSuccess)
+      return PSTL_ERR_LAUNCH;
+    allowed_dev = dev;
+  }
+  hipLaunchKernelGGL(k_chain2<RNG>, dim3((unsigned)n_wg), dim3(256), kLdsBytes, st, a);
+  return launch_status();
+}
+
+int launch_chain2(const ChainArgs& a, hipStream_t st) {
+  // in-kernel noise (PSTL_FLAG_RNG) rides in the MFMA shadow; a caller's noise tensor (the parity tests) or no noise at all
+  // is handled in the epilogue
+  return a.rng ? launch_chain2_t<true>(a, st) : launch_chain2_t<false>(a, st);
+}
+
+}  // namespace pstl

@@ -23,6 +23,7 @@
 
 #include <type_traits>
 
+#include "chain_args.hpp"
 #include "pstl_common.hpp"
 #include "rng.hpp"
 
@@ -41,7 +42,6 @@ constexpr int kCtrl = PSTL_CTRL;   // 40
 constexpr int kKx = 48;            // per-row input columns of layer 1 (40 + 1 + 6, padded to 48)
 constexpr int kTileRows = 16;
 constexpr int kG = 12;             // tiles per workgroup (upper bound; small batches use fewer, see tiles_per_group)
-constexpr int kMaxLaunchSteps = 128;  // reverse steps per launch (longer segments are split by pstl_rollout)
 
 // ---- packed weight buffer (float offsets) -----------------------------------------------------------------------
 struct EncOff {        // one scene encoder (in -> 256 -> 256 -> 32), weights as fp32 MFMA A operands (k_pack_a layout)
@@ -51,22 +51,6 @@ struct EncOff {        // one scene encoder (in -> 256 -> 256 -> 32), weights as
   long b1;             // [256]
   long a2;             // [2 T][16 q][4 r][64]
   long b2;             // [32]
-};
-struct ChainOff {       // one of policy_net / rect_net
-  long w1f;             // [224][256]  scene columns, transposed
-  long b1;              // [256]
-  long w1t;             // [32][256]   timestep columns, transposed (policy only)
-  long w1x;             // A-operand layout [16 T][3 q][4 r][64 lanes]
-  long w2;              // A-operand layout [16 T][16 q][4 r][64]
-  long b2;              // [256]
-  long w3;              // A-operand layout [3 j][16 T][4 r][64]
-  long b3;              // [48]
-  // split-bf16 A operands (v_mfma_f32_16x16x32_bf16): 8 words per (tile, k-block, lane): 4 of bf16 "hi" pairs, 4 of "lo"
-  long w1xb;            // [16 T][2 kb][8][64]
-  long w2b;             // [16 T][8 kb][8][64]
-  long w3b;             // [3 j][8 kb][8][64]
-  // split-f16 A operands (v_mfma_f32_16x16x32_f16), same shapes: pieces of kSplitW * w (see k_pack_a_split)
-  long w1xh, w2h, w3h;
 };
 struct MergeOff {
   long w0t, b0, w1t, b1, w2t, b2;  // [40][32],[32],[32][32],[32],[32][40],[40]
@@ -165,9 +149,6 @@ __global__ void k_pack_a(const float* W, int ld, int rows_valid, int n_tiles, in
 // low half first), a second one the four lo words (m >= 4).
 // Slot s of lane group g = l>>4 is column k = 32 kb + 16 (s>>2) + 4 g + (s&3): with this order the accumulator
 // registers of two neighbouring 16-feature tiles ARE one k-block of the next layer's B operand (see k_chain).
-constexpr float kSplitW = 1024.0f;   // weights are split as pieces of 2^10 w
-constexpr float kSplitX = 16.0f;     // activations as pieces of 2^4 x (|x| < 4094; absolute error floor 2^-29)
-
 __device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ unsigned f16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); }
 
@@ -227,45 +208,6 @@ __global__ void k_time_bias(const float* w1t /* [32][256] */, int steps, float* 
 }
 
 // ---- the MLP chain kernel ---------------------------------------------------------------------------------------
-struct ChainArgs {
-  long N;
-  int rows_per_scene;
-  int steps;
-  int step_hi, step_lo;
-  int mu_only;
-  int n_emit;
-  int clip;
-  float w_max, a_max;
-  ChainOff off;
-  const float* packed;
-  const float* base;     // (bs,256)
-  const float* tbias;    // (steps,256) or null (refine)
-  const float* stlp;     // (N,6)
-  const float* hl;       // (N,)
-  const float* beta;
-  const float* alpha;
-  const float* alpha_hat;
-  const float* noise;    // (steps-1,N,40) or null
-  int tiles_per_group;   // 16-row tiles owned by one workgroup (4..kG)
-  int rng;               // draw the noise in the kernel (seed, row_offset)
-  unsigned long long seed;
-  const unsigned long long* seed_dev;   // cfg->dyn: the seed is read from device memory instead (HIP-graph replay)
-  long row_offset;
-  float* x_inout;        // (N,40)
-  float* emit_out;       // (n_emit,N,40)
-  // refine
-  const float* init;     // (N,40)
-  const float* pooled;   // (bs,3,n_shards,40) or null
-  const float* scores;   // (N,)
-  float* out;            // (N,40)
-  int S, n_shards;
-  // training (N1): activations of rect_net kept for the backward pass; null = inference
-  float* h1_save;        // (N,256) relu(layer 1)
-  float* h2_save;        // (N,256) relu(layer 2)
-  float* pre_save;       // (N,40)  layer-3 output before tanh
-  unsigned* status;      // word 2 of the packed buffer's status block: set when a split-f16 launch leaves a non-finite value
-};
-
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -1745,6 +1687,14 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
   return launch_status();
 }
 
+// Batches that k_chain2 runs faster than k_chain: its workgroups own 256 rows for the whole launch, one per CU at a time, so
+// the launch takes ceil(workgroups / CUs) rounds -- it pays when those rounds are (nearly) full.
+inline bool chain2_pays(long N) {
+  const long cus = cu_count(), n_wg = (N + 255) / 256;
+  const long rounds = (n_wg + cus - 1) / cus;
+  return n_wg >= cus && n_wg * 8 >= rounds * cus * 7;   // >= 7/8 of the CU-rounds busy
+}
+
 // cfg->chain_waves: 0, 16 = both networks on split-f16 MFMA: every fp32 operand as two half pieces, three
 //                          v_mfma_f32_16x16x32_f16 products per fp32 product, fp32 accumulation (operands good to 2^-23:
 //                          results sit as close to the reference as an fp32 fmaf chain in another summation order does),
@@ -1758,7 +1708,12 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   // 0: the latency layout for batches that cannot give every CU a full five-tile pipeline (SPARSE, see k_chain); 16: the same
   // arithmetic in the throughput layout whatever the batch size (what large batches get either way; bit-identical results)
   const bool latency = chain_waves == 0;
-  if (chain_waves == 16) chain_waves = 0;
+  // 2: the row-stationary kernel (k_chain2, chain2_kernels.hip) for every launch it can take, whatever the batch size; 0:
+  // for the multi-step denoiser launches of batches that fill whole rounds of its 256-row workgroups (chain2_pays)
+  if constexpr (!REFINE) {
+    if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(a.N))) && chain2_eligible(a)) return launch_chain2(a, st);
+  }
+  if (chain_waves == 16 || chain_waves == 2) chain_waves = 0;
   if (REFINE && chain_waves == 32) chain_waves = 8;    // bf16 pieces cost the interval head up to 9e-5 per pass
   if (REFINE && a.h1_save && chain_waves != 0) chain_waves = chain_waves == 4 ? 4 : 8;   // (no bf16-piece training forward)
   if (chain_waves == 0) {

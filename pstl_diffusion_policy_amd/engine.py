@@ -235,7 +235,7 @@ class Sampler:
             chain_waves = int(os.environ.get("PSTL_CHAIN_WAVES", "0"))
         self.w, self.hp, self.chain_waves = weights, hp, int(chain_waves)
         self.chain_fallback = None       # why the exact-fp32 kernels replaced the requested arithmetic, if they did
-        if self.chain_waves in (0, 16) and not weights.split_f16_ok:
+        if self.chain_waves in (0, 16, 2) and not weights.split_f16_ok:
             self.use_exact_fp32("a chain weight is outside the split-f16 domain |w| < %g (max |w|: policy_net %g, rect_net %g)"
                                 % (ffi.SPLIT_F16_WMAX, weights.chain_wmax["policy_net"], weights.chain_wmax["rect_net"]))
         self.L = ffi.lib()
@@ -259,7 +259,7 @@ class Sampler:
         input |x| >= 4094)?  Returns False when all is well.  Otherwise the results of the region hold NaNs; with
         fallback=True the sampler is switched to the exact-fp32 kernels, the flag cleared and True returned -- the caller
         re-runs the batch; with fallback=False a FloatingPointError is raised."""
-        if self.chain_waves not in (0, 16) or not self.w.chain_overflowed(clear=True):
+        if self.chain_waves not in (0, 16, 2) or not self.w.chain_overflowed(clear=True):
             return False
         why = "a layer input left the split-f16 domain |x| < 4094 (the state became non-finite)"
         if not fallback:

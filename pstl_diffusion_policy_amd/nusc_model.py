@@ -120,7 +120,7 @@ class Net(nn.Module):
         outside the split-f16 domain (|w| < 63.9; PackedWeights reads the maximum the packer recorded)."""
         cw = self.chain_waves if self.chain_waves is not None else int(os.environ.get("PSTL_CHAIN_WAVES", "0"))
         pw = self.packed()
-        if cw in (0, 16) and not pw.split_f16_ok:
+        if cw in (0, 16, 2) and not pw.split_f16_ok:
             if not getattr(pw, "_warned", False):
                 pw._warned = True
                 warnings.warn("pstl: a chain weight is outside the split-f16 domain |w| < %g (policy_net %g, rect_net %g): "
@@ -134,7 +134,7 @@ class Net(nn.Module):
         Otherwise every result since the last check is undefined: with fallback=True a RuntimeWarning is issued, the net is
         switched to the exact-fp32 kernels for good (chain_waves = 8), the flag cleared and True returned -- the caller repeats
         the work; with fallback=False a FloatingPointError is raised.  Synchronises (one 4-byte copy)."""
-        if self.chain_arith() not in (0, 16) or not self.packed().chain_overflowed(clear=True):
+        if self.chain_arith() not in (0, 16, 2) or not self.packed().chain_overflowed(clear=True):
             return False
         why = "a layer input left the split-f16 domain |x| < 4094"
         if not fallback:

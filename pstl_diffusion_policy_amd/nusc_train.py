@@ -438,7 +438,7 @@ def diffusion_rollout(noise, net, batch_cuda, highlevel_dense, feature, args, co
         else:
             # domain guard of the split-f16 chain (Net.domain_check): in eager mode x_T is kept, so that a rollout that set the
             # flag is repeated on the exact-fp32 kernels from the same x_T and the same noise (supplied, or the same Philox seed)
-            eager = net.domain_check == "eager" and net.chain_arith() in (0, 16)
+            eager = net.domain_check == "eager" and net.chain_arith() in (0, 16, 2)
             x_T = x.clone() if eager else None
             sm = Sampler(net.packed(), net.hparams(), chain_waves=net.chain_arith())
             emit = sm.rollout(sb, feature.pstl["base_policy"], x, zs, steps, n_emit=n_emit, clip=args.diffusion_clip,

@@ -1,0 +1,146 @@
+"""GPU tests of k_chain2 (csrc/chain2_kernels.hip): the multi-step denoiser launch with the rows stationary in registers
+and the split-f16 weights streamed through LDS.  `chain_waves = 2` forces it for every launch it can take (any batch size);
+the default `chain_waves = 0` hands it the batches that fill whole rounds of its 256-row workgroups.  Its arithmetic is
+k_chain's default form in another summation order, so the two kernels agree to rounding, not bit for bit; everything else
+it must share with k_chain: the reference's goldens within 1e-4 (tests/test_gpu_parity.py runs every fixture with
+chain_waves = 2 too), the Philox stream, the emitted candidate list, shard invariance, the domain guard."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    from pstl_diffusion_policy_amd import ffi
+    ffi.lib()
+    return torch.device("cuda:0")
+
+
+def _hp():
+    from pstl_diffusion_policy_amd.synthetic import default_hparams
+    return default_hparams()
+
+
+def _setup(dev, bs, S, K, seed=5):
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    scene = make_scene_batch(bs, K=K, S=S, seed=seed, invalid_lane_frac=0.2, stlp_mode="wide")
+    return hp, scene, PackedWeights(golden_weights(), dev), SceneBatch(scene, S, hp, dev)
+
+
+# (scenes, samples): 3 S = rows per scene is a multiple of 16 and >= 48; the row counts are not multiples of the 256 rows a
+# workgroup owns (a ragged last workgroup), and workgroups straddle 2..6 scenes
+@pytest.mark.parametrize("bs,S", [(7, 16), (5, 64), (11, 32), (3, 48)])
+@pytest.mark.parametrize("noise", ["tensor", "kernel"])
+def test_chain2_agrees_with_chain(dev, bs, S, noise):
+    """Same inputs through k_chain (chain_waves 16) and k_chain2 (2): every intermediate of the full list within 2e-5 (the
+    two sum the same products in another order: observed <= 4e-6), identical shapes, nothing non-finite."""
+    from pstl_diffusion_policy_amd.engine import Sampler
+    hp, scene, w, sb = _setup(dev, bs, S, 3)
+    steps = 12
+    g = torch.Generator(device=dev).manual_seed(3)
+    x_T = torch.randn(sb.N, 40, device=dev, generator=g) if noise == "tensor" else None
+    z = torch.randn(steps - 1, sb.N, 40, device=dev, generator=g) if noise == "tensor" else None
+    outs = []
+    for cw in (16, 2):
+        sm = Sampler(w, hp, chain_waves=cw)
+        o = sm.sampling_region(sb, steps, x_T, z, rect_head=False, multi_cands=1, seed=99, full_list=True)
+        assert not w.chain_overflowed()
+        outs.append(o["controls_list"].clone())
+    assert outs[0].shape == outs[1].shape and torch.isfinite(outs[1]).all()
+    d = (outs[0] - outs[1]).abs().max().item()
+    assert 0.0 < d <= 2e-5, d      # (> 0: the second run did take the other kernel)
+
+
+def test_chain2_against_oracle_on_fresh_scenes(dev):
+    """No fixture: seeded scenes, weights and noise; CPU oracle vs HIP with k_chain2 forced, e7 + guidance (the guided,
+    single-step launches stay on k_chain: the segments between them are what k_chain2 runs)."""
+    from oracle import pstl_oracle as orc
+    from pstl_diffusion_policy_amd.engine import Sampler, acc_from_counts
+    bs, S, K, steps = 5, 16, 4, 14
+    hp, scene, w, sb = _setup(dev, bs, S, K, seed=4242)
+    sd = golden_weights()
+    g = torch.Generator().manual_seed(7)
+    N = bs * S * 3
+    x_T = torch.randn(N, 40, generator=g)
+    z = torch.randn(steps - 1, N, 40, generator=g)
+    guid = dict(enabled=True, before=3, niters=2, lr=0.01)
+    ref = orc.sampling_region(sd, {k: v.numpy() for k, v in scene.items()}, S, steps, hp, x_T, z, rect_head=True,
+                              multi_cands=5, guidance=guid, n_rolls=1)
+    sm = Sampler(w, hp, chain_waves=2)
+    out = sm.sampling_region(sb, steps, x_T.to(dev), z.to(dev), rect_head=True, multi_cands=5, guidance=guid, n_rolls=1,
+                             full_list=True)
+    cl = out["controls_list"].reshape(steps, N, 20, 2).cpu()
+    assert (cl - ref["controls_list"]).abs().max().item() <= 1e-4
+    assert (out["final_controls"].reshape(N, 20, 2).cpu() - ref["final_controls"]).abs().max().item() <= 1e-4
+    acc, sacc = acc_from_counts(out["counts"])
+    assert abs(acc - float(ref["final_acc"])) <= 0.005 and abs(sacc - float(ref["final_scene_acc"])) <= 0.005
+
+
+def test_chain2_in_kernel_noise_is_the_fill_normal_stream(dev):
+    """k_chain2 draws its noise in the shadow of layer 2's MFMAs, as single-instruction steps of Philox4x32-10 + Box-Muller:
+    the rollout must equal, bit for bit, the one fed with pstl_fill_normal's tensors (which the epilogue adds), and a block
+    of scenes evaluated alone with the right row_offset must reproduce its rows of the full batch."""
+    from pstl_diffusion_policy_amd.engine import Sampler, SceneBatch
+    bs, S, K, steps, seed = 21, 64, 3, 9, 20240229
+    hp, scene, w, sb = _setup(dev, bs, S, K, seed=8)
+    sm = Sampler(w, hp, chain_waves=2)
+    z = torch.stack([sm.fill_normal(sb, steps, i, seed) for i in range(steps - 1, 0, -1)])
+    x_T = sm.fill_normal(sb, steps, steps, seed)
+    guid = dict(enabled=True, before=3, niters=1, lr=0.01)
+    a = sm.sampling_region(sb, steps, None, None, rect_head=True, multi_cands=4, guidance=guid, seed=seed, full_list=True)
+    b = sm.sampling_region(sb, steps, x_T, z, rect_head=True, multi_cands=4, guidance=guid, full_list=True)
+    for k in ["controls_list", "final_controls", "final_scores", "counts"]:
+        assert torch.equal(a[k], b[k]), k
+    lo, hi = 6, 17
+    sub = {k: v[lo:hi].clone() for k, v in scene.items()}
+    part = sm.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=lo * S * 3, global_valid_sum=float(sb.valid.sum()),
+                                         global_rows=sb.N), steps, None, None, rect_head=True, multi_cands=4,
+                              guidance=guid, seed=seed)
+    r0, r1 = lo * S * 3, hi * S * 3
+    assert torch.equal(part["final_controls"], a["final_controls"][r0:r1])
+    assert torch.equal(part["final_scores"], a["final_scores"][r0:r1])
+
+
+def test_chain2_run_to_run_and_long_segments(dev):
+    """Bitwise repeatable; a 150-step rollout (two launches: a launch covers at most 128 reverse steps) agrees with k_chain."""
+    from pstl_diffusion_policy_amd.engine import Sampler
+    hp, scene, w, sb = _setup(dev, 4, 64, 2)
+    steps = 150
+    outs = {}
+    for cw in (2, 2, 16):
+        sm = Sampler(w, hp, chain_waves=cw)
+        o = sm.sampling_region(sb, steps, None, None, rect_head=False, multi_cands=3, seed=5)
+        outs.setdefault(cw, []).append(o["final_controls"].clone())
+    assert torch.equal(outs[2][0], outs[2][1])
+    assert (outs[2][0] - outs[16][0]).abs().max().item() <= 5e-5
+
+
+def test_chain2_domain_guard(dev):
+    """A layer input outside the split-f16 domain (|x| >= 4094) sets the sticky word of the packed buffer's status block in
+    k_chain2 as in k_chain: one hidden unit with bias 5000 and zero outgoing weights (exact for the fp32 kernels and the
+    oracle; 5000 x 2^4 overflows a half piece, 0 x inf follows)."""
+    import warnings
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    sd = {k: v.copy() for k, v in golden_weights().items()}
+    sd["policy_net.0.bias"][17] = 5000.0
+    sd["policy_net.2.weight"][:, 17] = 0.0
+    w = PackedWeights(sd, dev)
+    assert w.split_f16_ok
+    scene = make_scene_batch(4, K=2, S=64, seed=1, stlp_mode="wide")
+    sb = SceneBatch(scene, 64, hp, dev)
+    sm = Sampler(w, hp, chain_waves=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x = torch.randn(sb.N, 40, device=dev)
+        _, base_p, _ = sm.encode(sb, need_rect=False)
+        sm.rollout(sb, base_p, x, None, 8, n_emit=0, seed=3)
+        assert w.chain_overflowed(clear=True)

@@ -129,14 +129,16 @@ def test_dpp_loss_full_size_is_invariant_to_scene_order(ctx):
 
 
 def test_split_bf16_chain_tracks_the_fp32_chain_full_size(ctx):
-    """The default MLP-chain arithmetic (three bf16 MFMA products per fp32 product, fp32 accumulate) against the exact
-    fp32-MFMA variant of the same kernel, 786 432 rows through 99 chained reverse steps on the same in-kernel noise:
-    every one of the 31 million final controls stays within 6e-5 (observed 4.2e-5; the typical element is at 1e-5), inside
-    the 1e-4 parity gate (no guidance: the comparison is of the chain alone), and RefineNet's output likewise."""
+    """The default MLP-chain arithmetic (both networks: every fp32 operand as two IEEE-half pieces, three f16 MFMA products
+    per fp32 product, fp32 accumulate; at this size the multi-step launches run on the row-stationary kernel k_chain2)
+    against the exact fp32-MFMA variant, 786 432 rows through 99 chained reverse steps on the same in-kernel noise: every
+    one of the 31 million final controls stays within 6e-5 (the typical element is at 1e-6), inside the 1e-4 parity gate (no
+    guidance: the comparison is of the chain alone), and RefineNet's output likewise.  (The name is historical: round 1's
+    default had bfloat16 pieces.)"""
     from pstl_diffusion_policy_amd.engine import Sampler
     sb, dev = ctx["sb"], ctx["dev"]
     outs = {}
-    for cw in (8, 0):   # 0 = the default: denoiser on split-bf16 products, rect_net on fp32 MFMA
+    for cw in (8, 0):   # 0 = the default: both networks on split-f16 products
         sm = Sampler(ctx["sm"].w, ctx["hp"], chain_waves=cw)
         o = sm.sampling_region(sb, 100, None, None, rect_head=True, multi_cands=3, seed=77, want_scores3=False)
         outs[cw] = {k: o[k].clone() for k in ("final_controls", "sel_controls", "sel_idx", "sel_scores")}

@@ -125,7 +125,7 @@ def _run_region(dev, name, chain_waves=0):
     return d, meta, sb, out
 
 
-@pytest.mark.parametrize("chain_waves", [8, 4, 0, 16, 32])
+@pytest.mark.parametrize("chain_waves", [8, 4, 0, 16, 32, 2])
 @pytest.mark.parametrize("name", SAMPLING_CASES)
 def test_sampling_region_matches_reference(dev, name, chain_waves):
     from pstl_diffusion_policy_amd.engine import acc_from_counts
@@ -351,9 +351,11 @@ def test_full_size_properties(dev):
     assert torch.equal(total, full["counts"])
     # a shard small enough for 5-tile workgroups: its single-step (guided) denoiser launches walk their groups one by one,
     # while the full batch streams them through the pipeline without draining (CONT, mlp_kernels.hip) -- same bits
+    # (the full batch's multi-step segments run on k_chain2, which a 12 288-row shard would not choose for itself: forced, so
+    # that both sum in the same order; the single-step launches under test are k_chain's either way)
     lo, hi = 1000, 1064
     sub = {k: v[lo:hi].contiguous() for k, v in scene.items()}
-    part = sm.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=lo * S * 3, global_valid_sum=vsum, global_rows=N),
+    part = Sampler(sm.w, hp, chain_waves=2).sampling_region(SceneBatch(sub, S, hp, dev, row_offset=lo * S * 3, global_valid_sum=vsum, global_rows=N),
                               steps, None, None, rect_head=True, multi_cands=5, guidance=guid, seed=seed, want_scores3=False)
     assert torch.equal(part["final_controls"], full["final_controls"][lo * S * 3:hi * S * 3])
     assert torch.equal(part["final_scores"], full["final_scores"][lo * S * 3:hi * S * 3])
