@@ -58,6 +58,23 @@ constexpr float kSX = kSplitX, kSW = kSplitW, kAcc = kSX * kSW, kInvSW = 1.0f / 
 #ifndef PSTL_C2_ABL
 #define PSTL_C2_ABL 0
 #endif
+// -DPSTL_C2_STAMP: a diagnostic build that accumulates, per wave of workgroup 7, the shader cycles of the sections of a
+// tile-step (layer 1 | chunk 0 | chunk 1 | first halves of chunks 2..5 | second halves | chunks 6, 7 | tail | epilogue) and the launch's realtime span, written as 64-bit words
+// to the buffer passed as emit_out (n_emit must be 0): [wave][8 sections, cycles total, realtime ticks (100 MHz), steps]
+// (tools/dbg/chain2_stamps.py).  The stamps' waits drain the LDS reads in flight: read the SHARES, not the length.
+#ifdef PSTL_C2_STAMP
+#define C2_STAMP(k)                                                                                       \
+  {                                                                                                       \
+    FENCE();                                                                                              \
+    unsigned long long t_;                                                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+    st_sum[k] += t_ - st_prev;                                                                            \
+    st_prev = t_;                                                                                         \
+    FENCE();                                                                                              \
+  }
+#else
+#define C2_STAMP(k)
+#endif
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).  Every index is a
 // constant expression by construction (a run-time loop the unroller gives up on puts the arrays it indexes in scratch).
 template <class F, int... Is>
@@ -74,9 +91,11 @@ using Ic = std::integral_constant<int, I>;
 // one 1 KB LDS-DMA piece: lane l moves 16 bytes from sbase + voff to LDS byte address lds_dst + 16 l.  Issued from inline
 // assembly: invisible to the compiler's wait-count pass (a tracked LDS-DMA puts s_waitcnt vmcnt(0) in front of the wave's
 // next ds_read), waited for by the vmcnt(0) in front of each phase barrier.
-__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
+__device__ __forceinline__ void dma16x2(const void* sbase, unsigned voff, unsigned lds_dst) {   // two adjacent pieces
   if (PSTL_C2_ABL & 16) return;
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff),
+               "s"(sbase), "s"(lds_dst)
+               : "memory");
 }
 
 __device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
@@ -87,6 +106,15 @@ __device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __buil
 __device__ __forceinline__ void note_word(unsigned& ovf, unsigned w) {
   if (PSTL_C2_ABL & 128) return;
   asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(ovf) : "v"(w));
+}
+// the lo pieces of two values: f16(v k - hi) for both halves of the packed hi word (inline assembly: hipcc selects
+// v_cvt_f32_f16 x 2 + v_pk_fma_f32 + v_cvt_pk_f16_f32 for the C++ form; consumers are many instructions away, no hazard)
+__device__ __forceinline__ unsigned lo_word(float v0, float v1, float k, unsigned hi) {
+  unsigned lw;
+  asm volatile("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+               : "=&v"(lw)
+               : "v"(v0), "v"(v1), "s"(k), "v"(hi));
+  return lw;
 }
 __device__ __forceinline__ bool pieces_overflowed(unsigned ovf) { return (ovf & 0xffffu) >= 0x7c00u || (ovf >> 16) >= 0x7c00u; }
 // A value the optimiser must take as it comes at this point: stops it from hoisting `uniform pointer + lane offset` out of the
@@ -111,7 +139,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, col = lane & 15;
   constexpr int NM = 6 * RT;          // MFMAs per k-block
-  constexpr int NCONV = 32 * RT;      // conversion micro-steps per chunk (4 RT pairs x 8)
+  constexpr int NCONV = 24 * RT;      // conversion micro-steps per chunk (4 RT pairs x 6)
   constexpr int kLead = 4;            // slots between an LDS read of a constant part and the MFMA that takes it as C
   const long wg_row0 = (long)blockIdx.x * kWgRows;
   const long row0 = wg_row0 + (long)w * (16 * RT);           // first row of this wave
@@ -177,27 +205,26 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   f32x2 cm[2], cf[2];                 // conversion state of the two pairs in flight
   unsigned chw[2];
 
-  // pieces of four (scaled) values pairs -> words
-  auto split_quad2 = [&](const f32x4& u, const f32x4& v, f16x8& hi, f16x8& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      hi[i] = (_Float16)u[i];
-      hi[4 + i] = (_Float16)v[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      lo[i] = (_Float16)(u[i] - (float)hi[i]);
-      lo[4 + i] = (_Float16)(v[i] - (float)hi[4 + i]);
-    }
-    const uw4 hw = __builtin_bit_cast(uw4, hi);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) note_word(ovf, hw[r] & 0x7fff7fffu);
+  // the layer-1 B operands of row tile rt from its state quads: k-block 0 = output tiles j = 0, 1; k-block 1 = tile j = 2
+  // (x 32..39 | hl | stlp) and zeros.  Per pair of values: v_pk_mul_f32 (x 16), v_cvt_pk_f16_f32, the running maximum of
+  // |16 x| for the domain guard (x is signed: v_max3_f32 with |.| modifiers), and the fused lo word.
+  float ovfx = 0.0f;
+  auto x_pair = [&](float v0, float v1, unsigned& hw, unsigned& lw) {
+    const f32x2 m = f32x2{v0, v1} * kSX;
+    hw = __builtin_bit_cast(unsigned, __builtin_convertvector(m, f16x2));
+    asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ovfx) : "v"(m[0]), "v"(m[1]));
+    lw = lo_word(v0, v1, kSX, hw);
   };
-  // the layer-1 B operands of row tile rt from its state quads (x 16): k-block 0 = output tiles j = 0, 1; k-block 1 = tile
-  // j = 2 (x 32..39 | hl | stlp) and zeros
   auto make_x_pieces = [&](int rt, const f32x4& q0, const f32x4& q1, const f32x4& q2) {
-    split_quad2(q0 * kSX, q1 * kSX, xh[0][rt], xl[0][rt]);
-    split_quad2(q2 * kSX, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, xh[1][rt], xl[1][rt]);
+    unsigned h0[4], l0[4], h1[2], l1[2];
+    x_pair(q0[0], q0[1], h0[0], l0[0]);
+    x_pair(q0[2], q0[3], h0[1], l0[1]);
+    x_pair(q1[0], q1[1], h0[2], l0[2]);
+    x_pair(q1[2], q1[3], h0[3], l0[3]);
+    x_pair(q2[0], q2[1], h1[0], l1[0]);
+    x_pair(q2[2], q2[3], h1[1], l1[1]);
+    xh[0][rt] = __builtin_bit_cast(f16x8, uw4{h0[0], h0[1], h0[2], h0[3]}), xl[0][rt] = __builtin_bit_cast(f16x8, uw4{l0[0], l0[1], l0[2], l0[3]});
+    xh[1][rt] = __builtin_bit_cast(f16x8, uw4{h1[0], h1[1], 0u, 0u}), xl[1][rt] = __builtin_bit_cast(f16x8, uw4{l1[0], l1[1], 0u, 0u});
   };
 
   // ---- the initial state: lane (g, col) of row tile rt holds columns 16 j + 4 g .. + 3 of row 16 rt + col ----
@@ -241,32 +268,32 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   const unsigned* w2p = reinterpret_cast<const unsigned*>(a.packed + a.off.w2h);
   const unsigned* w3p = reinterpret_cast<const unsigned*>(a.packed + a.off.w3h);
   const unsigned lane16 = (unsigned)lane * 16u;
-  // piece k (0..5) of this wave's share (pieces w, w + 4, ...) of a phase; KIND 0: layer-1 phase q = c; 1 / 2: first /
-  // second half of layer-2 chunk c.  k >= 4: the W3 k-block that rides with the phase (c3)
-  auto issue_piece = [&](auto kind_tag, int c, int c3, int k, unsigned slot_byte) {
+  // pair k (0..2) of this wave's share of a phase: a pair = the hi and the lo piece of one (k-block, tile) -- adjacent in the
+  // packed buffer and in the slot, so ONE M0 / address set-up serves both (the instruction offset applies to the LDS address
+  // too).  k = 0, 1: pairs w, w + 4 of the 8 W1 / W2 pairs; KIND 0: layer-1 phase q = c; 1 / 2: first / second half of layer-2
+  // chunk c.  k = 2: pair w of the 3 pairs of the W3 k-block c3 that rides with the phase (wave 3 repeats pair 0).
+  auto issue_pair = [&](auto kind_tag, int c, int c3, int k, unsigned slot_byte) {
     constexpr int KIND = decltype(kind_tag)::value;
-    if (k < 4) {
-      const int qq = 4 * k + w;
-      const int kq = qq >> 2, t = (qq >> 1) & 1, hl = qq & 1;
+    if (k < 2) {
+      const int pp = 4 * k + w;               // = kq * 2 + t
+      const int kq = pp >> 1, t = pp & 1;
       if constexpr (KIND == 0) {   // kq = 2 cl + kb; tile 2 (2 q + cl) + t of W1 [16 T][2 kb][hi | lo]
-        const long blk = ((long)(2 * (2 * c + (kq >> 1)) + t) * 2 + (kq & 1)) * 2 + hl;
-        dma16(w1p + blk * 256, lane16, slot_byte + (unsigned)qq * 1024u);
+        const long blk = ((long)(2 * (2 * c + (kq >> 1)) + t) * 2 + (kq & 1)) * 2;
+        dma16x2(w1p + blk * 256, lane16, slot_byte + (unsigned)pp * 2048u);
       } else {                     // tile 2 c + t, k-block 4 half + kq of W2 [16 T][8 kb][hi | lo]
-        const long blk = ((long)(2 * c + t) * 8 + 4 * (KIND - 1) + kq) * 2 + hl;
-        dma16(w2p + blk * 256, lane16, slot_byte + (unsigned)qq * 1024u);
+        const long blk = ((long)(2 * c + t) * 8 + 4 * (KIND - 1) + kq) * 2;
+        dma16x2(w2p + blk * 256, lane16, slot_byte + (unsigned)pp * 2048u);
       }
-    } else {   // (branch-free: waves 2 and 3 issue pieces 2 and 3 a second time -- same bytes to the same place)
-      const int q0 = 4 * (k - 4) + w;
-      const int qq = q0 < 6 ? q0 : q0 - 4;
-      const int j = qq >> 1, hl = qq & 1;
-      const long blk = ((long)(j * 8 + c3) * 2 + hl);
-      dma16(w3p + blk * 256, lane16, slot_byte + 16384u + (unsigned)qq * 1024u);
+    } else {
+      const int j = w < 3 ? w : 0;
+      const long blk = ((long)(j * 8 + c3) * 2);
+      dma16x2(w3p + blk * 256, lane16, slot_byte + 16384u + (unsigned)j * 2048u);
     }
   };
 
   // prologue: phases P0 and P1 of the first tile-step
-  static_for<6>([&](auto k) { issue_piece(Ic<0>{}, 0, 7, decltype(k)::value, 0u); });
-  static_for<4>([&](auto k) { issue_piece(Ic<0>{}, 1, 0, decltype(k)::value, (unsigned)kSlotBytes); });
+  static_for<3>([&](auto k) { issue_pair(Ic<0>{}, 0, 7, decltype(k)::value, 0u); });
+  static_for<2>([&](auto k) { issue_pair(Ic<0>{}, 1, 0, decltype(k)::value, (unsigned)kSlotBytes); });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -281,11 +308,13 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
 #pragma unroll
   for (int u = 0; u < kLead; ++u) cst[u] = rd_cst(0, u / RT, u % RT);
 
-  // ReLU + split of the finished chunk's accumulators S into the packed pieces, as 8 single-instruction steps per pair of
-  // values, two pairs in flight: step i = 16 grp + 2 stage + which
+  // ReLU + split of the finished chunk's accumulators S into the packed pieces, as 6 steps of 1-2 instructions per pair of
+  // values, two pairs in flight: step i = 12 grp + 2 stage + which.  hi = f16(relu(v) / kSW) (v_pk_mul_f32 + v_cvt_pk_f16_f32),
+  // lo = f16(relu(v) / kSW - hi) as ONE fused multiply-add per half (v_fma_mixlo / mixhi_f16: the product with a power of two
+  // is exact, so this is the value the separate subtraction gives).
   auto conv_step = [&](auto& S, auto i_tag) {
     constexpr int i = decltype(i_tag)::value;
-    constexpr int which = i & 1, stage = (i >> 1) & 7, p = 2 * (i >> 4) + which;   // pair p = 4 rt + q
+    constexpr int which = i & 1, stage = (i % 12) >> 1, p = 2 * (i / 12) + which;   // pair p = 4 rt + q
     constexpr int rt = p >> 2, q = p & 3, t = q >> 1, e = (q & 1) * 2, word = 2 * t + (q & 1);
     if constexpr (stage == 0) {
       const float v0 = S[t][rt][e];   // (a copy: __builtin_bit_cast of a vector ELEMENT lvalue reads element 0)
@@ -294,19 +323,14 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       const float v1 = S[t][rt][e + 1];
       cm[which][1] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v1), 0));
     } else if constexpr (stage == 2) {
-      cm[which] *= kInvSW;
+      cf[which] = cm[which] * kInvSW;
     } else if constexpr (stage == 3) {
-      chw[which] = __builtin_bit_cast(unsigned, __builtin_convertvector(cm[which], f16x2));
+      chw[which] = __builtin_bit_cast(unsigned, __builtin_convertvector(cf[which], f16x2));
       phw[rt][word] = chw[which];
     } else if constexpr (stage == 4) {
-      cf[which][0] = (float)__builtin_bit_cast(f16x2, chw[which])[0];
-    } else if constexpr (stage == 5) {
-      cf[which][1] = (float)__builtin_bit_cast(f16x2, chw[which])[1];
       note_word(ovf, chw[which]);
-    } else if constexpr (stage == 6) {
-      cf[which] = cm[which] - cf[which];
     } else {
-      plw[rt][word] = __builtin_bit_cast(unsigned, __builtin_convertvector(cf[which], f16x2));
+      plw[rt][word] = lo_word(cm[which][0], cm[which][1], kInvSW, chw[which]);
     }
   };
   auto pieces_h = [&](int rt) { return __builtin_bit_cast(f16x8, uw4{phw[rt][0], phw[rt][1], phw[rt][2], phw[rt][3]}); };
@@ -322,20 +346,21 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       asm volatile("" : "+a"(bl[KB][rt]));
     }
   };
-  // conversion of a layer-1 chunk in NS steps per slot, and its pieces pinned as soon as a row tile's eight words are done
-  // (slot = 0 .. of the shadow the conversion runs in)
-  auto conv_h1_slot = [&](auto& S, auto kb_tag, auto slot_tag, auto ns_tag) {
-    constexpr int slot = decltype(slot_tag)::value, NS = decltype(ns_tag)::value;
-    static_for<NS>([&](auto u) {
-      constexpr int i = slot * NS + decltype(u)::value;
+  // conversion of a layer-1 chunk in the shadow of 48 slots: 3 steps in each of the first four slots, 2 in the others (96 in
+  // 46 slots), and its pieces pinned as soon as a row tile's words are done (hi words: step 24 rt + 19, lo: 24 rt + 23)
+  auto conv_h1_slot = [&](auto& S, auto kb_tag, auto slot_tag) {
+    constexpr int slot = decltype(slot_tag)::value;
+    constexpr int first = slot < 4 ? 3 * slot : 12 + 2 * (slot - 4), cnt = slot < 4 ? 3 : 2;
+    static_for<cnt>([&](auto u) {
+      constexpr int i = first + decltype(u)::value;
       if constexpr (i < NCONV) conv_step(S, Ic<i>{});
     });
-    // row tile rt is complete after step 32 (rt + 1) - 1, i.e. in slot (32 (rt + 1) - 1) / NS; pin hi and lo in the two slots after
     static_for<RT>([&](auto rt_tag) {
       constexpr int rt = decltype(rt_tag)::value;
-      constexpr int done = (32 * (rt + 1) - 1) / NS;
-      if constexpr (slot == done + 1) pin_h1(kb_tag, rt_tag, Ic<0>{});
-      if constexpr (slot == done + 2) pin_h1(kb_tag, rt_tag, Ic<1>{});
+      constexpr int eh = 24 * rt + 19, el = 24 * rt + 23;
+      constexpr int sh = eh < 12 ? eh / 3 : 4 + (eh - 12) / 2, sl = el < 12 ? el / 3 : 4 + (el - 12) / 2;
+      if constexpr (slot == sh + 1) pin_h1(kb_tag, rt_tag, Ic<0>{});
+      if constexpr (slot == sl + 1) pin_h1(kb_tag, rt_tag, Ic<1>{});
     });
   };
 
@@ -442,8 +467,10 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       if constexpr (m & 1) nl[m >> 1] = rdA(sl, pc);
       else nh[m >> 1] = rdA(sl, pc);
     }
-    constexpr int DS = (NM - 2) / 6;
-    if constexpr (kq == 2 && m >= 2 && (m - 2) % DS == 0 && (m - 2) / DS < NP) issue_piece(kind_tag, c_issue, c3_issue, (m - 2) / DS, s_nn);
+    // this wave's DMA share of the phase after next (NP = 4: two pairs; 6: + the W3 pair), spread over the third k-block
+    if constexpr (kq == 2 && m == 2) issue_pair(kind_tag, c_issue, c3_issue, 0, s_nn);
+    if constexpr (kq == 2 && m == NM / 2) issue_pair(kind_tag, c_issue, c3_issue, 1, s_nn);
+    if constexpr (kq == 2 && m == NM - 4 && NP == 6) issue_pair(kind_tag, c_issue, c3_issue, 2, s_nn);
   };
   auto end_kq = [&](auto kq_tag, auto&& mid) {
     constexpr int kq = decltype(kq_tag)::value;
@@ -484,10 +511,10 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
         // (k-block 1) fetch 0 .. kLead-1, slot m of k-block 0 fetches m + kLead
         if constexpr (kb == 1 && m >= NM - kLead && c1 < 7) cst[m - (NM - kLead)] = rd_cst(c1 + 1, (m - (NM - kLead)) / RT, (m - (NM - kLead)) % RT);
         if constexpr (kb == 0 && m + kLead < 2 * RT) cst[m + kLead] = rd_cst(c1, (m + kLead) / RT, (m + kLead) % RT);
-        // conversion of the chunk before this one: 3 steps per slot over this chunk's two k-blocks
+        // conversion of the chunk before this one, over this chunk's two k-blocks
         if constexpr (c1 > 0 && !(PSTL_C2_ABL & 2)) {
           auto& S = cl == 0 ? D1 : D0;
-          conv_h1_slot(S, Ic<c1 - 1>{}, Ic<kb * NM + m>{}, Ic<3>{});
+          conv_h1_slot(S, Ic<c1 - 1>{}, Ic<kb * NM + m>{});
         }
         FENCE();
       });
@@ -519,7 +546,9 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
           if constexpr (i0 < NCONV) conv_step(S, Ic<i0>{});
           if constexpr (i0 + 1 < NCONV) conv_step(S, Ic<i0 + 1>{});
         }
-        if constexpr (CONV == 2 && !(PSTL_C2_ABL & 2)) conv_h1_slot(S, Ic<7>{}, Ic<kq * NM + m>{}, Ic<2>{});
+        if constexpr (CONV == 2 && !(PSTL_C2_ABL & 2)) {
+          if constexpr (kq * NM + m < 48) conv_h1_slot(S, Ic<7>{}, Ic<kq * NM + m>{});
+        }
         if constexpr (HALF == 1 && kq == 3 && (m == 4 || m == 5)) bv[m - 4] = rd_bias(c_bias, m - 4);   // bias of the next chunk
         if constexpr (CONV == 1 && kq == 3 && m == 6) w3h[0] = rdA(s_cur, 16);
         if constexpr (CONV == 1 && kq == 3 && m == 7) w3l[0] = rdA(s_cur, 17);
@@ -535,6 +564,11 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   using No = std::false_type;
 
   const f32x4 sc = f32x4{a.w_max, a.a_max, a.w_max, a.a_max};
+#ifdef PSTL_C2_STAMP
+  unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev, st_rt0, st_t0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev), "=s"(st_rt0)::"memory");
+  st_t0 = st_prev;
+#endif
 #pragma unroll 1
   for (int n = 0; n < nsteps; ++n) {
     const int i = a.step_hi - n;
@@ -564,90 +598,125 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
     l1_phase(Ic<2>{}, accA, accB, Ic<1>{}, Ic<4>{}, 0, 0);          // issues A(0)
     l1_phase(Ic<3>{}, accA, accB, Ic<2>{}, Ic<4>{}, 0, 0);          // issues B(0)
     }
+    C2_STAMP(0)
     // ---- layers 2 + 3 ----
 #pragma unroll
     for (int t = 0; t < 2; ++t) bv[t] = rd_bias(0, t);
     l2_phase(accA, accB, Ic<0>{}, Ic<2>{}, No{}, Ic<1>{}, Ic<6>{}, 1, 0, 0, none, noslot);    // A(0): converts layer 1's chunk 7; issues A(1) + W3[0]
     l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 1, 0, 1, write_crow, [&](auto s_) { noise_slot(0, No{}, s_); });    // B(0); issues B(1)
+    C2_STAMP(1)
 #pragma unroll
     for (int j = 0; j < 3; ++j) b3v[j] = *reinterpret_cast<const f32x4*>(b3s + 16 * j + 4 * g);
     l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, Yes{}, Ic<1>{}, Ic<6>{}, 2, 1, 0, none, noslot);   // A(1): layer 3 of chunk 0
     l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 2, 0, 2, none, [&](auto s_) { noise_slot(0, Yes{}, s_); });
+    C2_STAMP(2)
 #pragma unroll 1
     for (int cc = 2; cc < 6; cc += 2) {
       l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, No{}, Ic<1>{}, Ic<6>{}, cc + 1, cc, 0, none, noslot);
+      C2_STAMP(3)
       l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, cc + 1, 0, cc + 1, none, [&](auto s_) { noise_slot(cc >> 1, No{}, s_); });
+      C2_STAMP(4)
       l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, No{}, Ic<1>{}, Ic<6>{}, cc + 2, cc + 1, 0, none, noslot);
+      C2_STAMP(3)
       l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, cc + 2, 0, cc + 2, none, [&](auto s_) { noise_slot(cc >> 1, Yes{}, s_); });
+      C2_STAMP(4)
     }
     l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, No{}, Ic<1>{}, Ic<6>{}, 7, 6, 0, none, noslot);    // A(6); issues A(7) + W3[6]
     l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 7, 0, 7, none, [&](auto s_) { noise_slot(3, No{}, s_); });
     l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, No{}, Ic<0>{}, Ic<6>{}, 0, 7, 0, none, noslot);    // A(7); issues P0 of the next step + W3[7]
     l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, No{}, Ic<0>{}, Ic<4>{}, 1, 0, 0, none, [&](auto s_) { noise_slot(3, Yes{}, s_); });    // B(7); issues P1 of the next step
+    C2_STAMP(5)
     // tail: layer 3 of chunk 7.  Its W3 blocks sit in the slot of the NEXT tile-step's first phase (s_cur now): landed and
     // published by the barrier in the middle of the phase just finished.
     w3h[0] = rdA(s_cur, 16);
     w3l[0] = rdA(s_cur, 17);
+    f32x4 qv[RT][3];   // RNG: Q = a x + sb z, made in the shadow of layer 2; otherwise x -- on their way while the tail computes
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) qv[rt][j] = xq[(rt * 3 + j) * 64];
     if (!(PSTL_C2_ABL & 64)) static_for<NCONV>([&](auto i_tag) { conv_step(accB, i_tag); });
     FENCE();
     layer3(s_cur, No{});
 
+    C2_STAMP(6)
     // ---- epilogue: eps = layer 3 + b3 (already in the accumulators); x' = a x + sb z - kk eps; candidates; next pieces ----
     const bool emit = i <= a.n_emit, last = i == a.step_lo;
     {
     // (global addresses = uniform pointer of the tile's first row + a 32-bit lane offset, re-derived here: see here())
     const unsigned ln = here((unsigned)lane);
     const unsigned lc = ln & 15u, lg = ln >> 4;
+    const float nk = -kk * kInvAcc;            // the accumulators carry the factor kAcc
+    const float nk2 = own2 ? nk : 0.0f;        // (tile j = 2, lanes g >= 2: the row constants stay what they are)
+    f32x4 xn[RT][3];
 #pragma unroll
     for (int rt = 0; rt < ((PSTL_C2_ABL & 8) ? 0 : RT); ++rt) {
-      const unsigned trow0 = (unsigned)row0 + 16u * (unsigned)rt;     // uniform
-      const bool in = trow0 + lc <= (unsigned)last_row;
-      f32x4 xn[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const bool upd = j < 2 || own2;
-        const float lkk = upd ? kk : 0.0f;
-        const f32x4 o = acc3[j][rt] * kInvAcc;
-        const unsigned loff = lc * (unsigned)kCtrl2 + (unsigned)(16 * j) + 4u * lg;
-        f32x4 qv;
-        if constexpr (RNG) {
-          qv = xq[(rt * 3 + j) * 64];   // Q = a x + sb z, made in the shadow of layer 2
-        } else {
-          const f32x4 x = xq[(rt * 3 + j) * 64];
+        f32x4 q = qv[rt][j];
+        if constexpr (!RNG) {
+          const bool upd = j < 2 || own2;
+          const unsigned trow0 = (unsigned)row0 + 16u * (unsigned)rt;
           f32x4 z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-          if (sb != 0.0f && upd && in)
-            z = *reinterpret_cast<const f32x4*>((a.noise + ((long)(a.steps - 1 - i) * a.N + trow0) * kCtrl2) + loff);
+          if (sb != 0.0f && upd && trow0 + lc <= (unsigned)last_row)
+            z = *reinterpret_cast<const f32x4*>((a.noise + ((long)(a.steps - 1 - i) * a.N + trow0) * kCtrl2) +
+                                                (lc * (unsigned)kCtrl2 + (unsigned)(16 * j) + 4u * lg));
           const float la = upd ? ca : 1.0f, lsb = upd ? sb : 0.0f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) qv[e] = __builtin_fmaf(la, x[e], lsb * z[e]);
+          for (int e = 0; e < 4; ++e) q[e] = __builtin_fmaf(la, q[e], lsb * z[e]);
         }
+        const float nkl = j < 2 ? nk : nk2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xn[j][e] = __builtin_fmaf(-lkk, o[e], qv[e]);
-        xq[(rt * 3 + j) * 64] = xn[j];
-        if (upd && in) {
-          if (last) {
-            *reinterpret_cast<f32x4*>((a.x_inout + (long)trow0 * kCtrl2) + loff) = xn[j];
-            if (!(fabsf((xn[j][0] + xn[j][1]) + (xn[j][2] + xn[j][3])) <= 3.0e38f)) atomicOr(a.status, 1u);
-          }
-          if (emit) {
-            f32x4 v = xn[j] * sc;
-            if (a.clip) {
+        for (int e = 0; e < 4; ++e) xn[rt][j][e] = __builtin_fmaf(nkl, acc3[j][rt][e], q[e]);
+        xq[(rt * 3 + j) * 64] = xn[rt][j];
+      }
+      make_x_pieces(rt, xn[rt][0], xn[rt][1], xn[rt][2]);
+    }
+    if (last || emit) {   // (uniform: the last step of the launch, and the steps whose state is a candidate)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = clip_keep_nan(v[e], sc[e]);
+      for (int rt = 0; rt < RT; ++rt) {
+        const unsigned trow0 = (unsigned)row0 + 16u * (unsigned)rt;     // uniform
+        const bool in = trow0 + lc <= (unsigned)last_row;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const unsigned loff = lc * (unsigned)kCtrl2 + (unsigned)(16 * j) + 4u * lg;
+          if ((j < 2 || own2) && in) {
+            const f32x4 v0 = xn[rt][j];
+            if (last) {
+              *reinterpret_cast<f32x4*>((a.x_inout + (long)trow0 * kCtrl2) + loff) = v0;
+              if (!(fabsf((v0[0] + v0[1]) + (v0[2] + v0[3])) <= 3.0e38f)) atomicOr(a.status, 1u);
             }
-            *reinterpret_cast<f32x4*>((a.emit_out + ((long)(a.n_emit - i) * a.N + trow0) * kCtrl2) + loff) = v;
+            if (emit) {
+              f32x4 v = v0 * sc;
+              if (a.clip) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = clip_keep_nan(v[e], sc[e]);
+              }
+              *reinterpret_cast<f32x4*>((a.emit_out + ((long)(a.n_emit - i) * a.N + trow0) * kCtrl2) + loff) = v;
+            }
           }
         }
       }
-      make_x_pieces(rt, xn[0], xn[1], xn[2]);
     }
     }
+    C2_STAMP(7)
     // the first chunk's constant part for the next step (its rows were written above, two or more barriers ago)
 #pragma unroll
     for (int u = 0; u < kLead; ++u) cst[u] = rd_cst(0, u / RT, u % RT);
   }
+#ifdef PSTL_C2_STAMP
+  {
+    unsigned long long t1_, r1_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_), "=s"(r1_)::"memory");
+    if (blockIdx.x == 7 && lane == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.emit_out) + w * 12;
+      for (int k = 0; k < 8; ++k) dbg[k] = st_sum[k];
+      dbg[8] = t1_ - st_t0, dbg[9] = r1_ - st_rt0, dbg[10] = (unsigned long long)nsteps;
+    }
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last step's look-ahead DMA
-  if (pieces_overflowed(ovf)) atomicOr(a.status, 1u);   // a layer input left |x| < 4094 somewhere in this launch
+  if (pieces_overflowed(ovf) || !(ovfx < 65520.0f)) atomicOr(a.status, 1u);   // a layer input left |x| < 4094 somewhere in this launch
 }
 
 }  // namespace
