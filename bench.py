@@ -173,12 +173,14 @@ BWD_BYTES_PER_ROW = 4 * (2 * 256 + 3 * 40 + 7)
 GRAPH_MAX_ROWS = 98304      # batches up to this many rows per GPU replay a captured HIP graph per step (see Job)
 
 
-def chain_layout(n_rows, cus=256):
-    """Which layout pstl_rollout picks for a batch (csrc/mlp_kernels.hip: sparse_tiles_per_group / tiles_per_group)."""
-    n_tiles = (n_rows + 15) // 16
-    if n_tiles < 5 * cus:
-        return "latency (%d tile(s) per workgroup, empty pipeline slots)" % ((n_tiles + cus - 1) // cus)
-    return "throughput (%d tiles per workgroup)" % max(5, min(12, n_tiles // 256))
+def chain_layout(cfg):
+    """Which kernel and layout pstl_rollout picks for the multi-step launches of a batch: asked of the library
+    (pstl_rollout_layout), not re-derived here."""
+    from pstl_diffusion_policy_amd import ffi
+    kern, g, rounds = ffi.rollout_layout(cfg)
+    return ["k_chain, latency layout (%d tile(s) per workgroup, empty pipeline slots)", "k_chain, throughput layout (%d tiles per "
+            "workgroup)", "k_chain2 (row-stationary: %d tiles = 256 rows per workgroup)", "k_chain, exact arithmetic (%d tiles per "
+            "workgroup)"][kern] % g + ", %d round(s) of workgroups" % rounds
 
 
 class Job:
@@ -517,15 +519,17 @@ def main():
     # the headline workload at other batch sizes: best of 3 x 3 timed steps each after 2 warm-ups
     sweep = None
     if extras and not train:
+        from pstl_diffusion_policy_amd import ffi as _ffi
+        layout_cfg = lambda nsc: _ffi.make_cfg(nsc, S * 3, S, a.neighbors, steps, hp, _ffi.PSTL_FLAG_RNG, a.chain_waves)
         sweep = []
         for sbs in (1, 16, 128, 512):
             if sbs >= a.scenes:
                 continue
             js = mk(a.workload, sbs)
             ms_ = js.measure_best(3, 2, 3)
-            sweep.append({"rows": js.N, "ms_per_step": ms_["ms_per_step"], "value": ms_["value"], "layout": chain_layout(js.N),
+            sweep.append({"rows": js.N, "ms_per_step": ms_["ms_per_step"], "value": ms_["value"], "layout": chain_layout(layout_cfg(sbs)),
                           "launches": "one HIP-graph replay per step" if js.use_graph else "eager", "timing": ms_["timing"]})
-        sweep.append({"rows": N, "ms_per_step": m["ms_per_step"], "value": m["value"], "layout": chain_layout(N),
+        sweep.append({"rows": N, "ms_per_step": m["ms_per_step"], "value": m["value"], "layout": chain_layout(layout_cfg(a.scenes)),
                       "launches": "one HIP-graph replay per step" if job.use_graph else "eager",
                       "timing": "the headline measurement (%d steps)" % a.steps})
     # VALU-issue roofline of the one-row-per-lane STL kernels (they are instruction-issue-bound, not HBM-bound): vector
@@ -571,7 +575,7 @@ def main():
                        "rows_per_gpu": N, "parallelism": "scene shards x%d, no data-path collective" % world,
                        "chain_waves": a.chain_waves,
                        "noise": "in-kernel Philox4x32-10" if a.noise == "kernel" else "torch.randn tensors"},
-            "stl_sat_rate": acc, "scene_sat_rate": sacc,
+            "stl_sat_rate": acc, "scene_sat_rate": sacc, "counts": [int(v) for v in counts.tolist()],
             "diversity": None if train else diversity_from_totals(div_totals),
             "roofline": {"bound": "mfma", "kernel": "k_chain (denoiser MLP chain, %d reverse steps per launch)" % nst,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -27,9 +27,10 @@
 extern "C" {
 #endif
 
-#define PSTL_ABI_VERSION 4   /* 2: pstl_encode_scene takes a work buffer; --joint and --refinement entry points
+#define PSTL_ABI_VERSION 5   /* 2: pstl_encode_scene takes a work buffer; --joint and --refinement entry points
                                 3: status block in the packed weight buffer (pstl_packed_status_offset)
-                                4: pstl_cfg.dyn -- run-time parameters in device memory (HIP-graph replay) */
+                                4: pstl_cfg.dyn -- run-time parameters in device memory (HIP-graph replay)
+                                5: pstl_rollout_layout; chain_waves = 2 (the row-stationary denoiser kernel) */
 
 /* compile-time shape of the path (reference defaults: nt=20, n_segs=15, hiddens=[256,256], feat 7*32) */
 #define PSTL_T 20
@@ -190,6 +191,15 @@ int pstl_rollout(const pstl_cfg* cfg, float* packed /* status block written */, 
                  const float* stlp /* (N,6) */, const float* hl /* (N,) */, const float* beta, const float* alpha,
                  const float* alpha_hat, const float* noise, int step_hi, int step_lo, int mu_only,
                  float* x_inout /* (N,40) */, float* emit_out, int n_emit, void* stream);
+
+/* Which kernel and layout pstl_rollout picks for a launch of cfg's batch with step_hi > step_lo (multi_step != 0) or
+ * step_hi == step_lo (0): a query for benchmarks and tools, so that they need not re-derive the rules of csrc/.  Writes
+ * kernel: 0 = k_chain, latency layout (tiles_per_group 1..5 sixteen-row tiles per workgroup, empty pipeline slots skipped);
+ *         1 = k_chain, throughput layout (tiles_per_group 5..12);  2 = k_chain2 (one 256-row workgroup per CU at a time:
+ *         tiles_per_group = 16); 3 = an exact-fp32 / bfloat16-piece variant (chain_waves 8, 4, 32: throughput layout);
+ * rounds: how many waves of workgroups the launch takes on this device's CUs.  Touches no GPU memory. */
+int pstl_rollout_layout(const pstl_cfg* cfg, int multi_step, int* kernel, int* tiles_per_group, int* rounds);
+
 
 /* out (N,40) = the N(0,1) values the kernels draw under PSTL_FLAG_RNG for reverse step `step` (step == cfg->steps
  * is the stream of the initial state x_T, reference nusc_train.py:563).  Philox4x32-10 + Box-Muller, a pure function of

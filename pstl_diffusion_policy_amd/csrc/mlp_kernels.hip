@@ -1711,7 +1711,7 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   // 2: the row-stationary kernel (k_chain2, chain2_kernels.hip) for every launch it can take, whatever the batch size; 0:
   // for the multi-step denoiser launches of batches that fill whole rounds of its 256-row workgroups (chain2_pays)
   if constexpr (!REFINE) {
-    if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(a.N))) && chain2_eligible(a)) return launch_chain2(a, st);
+    if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(a.N) && a.step_hi > a.step_lo)) && chain2_eligible(a)) return launch_chain2(a, st);
   }
   if (chain_waves == 16 || chain_waves == 2) chain_waves = 0;
   if (REFINE && chain_waves == 32) chain_waves = 8;    // bf16 pieces cost the interval head up to 9e-5 per pass
@@ -2036,6 +2036,28 @@ extern "C" int pstl_rollout(const pstl_cfg* cfg, float* packed, const float* bas
     a.step_lo = (hi - kMaxLaunchSteps + 1 > step_lo) ? hi - kMaxLaunchSteps + 1 : step_lo;
     if (int e = launch_chain_nw<false>(cfg->chain_waves, a, as_stream(stream))) return e;
   }
+  return PSTL_OK;
+}
+
+extern "C" int pstl_rollout_layout(const pstl_cfg* cfg, int multi_step, int* kernel, int* tiles, int* rounds) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!kernel || !tiles || !rounds) return PSTL_ERR_ARG;
+  const long N = n_rows(cfg), n_tiles = (N + kTileRows - 1) / kTileRows, cus = cu_count();
+  const int cw = cfg->chain_waves;
+  ChainArgs a = {};
+  a.N = N, a.rows_per_scene = cfg->rows_per_scene, a.step_hi = multi_step ? 2 : 1, a.step_lo = 1;
+  const bool ut = cfg->rows_per_scene % kTileRows == 0;
+  int k = 3, g = tiles_per_group(N);
+  if ((cw == 2 || (cw == 0 && chain2_pays(N) && multi_step)) && chain2_eligible(a)) {
+    k = 2, g = 16;
+  } else if (cw == 0 || cw == 16 || cw == 2) {
+    k = 1;
+    const int sg = (cw == 0 && ut) ? sparse_tiles_per_group(N) : 0;
+    if (sg > 0) k = 0, g = sg;
+    else if (multi_step) g = tiles_per_group_balanced(N);
+  }
+  const long n_groups = (n_tiles + g - 1) / g;
+  *kernel = k, *tiles = g, *rounds = (int)((n_groups + cus - 1) / cus);
   return PSTL_OK;
 }
 

@@ -821,8 +821,8 @@ PSTL_HD float pick4(const float (&a)[kCkStride], int i) {   // register array, d
 }
 
 // What the adjoint takes over from the forward sweep besides the scratch (checkpoints and suffix tables): 17 registers.
-// (k_guidance_iter's two-launch form hands both through device memory: the rows whose loss is active are compacted between
-// the sweeps, stl_kernels.hip.)
+// (A two-launch form of k_guidance_iter that handed both through device memory, the rows with an active loss compacted
+// between the sweeps, was measured in round 4 and not kept: profiles/r4/guidance_two_launch_compaction.patch.)
 struct AdjState {
   FwdOut fo;
   Rec rec;

@@ -1258,23 +1258,25 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float*
   const bool exact = cfg->chain_waves == 8 || cfg->chain_waves == 4;
   if (!exact && cfg->rows_per_scene % kFcRows == 0) {
     // one pass per layer (k_bwd_l2 / k_bwd_l1 above): each saved activation is read once
-    static int cus = 0;
-    if (cus == 0) {
-      int dev = 0;
+    // (per device: a process may drive several GPUs -- the CU count and the function attributes belong to the current one)
+    static int cus_dev = -1, cus = 0, lds_dev = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return PSTL_ERR_LAUNCH;
+    if (cus_dev != dev) {
       hipDeviceProp_t pr;
-      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
-                ? pr.multiProcessorCount : 256;
+      cus = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
       if (cus > kRedBlocks) cus = kRedBlocks;
+      cus_dev = dev;
     }
     const long n_chunks = (N + kFcRows - 1) / kFcRows;
     const int nb2 = (int)(n_chunks < cus ? n_chunks : cus);
-    static bool lds_ok = false;
+    const bool lds_ok = lds_dev == dev;
     if (!lds_ok) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_l2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_l2_lds()) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_l1<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_l1_lds()) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_l1<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_l1_lds()) != hipSuccess)
         return PSTL_ERR_LAUNCH;
-      lds_ok = true;
+      lds_dev = dev;
     }
     // layer 2 and dW3:  dH2 = (dO W3) * [h2 > 0], db2, dW3 = dO^T h2
     hipLaunchKernelGGL(k_pack_wt_bf, dim3(16 * 2 * 2), dim3(256), 0, st, w3, kHid, kCtrl, kHid, 2, wpack);
@@ -1390,7 +1392,9 @@ extern "C" int pstl_encoder_backward(const pstl_cfg* cfg, float* refine_work, co
   float* dtok = dfeat + bs * kFeat;     // (T,32)
   float* dh2 = dtok + bs * (K + 4) * 32;  // (tmax,256)
   float* dh1 = dh2 + tmax * kHid;       // (tmax,256)
-  // d fused = dH1 W1[:, 231:271] (the rect_net input columns merge_net feeds); no mask: a linear input
+  // d fused = dH1 W1[:, 231:271] (the rect_net input columns merge_net feeds); no mask: a linear input.  dH1 is in the work
+  // buffer only when pstl_refine_backward was asked to leave it there: without the flag this would read stale memory.
+  if (dfused && !(cfg->flags & PSTL_FLAG_KEEP_DH1)) return PSTL_ERR_ARG;
   if (dfused)
     if (int e = dgrad<8>(N, rw.dH1, kHid, kHid, rect_w1 + kFeat + 7, kIn, kCtrl, rw.wpack, nullptr, dfused, kCtrl, rw.part,
                          nullptr, st))

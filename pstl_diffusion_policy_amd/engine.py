@@ -620,19 +620,35 @@ class GraphCapture:
 
 
 class DynBlock:
-    """A pstl_dyn in device memory with a pinned host mirror: set(seed[, grad_scale]) queues ONE 16-byte copy on the current stream."""
+    """A pstl_dyn in device memory, set from the host: set(seed[, grad_scale]) queues ONE 16-byte copy on the current stream.
+    The copy is asynchronous and may run long after set() returns (behind a replay of milliseconds), so every call writes a
+    pinned mirror of its own -- a ring of them, each guarded by an event recorded behind its copy and waited for before the
+    slot is written again.  (One mirror rewritten per call let back-to-back set() + replay() pairs run several replays on the
+    LAST seed: the earlier copies read the mirror after the host had moved on.)"""
+    RING = 8
 
     def __init__(self, device):
-        self.host = torch.zeros(4, dtype=torch.float32).pin_memory()
-        self.host_np = self.host.numpy()
+        self.hosts = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
+        self.events = [None] * self.RING
         self.dev = torch.zeros(4, dtype=torch.float32, device=device)
+        self.calls = 0
+        self.grad_scale = 0.0
 
     def set(self, seed, grad_scale=None):
         seed = int(seed) & (2 ** 64 - 1)
-        self.host_np[0:2].view("uint32")[:] = (seed & 0xffffffff, seed >> 32)
+        slot = self.calls % self.RING
+        self.calls += 1
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()       # the copy that last read this mirror has run
         if grad_scale is not None:
-            self.host_np[2] = grad_scale
-        self.dev.copy_(self.host, non_blocking=True)
+            self.grad_scale = float(grad_scale)
+        h = self.hosts[slot].numpy()
+        h[0:2].view("uint32")[:] = (seed & 0xffffffff, seed >> 32)
+        h[2] = self.grad_scale
+        self.dev.copy_(self.hosts[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[slot] = ev
 
 
 def diversity_from_totals(totals, nt=ffi.T):
@@ -862,9 +878,22 @@ class RectTrainer:
         # optimiser: a layer input beyond the half range leaves plausible-looking garbage, not NaNs.  One 4-byte copy; the
         # step is then repeated on the exact-fp32 kernels (same noise: supplied, or the same Philox seed) and the sampler stays
         # there -- the caller sees `self.sm.chain_fallback` and a RuntimeWarning.
-        if sm.check_chain_domain():
+        # With several ranks the decision is the job's, not the rank's: the flags are MAX-reduced first, so that
+        # every rank repeats the step and switches arithmetic together -- gradients of two arithmetics are never mixed, and
+        # the shard split does not change which kernels ran.
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        hit = sm.chain_waves in (0, 16, 2) and sm.w.chain_overflowed(clear=True)
+        if multi and sm.chain_waves in (0, 16, 2):
+            flag = torch.tensor([1 if hit else 0], dtype=torch.int32)
+            if dist.get_backend(group) != "gloo":
+                flag = flag.to(sb.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            hit = bool(int(flag.item()))
+        if hit:
+            sm.use_exact_fp32("a layer input left the split-f16 domain |x| < 4094 (the state became non-finite)" +
+                              (" on some rank" if multi else ""))
             loss, rect, scores, g = forward_backward()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if multi:
             flat = torch.cat([g[k].reshape(-1) for k in names] + [loss.reshape(1)])
             if dist.get_backend(group) == "gloo":       # host tensors (ranks sharing a device in the tests); RCCL: in place
                 host = flat.cpu()

@@ -26,7 +26,7 @@ HID = 256
 FEAT = 224
 NEI_PREP = 12
 
-ABI_VERSION = 4      # include/pstl_hip.h PSTL_ABI_VERSION
+ABI_VERSION = 5      # include/pstl_hip.h PSTL_ABI_VERSION
 SPLIT_F16_WMAX = 63.9   # include/pstl_hip.h PSTL_SPLIT_F16_WMAX
 
 class PstlCfg(ctypes.Structure):
@@ -67,6 +67,7 @@ SIGNATURES = [
     ("pstl_encode_scene_work_floats", _Z, [_C]),
     ("pstl_encode_scene", _I, [_C] + [_P] * 14),
     ("pstl_rollout", _I, [_C] + [_P] * 9 + [_I, _I, _I, _P, _P, _I, _P]),
+    ("pstl_rollout_layout", _I, [_C, _I, _P, _P, _P]),
     ("pstl_generate_trajs", _I, [_C] + [_P] * 4),
     ("pstl_stl_forward", _I, [_C, _P, _P, _P, _I] + [_P] * 10),
     ("pstl_stl_signals", _I, [_C] + [_P] * 7),
@@ -120,6 +121,14 @@ def lib():
             fn.argtypes = argtypes
         _lib = L
     return _lib
+
+
+def rollout_layout(cfg, multi_step=True):
+    """(kernel, tiles_per_group, rounds) pstl_rollout picks for this batch (include/pstl_hip.h, pstl_rollout_layout)."""
+    k, g, r = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    check(lib().pstl_rollout_layout(ctypes.byref(cfg), int(bool(multi_step)), ctypes.addressof(k), ctypes.addressof(g),
+                                    ctypes.addressof(r)), "rollout_layout")
+    return k.value, g.value, r.value
 
 
 def check(code, what=""):

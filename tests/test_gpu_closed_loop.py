@@ -77,7 +77,7 @@ def test_latency_of_a_simulation_step_at_the_reference_settings(capsys):
     """The reference's closed-loop settings (nusc_sim.py: 64 samples x 3 modes = 192 rows, 100 diffusion steps, K = 8
     neighbours, maximize guidance on the last 10 steps, 5 candidates + RefineNet): wall-clock latency per simulation step
     with a device synchronisation on both sides, printed for the record (`pytest -s`, or the captured output of a failure)
-    and held to twice the measured median on one MI355X (0.86-0.91 ms: one HIP-graph replay per step)."""
+    and held below 3 ms (measured on one MI355X: 0.86-0.91 ms, one HIP-graph replay per step)."""
     from pstl_diffusion_policy_amd.nusc_sim import closed_loop
     def run():
         recs = closed_loop(golden_weights(), n_sim_steps=16, K=8, S=64, diffusion_steps=100, multi_cands=5, guidance=True,
@@ -91,7 +91,9 @@ def test_latency_of_a_simulation_step_at_the_reference_settings(capsys):
     with capsys.disabled():
         print("\nclosed loop: median %.2f ms, worst %.2f ms per simulation step (192 rows, 100 steps, K=8, guidance)" % (med, worst))
     assert all(math.isfinite(r["best_score"]) for r in recs)
-    assert med < 1.8, med      # twice the measured median (0.86-0.91 ms with the HIP-graph replay; round 3: 1.3, round 2: 2.7)
+    # wall clock including the host, on a shared box: the measured median is printed (0.86-0.91 ms with the HIP-graph replay;
+    # round 3: 1.3, round 2: 2.7); the bound only catches a return to per-launch host latency
+    assert med < 3.0, med
 
 
 def test_parameters_in_device_memory_equal_parameters_by_value():
@@ -153,3 +155,39 @@ def test_graph_replay_of_the_whole_region_equals_eager_including_counters():
         for a, k in zip(got, ("counts", "div_totals", "final_controls", "final_scores")):
             assert torch.equal(a, ref[k]), (seed, k)
         assert 0 < int(got[0][0]) <= int(got[0][1]) <= N
+
+
+def test_back_to_back_replays_each_see_their_own_seed():
+    """DynBlock.set() + GraphCapture.replay() twenty times with NO synchronisation in between (what bench.py's timed
+    loop does): every replay must run on the seed set for it -- its outputs, cloned on the stream, equal the eager run of that
+    seed.  (With one pinned mirror rewritten per call, the queued 16-byte copies read whatever seed the host wrote last.)"""
+    from pstl_diffusion_policy_amd.engine import DynBlock, GraphCapture, PackedWeights, Sampler, SceneBatch
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    dev = torch.device("cuda:0")
+    hp = default_hparams()
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    bs, S, steps = 64, 64, 20
+    scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=2, S=S, seed=3, stlp_mode="wide").items()
+             if k not in ("params", "pre_stlp", "tj_scores_prior")}
+    N = bs * S * 3
+    vsum = float(sum(scene[k].sum().item() for k in ("curr_id", "left_id", "right_id"))) * S
+    kw = dict(rect_head=False, multi_cands=1, want_scores3=False)
+    dyn = DynBlock(dev)
+    dyn.set(0, SceneBatch.loss_scale(vsum, N))
+
+    def body():
+        sb = SceneBatch(scene, S, hp, dev, global_valid_sum=vsum, global_rows=N, dyn=dyn.dev, scale_in_dyn=True)
+        return sm.sampling_region(sb, steps, None, None, seed=0, **kw)["final_controls"]
+
+    g = GraphCapture(body)
+    seeds = list(range(100, 120))
+    got = []
+    for seed in seeds:               # no synchronisation: the copies queue up behind the replays
+        dyn.set(seed)
+        got.append(g.replay().clone())
+    torch.cuda.synchronize()
+    sbe = SceneBatch(scene, S, hp, dev, global_valid_sum=vsum, global_rows=N)
+    for seed, a in zip(seeds, got):
+        ref = sm.sampling_region(sbe, steps, None, None, seed=seed, **kw)["final_controls"]
+        assert torch.equal(a, ref), seed
+    assert not torch.equal(got[0], got[1])

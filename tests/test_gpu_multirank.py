@@ -138,6 +138,40 @@ def test_bench_starts_its_own_ranks():
         assert refused.returncode != 0 and "refusing" in refused.stderr
 
 
+def test_bench_with_eight_ranks():
+    """`python bench.py --gpus 8` before a real 8-GPU node runs it: eight ranks (gloo + the shared device
+    when fewer than eight GPUs are visible, RCCL otherwise), one all-reduce of the valid-row statistics and one all-gather of
+    the 20 result words per step; the line says n_gpus = 8 and its counters are exactly those of the eight shards evaluated
+    one after the other in this process with the same global statistics, row offsets and seeds."""
+    from pstl_diffusion_policy_amd.engine import PackedWeights, Sampler, SceneBatch
+    from pstl_diffusion_policy_amd.nusc_model import init_state_dict
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    bs, S, K, steps, world = 8, 64, 2, 50, 8
+    ndev = torch.cuda.device_count()
+    run = _bench(["--gpus", "8", "--scenes", str(bs), "--steps", "1", "--warmup", "1", "--no_cpu_baseline"],
+                 None if ndev >= 8 else {"PSTL_BENCH_BACKEND": "gloo"})
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak"
+    N = bs * S * 3
+    assert line["config"]["rows_per_gpu"] == N and line["counts"][2] == world * N and line["counts"][5] == world * bs * 3
+    # the same eight shards, one after the other
+    dev = torch.device("cuda:0")
+    hp = default_hparams()
+    sm = Sampler(PackedWeights(init_state_dict(1007), dev), hp)
+    scenes = [make_scene_batch(bs, K=K, S=S, seed=1000 + r, invalid_lane_frac=0.2, stlp_mode="wide") for r in range(world)]
+    vsum = sum(float(sum(sc[k].sum().item() for k in ("curr_id", "left_id", "right_id"))) * S for sc in scenes)
+    total = torch.zeros(8, dtype=torch.int64, device=dev)
+    for r, sc in enumerate(scenes):
+        scene = {k: v.to(dev) for k, v in sc.items() if k not in ("pre_stlp", "tj_scores_prior")}
+        sb = SceneBatch(scene, S, hp, dev, global_valid_sum=vsum, global_rows=world * N, row_offset=r * N)
+        out = sm.sampling_region(sb, steps, None, None, rect_head=True, multi_cands=5,
+                                 guidance=dict(enabled=True, before=10, niters=1, lr=0.01), want_scores3=False,
+                                 seed=987654321 + 2, diversity=True)      # (the second call of the job: one warm-up, one step)
+        total += out["counts"]
+    assert line["counts"] == [int(v) for v in total.tolist()]
+
+
 # ---- N > 1 training: RectTrainer.train_step all-reduces the gradients (the loss is a mean over the GLOBAL batch) ---------
 T_BS, T_S, T_K, T_STEPS = 6, 16, 3, 10
 T_E7 = dict(stl_weight=1.0, diversity_weight=0.5, diversity_scale=1.0, rect_reg_loss=0.0, detach=False)

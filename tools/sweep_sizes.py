@@ -57,10 +57,10 @@ def main():
                 sm.rollout(sb, base_p, x, None, a.steps, n_emit=5, clip=True, seed=7)
             torch.cuda.synchronize()
             ms = [e0.elapsed_time(e1) for (e0, e1, n, _) in sm.trace][1:]
-            n_tiles = sb.N // 16
-            g = (n_tiles + 255) // 256 if n_tiles < 5 * 256 else max(5, min(12, n_tiles // 256))
-            rounds = -(-n_tiles // (g * 256)) if n_tiles >= 5 * 256 else 1
-            print(json.dumps(dict(rows=sb.N, tiles_per_group=g, rounds=rounds, chain_ms=sum(ms) / len(ms),
+            from pstl_diffusion_policy_amd import ffi      # the library says which layout it picked (pstl_rollout_layout)
+            kern, g, rounds = ffi.rollout_layout(sb.cfg(a.steps, ffi.PSTL_FLAG_RNG, sm.chain_waves))
+            print(json.dumps(dict(rows=sb.N, kernel=["k_chain latency", "k_chain", "k_chain2", "k_chain exact"][kern],
+                                  tiles_per_group=g, rounds=rounds, chain_ms=sum(ms) / len(ms),
                                   us_per_tile_step=1e3 * sum(ms) / len(ms) / ((a.steps - 1) * g * rounds))), flush=True)
             sm.trace = None
             continue
