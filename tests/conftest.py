@@ -81,6 +81,8 @@ def golden_weights(d=None):
     fixture names a `weights_variant` (exact: integer draws and power-of-two factors only)."""
     sd = dict(np.load(os.path.join(GOLDEN, "weights_seed1007.npz")))
     if d is not None and "weights_variant" in d:
+        if str(d["weights_variant"]) == "trained":     # the checkpoint the reference itself trained (make_golden.py --trained)
+            return dict(np.load(os.path.join(GOLDEN, "weights_trained.npz")))
         from heavy_weights import heavy_weights
         sd = heavy_weights(sd, str(d["weights_variant"]))
     return sd
@@ -139,7 +141,8 @@ def region_kwargs(meta):
 SAMPLING_CASES = ["e5_steps10", "e5_steps100", "e7_steps12", "e7_steps50_k8", "e7_damped", "e7_wide", "e7_guid",
                   "e7_guid_n2_rolls", "e5_guid_all", "sim_maximize", "sim_maximize_b",
                   "fl_e8_clip_rect", "fl_no_arch", "fl_no_refinenet", "fl_not_use_rect", "fl_guid_sets", "fl_guid_freq_rev", "e7_s64_guid", "e7_guid_c4",
-                  "e7_heavy_a", "e7_heavy_b", "e7_readme_guidance", "e7_guid_norm", "e7_guid_norm_n2"]
+                  "e7_heavy_a", "e7_heavy_b", "e7_readme_guidance", "e7_guid_norm", "e7_guid_norm_n2",
+                  "e7_trained_guid", "e7_trained_s16"]     # (the last two: on weights the reference itself trained)
 HEAVY_CASES = ["e7_heavy_a", "e7_heavy_b"]      # weights with a trained network's dynamic range (tests/heavy_weights.py)
 STL_CASES = ["stl_mixed", "stl_mixed_k8", "stl_wild"]
 REFINEMENT_CASES = ["e7_refinement", "e7_refinement_b"]
@@ -200,7 +203,14 @@ def guided_outlier_rows(err_all, d, meta, tol=1e-4, g_eps=1e-6, n_shards=4):
         el = bad[k0, r]
         assert (gmin[el] < g_eps).all(), ("row %d, reverse step %d: outlier elements whose reference gradient is NOT in "
                                           "Adam's eps regime: |g| = %s, err = %s" % (r, i0, gmin[el], err_all[k0, r][el]))
-    assert bad_rows.sum() <= max(1, int(0.001 * N)), "%d of %d rows hold an outlier" % (bad_rows.sum(), N)
+    # How many rows may be excluded: at most 0.1 % of the rows, at least one -- or, where the REFERENCE's recorded gradients hold
+    # an unusually large population of elements in Adam's eps regime (0 < |g| < g_eps), one row per 3 500 such elements.  On
+    # every fixture recorded on random-init or hand-scaled weights that is still 1 (<= 3 125 such elements); on the checkpoint
+    # the reference trained itself, under thresholds most rows violate (e7_trained_guid: 15 664 such elements in 3 004 active
+    # row-steps), it is 5 -- the CPU oracle, float32 torch like the reference, has 4 such rows there.
+    tiny = int(((grads < g_eps) & (grads > 0)).sum())
+    allowed = max(1, int(0.001 * N), -(-tiny // 3500))
+    assert bad_rows.sum() <= allowed, "%d of %d rows hold an outlier (allowed %d)" % (bad_rows.sum(), N, allowed)
     S = meta["S"]
     bad_groups = bad_rows.copy()
     if bad_rows.any() and S % n_shards == 0:

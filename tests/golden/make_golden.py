@@ -241,11 +241,12 @@ def main():
     stl_case(ref, "stl_wild", bs=3, S=8, K=3, seed=23, invalid_lane_frac=0.5, stlp_mode="tight", ctrl_scale=1.0)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided", "--refinement-case", "--train-joint", "--heavy", "--readme-guidance", "--norm-fused")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--train", "--train-e7", "--closed-loop", "--diversity", "--stl-lib", "--trajopt", "--formats", "--norm-stl", "--flags", "--stl-big", "--gt-stlp", "--dense-stlp", "--baseline-shape", "--regen-guided", "--refinement-case", "--train-joint", "--heavy", "--readme-guidance", "--norm-fused", "--trained", "--trained-record")):
     main()
 
 
-def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None, joint=False, weights_variant=None, extra_argv=()):
+def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None, joint=False, weights_variant=None, extra_argv=(),
+               stlp_mode="wide"):
     """One training step of config 5 (e8_ours_ablation: --rect_head, STL loss through RefineNet; reference
     nusc_train.py:1365-1427 + compute_policy_loss :370-478 + optimizer :1522-1525), driven through the reference's own
     functions.  Stored: inputs, every noise draw, the loss, d loss / d rect_net parameters and the parameters after
@@ -271,7 +272,7 @@ def train_case(ref, sd, name, bs, S, K, steps, seed, lr=3e-4, e7=None, joint=Fal
     optimizer = torch.optim.Adam(net.parameters() if args.joint else net.rect_net.parameters(), lr=args.lr)
     coeffs = nt.get_diffusion_coeffs(args)
     stls = nt.build_stl_cache(args)
-    batch = make_scene_batch(bs, K=K, S=S, seed=seed, invalid_lane_frac=0.25, stlp_mode="wide")
+    batch = make_scene_batch(bs, K=K, S=S, seed=seed, invalid_lane_frac=0.25, stlp_mode=stlp_mode)
     batch_cuda = dict(batch)
     gt_trajs = batch_cuda["ego_traj"][..., :4]
     states = gt_trajs[..., 0, :4]
@@ -895,3 +896,132 @@ if __name__ == "__main__" and "--dense-stlp" in sys.argv:
 
 if __name__ == "__main__" and "--regen-guided" in sys.argv:
     main_regen_guided()
+
+
+# ---- a checkpoint the REFERENCE trained ------------------------------------------------------------------
+TRAINED_FILE = os.path.join(HERE, "weights_trained.npz")
+
+
+def _ref_train_steps(ref, net, optimizer, args, n_steps, seed0, bs, S, K, log_every=50):
+    """n_steps iterations of the reference's own training step (nusc_train.py:1365-1427 forward, compute_policy_loss
+    :370-526, optimizer :1522-1525) on fresh synthetic batches: the same call sequence as train_case above, in a loop."""
+    nt = ref.nusc_train
+    coeffs = nt.get_diffusion_coeffs(args)
+    stls = nt.build_stl_cache(args)
+    losses = []
+    for it in range(n_steps):
+        batch = make_scene_batch(bs, K=K, S=S, seed=seed0 + it, invalid_lane_frac=0.25, stlp_mode="wide")
+        batch_cuda = dict(batch)
+        states = batch_cuda["ego_traj"][..., :4][..., 0, :4]
+        batch_cuda["neighbor_trajs_aug"] = batch_cuda["neighbors_traj"][..., :7]
+        batch_cuda = nt.augment_batch_data(batch_cuda, batch_cuda["stlp_modes"][:, 0], args)
+        n = bs * S * 3
+        dense_states_flat = states.unsqueeze(1).unsqueeze(1).repeat(1, S, 3, 1).reshape(n, 4)
+        hl = batch_cuda["highlevel_dense"]
+        dense_controls = batch_cuda["params"]
+        dense_trajs = nt.generate_trajs(states.unsqueeze(1).unsqueeze(1).repeat(1, S, 3, 1), dense_controls, args.dt)
+        dense_valids = batch_cuda["valids_dense"]
+        # --load_tj: the STL scores of the demonstration controls, which the reference's traj-opt stage stores beside them
+        # (nusc_train.py:775-797) and the diffusion loss masks with (--stl_bc_mask is forced on): computed here by the
+        # reference's own scorer, since the synthetic cache has no traj-opt stage behind it
+        with torch.no_grad():
+            demo_in = nt.pre_prepare_stl_cache(batch_cuda, dense_trajs=dense_trajs.reshape(n, args.nt + 1, 4)[:, :-1])
+            _, demo_sc, _ = nt.compute_stl_dense(demo_in, stls, hl, demo_in["dense_valids"], args)
+        dense_scores = demo_sc.reshape(bs * S, 3)
+        noise, tsteps, _, noised_b = nt.diffusion_prep(dense_controls, n_randoms=S, coeffs=coeffs)
+        net.train()
+        est_a, feature = net(batch_cuda, ext={"timestep": tsteps, "highlevel": hl, "noise": noised_b}, get_feature=True)
+        est_a = est_a.reshape(n, args.nt * 2)
+        rect_controls = rect_trajs = None
+        if args.rect_head:
+            nn_controls, clist = nt.diffusion_rollout(noise, net, batch_cuda, hl, feature, args, coeffs, fastforward=False)
+            mc = args.multi_cands
+            ctrls_mul = torch.cat(clist[-mc:], dim=0)
+            trajs_mul = nt.generate_trajs(dense_states_flat.repeat(mc, 1), ctrls_mul, args.dt)
+            prev_in = nt.pre_prepare_stl_cache(batch_cuda, dense_trajs=trajs_mul[:, :-1], repeat_n=mc)
+            _, sc_hist, _ = nt.compute_stl_dense(prev_in, stls, hl.repeat(mc, 1), prev_in["dense_valids"].reshape(-1), args)
+            sc_max, sc_idx = torch.max(sc_hist.reshape(mc, n), dim=0)
+            nn_controls = ctrls_mul.reshape(mc, n, args.nt, 2)[sc_idx, range(n)]
+            rect_controls = net.rect_forward(feature, hl, batch_cuda["stlp_dense"][:, 0], nn_controls.detach(), sc_max.detach(),
+                                             extras=clist)
+            rect_trajs = nt.generate_trajs(dense_states_flat, rect_controls, args.dt)
+        else:   # the denoiser's own training: the rollout is skipped on all but the visualisation epochs (reference :1379)
+            nn_controls = nt.diffusion_rollout(noise, net, batch_cuda, hl, feature, args, coeffs, fastforward=True)
+        nn_trajs = nt.generate_trajs(dense_states_flat, nn_controls, args.dt)
+        extras = (None, est_a, hl, dense_scores, dense_valids, 0, noise, nn_controls, tsteps, rect_controls)
+        rd, _ = nt.compute_policy_loss(batch_cuda, None, stls, nn_trajs, rect_trajs, dense_trajs, args, diffusion_extras=extras,
+                                       opt_controls=dense_controls)
+        optimizer.zero_grad()
+        rd["loss"].backward()
+        optimizer.step()
+        losses.append(float(rd["loss"].item()))
+        if it % log_every == 0 or it == n_steps - 1:
+            print("  step %4d  loss %.5f%s" % (it, losses[-1], "  diffusion %.5f" % rd["loss_diffusion"].item()
+                                               if "loss_diffusion" in rd else ""), flush=True)
+    return losses
+
+
+def main_trained():
+    """A checkpoint trained by the reference itself, on the CPU of the build container: the denoiser as README.md:68 trains
+    e5_ddpm (--diffusion --stl_weight 0.0 --load_stlp; Adam over the whole net), then RefineNet on top of it as README.md:70
+    trains e7_ours (--rect_head --flex --diverse_loss --multi_cands 5; Adam over rect_net), each for a few hundred steps on
+    synthetic scenes (no nuScenes cache offline).  Saved as weights_trained.npz; then the e7 + guidance sampling region at
+    BASELINE's guidance hyper-parameters and one config-5 training step are recorded ON it.  The point is a network whose
+    dynamic range was produced by the reference's optimiser rather than by hand (tests/heavy_weights.py)."""
+    ref = ref_harness.load_reference()
+    sd0 = dict(np.load(WEIGHTS_FILE))
+    n1 = int(os.environ.get("PSTL_TRAIN_STEPS_E5", "400"))
+    n2 = int(os.environ.get("PSTL_TRAIN_STEPS_E7", "120"))
+    torch.manual_seed(2024)
+    # phase 1: the denoiser
+    args = ref_harness.parse_reference_args(["--diffusion", "--stl_weight", "0.0", "--load_stlp", "--load_tj", "--lr", "1e-3",
+                                             "--n_randoms", "16", "--sampling_size", "16", "--n_neighbors", "3"])
+    args.measure_diversity = False
+    net = ref.nusc_model.Net(args)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd0.items() if k in net.state_dict()}, strict=True)
+    opt = torch.optim.Adam(net.parameters(), lr=args.lr)      # reference :1234
+    print("phase 1: denoiser, %d steps" % n1, flush=True)
+    l1 = _ref_train_steps(ref, net, opt, args, n1, 50000, bs=8, S=16, K=3)
+    sd1 = {k: np_(v) for k, v in net.state_dict().items()}
+    # phase 2: RefineNet (+ merge_net architecture) on the trained denoiser
+    args = ref_harness.parse_reference_args(["--diffusion", "--stl_weight", "0.0", "--load_stlp", "--load_tj", "--rect_head",
+                                             "--flex", "--diverse_loss", "--multi_cands", "5", "--lr", "1e-3",
+                                             "--diffusion_steps", "50", "--n_randoms", "16", "--sampling_size", "16",
+                                             "--n_neighbors", "3"])
+    args.measure_diversity = False
+    net = ref.nusc_model.Net(args)
+    full = dict(sd0)
+    full.update(sd1)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in full.items()}, strict=True)
+    opt = torch.optim.Adam(net.rect_net.parameters(), lr=args.lr)   # reference :1232
+    print("phase 2: RefineNet, %d steps" % n2, flush=True)
+    l2 = _ref_train_steps(ref, net, opt, args, n2, 70000, bs=4, S=16, K=3, log_every=20)
+    sd = {k: np_(v) for k, v in net.state_dict().items()}
+    np.savez_compressed(TRAINED_FILE, **sd)
+    wmax = {k.split(".")[0]: 0.0 for k in sd}
+    for k, v in sd.items():
+        wmax[k.split(".")[0]] = max(wmax[k.split(".")[0]], float(np.abs(v).max()))
+    print("trained checkpoint -> %s (%.1f KB); denoiser loss %.4f -> %.4f, RefineNet loss %.4f -> %.4f; max |w| per net: %s"
+          % (os.path.basename(TRAINED_FILE), os.path.getsize(TRAINED_FILE) / 1024, np.mean(l1[:10]), np.mean(l1[-10:]),
+             np.mean(l2[:5]), np.mean(l2[-5:]), {k: round(v, 3) for k, v in wmax.items()}))
+    record_on_trained(ref, sd)
+
+
+def record_on_trained(ref=None, sd=None):
+    ref = ref or ref_harness.load_reference()
+    sd = sd or dict(np.load(TRAINED_FILE))
+    e7c5 = ["--diffusion", "--load_stlp", "--rect_head", "--flex", "--diverse_loss", "--multi_cands", "5"]
+    gd = ["--guidance", "--guidance_before", "10", "--guidance_niters", "1", "--guidance_lr", "0.01"]
+    # (a trained sampler satisfies the "wide" thresholds of the other fixtures on every row: one case keeps them, the others
+    # take the tighter "loose" ones, so that guidance, candidate selection and RefineNet have violated rows to work on)
+    sampling_case(ref, sd, "e7_trained_guid", e7c5 + gd, bs=2, S=64, K=2, steps=50, seed=191, stlp_mode="loose",
+                  invalid_lane_frac=0.25, weights_variant="trained")
+    sampling_case(ref, sd, "e7_trained_s16", e7c5 + gd, bs=3, S=16, K=3, steps=50, seed=192, stlp_mode="wide",
+                  weights_variant="trained")
+    train_case(ref, sd, "train_e8_trained", bs=3, S=16, K=3, steps=10, seed=193, weights_variant="trained", stlp_mode="loose")
+
+
+if __name__ == "__main__" and "--trained" in sys.argv:
+    main_trained()
+if __name__ == "__main__" and "--trained-record" in sys.argv:
+    record_on_trained()

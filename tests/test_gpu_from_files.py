@@ -72,3 +72,32 @@ def test_refinenet_training_from_files_updates_the_checkpoint(tmp_path, capsys):
         nt.main(base + ["--stl_weight", "1.0", "-P", str(tmp_path / "no_such.ckpt")])
     md = nt.main(base + ["--stl_weight", "1.0", "--epochs", "1", "--allow_random_init", "-P", str(tmp_path / "no_such.ckpt")])
     assert np.isfinite(md("loss"))
+
+
+@pytest.mark.parametrize("extra", [["--rect_head", "--flex", "--diverse_loss", "--multi_cands", "3"],
+                                   ["--rect_head", "--flex", "--diverse_loss", "--multi_cands", "3", "--guidance", "--guidance_before",
+                                    "4", "--guidance_niters", "1", "--guidance_lr", "0.01", "--n_rolls", "2"],
+                                   ["--flex"]])
+def test_kernel_noise_graph_replay_equals_the_eager_region(tmp_path, capsys, extra):
+    """--kernel_noise: run_sampling_test replays ONE captured HIP graph per batch (nusc_train._GraphRegion); --no_graph keeps
+    the eager launches.  Same generator state in, same printed line out -- every batch, every column (the satisfaction rates
+    and the diversity / ADE / FDE metrics of the sampled controls are functions of every row)."""
+    from pstl_diffusion_policy_amd import nusc_dataset as nd
+    from pstl_diffusion_policy_amd import nusc_train as nt
+    from pstl_diffusion_policy_amd.nusc_model import init_state_dict
+    root = str(tmp_path / "e7")
+    base = ["--diffusion", "--load_stlp", "--n_randoms", "16", "--sampling_size", "16", "--n_neighbors", "3", "--batch_size", "4",
+            "--diffusion_steps", "12", "--cache_path", root, "--run_sampling_test", "--test", "--kernel_noise"] + extra
+    nd.write_synthetic_experiment(root, 40, nt.generate_parser(base), seed=7)
+    sd = init_state_dict(1007)
+    if "--rect_head" not in extra:      # an e5 checkpoint holds no RefineNet
+        sd = {k: v for k, v in sd.items() if not k.startswith(("rect_net.", "merge_net."))}
+    nd.save_checkpoint(sd, os.path.join(root, "models"))
+    lines = {}
+    for mode in ([], ["--no_graph"]):
+        torch.manual_seed(123)
+        nt.main(base + mode + ["-P", nd.smart_path(root)])
+        out = capsys.readouterr().out
+        lines[bool(mode)] = [l.split("||| T:")[0] for l in out.splitlines() if l.startswith("###[")]
+    assert len(lines[False]) >= 1 and lines[False] == lines[True], (lines[False], lines[True])
+    print("batches compared:", len(lines[False]))

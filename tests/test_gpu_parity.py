@@ -129,7 +129,7 @@ def _run_region(dev, name, chain_waves=0):
 @pytest.mark.parametrize("name", SAMPLING_CASES)
 def test_sampling_region_matches_reference(dev, name, chain_waves):
     from pstl_diffusion_policy_amd.engine import acc_from_counts
-    if chain_waves == 32 and name in HEAVY_CASES:
+    if chain_waves == 32 and name in HEAVY_CASES + ["e7_trained_guid"]:
         # bfloat16 pieces carry an operand to 2^-17: 8e-6 from the reference on random-init weights, but with hidden
         # activations in the hundreds (e7_heavy_b) rows leave 1e-4 within a few un-guided steps -- the round-1 default is not a
         # 1e-4 arithmetic at a trained network's dynamic range.  test_gpu_chain_domain.py records its deviation next to the

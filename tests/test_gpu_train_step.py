@@ -22,7 +22,7 @@ def _setup(d, dev):
 
 # train_e8_heavy: rect_net with a trained network's dynamic range (tests/heavy_weights.py): the training forward pass runs
 # on the split-f16 chain too
-@pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b", "train_e8_heavy", "train_e8_norm"])
+@pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b", "train_e8_heavy", "train_e8_norm", "train_e8_trained"])
 def test_rect_train_step_matches_reference(name):
     dev = torch.device("cuda:0")
     d = load_golden(name)

@@ -8,7 +8,7 @@ from oracle import pstl_oracle as orc
 from pstl_diffusion_policy_amd.synthetic import default_hparams
 
 
-@pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b", "train_e8_heavy", "train_e8_norm"])
+@pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b", "train_e8_heavy", "train_e8_norm", "train_e8_trained"])
 def test_rect_train_step_matches_reference(name):
     d = load_golden(name)
     bs, S, K, steps, seed, mc = [int(v) for v in d["meta"]]

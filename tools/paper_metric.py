@@ -31,7 +31,7 @@ def main():
     import io
     args = sys.argv[1:]
     batches = int(args[args.index("--batches") + 1]) if "--batches" in args else 8
-    extra = ["--kernel_noise"] if "--kernel_noise" in args else []
+    extra = (["--kernel_noise"] if "--kernel_noise" in args else []) + (["--no_graph"] if "--no_graph" in args else [])
     from pstl_diffusion_policy_amd import nusc_train as nt
     out = {"rows_per_batch": 128 * 64 * 3, "batches": batches, "noise": "in-kernel Philox" if extra else "torch.randn_like per step"}
     for name, argv in CONFIGS.items():
