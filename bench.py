@@ -536,7 +536,7 @@ def main():
     # instructions per row-evaluation from the committed PMC pass (SQ_INSTS_VALU / rows of that launch) x the row-evaluation
     # rate measured live in this run x 4 issue cycles per wavefront instruction / (1024 SIMDs x the clock of the PMC run)
     pmc_path = None
-    for rnd in ("r4", "r3", "r2"):
+    for rnd in ("r5", "r4", "r3", "r2"):
         cand = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
         if os.path.exists(cand):
             pmc_path = cand
@@ -559,6 +559,9 @@ def main():
                   and a.noise == "kernel" and not a.chain_waves)
     if is_default and pj.get("summary_dominant_kernel"):
         traffic = pj["summary_dominant_kernel"]["hbm_bytes_per_launch_corrected"]
+    from pstl_diffusion_policy_amd import ffi as _ffi2
+    dom_kernel = "k_chain2" if _ffi2.rollout_layout(_ffi2.make_cfg(bs, S * 3, S, a.neighbors, steps, hp, _ffi2.PSTL_FLAG_RNG,
+                                                                    a.chain_waves))[0] == 2 else "k_chain"
     line = None
     if rank == 0:
         line = {
@@ -577,7 +580,7 @@ def main():
                        "noise": "in-kernel Philox4x32-10" if a.noise == "kernel" else "torch.randn tensors"},
             "stl_sat_rate": acc, "scene_sat_rate": sacc, "counts": [int(v) for v in counts.tolist()],
             "diversity": None if train else diversity_from_totals(div_totals),
-            "roofline": {"bound": "mfma", "kernel": "k_chain (denoiser MLP chain, %d reverse steps per launch)" % nst,
+            "roofline": {"bound": "mfma", "kernel": "%s (denoiser MLP chain, %d reverse steps per launch)" % (dom_kernel, nst),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "peak_note": ("dense f16/bf16 MFMA peak 2516.8 TFLOP/s / 3 products per f32 product"

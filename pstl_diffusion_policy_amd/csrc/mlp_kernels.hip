@@ -1711,7 +1711,7 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   // 2: the row-stationary kernel (k_chain2, chain2_kernels.hip) for every launch it can take, whatever the batch size; 0:
   // for the multi-step denoiser launches of batches that fill whole rounds of its 256-row workgroups (chain2_pays)
   if constexpr (!REFINE) {
-    if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(a.N) && a.step_hi > a.step_lo)) && chain2_eligible(a)) return launch_chain2(a, st);
+    if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(a.N))) && chain2_eligible(a)) return launch_chain2(a, st);
   }
   if (chain_waves == 16 || chain_waves == 2) chain_waves = 0;
   if (REFINE && chain_waves == 32) chain_waves = 8;    // bf16 pieces cost the interval head up to 9e-5 per pass

@@ -457,6 +457,16 @@ PSTL_HD void clearance_from_winner(const StlEnv& env, const float* nei, int t, f
 struct alignas(8) f2 {
   float x, y;
 };
+PSTL_HD void store_quad(float* p, float x, float y, float z, float w) {   // one 16-byte store (p 16-byte aligned)
+#if defined(__HIPCC__)
+  typedef float st4 __attribute__((ext_vector_type(4)));
+  st4 v;
+  v.x = x, v.y = y, v.z = z, v.w = w;
+  *reinterpret_cast<st4*>(p) = v;
+#else
+  p[0] = x, p[1] = y, p[2] = z, p[3] = w;
+#endif
+}
 PSTL_HD void store_pair(float* p, float x, float y) {   // one 8-byte store
 #if defined(__HIPCC__)
   typedef float st2 __attribute__((ext_vector_type(2)));

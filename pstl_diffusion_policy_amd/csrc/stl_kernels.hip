@@ -403,13 +403,21 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
     return x;
   };
   // the update of time step t: Adam on (w, a), and on the last iteration the noise (quad z4 of steps t | 1 and t & ~1) and emission
-  auto apply = [=](int t, float gw, float ga, float w0, float a0, const f4& z4) {
+  // (Both callers walk t = T-1 ... 0, an odd step right before its even neighbour: the odd step's results wait in `held` and
+  // leave with the even step's as ONE 16-byte store per tensor -- half the store instructions of the 8-byte pairs this kernel
+  // used to issue, each of which touches 64 lines of the row-major state: a wavefront's rows are 480 bytes apart.  Nothing
+  // reads mu[2t .. 2t+3] between the two steps: the adjoint only looks at earlier time steps.)
+  auto apply = [=](int t, float gw, float ga, float w0, float a0, const f4& z4, f4& held_mu, f4& held_em) {
     const int o = (t & 1) * 2;
     float ew = 0.0f, ea = 0.0f;
     const float nw = update(2 * t, w0, gw, a.wscale, o ? z4.z : z4.x, &ew);
     const float na = update(2 * t + 1, a0, ga, a.ascale, o ? z4.w : z4.y, &ea);
-    store_pair(mu + 2 * t, nw, na);                      // 8-byte gather stores: (w, a) of a step together
-    if (last && er) store_pair(er + 2 * t, ew, ea);
+    if (t & 1) {
+      held_mu.x = nw, held_mu.y = na, held_em.x = ew, held_em.y = ea;
+    } else {
+      store_quad(mu + 2 * t, nw, na, held_mu.x, held_mu.y);
+      if (last && er) store_quad(er + 2 * t, ew, ea, held_em.x, held_em.y);
+    }
   };
   if constexpr (SPLIT) {
     // Wave 0 leaves every step's gradient and stored controls in LDS; after a barrier each wave updates its own two steps
@@ -492,10 +500,11 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
       normal4(seed, a.row_offset + row, wq, a.step, zz);
       z4 = f4{zz[0], zz[1], zz[2], zz[3]};
     }
+    f4 held_mu = f4{0.0f, 0.0f, 0.0f, 0.0f}, held_em = held_mu;
     for (int t = 2 * wq + 1; t >= 2 * wq; --t) {
       float w0, a0;
       ctrl_pair(mu, 1, t, w0, a0);   // (the stored controls of this wave's own steps; nobody else reads or rewrites them)
-      apply(t, has_grad ? *slot(t, 0) : 0.0f, has_grad ? *slot(t, 1) : 0.0f, w0, a0, z4);
+      apply(t, has_grad ? *slot(t, 0) : 0.0f, has_grad ? *slot(t, 1) : 0.0f, w0, a0, z4, held_mu, held_em);
     }
   } else {
     // mu[2t], mu[2t+1] are rewritten by emit(t) while the adjoint walks t = T-1 ... 0; the adjoint has already taken every
@@ -503,7 +512,8 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
     stl_eval_grad<NORM>(
         a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
         [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
-        [=, z4 = f4{0.0f, 0.0f, 0.0f, 0.0f}](int t, float gw, float ga, float w0, float a0) mutable {
+        [=, z4 = f4{0.0f, 0.0f, 0.0f, 0.0f}, held_mu = f4{0.0f, 0.0f, 0.0f, 0.0f}, held_em = f4{0.0f, 0.0f, 0.0f, 0.0f}](
+            int t, float gw, float ga, float w0, float a0) mutable {
           // a noise quad covers two time steps (elements 4q .. 4q+3); emit() comes in the order t = T-1 ... 0, so the quad is
           // drawn at the odd step and kept for the even one: one Philox draw per two time steps
           if (a.rng && a.step > 1 && last && (t & 1)) {
@@ -511,7 +521,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
             normal4(seed, a.row_offset + row, t >> 1, a.step, zz);
             z4 = f4{zz[0], zz[1], zz[2], zz[3]};
           }
-          apply(t, gw, ga, w0, a0, z4);
+          apply(t, gw, ga, w0, a0, z4, held_mu, held_em);
         },
         1, gs == 0.0f);   // an invalid lane has zero loss weight: Adam sees exact zeros, only the noise is added
   }

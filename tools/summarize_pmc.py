@@ -21,6 +21,8 @@ def short(name):
     m = re.search(r"k_chain<(\d+), (true|false), \d+, (?:true|false), (\d+)", name)
     if m:      # waves, REFINE, PT (0 = exact fp32 MFMA, 1 = bfloat16 pieces, 2 = half pieces): the bench runs an fp32 leg too
         n = "k_chain<%s,%s,pt%s>" % m.groups()
+    elif "k_chain2" in name:      # the row-stationary multi-step kernel (round 5): <true> draws its noise itself
+        n = "k_chain2<%s>" % ("rng" if "k_chain2<true>" in name else "noise_in")
     elif "k_chain" in name:
         n = "k_chain<8,%s>" % ("true" if "k_chain<8, true" in name else "false")
     return n
@@ -55,11 +57,13 @@ for tag, per in passes.items():
         out["per_kernel"][tag][k] = {name: sum(e.get(name, 0.0) for e in ds) / len(ds) for name in keys}
         out["per_kernel"][tag][k]["launches_averaged"] = len(ds)
 dom = DOM
+if "k_chain2<rng>" in out["per_kernel"]["SQ"] or "k_chain2<rng>" in out["per_kernel"]["FETCH_SIZE"]:
+    dom = "k_chain2<rng>"       # the default bench's multi-step launches run on k_chain2 at this size
 f = out["per_kernel"]["FETCH_SIZE"].get(dom, {})
 w = out["per_kernel"]["WRITE_SIZE"].get(dom, {})
 sq = out["per_kernel"]["SQ"].get(dom, {})
-summ = {"kernel": "k_chain<8,false,...> (multi-step denoiser launch of the default bench: 786432 rows, in-kernel noise, "
-                  "split-f16 MFMA unless the bench was run with another --chain_waves)",
+summ = {"kernel": dom + " (multi-step denoiser launch of the default bench: 786432 rows, in-kernel noise, "
+                        "split-f16 MFMA unless the bench was run with another --chain_waves)",
         "FETCH_SIZE_KB": f.get("FETCH_SIZE"), "WRITE_SIZE_KB": w.get("WRITE_SIZE"),
         "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); WRITE_SIZE as reported"}
 if f.get("FETCH_SIZE") is not None and w.get("WRITE_SIZE") is not None:
