@@ -47,7 +47,8 @@ constexpr int kOffBrow = kOffCrow + kMaxScn * 1024;          // [kMaxScn][256] b
 constexpr int kOffB2 = kOffBrow + kMaxScn * 1024;            // [256] b2 x kAcc
 constexpr int kOffB3 = kOffB2 + 1024;                        // [48]  b3 x kAcc
 constexpr int kOffCoef = kOffB3 + 192;                       // [kMaxLaunchSteps][4] kk, a, sb, 0
-constexpr int kLdsBytes = kOffCoef + kMaxLaunchSteps * 16;
+constexpr int kOffRc = kOffCoef + kMaxLaunchSteps * 16;         // MU: [4 waves][RT][4][64] the next tile's hl | stlp words (lanes g >= 2)
+constexpr int kLdsBytes = kOffRc + 4 * RT * 4 * 64 * 4;
 
 constexpr float kSX = kSplitX, kSW = kSplitW, kAcc = kSX * kSW, kInvSW = 1.0f / kSW, kInvAcc = 1.0f / kAcc;
 
@@ -98,6 +99,17 @@ __device__ __forceinline__ void dma16x2(const void* sbase, unsigned voff, unsign
                : "memory");
 }
 
+// MU: single pieces of the next tile's state -- 16 bytes per lane from sbase + voff, 4 bytes per lane from a per-lane pointer
+__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma4(const float* p, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(p), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 __device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // domain guard of the split-f16 arithmetic (see note_pieces in mlp_kernels.hip): running v_pk_max_u16 of the hi pieces
@@ -132,7 +144,13 @@ __device__ __forceinline__ float clip_keep_nan(float v, float m) { return v < -m
 //            tail of the step before
 //   P4+2c    layers 2/3, chunk c, k-blocks 0..3; for c >= 1 also W3's k-block c-1 (pieces 16..21)
 //   P5+2c    chunk c, k-blocks 4..7
-template <bool RNG>
+//
+// MU (mu_only = 1, one reverse step per launch: the guided phase): the same tile-step, but the loop walks TILES instead of
+// reverse steps -- one workgroup per CU takes tiles blockIdx.x, + gridDim.x, ... so that the weight stream, the tables and the
+// launch are paid once per CU and not once per 256 rows.  The next tile's state arrives by LDS-DMA straight into the wave's
+// lane-private image (issued in the tail, when the current tile's image has been read), its scene rows in the middle of
+// chunk 6's phases.
+template <bool RNG, bool MU>
 __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -141,27 +159,33 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   constexpr int NM = 6 * RT;          // MFMAs per k-block
   constexpr int NCONV = 24 * RT;      // conversion micro-steps per chunk (4 RT pairs x 6)
   constexpr int kLead = 4;            // slots between an LDS read of a constant part and the MFMA that takes it as C
-  const long wg_row0 = (long)blockIdx.x * kWgRows;
-  const long row0 = wg_row0 + (long)w * (16 * RT);           // first row of this wave
-  const int nsteps = a.step_hi - a.step_lo + 1;
+  long wg_row0 = (long)blockIdx.x * kWgRows;
+  long row0 = wg_row0 + (long)w * (16 * RT);                 // first row of this wave
+  const int nsteps = MU ? 1 : a.step_hi - a.step_lo + 1;
+  const long n_tiles = (a.N + kWgRows - 1) / kWgRows;
+  const int n_iter = MU ? (int)((n_tiles - 1 - (long)blockIdx.x) / (long)gridDim.x) + 1 : nsteps;   // tile-steps of this workgroup
 
   float* crow = reinterpret_cast<float*>(smem + kOffCrow);
   float* brow = reinterpret_cast<float*>(smem + kOffBrow);
   float* b2s = reinterpret_cast<float*>(smem + kOffB2);
   float* b3s = reinterpret_cast<float*>(smem + kOffB3);
   f32x4* coef = reinterpret_cast<f32x4*>(smem + kOffCoef);
+  float* tbs = reinterpret_cast<float*>(smem + kOffCoef + 1024);   // MU (one coefficient entry): the launch's timestep row
   f32x4* xq = reinterpret_cast<f32x4*>(smem + kOffXq) + (w * RT * 3) * 64 + lane;   // [rt][j] at (rt*3 + j)*64
 
   // ---- scenes of this workgroup's rows; per-row-tile scene slot (a 16-row tile lies in one scene: rows_per_scene % 16 == 0) ----
   const long last_row = a.N - 1;
-  const long scene_first = wg_row0 / a.rows_per_scene;
+  long scene_first = wg_row0 / a.rows_per_scene;
   int scn[RT];
+  auto set_scn = [&] {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    long r = row0 + 16 * rt;
-    if (r > last_row) r = last_row;
-    scn[rt] = (int)(r / a.rows_per_scene - scene_first);
-  }
+    for (int rt = 0; rt < RT; ++rt) {
+      long r = row0 + 16 * rt;
+      if (r > last_row) r = last_row;
+      scn[rt] = (int)(r / a.rows_per_scene - scene_first);
+    }
+  };
+  set_scn();
 
   // ---- tables ----
   {
@@ -172,9 +196,10 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       const float al = a.alpha[i], ah = a.alpha_hat[i], be = a.beta[i];
       const float c1 = (1.0f - al) / sqrtf(1.0f - ah), inv_sa = 1.0f / sqrtf(al);
       const float kk = inv_sa * c1;
-      const bool noisy = i > 1 && (RNG || a.noise);   // the reference adds zeros at the last step
+      const bool noisy = !MU && i > 1 && (RNG || a.noise);   // the reference adds zeros at the last step
       coef[tid] = f32x4{kk, inv_sa - kk, noisy ? sqrtf(be) : 0.0f, 0.0f};
     }
+    if (MU) tbs[tid] = a.tbias[(long)a.step_hi * kHid2 + tid];
     const long nscn_rows = (wg_row0 + kWgRows - 1 > last_row ? last_row : wg_row0 + kWgRows - 1);
     const int nscn = (int)(nscn_rows / a.rows_per_scene - scene_first) + 1;
     for (int s = 0; s < kMaxScn; ++s) {
@@ -248,7 +273,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       xq[(rt * 3 + 1) * 64] = q1;
       xq[(rt * 3 + 2) * 64] = q2;
       make_x_pieces(rt, q0, q1, q2);
-      if (a.n_emit >= a.steps && a.step_hi == a.steps - 1 && row0 + 16 * rt + col <= last_row) {   // x_T is entry 0 of the full list
+      if (!MU && a.n_emit >= a.steps && a.step_hi == a.steps - 1 && row0 + 16 * rt + col <= last_row) {   // x_T is entry 0 of the full list
         const f32x4 sc = f32x4{a.w_max, a.a_max, a.w_max, a.a_max};
         float* er = a.emit_out + ((long)(a.n_emit - a.steps) * a.N + r) * kCtrl2;
         f32x4 v0 = q0 * sc, v1 = q1 * sc, v2 = q2 * sc;
@@ -569,23 +594,55 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev), "=s"(st_rt0)::"memory");
   st_t0 = st_prev;
 #endif
+  float* rcw = reinterpret_cast<float*>(smem + kOffRc) + (w * RT * 4) * 64 + lane;   // [rt][e] at (rt*4 + e)*64
+  if constexpr (MU) {   // (a workgroup's last tile makes pieces of what lies here: they are not used, but the domain guard sees them)
+#pragma unroll
+    for (int u = 0; u < RT * 4; ++u) rcw[u * 64] = 0.0f;
+  }
 #pragma unroll 1
-  for (int n = 0; n < nsteps; ++n) {
-    const int i = a.step_hi - n;
-    const f32x4 cf4 = coef[n];
+  for (int n = 0;; ++n) {   // (left by the break behind the last epilogue: n_iter >= 1)
+    const int i = MU ? a.step_hi : a.step_hi - n;
+    const f32x4 cf4 = coef[MU ? 0 : n];
     const float kk = cf4[0], ca = cf4[1], sb = cf4[2];
     n_ca = ca, n_sb = sb, n_step = i;
+    const bool more = n + 1 < n_iter;
     // the timestep row of the NEXT step, on its way while this one computes
     float tb_next = 0.0f;
-    if (n + 1 < nsteps) tb_next = a.tbias[(long)(i - 1) * kHid2 + tid];
+    if (!MU && more) tb_next = a.tbias[(long)(i - 1) * kHid2 + tid];
     auto none = [] {};
     auto noslot = [](auto) {};
     // the constant rows of the next step, written right behind the barrier of B(0): every wave is past layer 1's reads of
     // this step's rows (two barriers ago), the next reads come after the barriers of the remaining phases
     auto write_crow = [&] {
-      if (n + 1 < nsteps) {
+      if (!MU && more) {
 #pragma unroll
         for (int s = 0; s < kMaxScn; ++s) crow[s * 256 + tid] = (brow[s * 256 + tid] + tb_next) * kAcc;
+      }
+    };
+    // MU: the next tile of this workgroup, its scenes' rows requested behind the barrier of A(6) and written behind B(6)'s
+    const long nwg_row0 = wg_row0 + (long)gridDim.x * kWgRows;
+    const long nscene_first = (MU && more) ? nwg_row0 / a.rows_per_scene : 0;
+    // (by LDS-DMA into the table of scene rows, which this mode does not use otherwise: each wave moves its own 64 columns and
+    // reads them back itself, behind the wait in front of the next barrier)
+    auto load_nbase = [&] {
+      if constexpr (MU) {
+        if (more) {
+          const long lr = nwg_row0 + kWgRows - 1 > last_row ? last_row : nwg_row0 + kWgRows - 1;
+          const int nscn = (int)(lr / a.rows_per_scene - nscene_first) + 1;
+          const unsigned voff = here((unsigned)tid) * 4u;
+#pragma unroll
+          for (int s = 0; s < kMaxScn; ++s)
+            dma4(a.base + (nscene_first + (s < nscn ? s : nscn - 1)) * kHid2, voff, (unsigned)kOffBrow + (unsigned)(s * 1024 + w * 256));
+        }
+      }
+    };
+    auto write_ncrow = [&] {
+      if constexpr (MU) {
+        if (more) {
+          const float tbc = tbs[tid];
+#pragma unroll
+          for (int s = 0; s < kMaxScn; ++s) crow[s * 256 + tid] = (brow[s * 256 + tid] + tbc) * kAcc;
+        }
       }
     };
 
@@ -621,8 +678,8 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, cc + 2, 0, cc + 2, none, [&](auto s_) { noise_slot(cc >> 1, Yes{}, s_); });
       C2_STAMP(4)
     }
-    l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, No{}, Ic<1>{}, Ic<6>{}, 7, 6, 0, none, noslot);    // A(6); issues A(7) + W3[6]
-    l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 7, 0, 7, none, [&](auto s_) { noise_slot(3, No{}, s_); });
+    l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, No{}, Ic<1>{}, Ic<6>{}, 7, 6, 0, load_nbase, noslot);    // A(6); issues A(7) + W3[6]
+    l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 7, 0, 7, write_ncrow, [&](auto s_) { noise_slot(3, No{}, s_); });
     l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, No{}, Ic<0>{}, Ic<6>{}, 0, 7, 0, none, noslot);    // A(7); issues P0 of the next step + W3[7]
     l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, No{}, Ic<0>{}, Ic<4>{}, 1, 0, 0, none, [&](auto s_) { noise_slot(3, Yes{}, s_); });    // B(7); issues P1 of the next step
     C2_STAMP(5)
@@ -636,12 +693,45 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) qv[rt][j] = xq[(rt * 3 + j) * 64];
     if (!(PSTL_C2_ABL & 64)) static_for<NCONV>([&](auto i_tag) { conv_step(accB, i_tag); });
+    if constexpr (MU) {
+      // the next tile's state, straight into this wave's image (its reads above have returned): per row tile three 16-byte
+      // pieces (lane (g, col): columns 16 j + 4 g .. of row col; tile j = 2 holds x only in lanes g < 2) and four 4-byte
+      // pieces with the row constants of lanes g >= 2 (g = 2: hl, stlp 0..2; g = 3: stlp 3..5 and a word that is dropped)
+      if (more) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned ln = here((unsigned)lane);
+        const unsigned lc = ln & 15u, lg = ln >> 4;
+        const long nrow0 = nwg_row0 + (long)w * (16 * RT);
+        static_for<RT>([&](auto rt_tag) {
+          constexpr int rt = decltype(rt_tag)::value;
+          long tb0 = nrow0 + 16 * rt;                                  // (uniform)
+          if (tb0 > last_row) tb0 = last_row;
+          const unsigned rem = (unsigned)(last_row - tb0);
+          const unsigned lr = lc < rem ? lc : rem;                     // rows behind the end repeat the last one
+          const float* xb = a.x_inout + tb0 * kCtrl2;
+          const unsigned voff = lr * (unsigned)(kCtrl2 * 4) + lg * 16u;
+          const unsigned dst = (unsigned)kOffXq + (unsigned)((w * RT * 3 + rt * 3) * 64) * 16u;
+          dma16(xb, voff, dst);
+          dma16(xb + 16, voff, dst + 1024u);
+          dma16(xb + 32, lr * (unsigned)(kCtrl2 * 4) + (lg & 1u) * 16u, dst + 2048u);
+          const float* spb = a.stlp + tb0 * 6;
+          const float* p0 = lg == 2u ? (a.hl + tb0) + lr : spb + (lr * 6u + 3u);
+          const unsigned o1 = lr * 24u + (lg == 2u ? 0u : 16u);
+          const unsigned rdst = (unsigned)kOffRc + (unsigned)((w * RT * 4 + rt * 4) * 64) * 4u;
+          dma4(p0, rdst);
+          dma4(spb, o1, rdst + 256u);
+          dma4(spb, o1 + 4u, rdst + 512u);
+          dma4(spb, o1 + (lg == 2u ? 8u : 4u), rdst + 768u);
+          FENCE();
+        });
+      }
+    }
     FENCE();
     layer3(s_cur, No{});
 
     C2_STAMP(6)
     // ---- epilogue: eps = layer 3 + b3 (already in the accumulators); x' = a x + sb z - kk eps; candidates; next pieces ----
-    const bool emit = i <= a.n_emit, last = i == a.step_lo;
+    const bool emit = !MU && i <= a.n_emit, last = MU || i == a.step_lo;
     {
     // (global addresses = uniform pointer of the tile's first row + a 32-bit lane offset, re-derived here: see here())
     const unsigned ln = here((unsigned)lane);
@@ -658,7 +748,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
           const bool upd = j < 2 || own2;
           const unsigned trow0 = (unsigned)row0 + 16u * (unsigned)rt;
           f32x4 z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-          if (sb != 0.0f && upd && trow0 + lc <= (unsigned)last_row)
+          if (!MU && sb != 0.0f && upd && trow0 + lc <= (unsigned)last_row)   // (MU: mu only, no noise term)
             z = *reinterpret_cast<const f32x4*>((a.noise + ((long)(a.steps - 1 - i) * a.N + trow0) * kCtrl2) +
                                                 (lc * (unsigned)kCtrl2 + (unsigned)(16 * j) + 4u * lg));
           const float la = upd ? ca : 1.0f, lsb = upd ? sb : 0.0f;
@@ -668,13 +758,12 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
         const float nkl = j < 2 ? nk : nk2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) xn[rt][j][e] = __builtin_fmaf(nkl, acc3[j][rt][e], q[e]);
-        xq[(rt * 3 + j) * 64] = xn[rt][j];
+        if constexpr (!MU) xq[(rt * 3 + j) * 64] = xn[rt][j];
       }
-      make_x_pieces(rt, xn[rt][0], xn[rt][1], xn[rt][2]);
+      if constexpr (!MU) make_x_pieces(rt, xn[rt][0], xn[rt][1], xn[rt][2]);
     }
-    if (last || emit) {   // (uniform: the last step of the launch, and the steps whose state is a candidate)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
+    auto store_tile = [&](int rt) {
+      {
         const unsigned trow0 = (unsigned)row0 + 16u * (unsigned)rt;     // uniform
         const bool in = trow0 + lc <= (unsigned)last_row;
 #pragma unroll
@@ -697,7 +786,40 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
           }
         }
       }
+    };
+    if constexpr (MU) {
+      // (the last tile leaves the loop HERE, so that the pieces are redefined on every path to the back edge: under an
+      // `if (more)` the old ones stay live through the whole tile-step as far as the register allocator can tell -- 64 registers)
+      {
+        // the next tile's pieces from its image, row tile by row tile, each followed by the stores of this tile's result (after
+        // the wait: stores in flight would be waited for too; interleaved: the results leave the registers as the pieces fill them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          // (the last tile of the workgroup makes pieces of whatever its image holds -- nobody uses them: an `if (more)` around
+          // this would leave the old pieces live through the whole tile-step as far as the register allocator can tell)
+          const f32x4 q0 = xq[(rt * 3 + 0) * 64], q1 = xq[(rt * 3 + 1) * 64];
+          f32x4 q2 = xq[(rt * 3 + 2) * 64];
+          const f32x4 rc = f32x4{rcw[(rt * 4 + 0) * 64], rcw[(rt * 4 + 1) * 64], rcw[(rt * 4 + 2) * 64], rcw[(rt * 4 + 3) * 64]};
+          if (!own2) q2 = f32x4{rc[0], rc[1], rc[2], g == 2 ? rc[3] : 0.0f};
+          FENCE();
+          store_tile(rt);
+          FENCE();
+          make_x_pieces(rt, q0, q1, q2);
+          FENCE();
+        }
+      }
+    } else {
+      if (last || emit) {   // (uniform: the last step of the launch, and the steps whose state is a candidate)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) store_tile(rt);
+      }
     }
+    }
+    if (!more) break;
+    if constexpr (MU) {
+      wg_row0 = nwg_row0, row0 = nwg_row0 + (long)w * (16 * RT), scene_first = nscene_first;
+      set_scn();
     }
     C2_STAMP(7)
     // the first chunk's constant part for the next step (its rows were written above, two or more barriers ago)
@@ -722,36 +844,39 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
 }  // namespace
 
 bool chain2_eligible(const ChainArgs& a) {
-  // multi-step segments only: a single-step launch (the guided phase's mu_only steps) pays this kernel's per-workgroup
-  // prologue -- state, constant rows, the first two phases of the weight stream -- for ONE tile-step: measured 0.61 ms against
-  // k_chain's streamed single-step layout at 0.55 ms (786 432 rows)
-  if (a.mu_only || a.step_hi <= a.step_lo) return false;
+  // multi-step segments, and the single-step launches of the guided phase (mu_only = 1) in the form whose workgroups walk
+  // several tiles (one workgroup per 256 rows pays the prologue -- state, constant rows, the first two phases of the weight
+  // stream -- for ONE tile-step: measured 0.61 ms against k_chain's streamed single-step layout at 0.55 ms, 786 432 rows)
+  if (a.mu_only ? (a.mu_only != 1 || a.step_hi != a.step_lo) : a.step_hi <= a.step_lo) return false;
   if (a.h1_save || a.h2_save || a.pre_save || a.init) return false;  // policy_net inference only
   if (a.rows_per_scene % 16 != 0 || a.rows_per_scene < 48) return false;
   if (a.step_hi - a.step_lo + 1 > kMaxLaunchSteps) return false;
   return true;
 }
 
-template <bool RNG>
+template <bool RNG, bool MU>
 static int launch_chain2_t(const ChainArgs& a, hipStream_t st) {
-  const long n_wg = (a.N + kWgRows - 1) / kWgRows;
-  static int allowed_dev = -1;
+  long n_wg = (a.N + kWgRows - 1) / kWgRows;
+  static int allowed_dev = -1, cus = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return PSTL_ERR_LAUNCH;
   if (allowed_dev != dev) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<RNG>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) !=
-        hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<RNG, MU>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) !=
+            hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       return PSTL_ERR_LAUNCH;
     allowed_dev = dev;
   }
-  hipLaunchKernelGGL(k_chain2<RNG>, dim3((unsigned)n_wg), dim3(256), kLdsBytes, st, a);
+  if (MU && n_wg > cus) n_wg = cus;   // one workgroup per CU walks the tiles
+  hipLaunchKernelGGL((k_chain2<RNG, MU>), dim3((unsigned)n_wg), dim3(256), kLdsBytes, st, a);
   return launch_status();
 }
 
 int launch_chain2(const ChainArgs& a, hipStream_t st) {
   // in-kernel noise (PSTL_FLAG_RNG) rides in the MFMA shadow; a caller's noise tensor (the parity tests) or no noise at all
   // is handled in the epilogue
-  return a.rng ? launch_chain2_t<true>(a, st) : launch_chain2_t<false>(a, st);
+  if (a.mu_only) return launch_chain2_t<false, true>(a, st);
+  return a.rng ? launch_chain2_t<true, false>(a, st) : launch_chain2_t<false, false>(a, st);
 }
 
 }  // namespace pstl

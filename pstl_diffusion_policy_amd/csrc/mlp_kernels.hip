@@ -1687,9 +1687,13 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
   return launch_status();
 }
 
-// Batches that k_chain2 runs faster than k_chain: its workgroups own 256 rows for the whole launch, one per CU at a time, so
-// the launch takes ceil(workgroups / CUs) rounds -- it pays when those rounds are (nearly) full.
-inline bool chain2_pays(long N) {
+// Batches that k_chain2 runs faster than k_chain.  Multi-step launches: its workgroups own 256 rows for the whole launch, one
+// per CU at a time, so the launch takes ceil(workgroups / CUs) rounds -- it pays when those rounds are (nearly) full.  The
+// single-step launches of the guided phase: one workgroup per CU walks the tiles, no rounds -- measured faster than k_chain's
+// single-step layout at every size from 32 832 rows up (31 against 46 us; 786 432 rows: 335 against 445 us), so it takes
+// every batch the latency layout does not (profiles/r5/chain2_single_step_sizes.txt).
+inline bool chain2_pays(long N, bool single_step) {
+  if (single_step) return sparse_tiles_per_group(N) == 0;
   const long cus = cu_count(), n_wg = (N + 255) / 256;
   const long rounds = (n_wg + cus - 1) / cus;
   return n_wg >= cus && n_wg * 8 >= rounds * cus * 7;   // >= 7/8 of the CU-rounds busy
@@ -1711,7 +1715,8 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   // 2: the row-stationary kernel (k_chain2, chain2_kernels.hip) for every launch it can take, whatever the batch size; 0:
   // for the multi-step denoiser launches of batches that fill whole rounds of its 256-row workgroups (chain2_pays)
   if constexpr (!REFINE) {
-    if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(a.N))) && chain2_eligible(a)) return launch_chain2(a, st);
+    if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(a.N, a.step_hi == a.step_lo))) && chain2_eligible(a))
+      return launch_chain2(a, st);
   }
   if (chain_waves == 16 || chain_waves == 2) chain_waves = 0;
   if (REFINE && chain_waves == 32) chain_waves = 8;    // bf16 pieces cost the interval head up to 9e-5 per pass
@@ -2045,10 +2050,10 @@ extern "C" int pstl_rollout_layout(const pstl_cfg* cfg, int multi_step, int* ker
   const long N = n_rows(cfg), n_tiles = (N + kTileRows - 1) / kTileRows, cus = cu_count();
   const int cw = cfg->chain_waves;
   ChainArgs a = {};
-  a.N = N, a.rows_per_scene = cfg->rows_per_scene, a.step_hi = multi_step ? 2 : 1, a.step_lo = 1;
+  a.N = N, a.rows_per_scene = cfg->rows_per_scene, a.step_hi = multi_step ? 2 : 1, a.step_lo = 1, a.mu_only = multi_step ? 0 : 1;
   const bool ut = cfg->rows_per_scene % kTileRows == 0;
   int k = 3, g = tiles_per_group(N);
-  if ((cw == 2 || (cw == 0 && chain2_pays(N) && multi_step)) && chain2_eligible(a)) {
+  if ((cw == 2 || (cw == 0 && chain2_pays(N, !multi_step))) && chain2_eligible(a)) {
     k = 2, g = 16;
   } else if (cw == 0 || cw == 16 || cw == 2) {
     k = 1;

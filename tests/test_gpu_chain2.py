@@ -144,3 +144,61 @@ def test_chain2_domain_guard(dev):
         _, base_p, _ = sm.encode(sb, need_rect=False)
         sm.rollout(sb, base_p, x, None, 8, n_emit=0, seed=3)
         assert w.chain_overflowed(clear=True)
+
+
+# 134 400 and 200 000+ rows: more 256-row tiles than CUs, so that the single-step form's workgroups walk 2-4 tiles each (and
+# the last workgroups one fewer); the second size is not a multiple of 256 and its scenes have 48 rows (7 scenes per tile)
+@pytest.mark.parametrize("bs,S", [(700, 64), (4201, 16)])
+def test_chain2_single_step_form_walks_tiles(dev, bs, S):
+    """The guided phase's launches (mu_only = 1, one reverse step): k_chain2's form whose workgroups walk several tiles --
+    next state by LDS-DMA into the wave's image, scene rows re-read per tile -- against k_chain's single-step layout on the
+    same state: the plain launch, and the whole guided sampling region around it."""
+    from pstl_diffusion_policy_amd.engine import Sampler, SceneBatch
+    hp, scene, w, sb = _setup(dev, bs, S, 2, seed=77)
+    assert sb.N > 2 * 256 * torch.cuda.get_device_properties(0).multi_processor_count
+    g = torch.Generator(device=dev).manual_seed(11)
+    x0 = torch.randn(sb.N, 40, device=dev, generator=g)
+    import ctypes
+    from pstl_diffusion_policy_amd import ffi
+    from pstl_diffusion_policy_amd.engine import diffusion_coeffs
+    steps, i = 10, 4
+    beta, alpha, alpha_hat = diffusion_coeffs(steps, dev)
+    mus = []
+    for cw in (16, 2):
+        sm = Sampler(w, hp, chain_waves=cw)
+        _, base_p, _ = sm.encode(sb, need_rect=False)
+        x = x0.clone()
+        cfg = sb.cfg(steps, 0, cw, 0)
+        ffi.check(sm.L.pstl_rollout(ctypes.byref(cfg), ffi.ptr(w.packed), ffi.ptr(base_p), ffi.ptr(w.tbias(steps)),
+                                    ffi.ptr(sb.stlp), ffi.ptr(sb.hl), ffi.ptr(beta), ffi.ptr(alpha), ffi.ptr(alpha_hat),
+                                    ffi.ptr(None), i, i, 1, ffi.ptr(x), ffi.ptr(sm.debug_buf), 0, ffi.stream()), "rollout")
+        torch.cuda.synchronize()
+        assert not w.chain_overflowed()
+        mus.append(x)
+    d = (mus[0] - mus[1]).abs().max().item()
+    assert 0.0 < d <= 2e-6, d
+    # a block of scenes launched alone (fewer tiles than CUs: every workgroup has ONE tile) gives the rows of the walk bit for bit
+    lo, hi = bs // 3, bs // 3 + 40
+    r0, r1 = lo * S * 3, hi * S * 3
+    sub = SceneBatch({k: v[lo:hi].clone() for k, v in scene.items()}, S, hp, dev, row_offset=r0,
+                     global_valid_sum=float(sb.valid.sum()), global_rows=sb.N)
+    sm = Sampler(w, hp, chain_waves=2)
+    _, base_s, _ = sm.encode(sub, need_rect=False)
+    xs = x0[r0:r1].clone()
+    cfg = sub.cfg(steps, 0, 2, 0)
+    ffi.check(sm.L.pstl_rollout(ctypes.byref(cfg), ffi.ptr(w.packed), ffi.ptr(base_s), ffi.ptr(w.tbias(steps)),
+                                ffi.ptr(sub.stlp), ffi.ptr(sub.hl), ffi.ptr(beta), ffi.ptr(alpha), ffi.ptr(alpha_hat),
+                                ffi.ptr(None), i, i, 1, ffi.ptr(xs), ffi.ptr(sm.debug_buf), 0, ffi.stream()), "rollout")
+    assert torch.equal(xs, mus[1][r0:r1])
+    guid = dict(enabled=True, before=4, niters=1, lr=0.01)
+    outs = []
+    for cw in (16, 2):
+        sm = Sampler(w, hp, chain_waves=cw)
+        o = sm.sampling_region(sb, 9, None, None, rect_head=False, multi_cands=2, guidance=guid, seed=5)
+        outs.append(o["final_controls"].clone())
+    assert torch.isfinite(outs[1]).all()
+    # the guided steps take a signed Adam step of lr = 0.01 per control: where a gradient component is zero to rounding, the last
+    # bits of mu decide its sign, so a row in a thousand legitimately differs by up to 2 lr -- and no row by more
+    dr = (outs[0] - outs[1]).abs().reshape(sb.N, -1).max(dim=1).values
+    assert (dr > 5e-5).sum().item() <= max(1, sb.N // 400), (dr > 5e-5).sum().item()
+    assert dr.max().item() <= 0.2      # (four guided steps, each may turn a sign: 4 x 2 lr, and what the denoiser makes of it)

@@ -376,7 +376,10 @@ def test_streamed_single_step_launches_equal_the_grouped_ones(dev, noise):
     bs, S, K, steps, seed = 256, 64, 3, 14, 11
     scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=K, S=S, seed=9, invalid_lane_frac=0.2, stlp_mode="wide").items()
              if k not in ("params", "pre_stlp", "tj_scores_prior")}
-    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    # chain_waves = 16: k_chain for every launch (with 0 the whole batch's mu-only launches go to k_chain2, whose sums run in
+    # another order); the shards are evaluated in the throughput layout (16) and in the latency layout (0: 384 tiles) alike
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp, chain_waves=16)
+    sm_lat = Sampler(sm.w, hp, chain_waves=0)
     guid = dict(enabled=True, freq=2, niters=1, lr=0.01)
     sb = SceneBatch(scene, S, hp, dev)
     N = sb.N
@@ -390,12 +393,13 @@ def test_streamed_single_step_launches_equal_the_grouped_ones(dev, noise):
         hi = lo + 32
         sub = {k: v[lo:hi].contiguous() for k, v in scene.items()}
         r0, r1 = lo * S * 3, hi * S * 3
-        part = sm.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=r0, global_valid_sum=vsum, global_rows=N), steps,
-                                  None if x_T is None else x_T[r0:r1].contiguous(),
-                                  None if z is None else z[:, r0:r1].contiguous(), **kw)
-        for k in ("final_controls", "final_scores", "sel_controls", "cand_scores"):
-            a, b = part[k], (full[k][:, r0:r1] if k == "cand_scores" else full[k][r0:r1])
-            assert torch.equal(a, b), k
+        for smp in (sm, sm_lat):
+            part = smp.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=r0, global_valid_sum=vsum, global_rows=N), steps,
+                                       None if x_T is None else x_T[r0:r1].contiguous(),
+                                       None if z is None else z[:, r0:r1].contiguous(), **kw)
+            for k in ("final_controls", "final_scores", "sel_controls", "cand_scores"):
+                a, b = part[k], (full[k][:, r0:r1] if k == "cand_scores" else full[k][r0:r1])
+                assert torch.equal(a, b), (k, smp.chain_waves)
 
 
 @pytest.mark.parametrize("bs", [112, 267])
