@@ -55,7 +55,8 @@ constexpr float kSX = kSplitX, kSW = kSplitW, kAcc = kSX * kSW, kInvSW = 1.0f / 
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 // Timing-only ablations (tools/dbg/build_variants2.sh + time_variants.py; the results are garbage): bits 1 noise steps,
 // 2 layer-1 conversions + pins, 4 layer-2 conversions, 8 epilogue, 16 LDS-DMA, 32 phase barriers, 64 the tail's conversion,
-// 128 the domain guard's running maximum, 256 layer 1 altogether, 512 layer 3
+// 128 the domain guard's running maximum, 256 layer 1 altogether, 512 layer 3, 1024 the wait for the LDS-DMA in front of
+// the phase barriers (the DMA is still issued)
 #ifndef PSTL_C2_ABL
 #define PSTL_C2_ABL 0
 #endif
@@ -99,6 +100,15 @@ __device__ __forceinline__ void dma16x2(const void* sbase, unsigned voff, unsign
                : "memory");
 }
 
+// four adjacent pieces behind ONE M0 write: issuing a vector memory instruction costs the wave ~40 cycles, the M0 write ~15 more,
+// each further instruction of a burst next to nothing (tools/dbg/dma_issue_cost.hip, profiles/r5/dma_issue_cost.txt)
+__device__ __forceinline__ void dma16x4(const void* sbase, unsigned voff, unsigned lds_dst) {
+  if (PSTL_C2_ABL & 16) return;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff),
+               "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
 // MU: single pieces of the next tile's state -- 16 bytes per lane from sbase + voff, 4 bytes per lane from a per-lane pointer
 __device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
@@ -138,8 +148,9 @@ __device__ __forceinline__ unsigned here(unsigned v) {
 }
 __device__ __forceinline__ float clip_keep_nan(float v, float m) { return v < -m ? -m : (v > m ? m : v); }
 
-// Phases of a tile-step and what their ring slot holds (1 KB pieces; piece kq*4 + t*2 + hl is the A operand of tile t,
-// piece hl of the phase's k-block kq):
+// Phases of a tile-step and what their ring slot holds (1 KB pieces; the A operand of tile t, piece hl of the phase's
+// k-block kq is piece pidx(kq, 2 t + hl) = (2 t + (kq >> 1)) * 4 + (kq & 1) * 2 + hl: the four pieces a wave fetches -- those
+// of one tile and two k-blocks, adjacent in the packed buffer -- are adjacent in the slot as well, one burst behind one M0):
 //   P0..P3   layer 1, phase q: chunks 2q, 2q+1 (kq = 2 cl + kb); P0 also carries W3's k-block 7 (pieces 16..21) for the
 //            tail of the step before
 //   P4+2c    layers 2/3, chunk c, k-blocks 0..3; for c >= 1 also W3's k-block c-1 (pieces 16..21)
@@ -293,32 +304,30 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   const unsigned* w2p = reinterpret_cast<const unsigned*>(a.packed + a.off.w2h);
   const unsigned* w3p = reinterpret_cast<const unsigned*>(a.packed + a.off.w3h);
   const unsigned lane16 = (unsigned)lane * 16u;
-  // pair k (0..2) of this wave's share of a phase: a pair = the hi and the lo piece of one (k-block, tile) -- adjacent in the
-  // packed buffer and in the slot, so ONE M0 / address set-up serves both (the instruction offset applies to the LDS address
-  // too).  k = 0, 1: pairs w, w + 4 of the 8 W1 / W2 pairs; KIND 0: layer-1 phase q = c; 1 / 2: first / second half of layer-2
-  // chunk c.  k = 2: pair w of the 3 pairs of the W3 k-block c3 that rides with the phase (wave 3 repeats pair 0).
-  auto issue_pair = [&](auto kind_tag, int c, int c3, int k, unsigned slot_byte) {
+  // this wave's share of a phase's W1 / W2 pieces: wave w = 2 t + kh fetches tile t of the phase, k-blocks 2 kh, 2 kh + 1, both
+  // pieces each -- 4 KB that are contiguous in the packed buffer ([tile][k-block][hi | lo]) and in the slot.  KIND 0: layer-1
+  // phase q = c (its four tiles 4 q + 2 cl + t, k-blocks kq = 2 cl + kb: wave w fetches tile 4 q + 2 (w & 1) + (w >> 1)); 1 / 2:
+  // first / second half of layer-2 chunk c (tile 2 c + t, k-blocks 4 half + kq)
+  auto issue_w = [&](auto kind_tag, int c, unsigned slot_byte) {
     constexpr int KIND = decltype(kind_tag)::value;
-    if (k < 2) {
-      const int pp = 4 * k + w;               // = kq * 2 + t
-      const int kq = pp >> 1, t = pp & 1;
-      if constexpr (KIND == 0) {   // kq = 2 cl + kb; tile 2 (2 q + cl) + t of W1 [16 T][2 kb][hi | lo]
-        const long blk = ((long)(2 * (2 * c + (kq >> 1)) + t) * 2 + (kq & 1)) * 2;
-        dma16x2(w1p + blk * 256, lane16, slot_byte + (unsigned)pp * 2048u);
-      } else {                     // tile 2 c + t, k-block 4 half + kq of W2 [16 T][8 kb][hi | lo]
-        const long blk = ((long)(2 * c + t) * 8 + 4 * (KIND - 1) + kq) * 2;
-        dma16x2(w2p + blk * 256, lane16, slot_byte + (unsigned)pp * 2048u);
-      }
+    const unsigned dst = slot_byte + (unsigned)w * 4096u;
+    if constexpr (KIND == 0) {
+      dma16x4(w1p + (long)(4 * c + 2 * (w & 1) + (w >> 1)) * 4 * 256, lane16, dst);
     } else {
-      const int j = w < 3 ? w : 0;
-      const long blk = ((long)(j * 8 + c3) * 2);
-      dma16x2(w3p + blk * 256, lane16, slot_byte + 16384u + (unsigned)j * 2048u);
+      dma16x4(w2p + ((long)(2 * c + (w >> 1)) * 8 + 4 * (KIND - 1) + 2 * (w & 1)) * 2 * 256, lane16, dst);
     }
   };
+  // pair w of the 3 (hi | lo) pairs of the W3 k-block c3 that rides with the phase (wave 3 repeats pair 0)
+  auto issue_w3 = [&](int c3, unsigned slot_byte) {
+    const int j = w < 3 ? w : 0;
+    dma16x2(w3p + (long)(j * 8 + c3) * 2 * 256, lane16, slot_byte + 16384u + (unsigned)j * 2048u);
+  };
+  constexpr auto pidx = [](int kq, int m) { return (2 * (m >> 1) + (kq >> 1)) * 4 + (kq & 1) * 2 + (m & 1); };
 
   // prologue: phases P0 and P1 of the first tile-step
-  static_for<3>([&](auto k) { issue_pair(Ic<0>{}, 0, 7, decltype(k)::value, 0u); });
-  static_for<2>([&](auto k) { issue_pair(Ic<0>{}, 1, 0, decltype(k)::value, (unsigned)kSlotBytes); });
+  issue_w(Ic<0>{}, 0, 0u);
+  issue_w3(7, 0u);
+  issue_w(Ic<0>{}, 1, (unsigned)kSlotBytes);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   auto rd_cst = [&](int c1, int t, int rt) { return *reinterpret_cast<const f32x4*>(crow + scn[rt] * 256 + 16 * (2 * c1 + t) + 4 * g); };
 
 #pragma unroll
-  for (int t = 0; t < 2; ++t) ah[t] = rdA(s_cur, t * 2), al[t] = rdA(s_cur, t * 2 + 1);
+  for (int t = 0; t < 2; ++t) ah[t] = rdA(s_cur, pidx(0, t * 2)), al[t] = rdA(s_cur, pidx(0, t * 2 + 1));
 #pragma unroll
   for (int u = 0; u < kLead; ++u) cst[u] = rd_cst(0, u / RT, u % RT);
 
@@ -488,20 +497,20 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
     constexpr int kq = decltype(kq_tag)::value, m = decltype(m_tag)::value, NP = decltype(np_tag)::value;
     if constexpr (m < 4) {   // (kq == 3: the next phase's first k-block; its slot was published by this phase's barrier)
       const unsigned sl = kq < 3 ? s_cur : s_nxt;
-      constexpr int pc = (kq < 3 ? (kq + 1) * 4 : 0) + m;
+      constexpr int pc = pidx(kq < 3 ? kq + 1 : 0, m);
       if constexpr (m & 1) nl[m >> 1] = rdA(sl, pc);
       else nh[m >> 1] = rdA(sl, pc);
     }
-    // this wave's DMA share of the phase after next (NP = 4: two pairs; 6: + the W3 pair), spread over the third k-block
-    if constexpr (kq == 2 && m == 2) issue_pair(kind_tag, c_issue, c3_issue, 0, s_nn);
-    if constexpr (kq == 2 && m == NM / 2) issue_pair(kind_tag, c_issue, c3_issue, 1, s_nn);
-    if constexpr (kq == 2 && m == NM - 4 && NP == 6) issue_pair(kind_tag, c_issue, c3_issue, 2, s_nn);
+    // this wave's DMA share of the phase after next (NP = 4: its four W1 / W2 pieces; 6: + the W3 pair), in the third k-block
+    if constexpr (kq == 2 && m == 2) issue_w(kind_tag, c_issue, s_nn);
+    if constexpr (kq == 2 && m == NM / 2 && NP == 6) issue_w3(c3_issue, s_nn);
   };
   auto end_kq = [&](auto kq_tag, auto&& mid) {
     constexpr int kq = decltype(kq_tag)::value;
     if constexpr (kq == 1) {
       // every wave's share of phase p + 1 has landed (issued a whole phase ago), every wave is done with phase p - 1
       if (PSTL_C2_ABL & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (PSTL_C2_ABL & 1024) asm volatile("s_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       FENCE();
       mid();   // (nothing of this wave is in flight here: a compiler-counted global load consumed now waits for nothing)
@@ -833,7 +842,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
     if (blockIdx.x == 7 && lane == 0) {
       unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.emit_out) + w * 12;
       for (int k = 0; k < 8; ++k) dbg[k] = st_sum[k];
-      dbg[8] = t1_ - st_t0, dbg[9] = r1_ - st_rt0, dbg[10] = (unsigned long long)nsteps;
+      dbg[8] = t1_ - st_t0, dbg[9] = r1_ - st_rt0, dbg[10] = (unsigned long long)n_iter;
     }
   }
 #endif

@@ -1,6 +1,6 @@
 """Section shares of k_chain2's tile-step from a -DPSTL_C2_STAMP build (tools/dbg/build_variants2.sh stamp:"-DPSTL_C2_STAMP"):
-    python tools/dbg/chain2_stamps.py [variant-name, default "stamp"]
-Runs the 39-step denoiser launch of the default workload (786 432 rows, in-kernel noise) and prints, per wave of workgroup
+    python tools/dbg/chain2_stamps.py [--single] [variant-name, default "stamp"]
+Runs the 39-step denoiser launch (--single: the guided phase's mu-only launch of one reverse step, whose workgroups walk tiles) of the default workload (786 432 rows, in-kernel noise) and prints, per wave of workgroup
 7, the cycles per tile-step of each section and the in-kernel clock (shader cycles / realtime ticks x 100 MHz)."""
 import ctypes
 import os
@@ -15,7 +15,9 @@ from pstl_diffusion_policy_amd.engine import PackedWeights, Sampler, SceneBatch,
 from pstl_diffusion_policy_amd.nusc_model import init_state_dict  # noqa: E402
 from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch  # noqa: E402
 
-name = sys.argv[1] if len(sys.argv) > 1 else "stamp"
+single = "--single" in sys.argv
+argv = [a for a in sys.argv[1:] if a != "--single"]
+name = argv[0] if argv else "stamp"
 L = ctypes.CDLL(os.path.join(ROOT, "tools", "dbg", "_variants", "libpstl_%s.so" % name))
 for n, restype, argtypes in ffi.SIGNATURES:
     fn = getattr(L, n)
@@ -29,14 +31,14 @@ scene = {k: v.to(dev) for k, v in scene.items() if k not in ("pre_stlp", "tj_sco
 sb = SceneBatch(scene, S, hp, dev)
 _, base_p, _ = Sampler(w, hp).encode(sb, need_rect=False)
 beta, alpha, ah = diffusion_coeffs(steps, dev)
-cfg = sb.cfg(steps, ffi.PSTL_FLAG_RNG, 0, 11)
+cfg = sb.cfg(steps, ffi.PSTL_FLAG_RNG, 2, 11)
 dbg = torch.zeros(48, dtype=torch.int64, device=dev)
 names = ["layer 1", "chunk 0", "chunk 1", "A phases of chunks 2-5", "B phases of chunks 2-5", "chunks 6-7", "tail", "epilogue"]
 for rep in range(3):
     x = torch.randn(sb.N, 40, device=dev)
     ffi.check(L.pstl_rollout(ctypes.byref(cfg), ffi.ptr(w.packed), ffi.ptr(base_p), ffi.ptr(w.tbias(steps)), ffi.ptr(sb.stlp),
-                             ffi.ptr(sb.hl), ffi.ptr(beta), ffi.ptr(alpha), ffi.ptr(ah), ffi.ptr(None), steps - 1, 1, 0,
-                             ffi.ptr(x), ctypes.c_void_p(dbg.data_ptr()), 0, ffi.stream()))
+                             ffi.ptr(sb.hl), ffi.ptr(beta), ffi.ptr(alpha), ffi.ptr(ah), ffi.ptr(None),
+                             5 if single else steps - 1, 5 if single else 1, 1 if single else 0, ffi.ptr(x), ctypes.c_void_p(dbg.data_ptr()), 0, ffi.stream()))
     torch.cuda.synchronize()
 d = dbg.cpu().reshape(-1, 12)[:4]
 for wv in range(4):
