@@ -346,6 +346,8 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   // values, two pairs in flight: step i = 12 grp + 2 stage + which.  hi = f16(relu(v) / kSW) (v_pk_mul_f32 + v_cvt_pk_f16_f32),
   // lo = f16(relu(v) / kSW - hi) as ONE fused multiply-add per half (v_fma_mixlo / mixhi_f16: the product with a power of two
   // is exact, so this is the value the separate subtraction gives).
+  // (the domain guard takes the hi words of both pairs in flight in one v_pk_maximum3_f16: halves >= +0, their order is the
+  // integers'; infinity and NaN come out on top)
   auto conv_step = [&](auto& S, auto i_tag) {
     constexpr int i = decltype(i_tag)::value;
     constexpr int which = i & 1, stage = (i % 12) >> 1, p = 2 * (i / 12) + which;   // pair p = 4 rt + q
@@ -362,7 +364,11 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       chw[which] = __builtin_bit_cast(unsigned, __builtin_convertvector(cf[which], f16x2));
       phw[rt][word] = chw[which];
     } else if constexpr (stage == 4) {
+#ifdef PSTL_C2_OLDGUARD
       note_word(ovf, chw[which]);
+#else
+      if constexpr (which == 1 && !(PSTL_C2_ABL & 128)) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(ovf) : "v"(chw[0]), "v"(chw[1]));
+#endif
     } else {
       plw[rt][word] = lo_word(cm[which][0], cm[which][1], kInvSW, chw[which]);
     }

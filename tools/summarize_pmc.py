@@ -21,8 +21,10 @@ def short(name):
     m = re.search(r"k_chain<(\d+), (true|false), \d+, (?:true|false), (\d+)", name)
     if m:      # waves, REFINE, PT (0 = exact fp32 MFMA, 1 = bfloat16 pieces, 2 = half pieces): the bench runs an fp32 leg too
         n = "k_chain<%s,%s,pt%s>" % m.groups()
-    elif "k_chain2" in name:      # the row-stationary multi-step kernel (round 5): <true> draws its noise itself
-        n = "k_chain2<%s>" % ("rng" if "k_chain2<true>" in name else "noise_in")
+    elif "k_chain2" in name:      # the row-stationary kernel (round 5), <RNG, MU>: <true, false> draws its noise itself,
+        # <false, true> is the single-step (mu-only) form whose workgroups walk the tiles
+        n = "k_chain2<%s>" % ("rng" if "k_chain2<true, false>" in name else "single_step" if "k_chain2<false, true>" in name
+                              else "noise_in")
     elif "k_chain" in name:
         n = "k_chain<8,%s>" % ("true" if "k_chain<8, true" in name else "false")
     return n
