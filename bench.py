@@ -495,8 +495,12 @@ def main():
                       "kernel_ms": mx["kernel_ms"], "achieved": mx["achieved"], "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                       "frac": mx["achieved"] / PEAK_FP32_MATRIX_TFLOPS,
                       "note": "v_mfma_f32_16x16x4_f32 chains (exact f32), same step, same run"}
+    # (which kernel the multi-step denoiser launches of this batch run on: the library's own answer)
+    from pstl_diffusion_policy_amd import ffi as _ffi2
+    dom_kernel = "k_chain2" if _ffi2.rollout_layout(_ffi2.make_cfg(bs, S * 3, S, a.neighbors, steps, hp, _ffi2.PSTL_FLAG_RNG,
+                                                                    a.chain_waves))[0] == 2 else "k_chain"
     # BASELINE configs 2, 3 and 5 in the driver's own run: three timed steps each after two warm-ups,
-    # same shard size, each with the roofline fraction of ITS dominant launch (the 49-step k_chain)
+    # same shard size, each with the roofline fraction of ITS dominant launch (the 49-step denoiser launch)
     also = None
     if extras:
         also = {}
@@ -508,7 +512,7 @@ def main():
             mw = jw.measure_best(3, 2, 2)
             rec = {"steps": 3, "timing": mw["timing"], "ms_per_step": mw["ms_per_step"], "value": mw["value"], "unit": "trajectories/s",
                    "stl_sat_rate": acc_from_counts(mw["counts"])[0],
-                   "roofline": {"bound": "mfma", "kernel": "k_chain (%d reverse steps per launch)" % mw["kernel_steps"],
+                   "roofline": {"bound": "mfma", "kernel": "%s (%d reverse steps per launch)" % (dom_kernel, mw["kernel_steps"]),
                                 "kernel_ms": mw["kernel_ms"], "achieved": mw["achieved"], "peak": peak, "unit": "TFLOP/s",
                                 "frac": mw["achieved"] / peak}}
             if "backward" in mw:
@@ -559,9 +563,6 @@ def main():
                   and a.noise == "kernel" and not a.chain_waves)
     if is_default and pj.get("summary_dominant_kernel"):
         traffic = pj["summary_dominant_kernel"]["hbm_bytes_per_launch_corrected"]
-    from pstl_diffusion_policy_amd import ffi as _ffi2
-    dom_kernel = "k_chain2" if _ffi2.rollout_layout(_ffi2.make_cfg(bs, S * 3, S, a.neighbors, steps, hp, _ffi2.PSTL_FLAG_RNG,
-                                                                    a.chain_waves))[0] == 2 else "k_chain"
     line = None
     if rank == 0:
         line = {

@@ -324,6 +324,10 @@ struct GuideArgs {
 constexpr int kGeoFloats = kGeoSlots * kT;   // per lane
 
 // (SPLIT: two ten-wave workgroups per CU -- 74 KB of LDS each at K = 2 -- need five wavefronts per SIMD: <= 96 registers)
+// -DPSTL_G_ABL=1 / 2: timing-only builds that bound what another layout of the state could gain (tools/dbg/guidance_layout_bound.sh)
+#ifndef PSTL_G_ABL
+#define PSTL_G_ABL 0
+#endif
 template <bool MULTI, bool STAGED, bool NORM = false, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1) void k_guidance_iter(GuideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -415,8 +419,19 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
     if (t & 1) {
       held_mu.x = nw, held_mu.y = na, held_em.x = ew, held_em.y = ea;
     } else {
+#if PSTL_G_ABL == 1      // timing only: no state / candidate stores at all (what ANY store layout could save at most)
+      if (nw == 12345.678f) mu[0] = ew + ea + held_em.x + held_mu.x;
+#elif PSTL_G_ABL == 2    // timing only: element-major addresses (a wavefront's lanes 12 bytes apart instead of 480)
+      float* me = a.mu + row + (long)(2 * t) * a.N;
+      me[0] = nw, me[a.N] = na, me[2 * a.N] = held_mu.x, me[3 * a.N] = held_mu.y;
+      if (last && er) {
+        float* ee = a.emit_out + row + (long)(2 * t) * a.N;
+        ee[0] = ew, ee[a.N] = ea, ee[2 * a.N] = held_em.x, ee[3 * a.N] = held_em.y;
+      }
+#else
       store_quad(mu + 2 * t, nw, na, held_mu.x, held_mu.y);
       if (last && er) store_quad(er + 2 * t, ew, ea, held_em.x, held_em.y);
+#endif
     }
   };
   if constexpr (SPLIT) {
@@ -510,7 +525,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
     // mu[2t], mu[2t+1] are rewritten by emit(t) while the adjoint walks t = T-1 ... 0; the adjoint has already taken every
     // value it still needs from earlier time steps only (and hands the current one to emit, so mu is not read here)
     stl_eval_grad<NORM>(
-        a.env, r, lanes, nei, a.K, a.s0 + b * 4, mu, st, a.wscale, a.ascale,
+        a.env, r, lanes, nei, a.K, a.s0 + b * 4, PSTL_G_ABL == 2 ? a.mu + row : mu, st, a.wscale, a.ascale,
         [=](float score) { return (thres - score > 0.0f) ? -gs : 0.0f; },
         [=, z4 = f4{0.0f, 0.0f, 0.0f, 0.0f}, held_mu = f4{0.0f, 0.0f, 0.0f, 0.0f}, held_em = f4{0.0f, 0.0f, 0.0f, 0.0f}](
             int t, float gw, float ga, float w0, float a0) mutable {
@@ -523,7 +538,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
           }
           apply(t, gw, ga, w0, a0, z4, held_mu, held_em);
         },
-        1, gs == 0.0f);   // an invalid lane has zero loss weight: Adam sees exact zeros, only the noise is added
+        PSTL_G_ABL == 2 ? a.N : 1, gs == 0.0f);   // an invalid lane has zero loss weight: Adam sees exact zeros, only the noise is added
   }
 }
 

@@ -117,3 +117,40 @@ def test_refinement_matches_the_reference_harness(name):
     assert ok.mean() >= 0.8, ok.mean()
     np.testing.assert_allclose(out["final_scores"].numpy()[ok], d["final_scores"][ok], rtol=1e-4, atol=2e-3)
     assert abs(float(out["final_acc"]) - float(d["final_acc"])) <= 0.03
+
+
+def test_trained_checkpoint_sits_inside_the_split_f16_domain(monkeypatch, capsys):
+    """The checkpoint the reference trained itself (weights_trained.npz, tests/golden/make_golden.py --trained) against the
+    domain of the default arithmetic (include/pstl_hip.h: |w| < 63.9 for the chain weights, every layer input |x| < 4094):
+    max |w| per network, and the largest input any layer of policy_net / rect_net sees over the whole guided sampling of the
+    e7_trained_guid fixture (x_T ~ N(0, 1), 100 reverse steps) -- printed (pytest -s) and asserted with a factor 10 to spare."""
+    d = load_golden("e7_trained_guid")
+    meta = golden_meta(d)
+    sd = _weights_for(meta, d)
+    wmax = {}
+    for k, v in sd.items():
+        if k.endswith("weight") and k.split(".")[0] in ("policy_net", "rect_net"):
+            wmax[k.split(".")[0]] = max(wmax.get(k.split(".")[0], 0.0), float(np.abs(v).max()))
+    seen = {}
+    plain = orc.relu_mlp
+
+    def watched(sd_, prefix, x):
+        h = x
+        for i, idx in enumerate((0, 2, 4)):
+            seen[(prefix, i)] = max(seen.get((prefix, i), 0.0), float(h.abs().max()))
+            w, b = orc._t(sd_["%s.%d.weight" % (prefix, idx)]), orc._t(sd_["%s.%d.bias" % (prefix, idx)])
+            h = torch.addmm(b, h.reshape(-1, h.shape[-1]), w.t()).reshape(h.shape[:-1] + (w.shape[0],))
+            if i < 2:
+                h = torch.relu(h)
+        return h
+
+    monkeypatch.setattr(orc, "relu_mlp", watched)
+    out = orc.sampling_region(sd, scene_from_golden(d), meta["S"], meta["steps"], hparams_for(d), d["x_T"], d["z"], **region_kwargs(meta))
+    monkeypatch.setattr(orc, "relu_mlp", plain)
+    assert np.isfinite(out["final_controls"].numpy()).all()
+    amax = {p: max(v for (q, _), v in seen.items() if q == p) for p in ("policy_net", "rect_net")}
+    with capsys.disabled():
+        print("\n  trained checkpoint: max |w| %s (limit 63.9), max |layer input| %s (limit 4094); per layer: %s" % (
+            {k: round(v, 3) for k, v in wmax.items()}, {k: round(v, 2) for k, v in amax.items()},
+            {"%s.%d" % k: round(v, 2) for k, v in sorted(seen.items())}))
+    assert max(wmax.values()) < 6.39 and max(amax.values()) < 409.4
