@@ -30,7 +30,9 @@ extern "C" {
 #define PSTL_ABI_VERSION 5   /* 2: pstl_encode_scene takes a work buffer; --joint and --refinement entry points
                                 3: status block in the packed weight buffer (pstl_packed_status_offset)
                                 4: pstl_cfg.dyn -- run-time parameters in device memory (HIP-graph replay)
-                                5: pstl_rollout_layout; chain_waves = 2 (the row-stationary denoiser kernel) */
+                                5: pstl_rollout_layout; chain_waves = 2 (the row-stationary denoiser kernel);
+                                   pstl_train_create / pstl_train_destroy and the (empty) context argument of
+                                   pstl_refine_backward are gone */
 
 /* compile-time shape of the path (reference defaults: nt=20, n_segs=15, hiddens=[256,256], feat 7*32) */
 #define PSTL_T 20
@@ -272,9 +274,6 @@ int pstl_refine_train_forward(const pstl_cfg* cfg, float* packed, const float* b
  * divides by N * clip(mean(valid), 1e-2)). */
 int pstl_loss_grad(const pstl_cfg* cfg, const float* scores, const float* valid, float grad_scale, float* dscore,
                    float* loss_parts, void* stream);
-/* Context of the backward pass (it once held a vendor-BLAS handle; now empty, kept for the signatures). */
-int pstl_train_create(void** ctx);
-int pstl_train_destroy(void* ctx);
 size_t pstl_train_work_floats(const pstl_cfg* cfg);
 /* d loss / d rect_net parameters given dcontrols = d loss / d out_controls (from pstl_stl_backward).  w2, w3: the
  * reference-layout weights rect_net.2.weight (256,256), rect_net.4.weight (40,256).  Gradients in the reference layout:
@@ -287,7 +286,7 @@ size_t pstl_train_work_floats(const pstl_cfg* cfg);
  * saved activations) unless cfg->chain_waves is 8 or 4 (the exact-fp32 request) or rows_per_scene is not a multiple of 32,
  * where they are fp32-MFMA contractions in launches of their own; dw1[:, :224] and the bias gradients are always fp32.
  * Against the reference's autograd: rtol 5e-3 (tested).  pstl_encoder_backward needs PSTL_FLAG_KEEP_DH1 in cfg->flags. */
-int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float* w2, const float* w3, const float* feature,
+int pstl_refine_backward(const pstl_cfg* cfg, const float* w2, const float* w3, const float* feature,
                          const float* stlp, const float* hl, const float* init_controls,
                          const float* pooled /* (bs,3,n_shards,40) from the forward call; null with PSTL_FLAG_NO_MERGE */,
                          const float* prev_scores, const float* h1, const float* h2, const float* pre,

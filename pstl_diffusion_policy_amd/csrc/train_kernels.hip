@@ -20,10 +20,6 @@ constexpr int kHid = PSTL_HID, kCtrl = PSTL_CTRL, kFeat = PSTL_FEAT;
 constexpr int kX47 = 47;   // hl 1 | stlp 6 | init 40  = input columns 224..270 of rect_net layer 1
 constexpr int kIn = kFeat + kX47;  // 271
 
-struct TrainCtx {
-  int unused;   // (the context once held a rocBLAS handle; the entry points keep their signatures)
-};
-
 // dO = dcontrols * [prev_score < 0] * d interval / d raw * (1 - raw^2), raw = tanh(pre)   (nusc_model.py:212-229)
 // x47 = [hl | stlp | init]
 // With the merge_net architecture (pooled != null) the last 40 input columns are init + pooled[scene, mode, shard].
@@ -1199,18 +1195,6 @@ struct RefineWork {
 
 using namespace pstl;
 
-extern "C" int pstl_train_create(void** ctx) {
-  if (!ctx) return PSTL_ERR_ARG;
-  *ctx = new TrainCtx();
-  return PSTL_OK;
-}
-
-extern "C" int pstl_train_destroy(void* ctx) {
-  if (!ctx) return PSTL_ERR_ARG;
-  delete static_cast<TrainCtx*>(ctx);
-  return PSTL_OK;
-}
-
 extern "C" size_t pstl_train_work_floats(const pstl_cfg* cfg) {
   if (check_cfg(cfg)) return 0;
   const long N = n_rows(cfg);
@@ -1228,14 +1212,14 @@ extern "C" int pstl_loss_grad(const pstl_cfg* cfg, const float* scores, const fl
   return launch_status();
 }
 
-extern "C" int pstl_refine_backward(const pstl_cfg* cfg, void* ctx, const float* w2 /* (256,256) */,
+extern "C" int pstl_refine_backward(const pstl_cfg* cfg, const float* w2 /* (256,256) */,
                                     const float* w3 /* (40,256) */, const float* feature /* (bs,224) */, const float* stlp,
                                     const float* hl, const float* init_controls, const float* pooled,
                                     const float* prev_scores, const float* h1, const float* h2, const float* pre,
                                     const float* dcontrols, float* work, float* dw1 /* (256,271) */, float* db1,
                                     float* dw2, float* db2, float* dw3 /* (40,256) */, float* db3, void* stream) {
   if (int e = check_cfg(cfg)) return e;
-  if (!ctx || !w2 || !w3 || !feature || !stlp || !hl || !init_controls || !prev_scores || !h1 || !h2 || !pre ||
+  if (!w2 || !w3 || !feature || !stlp || !hl || !init_controls || !prev_scores || !h1 || !h2 || !pre ||
       !dcontrols || !work || !dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3)
     return PSTL_ERR_ARG;
   if (cfg->flags & PSTL_FLAG_CLIP_RECT) return PSTL_ERR_SHAPE;  // the reference trains without --clip_rect

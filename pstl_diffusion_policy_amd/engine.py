@@ -697,15 +697,6 @@ class RectTrainer:
     def __init__(self, sampler):
         self.sm = sampler
         self.L = sampler.L
-        self.ctx = ctypes.c_void_p()
-        ffi.check(self.L.pstl_train_create(ctypes.byref(self.ctx)), "train_create")
-
-    def __del__(self):
-        try:
-            if self.ctx:
-                self.L.pstl_train_destroy(self.ctx)
-        except Exception:
-            pass
 
     def loss_and_grads(self, sb, feature, base_rect, w2, w3, init_controls, prev_scores, e7=None, stl_weight=1.0, merge=None,
                        clip_rect=False, joint=None):
@@ -780,7 +771,7 @@ class RectTrainer:
             bev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), N)
             bev[0].record()
             self.sm.trace_bwd.append(bev)
-        ffi.check(self.L.pstl_refine_backward(ctypes.byref(cfg), self.ctx, ffi.ptr(w2c),
+        ffi.check(self.L.pstl_refine_backward(ctypes.byref(cfg), ffi.ptr(w2c),
                                               ffi.ptr(w3c), ffi.ptr(feature), ffi.ptr(sb.stlp),
                                               ffi.ptr(sb.hl), ffi.ptr(init_controls), ffi.ptr(pooled), ffi.ptr(prev_scores),
                                               ffi.ptr(h1), ffi.ptr(h2), ffi.ptr(pre), ffi.ptr(dctrl), ffi.ptr(work),

@@ -78,10 +78,8 @@ SIGNATURES = [
     ("pstl_select_plan", _I, [_C] + [_P] * 5),
     ("pstl_refine_train_forward", _I, [_C] + [_P] * 12),
     ("pstl_loss_grad", _I, [_C, _P, _P, _F, _P, _P, _P]),
-    ("pstl_train_create", _I, [_P]),
-    ("pstl_train_destroy", _I, [_P]),
     ("pstl_train_work_floats", _Z, [_C]),
-    ("pstl_refine_backward", _I, [_C] + [_P] * 21),
+    ("pstl_refine_backward", _I, [_C] + [_P] * 20),
     ("pstl_diversity", _I, [_C, _P, _P, _I] + [_P] * 8),
     ("pstl_stl_program_forward", _I, [_P, _I, _P, _L, _I, _P, _F, _I, _P, _P, _P]),
     ("pstl_stl_program_backward", _I, [_P, _I, _P, _L, _I, _P, _F, _I, _P, _P, _P, _P]),
