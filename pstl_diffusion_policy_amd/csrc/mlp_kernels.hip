@@ -312,6 +312,12 @@ __device__ __forceinline__ int xs_addr(int k, int c) { return (((k >> 4) * 64) +
 template <int NW, bool REFINE, int ABL = 0, bool UT = false, int PT = 0, bool PERSIST = false, bool SAVE = false,
           bool SPARSE = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
+#ifdef PSTL_WG_TIMES   // diagnostic build (tools/dbg/wg_finish_times.py): when and where every workgroup started and ended
+  unsigned long long wg_t0;
+  unsigned wg_hw, wg_xcc;
+  asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+               : "=s"(wg_t0), "=s"(wg_hw), "=s"(wg_xcc));
+#endif
   constexpr bool BF = PT != 0;      // the operands are split into two 16-bit pieces
   constexpr bool F16 = PT == 2;     // ... of IEEE half (scaled, see k_pack_a_split); PT == 1: bfloat16 pieces
   typedef std::conditional_t<F16, f16x8, bf16x8> pv8;
@@ -1137,6 +1143,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_chain(ChainArgs a) {
   }
   if constexpr (F16)
     if (pieces_overflowed(ovf)) atomicOr(a.status, 1u);   // a layer input left |x| < 4094 somewhere in this launch
+#ifdef PSTL_WG_TIMES
+  if (!REFINE && a.n_emit == 0 && a.step_hi > a.step_lo) {   // (the multi-step launch; emit_out is the caller's debug buffer)
+    __syncthreads();
+    unsigned long long wg_t1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1));
+    if (threadIdx.x == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(a.emit_out) + 4 * (long)blockIdx.x;
+      o[0] = wg_t0, o[1] = wg_t1, o[2] = wg_hw, o[3] = wg_xcc;
+    }
+  }
+#endif
 }
 
 // ---- scene encoder (A1) -----------------------------------------------------------------------------------------
