@@ -122,13 +122,9 @@ __device__ __forceinline__ void dma4(const void* sbase, unsigned voff, unsigned 
 
 __device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-// domain guard of the split-f16 arithmetic (see note_pieces in mlp_kernels.hip): running v_pk_max_u16 of the hi pieces
-// (as an asm statement: written as a max() chain the optimiser re-associates it and sinks the whole chain behind the
-// phases, keeping -- spilling -- every hi word until then)
-__device__ __forceinline__ void note_word(unsigned& ovf, unsigned w) {
-  if (PSTL_C2_ABL & 128) return;
-  asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(ovf) : "v"(w));
-}
+// (The domain guard of the split-f16 arithmetic -- see note_pieces in mlp_kernels.hip -- is a running maximum of the hi pieces,
+// kept by an asm statement in conv_step: written as a max() chain the optimiser re-associates it and sinks the whole chain
+// behind the phases, keeping -- spilling -- every hi word until then.)
 // the lo pieces of two values: f16(v k - hi) for both halves of the packed hi word (inline assembly: hipcc selects
 // v_cvt_f32_f16 x 2 + v_pk_fma_f32 + v_cvt_pk_f16_f32 for the C++ form; consumers are many instructions away, no hazard)
 __device__ __forceinline__ unsigned lo_word(float v0, float v1, float k, unsigned hi) {
@@ -364,11 +360,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       chw[which] = __builtin_bit_cast(unsigned, __builtin_convertvector(cf[which], f16x2));
       phw[rt][word] = chw[which];
     } else if constexpr (stage == 4) {
-#ifdef PSTL_C2_OLDGUARD
-      note_word(ovf, chw[which]);
-#else
       if constexpr (which == 1 && !(PSTL_C2_ABL & 128)) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(ovf) : "v"(chw[0]), "v"(chw[1]));
-#endif
     } else {
       plw[rt][word] = lo_word(cm[which][0], cm[which][1], kInvSW, chw[which]);
     }
