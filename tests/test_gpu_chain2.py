@@ -202,3 +202,26 @@ def test_chain2_single_step_form_walks_tiles(dev, bs, S):
     dr = (outs[0] - outs[1]).abs().reshape(sb.N, -1).max(dim=1).values
     assert (dr > 5e-5).sum().item() <= max(1, sb.N // 400), (dr > 5e-5).sum().item()
     assert dr.max().item() <= 0.2      # (four guided steps, each may turn a sign: 4 x 2 lr, and what the denoiser makes of it)
+
+
+# 48 rows (the smallest batch the kernel takes: one scene of 16 samples x 3 modes, a quarter of a wave's rows), 96, 432; steps = 3
+# is a two-step launch, the shortest k_chain2 runs
+@pytest.mark.parametrize("bs,S,steps", [(1, 16, 3), (2, 16, 6), (3, 48, 4), (1, 16, 150)])
+def test_chain2_minimal_shapes_against_oracle(dev, bs, S, steps):
+    """Workgroups that are mostly empty: rows behind the end repeat the last row and are never stored; with guidance on the
+    last two steps the single-step form runs with one (partial) tile."""
+    from oracle import pstl_oracle as orc
+    from pstl_diffusion_policy_amd.engine import Sampler, acc_from_counts
+    hp, scene, w, sb = _setup(dev, bs, S, 2, seed=31 + bs)
+    N = sb.N
+    g = torch.Generator().manual_seed(steps)
+    x_T = torch.randn(N, 40, generator=g)
+    z = torch.randn(steps - 1, N, 40, generator=g)
+    guid = dict(enabled=True, before=2, niters=1, lr=0.01) if steps < 100 else None
+    ref = orc.sampling_region(golden_weights(), {k: v.numpy() for k, v in scene.items()}, S, steps, hp, x_T, z, rect_head=True,
+                              multi_cands=2, guidance=guid)
+    out = Sampler(w, hp, chain_waves=2).sampling_region(sb, steps, x_T.to(dev), z.to(dev), rect_head=True, multi_cands=2, guidance=guid)
+    assert not w.chain_overflowed()
+    assert (out["final_controls"].reshape(N, 20, 2).cpu() - ref["final_controls"]).abs().max().item() <= 1e-4
+    acc, sacc = acc_from_counts(out["counts"])
+    assert abs(acc - float(ref["final_acc"])) <= 0.005 and abs(sacc - float(ref["final_scene_acc"])) <= 0.005
