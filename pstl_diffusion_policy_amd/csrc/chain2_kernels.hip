@@ -231,9 +231,11 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   unsigned phw[RT][4], plw[RT][4];    // pieces of the finished chunk, as packed words
   f16x8 ah[2], al[2], nh[2], nl[2];   // A operands of the current / the next k-block
   f16x8 w3h[2], w3l[2];               // layer 3's A operands, double buffered over j
-  f32x4 bv[2];                        // layer-2 bias of the chunk that starts next
-  f32x4 cst[2 * RT];                  // layer-1 constant parts (scene + timestep) on their way: read kLead slots ahead of the MFMA that starts from them
-  f32x4 b3v[3];
+  // (What a chunk's accumulators start from -- layer 1: the scene / timestep part, layer 2: the bias, layer 3: b3 -- is read
+  // from LDS STRAIGHT INTO the accumulator registers, kLead slots or more ahead, and every MFMA accumulates in place.  With a
+  // separate C operand the registers it dies in are free the moment the MFMA has issued, while the MFMA is still reading them:
+  // an inline-assembly statement with a fresh output register right behind it -- the conversions' -- could be given exactly
+  // those, and the compiler pads that hazard for its own instructions only.)
   f32x2 cm[2], cf[2];                 // conversion state of the two pairs in flight
   unsigned chw[2];
 
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) ah[t] = rdA(s_cur, pidx(0, t * 2)), al[t] = rdA(s_cur, pidx(0, t * 2 + 1));
 #pragma unroll
-  for (int u = 0; u < kLead; ++u) cst[u] = rd_cst(0, u / RT, u % RT);
+  for (int u = 0; u < kLead; ++u) accA[u / RT][u % RT] = rd_cst(0, u / RT, u % RT);
 
   // ReLU + split of the finished chunk's accumulators S into the packed pieces, as 6 steps of 1-2 instructions per pair of
   // values, two pairs in flight: step i = 12 grp + 2 stage + which.  hi = f16(relu(v) / kSW) (v_pk_mul_f32 + v_cvt_pk_f16_f32),
@@ -481,8 +483,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       constexpr int j = m / (3 * RT), pr = (m / RT) % 3, rt = m % RT;
       const f16x8 wa = pr == 1 ? w3l[j & 1] : w3h[j & 1];
       const f16x8 pb = pr == 2 ? pieces_l(rt) : pieces_h(rt);
-      if constexpr (FIRST && pr == 0) acc3[j][rt] = mfma(wa, pb, b3v[j]);
-      else acc3[j][rt] = mfma(wa, pb, acc3[j][rt]);
+      acc3[j][rt] = mfma(wa, pb, acc3[j][rt]);   // (FIRST: the accumulators hold b3, read into them behind B(0))
       if constexpr (j < 2 && pr == 0 && rt == 0) w3h[(j + 1) & 1] = rdA(slot, 16 + (j + 1) * 2);
       if constexpr (j < 2 && pr == 0 && rt == 1) w3l[(j + 1) & 1] = rdA(slot, 16 + (j + 1) * 2 + 1);
       FENCE();
@@ -536,13 +537,15 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
         const f16x8 wa = pr == 1 ? al[t] : ah[t];
         const f16x8 xb = pr == 2 ? xl[kb][rt] : xh[kb][rt];
         auto& D = cl == 0 ? D0 : D1;
-        if constexpr (kb == 0 && pr == 0) D[t][rt] = mfma(wa, xb, cst[m]);   // starts from the scene / timestep part (m = t RT + rt)
-        else D[t][rt] = mfma(wa, xb, D[t][rt]);
+        auto& Dn = cl == 0 ? D1 : D0;   // the next chunk's accumulators = the chunk before's, converted in this chunk's shadow
+        D[t][rt] = mfma(wa, xb, D[t][rt]);   // (the first 2 RT start from the scene / timestep part, read into D: below)
         common_fill(kq_tag, m_tag, kind_tag, np_tag, c_issue, c3_issue);
-        // the constant parts of the chunk's first 2 RT MFMAs, kLead slots ahead: the last kLead slots of the chunk before
-        // (k-block 1) fetch 0 .. kLead-1, slot m of k-block 0 fetches m + kLead
-        if constexpr (kb == 1 && m >= NM - kLead && c1 < 7) cst[m - (NM - kLead)] = rd_cst(c1 + 1, (m - (NM - kLead)) / RT, (m - (NM - kLead)) % RT);
-        if constexpr (kb == 0 && m + kLead < 2 * RT) cst[m + kLead] = rd_cst(c1, (m + kLead) / RT, (m + kLead) % RT);
+        // the constant parts a chunk's first 2 RT MFMAs (m = t RT + rt) start from, kLead slots ahead, into the accumulators
+        // themselves: the last kLead slots of the chunk before (k-block 1) fetch those of MFMAs 0 .. kLead-1 (the chunk before
+        // THAT one's accumulators (t = 0) are converted by slot 42), slot m of k-block 0 fetches that of MFMA m + kLead
+        if constexpr (kb == 1 && m >= NM - kLead && c1 < 7)
+          Dn[(m - (NM - kLead)) / RT][(m - (NM - kLead)) % RT] = rd_cst(c1 + 1, (m - (NM - kLead)) / RT, (m - (NM - kLead)) % RT);
+        if constexpr (kb == 0 && m + kLead < 2 * RT) D[(m + kLead) / RT][(m + kLead) % RT] = rd_cst(c1, (m + kLead) / RT, (m + kLead) % RT);
         // conversion of the chunk before this one, over this chunk's two k-blocks
         if constexpr (c1 > 0 && !(PSTL_C2_ABL & 2)) {
           auto& S = cl == 0 ? D1 : D0;
@@ -570,8 +573,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
         constexpr int pr = m / (2 * RT), t = (m / RT) % 2, rt = m % RT;
         const f16x8 wa = pr == 1 ? al[t] : ah[t];
         const f16x8 xb = pr == 2 ? bl[kb][rt] : bh[kb][rt];
-        if constexpr (HALF == 0 && kq == 0 && pr == 0) D[t][rt] = mfma(wa, xb, bv[t]);   // the chunk starts from its bias
-        else D[t][rt] = mfma(wa, xb, D[t][rt]);
+        D[t][rt] = mfma(wa, xb, D[t][rt]);   // (a chunk starts from its bias, read into D by the phase before)
         common_fill(kq_tag, m_tag, kind_tag, np_tag, c_issue, c3_issue);
         if constexpr (CONV == 1 && !(PSTL_C2_ABL & 4)) {
           constexpr int i0 = 2 * (kq * NM + m);
@@ -581,7 +583,8 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
         if constexpr (CONV == 2 && !(PSTL_C2_ABL & 2)) {
           if constexpr (kq * NM + m < 48) conv_h1_slot(S, Ic<7>{}, Ic<kq * NM + m>{});
         }
-        if constexpr (HALF == 1 && kq == 3 && (m == 4 || m == 5)) bv[m - 4] = rd_bias(c_bias, m - 4);   // bias of the next chunk
+        // bias of the next chunk, into its accumulators (= the chunk before's: converted in the first half's shadow)
+        if constexpr (HALF == 1 && kq == 3 && m < 2 * RT) S[m / RT][m % RT] = rd_bias(c_bias, m / RT);
         if constexpr (CONV == 1 && kq == 3 && m == 6) w3h[0] = rdA(s_cur, 16);
         if constexpr (CONV == 1 && kq == 3 && m == 7) w3l[0] = rdA(s_cur, 17);
         slot_fn(Ic<kq * NM + m>{});
@@ -665,12 +668,16 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
     C2_STAMP(0)
     // ---- layers 2 + 3 ----
 #pragma unroll
-    for (int t = 0; t < 2; ++t) bv[t] = rd_bias(0, t);
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) accA[t][rt] = rd_bias(0, t);   // (layer 1's chunk 6 left these registers a phase ago)
     l2_phase(accA, accB, Ic<0>{}, Ic<2>{}, No{}, Ic<1>{}, Ic<6>{}, 1, 0, 0, none, noslot);    // A(0): converts layer 1's chunk 7; issues A(1) + W3[0]
     l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 1, 0, 1, write_crow, [&](auto s_) { noise_slot(0, No{}, s_); });    // B(0); issues B(1)
     C2_STAMP(1)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) b3v[j] = *reinterpret_cast<const f32x4*>(b3s + 16 * j + 4 * g);
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc3[j][rt] = *reinterpret_cast<const f32x4*>(b3s + 16 * j + 4 * g);
     l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, Yes{}, Ic<1>{}, Ic<6>{}, 2, 1, 0, none, noslot);   // A(1): layer 3 of chunk 0
     l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 2, 0, 2, none, [&](auto s_) { noise_slot(0, Yes{}, s_); });
     C2_STAMP(2)
@@ -831,7 +838,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
     C2_STAMP(7)
     // the first chunk's constant part for the next step (its rows were written above, two or more barriers ago)
 #pragma unroll
-    for (int u = 0; u < kLead; ++u) cst[u] = rd_cst(0, u / RT, u % RT);
+    for (int u = 0; u < kLead; ++u) accA[u / RT][u % RT] = rd_cst(0, u / RT, u % RT);
   }
 #ifdef PSTL_C2_STAMP
   {
