@@ -400,9 +400,9 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   };
 
   // ---- in-kernel noise (RNG): Philox4x32-10 + Box-Muller of rng.hpp (normal4: same operations, same bits), and
-  // Q = a x + sb z written over x in the wave's LDS image, as single-instruction-sized steps that ride in the shadow of the
-  // MFMAs of the second halves of layer 2's chunks (no conversion runs there): 64 steps per quad, 1.5 quads per phase; the
-  // two phases of chunk pair p do the three quads j = 0, 1, 2 of row tile p.
+  // Q = a x + sb z written over x in the wave's LDS image, as single-instruction-sized steps that ride beside the MFMAs of
+  // layer 2 where no conversion runs (the second halves of its chunks and layer 3's k-blocks: noise_l3 / noise_b below): 64
+  // steps per quad, 1.5 quads = 96 steps per chunk; chunk pair p does the three quads j = 0, 1, 2 of row tile p.
   unsigned qx = 0, qy = 0, qz = 0, qw = 0, qtx = 0;
   unsigned long long qp0 = 0, qp1 = 0;
   float qu0 = 0.0f, qu1 = 0.0f, qu2 = 0.0f, qu3 = 0.0f, qr0 = 0.0f, qr1 = 0.0f;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       xq[(rt * 3 + j) * 64] = qzv;
     }
   };
-  // slot s (0..95) of the second-half phase of chunk 2 p (EVEN) / 2 p + 1 (odd)
+  // step s (0..95) of the sequence of chunk 2 p (EVEN) / 2 p + 1 (odd)
   auto noise_slot = [&](int p, auto odd_tag, auto s_tag) {
     constexpr int s = decltype(s_tag)::value;
     constexpr bool ODD = decltype(odd_tag)::value;
@@ -475,10 +475,22 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
     }
   };
 
+  // Where a chunk's 96 steps ride (an MFMA leaves ~8 cycles of issue beside it: profiles/r5/valu_beside_mfma.txt; 96 steps are
+  // ~1 000 cycles, a phase's 96 slots have 770): the first 24 in two of every three slots of layer 3's k-block behind the chunk's
+  // first-half phase -- slots that carry nothing else --, the other 72 in three of every four slots of its second-half phase.
+  // Chunk 0 has no layer-3 block in front of it: all 96 in its second half.
+  auto noise_l3 = [&](int p, auto odd_tag, auto k_tag) {
+    constexpr int k = decltype(k_tag)::value;
+    if constexpr (k % 3 != 2) noise_slot(p, odd_tag, Ic<k - k / 3>{});
+  };
+  auto noise_b = [&](int p, auto odd_tag, auto k_tag) {
+    constexpr int k = decltype(k_tag)::value;
+    if constexpr (k % 4 != 3) noise_slot(p, odd_tag, Ic<24 + k - k / 4>{});
+  };
+
   // one k-block of layer 3: the pieces of a finished chunk against its W3 blocks (pieces 16..21 of `slot`; the first pair
-  // w3h[0] / w3l[0] was read by the caller).  FIRST: the accumulators start from the bias.
-  auto layer3 = [&](unsigned slot, auto first_tag) {
-    constexpr bool FIRST = decltype(first_tag)::value;
+  // w3h[0] / w3l[0] was read by the caller); fn(k): what else rides in slot k
+  auto layer3 = [&](unsigned slot, auto&& fn) {
     static_for<9 * RT>([&](auto m_tag) {
       constexpr int m = decltype(m_tag)::value;
       constexpr int j = m / (3 * RT), pr = (m / RT) % 3, rt = m % RT;
@@ -487,6 +499,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       acc3[j][rt] = mfma(wa, pb, acc3[j][rt]);   // (FIRST: the accumulators hold b3, read into them behind B(0))
       if constexpr (j < 2 && pr == 0 && rt == 0) w3h[(j + 1) & 1] = rdA(slot, 16 + (j + 1) * 2);
       if constexpr (j < 2 && pr == 0 && rt == 1) w3l[(j + 1) & 1] = rdA(slot, 16 + (j + 1) * 2 + 1);
+      fn(m_tag);
       FENCE();
     });
   };
@@ -561,7 +574,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
 
   // ---- a layer-2 phase on D (chunk c, half HALF).  CONV 1: the layer-2 chunk before (S) is converted in its shadow and its
   // layer 3 follows the fourth k-block; CONV 2: S is layer 1's last chunk (pieces -> k-block 7 of h1).
-  auto l2_phase = [&](auto& D, auto& S, auto half_tag, auto conv_tag, auto l3first_tag, auto kind_tag, auto np_tag, int c_issue,
+  auto l2_phase = [&](auto& D, auto& S, auto half_tag, auto conv_tag, auto&& l3_fn, auto kind_tag, auto np_tag, int c_issue,
                       int c3_issue, int c_bias, auto&& mid, auto&& slot_fn) {
     constexpr int HALF = decltype(half_tag)::value;
     constexpr int CONV = decltype(conv_tag)::value;
@@ -593,7 +606,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       });
       end_kq(kq_tag, mid);
     });
-    if constexpr (CONV == 1 && !(PSTL_C2_ABL & 512)) layer3(s_cur, l3first_tag);
+    if constexpr (CONV == 1 && !(PSTL_C2_ABL & 512)) layer3(s_cur, l3_fn);
     rotate();
   };
   using Yes = std::true_type;
@@ -672,31 +685,31 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) accA[t][rt] = rd_bias(0, t);   // (layer 1's chunk 6 left these registers a phase ago)
-    l2_phase(accA, accB, Ic<0>{}, Ic<2>{}, No{}, Ic<1>{}, Ic<6>{}, 1, 0, 0, none, noslot);    // A(0): converts layer 1's chunk 7; issues A(1) + W3[0]
-    l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 1, 0, 1, write_crow, [&](auto s_) { noise_slot(0, No{}, s_); });    // B(0); issues B(1)
+    l2_phase(accA, accB, Ic<0>{}, Ic<2>{}, noslot, Ic<1>{}, Ic<6>{}, 1, 0, 0, none, noslot);    // A(0): converts layer 1's chunk 7; issues A(1) + W3[0]
+    l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, 1, 0, 1, write_crow, [&](auto s_) { noise_slot(0, No{}, s_); });    // B(0); issues B(1)
     C2_STAMP(1)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc3[j][rt] = *reinterpret_cast<const f32x4*>(b3s + 16 * j + 4 * g);
-    l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, Yes{}, Ic<1>{}, Ic<6>{}, 2, 1, 0, none, noslot);   // A(1): layer 3 of chunk 0
-    l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 2, 0, 2, none, [&](auto s_) { noise_slot(0, Yes{}, s_); });
+    l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(0, Yes{}, k_); }, Ic<1>{}, Ic<6>{}, 2, 1, 0, none, noslot);   // A(1): layer 3 of chunk 0
+    l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, 2, 0, 2, none, [&](auto s_) { noise_b(0, Yes{}, s_); });
     C2_STAMP(2)
 #pragma unroll 1
     for (int cc = 2; cc < 6; cc += 2) {
-      l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, No{}, Ic<1>{}, Ic<6>{}, cc + 1, cc, 0, none, noslot);
+      l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(cc >> 1, No{}, k_); }, Ic<1>{}, Ic<6>{}, cc + 1, cc, 0, none, noslot);
       C2_STAMP(3)
-      l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, cc + 1, 0, cc + 1, none, [&](auto s_) { noise_slot(cc >> 1, No{}, s_); });
+      l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, cc + 1, 0, cc + 1, none, [&](auto s_) { noise_b(cc >> 1, No{}, s_); });
       C2_STAMP(4)
-      l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, No{}, Ic<1>{}, Ic<6>{}, cc + 2, cc + 1, 0, none, noslot);
+      l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(cc >> 1, Yes{}, k_); }, Ic<1>{}, Ic<6>{}, cc + 2, cc + 1, 0, none, noslot);
       C2_STAMP(3)
-      l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, cc + 2, 0, cc + 2, none, [&](auto s_) { noise_slot(cc >> 1, Yes{}, s_); });
+      l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, cc + 2, 0, cc + 2, none, [&](auto s_) { noise_b(cc >> 1, Yes{}, s_); });
       C2_STAMP(4)
     }
-    l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, No{}, Ic<1>{}, Ic<6>{}, 7, 6, 0, load_nbase, noslot);    // A(6); issues A(7) + W3[6]
-    l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, No{}, Ic<2>{}, Ic<4>{}, 7, 0, 7, write_ncrow, [&](auto s_) { noise_slot(3, No{}, s_); });
-    l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, No{}, Ic<0>{}, Ic<6>{}, 0, 7, 0, none, noslot);    // A(7); issues P0 of the next step + W3[7]
-    l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, No{}, Ic<0>{}, Ic<4>{}, 1, 0, 0, none, [&](auto s_) { noise_slot(3, Yes{}, s_); });    // B(7); issues P1 of the next step
+    l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(3, No{}, k_); }, Ic<1>{}, Ic<6>{}, 7, 6, 0, load_nbase, noslot);    // A(6); issues A(7) + W3[6]
+    l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, 7, 0, 7, write_ncrow, [&](auto s_) { noise_b(3, No{}, s_); });
+    l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(3, Yes{}, k_); }, Ic<0>{}, Ic<6>{}, 0, 7, 0, none, noslot);    // A(7); issues P0 of the next step + W3[7]
+    l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, noslot, Ic<0>{}, Ic<4>{}, 1, 0, 0, none, [&](auto s_) { noise_b(3, Yes{}, s_); });    // B(7); issues P1 of the next step
     C2_STAMP(5)
     // tail: layer 3 of chunk 7.  Its W3 blocks sit in the slot of the NEXT tile-step's first phase (s_cur now): landed and
     // published by the barrier in the middle of the phase just finished.
@@ -742,7 +755,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       }
     }
     FENCE();
-    layer3(s_cur, No{});
+    layer3(s_cur, noslot);
 
     C2_STAMP(6)
     // ---- epilogue: eps = layer 3 + b3 (already in the accumulators); x' = a x + sb z - kk eps; candidates; next pieces ----
