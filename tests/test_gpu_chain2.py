@@ -225,3 +225,42 @@ def test_chain2_minimal_shapes_against_oracle(dev, bs, S, steps):
     assert (out["final_controls"].reshape(N, 20, 2).cpu() - ref["final_controls"]).abs().max().item() <= 1e-4
     acc, sacc = acc_from_counts(out["counts"])
     assert abs(acc - float(ref["final_acc"])) <= 0.005 and abs(sacc - float(ref["final_scene_acc"])) <= 0.005
+
+
+def test_chain2_under_hip_graph_replay(dev):
+    """A captured sampling region whose denoiser launches are ALL k_chain2 (196 608 rows = three full rounds of its workgroups for
+    the multi-step launch; the guided phase's single-step launches walk three tiles per CU), the seed read from device memory
+    (cfg.dyn): two replays with different seeds equal the eager runs bit for bit, and the library says which kernel ran."""
+    from pstl_diffusion_policy_amd import ffi
+    from pstl_diffusion_policy_amd.engine import DynBlock, GraphCapture, PackedWeights, Sampler, SceneBatch
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    bs, S, steps = 1024, 64, 8
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp)      # chain_waves = 0: the dispatch rule chooses
+    scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=2, S=S, seed=12, invalid_lane_frac=0.2, stlp_mode="wide").items()
+             if k not in ("params", "pre_stlp", "tj_scores_prior")}
+    N = bs * S * 3
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if N < 3 * 256 * cus or N % (256 * cus) != 0:
+        pytest.skip("sized for 256 CUs")
+    cfg = SceneBatch(scene, S, hp, dev).cfg(steps, ffi.PSTL_FLAG_RNG, 0, 0)
+    assert ffi.rollout_layout(cfg, True)[0] == 2 and ffi.rollout_layout(cfg, False)[0] == 2
+    vsum = float(sum(scene[k].sum().item() for k in ("curr_id", "left_id", "right_id"))) * S
+    guid = dict(enabled=True, before=3, niters=1, lr=0.01)
+    kw = dict(rect_head=True, multi_cands=2, guidance=guid, want_scores3=False)
+    dyn = DynBlock(dev)
+    dyn.set(0, SceneBatch.loss_scale(vsum, N))
+
+    def body():
+        sb = SceneBatch(scene, S, hp, dev, global_valid_sum=vsum, global_rows=N, dyn=dyn.dev, scale_in_dyn=True)
+        o = sm.sampling_region(sb, steps, None, None, seed=0, **kw)
+        return o["counts"], o["final_controls"], o["final_scores"]
+
+    g = GraphCapture(body)
+    for seed in (41, 42):
+        dyn.set(seed)
+        got = [t.clone() for t in g.replay()]
+        ref = sm.sampling_region(SceneBatch(scene, S, hp, dev, global_valid_sum=vsum, global_rows=N), steps, None, None, seed=seed, **kw)
+        for a, k in zip(got, ("counts", "final_controls", "final_scores")):
+            assert torch.equal(a, ref[k]), (seed, k)
+    assert not sm.w.chain_overflowed()
