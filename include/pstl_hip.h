@@ -200,7 +200,8 @@ int pstl_rollout(const pstl_cfg* cfg, float* packed /* status block written */, 
  * need not re-derive the rules of csrc/.  Writes
  * kernel: 0 = k_chain, latency layout (tiles_per_group 1..5 sixteen-row tiles per workgroup, empty pipeline slots skipped);
  *         1 = k_chain, throughput layout (tiles_per_group 5..12);  2 = k_chain2 (one 256-row workgroup per CU at a time:
- *         tiles_per_group = 16; a single-step launch starts one workgroup per CU, which walks `rounds` such tiles);
+ *         tiles_per_group = 16; a single-step launch starts one workgroup per CU, which walks `rounds` such tiles -- of 8
+ *         sixteen-row tiles = 128 rows where 256-row tiles would leave CUs idle);
  *         3 = an exact-fp32 / bfloat16-piece variant (chain_waves 8, 4, 32: throughput layout);
  * rounds: how many waves of workgroups the launch takes on this device's CUs.  Touches no GPU memory. */
 int pstl_rollout_layout(const pstl_cfg* cfg, int multi_step, int* kernel, int* tiles_per_group, int* rounds);

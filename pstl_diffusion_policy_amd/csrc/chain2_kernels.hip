@@ -35,20 +35,24 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int RT = 4;                      // 16-row tiles per wave
-constexpr int kWgRows = 4 * 16 * RT;       // 256 rows per workgroup
+// RT = 16-row tiles per wave (template parameter of the kernel): 4 -- 256 rows per workgroup -- everywhere but in the single-step
+// form of batches that would leave CUs idle with 256-row tiles, which takes 2 (128 rows per workgroup)
 constexpr int kCtrl2 = 40, kHid2 = 256;
 constexpr int kSlotBytes = 22 * 1024, kRing = 3;
 constexpr int kMaxScn = 7;                 // scenes a workgroup's 256 rows may touch (rows_per_scene >= 48)
 // LDS carve (bytes)
-constexpr int kOffXq = kRing * kSlotBytes;                   // [4 waves][RT][3][64] f32x4: the state x, lane-private
-constexpr int kOffCrow = kOffXq + 4 * RT * 3 * 64 * 16;      // [kMaxScn][256] (base[scene] + tbias[step]) x kAcc
-constexpr int kOffBrow = kOffCrow + kMaxScn * 1024;          // [kMaxScn][256] base[scene]
-constexpr int kOffB2 = kOffBrow + kMaxScn * 1024;            // [256] b2 x kAcc
-constexpr int kOffB3 = kOffB2 + 1024;                        // [48]  b3 x kAcc
-constexpr int kOffCoef = kOffB3 + 192;                       // [kMaxLaunchSteps][4] kk, a, sb, 0
-constexpr int kOffRc = kOffCoef + kMaxLaunchSteps * 16;         // MU: [4 waves][RT][4][64] the next tile's hl | stlp words (lanes g >= 2)
-constexpr int kLdsBytes = kOffRc + 4 * RT * 4 * 64 * 4;
+template <int RT>
+struct Carve {
+  static constexpr int kWgRows = 4 * 16 * RT;                           // rows per workgroup
+  static constexpr int kOffXq = kRing * kSlotBytes;                     // [4 waves][RT][3][64] f32x4: the state x, lane-private
+  static constexpr int kOffCrow = kOffXq + 4 * RT * 3 * 64 * 16;        // [kMaxScn][256] (base[scene] + tbias[step]) x kAcc
+  static constexpr int kOffBrow = kOffCrow + kMaxScn * 1024;            // [kMaxScn][256] base[scene]
+  static constexpr int kOffB2 = kOffBrow + kMaxScn * 1024;              // [256] b2 x kAcc
+  static constexpr int kOffB3 = kOffB2 + 1024;                          // [48]  b3 x kAcc
+  static constexpr int kOffCoef = kOffB3 + 192;                         // [kMaxLaunchSteps][4] kk, a, sb, 0
+  static constexpr int kOffRc = kOffCoef + kMaxLaunchSteps * 16;        // MU: [4 waves][RT][4][64] the next tile's hl | stlp words (lanes g >= 2)
+  static constexpr int kLdsBytes = kOffRc + 4 * RT * 4 * 64 * 4;
+};
 
 constexpr float kSX = kSplitX, kSW = kSplitW, kAcc = kSX * kSW, kInvSW = 1.0f / kSW, kInvAcc = 1.0f / kAcc;
 
@@ -157,8 +161,12 @@ __device__ __forceinline__ float clip_keep_nan(float v, float m) { return v < -m
 // launch are paid once per CU and not once per 256 rows.  The next tile's state arrives by LDS-DMA straight into the wave's
 // lane-private image (issued in the tail, when the current tile's image has been read), its scene rows in the middle of
 // chunk 6's phases.
-template <bool RNG, bool MU>
+template <bool RNG, bool MU, int RT>
 __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
+  static_assert(RT == 4 || (RT == 2 && MU && !RNG), "the noise steps are laid out for four row tiles per wave");
+  typedef Carve<RT> C;
+  constexpr int kWgRows = C::kWgRows, kOffXq = C::kOffXq, kOffCrow = C::kOffCrow, kOffBrow = C::kOffBrow, kOffB2 = C::kOffB2,
+                kOffB3 = C::kOffB3, kOffCoef = C::kOffCoef, kOffRc = C::kOffRc;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
           if constexpr (i0 + 1 < NCONV) conv_step(S, Ic<i0 + 1>{});
         }
         if constexpr (CONV == 2 && !(PSTL_C2_ABL & 2)) {
-          if constexpr (kq * NM + m < 48) conv_h1_slot(S, Ic<7>{}, Ic<kq * NM + m>{});
+          if constexpr (kq * NM + m < 2 * NM) conv_h1_slot(S, Ic<7>{}, Ic<kq * NM + m>{});
         }
         // bias of the next chunk, into its accumulators (= the chunk before's: converted in the first half's shadow)
         if constexpr (HALF == 1 && kq == 3 && m < 2 * RT) S[m / RT][m % RT] = rd_bias(c_bias, m / RT);
@@ -882,29 +890,43 @@ bool chain2_eligible(const ChainArgs& a) {
   return true;
 }
 
-template <bool RNG, bool MU>
+template <bool RNG, bool MU, int RT>
 static int launch_chain2_t(const ChainArgs& a, hipStream_t st) {
-  long n_wg = (a.N + kWgRows - 1) / kWgRows;
+  long n_wg = (a.N + Carve<RT>::kWgRows - 1) / Carve<RT>::kWgRows;
   static int allowed_dev = -1, cus = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return PSTL_ERR_LAUNCH;
   if (allowed_dev != dev) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<RNG, MU>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) !=
-            hipSuccess ||
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<RNG, MU, RT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            Carve<RT>::kLdsBytes) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       return PSTL_ERR_LAUNCH;
     allowed_dev = dev;
   }
   if (MU && n_wg > cus) n_wg = cus;   // one workgroup per CU walks the tiles
-  hipLaunchKernelGGL((k_chain2<RNG, MU>), dim3((unsigned)n_wg), dim3(256), kLdsBytes, st, a);
+  hipLaunchKernelGGL((k_chain2<RNG, MU, RT>), dim3((unsigned)n_wg), dim3(256), Carve<RT>::kLdsBytes, st, a);
   return launch_status();
+}
+
+// Rows per workgroup of a launch.  Multi-step: 256.  Single-step (the workgroups walk tiles): 128 where that takes less time
+// per CU -- a 128-row tile-step is 0.6 of a 256-row one (16-17 against 26-29 us measured: each A operand read feeds half the
+// MFMAs), so it pays exactly where 256-row tiles would leave CUs idle: 24 576 rows are 96 tiles of 256 on 256 CUs or 192 of
+// 128 (29.7 -> 19.1 us per launch), 98 304 rows two of 256 per CU or three of 128 (61.6 -> 53.4 us).  Same bits either way.
+int chain2_wg_rows(const ChainArgs& a) {
+  if (!a.mu_only) return 256;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return 256;
+  const long t4 = (a.N + 255) / 256, t2 = (a.N + 127) / 128;
+  const long r4 = (t4 + cus - 1) / cus, r2 = (t2 + cus - 1) / cus;
+  return r2 * 60 < r4 * 100 ? 128 : 256;
 }
 
 int launch_chain2(const ChainArgs& a, hipStream_t st) {
   // in-kernel noise (PSTL_FLAG_RNG) rides in the MFMA shadow; a caller's noise tensor (the parity tests) or no noise at all
   // is handled in the epilogue
-  if (a.mu_only) return launch_chain2_t<false, true>(a, st);
-  return a.rng ? launch_chain2_t<true, false>(a, st) : launch_chain2_t<false, false>(a, st);
+  if (a.mu_only) return chain2_wg_rows(a) == 128 ? launch_chain2_t<false, true, 2>(a, st) : launch_chain2_t<false, true, 4>(a, st);
+  return a.rng ? launch_chain2_t<true, false, 4>(a, st) : launch_chain2_t<false, false, 4>(a, st);
 }
 
 }  // namespace pstl

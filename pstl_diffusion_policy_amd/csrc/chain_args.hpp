@@ -73,6 +73,7 @@ struct ChainArgs {
 // and all 256 hidden features) and the split-f16 weights streamed L2 -> LDS; same arithmetic as k_chain's default form, other
 // summation order.  chain2_eligible: the launches it takes (see there).  Returns a PSTL_* status.
 bool chain2_eligible(const ChainArgs& a);
+int chain2_wg_rows(const ChainArgs& a);   // rows per workgroup the launch would use: 256, or 128 for some single-step launches
 int launch_chain2(const ChainArgs& a, hipStream_t st);
 
 }  // namespace pstl

@@ -2071,7 +2071,7 @@ extern "C" int pstl_rollout_layout(const pstl_cfg* cfg, int multi_step, int* ker
   const bool ut = cfg->rows_per_scene % kTileRows == 0;
   int k = 3, g = tiles_per_group(N);
   if ((cw == 2 || (cw == 0 && chain2_pays(N, !multi_step))) && chain2_eligible(a)) {
-    k = 2, g = 16;
+    k = 2, g = chain2_wg_rows(a) / kTileRows;
   } else if (cw == 0 || cw == 16 || cw == 2) {
     k = 1;
     const int sg = (cw == 0 && ut) ? sparse_tiles_per_group(N) : 0;
