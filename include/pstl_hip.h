@@ -88,9 +88,9 @@ typedef struct pstl_cfg {
                               fewer than five 16-row tiles per CU -- the closed-loop caller's 192 rows -- run
                               their denoiser launches in a latency layout, 1..4 tiles per workgroup; 16: always
                               the throughput layout; the results are bit-identical; 0 also hands the multi-step
-                              denoiser launches of batches that fill whole rounds of 256-row workgroups -- >= 65 536
-                              rows on 256 CUs -- and the single-step (mu_only = 1) launches of every batch above the
-                              latency layout's sizes to the row-stationary kernel k_chain2: same arithmetic and domain,
+                              denoiser launches of batches that (nearly) fill rounds of 256- or 192-row workgroups --
+                              from 45 056 rows on 256 CUs -- and the single-step (mu_only = 1) launches of every batch
+                              above the latency layout's sizes to the row-stationary kernel k_chain2: same arithmetic and domain,
                               another summation order; 2: k_chain2 for every launch it can take whatever the batch
                               size, the other launches as 16); 8 or 4 = fp32
                               MFMA (v_mfma_f32_16x16x4_f32) with 8 / 4 waves per workgroup; 32 = policy_net
@@ -199,9 +199,10 @@ int pstl_rollout(const pstl_cfg* cfg, float* packed /* status block written */, 
  * step_hi == step_lo with mu_only = 1 (0: the guided phase's launches): a query for benchmarks and tools, so that they
  * need not re-derive the rules of csrc/.  Writes
  * kernel: 0 = k_chain, latency layout (tiles_per_group 1..5 sixteen-row tiles per workgroup, empty pipeline slots skipped);
- *         1 = k_chain, throughput layout (tiles_per_group 5..12);  2 = k_chain2 (one 256-row workgroup per CU at a time:
- *         tiles_per_group = 16; a single-step launch starts one workgroup per CU, which walks `rounds` such tiles -- of 8
- *         sixteen-row tiles = 128 rows where 256-row tiles would leave CUs idle);
+ *         1 = k_chain, throughput layout (tiles_per_group 5..12);  2 = k_chain2 (one workgroup per CU at a time, of
+ *         tiles_per_group = 16 sixteen-row tiles = 256 rows, or 12 = 192 rows where that fills the rounds better; a
+ *         single-step launch starts one workgroup per CU, which walks `rounds` tiles of 16 -- or 8, where 256-row tiles
+ *         would leave CUs idle);
  *         3 = an exact-fp32 / bfloat16-piece variant (chain_waves 8, 4, 32: throughput layout);
  * rounds: how many waves of workgroups the launch takes on this device's CUs.  Touches no GPU memory. */
 int pstl_rollout_layout(const pstl_cfg* cfg, int multi_step, int* kernel, int* tiles_per_group, int* rounds);

@@ -163,7 +163,7 @@ __device__ __forceinline__ float clip_keep_nan(float v, float m) { return v < -m
 // chunk 6's phases.
 template <bool RNG, bool MU, int RT>
 __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
-  static_assert(RT == 4 || (RT == 2 && MU && !RNG), "the noise steps are laid out for four row tiles per wave");
+  static_assert(RT == 4 || (RT == 3 && !MU) || (RT == 2 && MU && !RNG), "see noise_l3 / noise_b: chunk pair p draws row tile p's noise");
   typedef Carve<RT> C;
   constexpr int kWgRows = C::kWgRows, kOffXq = C::kOffXq, kOffCrow = C::kOffCrow, kOffBrow = C::kOffBrow, kOffB2 = C::kOffB2,
                 kOffB3 = C::kOffB3, kOffCoef = C::kOffCoef, kOffRc = C::kOffRc;
@@ -487,13 +487,36 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   // ~1 000 cycles, a phase's 96 slots have 770): the first 24 in two of every three slots of layer 3's k-block behind the chunk's
   // first-half phase -- slots that carry nothing else --, the other 72 in three of every four slots of its second-half phase.
   // Chunk 0 has no layer-3 block in front of it: all 96 in its second half.
+  // (RT = 3: a phase has 72 slots, the layer-3 block 27 -- the first 24 steps in the block's first 24 slots, the other 72 one per
+  // slot of the phase; chunk 0 doubles up in its first 24 slots; chunk pair 3 has no row tile to draw for.)
   auto noise_l3 = [&](int p, auto odd_tag, auto k_tag) {
     constexpr int k = decltype(k_tag)::value;
-    if constexpr (k % 3 != 2) noise_slot(p, odd_tag, Ic<k - k / 3>{});
+    if constexpr (RT == 4) {
+      if constexpr (k % 3 != 2) noise_slot(p, odd_tag, Ic<k - k / 3>{});
+    } else if constexpr (RT == 3) {
+      if constexpr (k < 24) noise_slot(p, odd_tag, Ic<k>{});
+    }
   };
   auto noise_b = [&](int p, auto odd_tag, auto k_tag) {
     constexpr int k = decltype(k_tag)::value;
-    if constexpr (k % 4 != 3) noise_slot(p, odd_tag, Ic<24 + k - k / 4>{});
+    if constexpr (RT == 4) {
+      if constexpr (k % 4 != 3) noise_slot(p, odd_tag, Ic<24 + k - k / 4>{});
+    } else if constexpr (RT == 3) {
+      noise_slot(p, odd_tag, Ic<24 + k>{});
+    }
+  };
+  auto noise_b0 = [&](auto k_tag) {   // chunk 0: all 96 steps in its second-half phase
+    constexpr int k = decltype(k_tag)::value;
+    if constexpr (RT == 4) {
+      noise_slot(0, std::false_type{}, k_tag);
+    } else if constexpr (RT == 3) {
+      if constexpr (k < 24) {
+        noise_slot(0, std::false_type{}, Ic<2 * k>{});
+        noise_slot(0, std::false_type{}, Ic<2 * k + 1>{});
+      } else {
+        noise_slot(0, std::false_type{}, Ic<24 + k>{});
+      }
+    }
   };
 
   // one k-block of layer 3: the pieces of a finished chunk against its W3 blocks (pieces 16..21 of `slot`; the first pair
@@ -694,7 +717,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) accA[t][rt] = rd_bias(0, t);   // (layer 1's chunk 6 left these registers a phase ago)
     l2_phase(accA, accB, Ic<0>{}, Ic<2>{}, noslot, Ic<1>{}, Ic<6>{}, 1, 0, 0, none, noslot);    // A(0): converts layer 1's chunk 7; issues A(1) + W3[0]
-    l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, 1, 0, 1, write_crow, [&](auto s_) { noise_slot(0, No{}, s_); });    // B(0); issues B(1)
+    l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, 1, 0, 1, write_crow, [&](auto s_) { noise_b0(s_); });    // B(0); issues B(1)
     C2_STAMP(1)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
@@ -714,10 +737,10 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, cc + 2, 0, cc + 2, none, [&](auto s_) { noise_b(cc >> 1, Yes{}, s_); });
       C2_STAMP(4)
     }
-    l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(3, No{}, k_); }, Ic<1>{}, Ic<6>{}, 7, 6, 0, load_nbase, noslot);    // A(6); issues A(7) + W3[6]
-    l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, 7, 0, 7, write_ncrow, [&](auto s_) { noise_b(3, No{}, s_); });
-    l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(3, Yes{}, k_); }, Ic<0>{}, Ic<6>{}, 0, 7, 0, none, noslot);    // A(7); issues P0 of the next step + W3[7]
-    l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, noslot, Ic<0>{}, Ic<4>{}, 1, 0, 0, none, [&](auto s_) { noise_b(3, Yes{}, s_); });    // B(7); issues P1 of the next step
+    l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, [&](auto k_) { if constexpr (RT > 3) noise_l3(3, No{}, k_); }, Ic<1>{}, Ic<6>{}, 7, 6, 0, load_nbase, noslot);    // A(6); issues A(7) + W3[6]
+    l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, 7, 0, 7, write_ncrow, [&](auto s_) { if constexpr (RT > 3) noise_b(3, No{}, s_); });
+    l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, [&](auto k_) { if constexpr (RT > 3) noise_l3(3, Yes{}, k_); }, Ic<0>{}, Ic<6>{}, 0, 7, 0, none, noslot);    // A(7); issues P0 of the next step + W3[7]
+    l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, noslot, Ic<0>{}, Ic<4>{}, 1, 0, 0, none, [&](auto s_) { if constexpr (RT > 3) noise_b(3, Yes{}, s_); });    // B(7); issues P1 of the next step
     C2_STAMP(5)
     // tail: layer 3 of chunk 7.  Its W3 blocks sit in the slot of the NEXT tile-step's first phase (s_cur now): landed and
     // published by the barrier in the middle of the phase just finished.
@@ -890,6 +913,10 @@ bool chain2_eligible(const ChainArgs& a) {
   return true;
 }
 
+// a 192-row tile-step in per cent of a 256-row one: 21.1 against 25.1 us at 786 432 rows (16 against 12 rounds: 13.17 against
+// 12.55 ms per 39-step launch), 20.8 against 26.8 at 196 608 rows (profiles/r5/chain2_192_row_workgroups.txt)
+constexpr int kCost192 = 82;
+
 template <bool RNG, bool MU, int RT>
 static int launch_chain2_t(const ChainArgs& a, hipStream_t st) {
   long n_wg = (a.N + Carve<RT>::kWgRows - 1) / Carve<RT>::kWgRows;
@@ -913,19 +940,35 @@ static int launch_chain2_t(const ChainArgs& a, hipStream_t st) {
 // MFMAs), so it pays exactly where 256-row tiles would leave CUs idle: 24 576 rows are 96 tiles of 256 on 256 CUs or 192 of
 // 128 (29.7 -> 19.1 us per launch), 98 304 rows two of 256 per CU or three of 128 (61.6 -> 53.4 us).  Same bits either way.
 int chain2_wg_rows(const ChainArgs& a) {
-  if (!a.mu_only) return 256;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     return 256;
-  const long t4 = (a.N + 255) / 256, t2 = (a.N + 127) / 128;
-  const long r4 = (t4 + cus - 1) / cus, r2 = (t2 + cus - 1) / cus;
+  const long t4 = (a.N + 255) / 256, r4 = (t4 + cus - 1) / cus;
+#ifdef PSTL_C2_FORCE_ROWS
+  if (!a.mu_only) return PSTL_C2_FORCE_ROWS;
+#endif
+  if (!a.mu_only) {   // multi-step: rounds of 192-row workgroups (three row tiles per wave) where they take less time
+    const long t3 = (a.N + 191) / 192, r3 = (t3 + cus - 1) / cus;
+    return r3 * kCost192 < r4 * 100 ? 192 : 256;
+  }
+  const long t2 = (a.N + 127) / 128, r2 = (t2 + cus - 1) / cus;
   return r2 * 60 < r4 * 100 ? 128 : 256;
+}
+
+long chain2_step_cost(const ChainArgs& a) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return 1L << 40;
+  const int rows = chain2_wg_rows(a);
+  const long t = (a.N + rows - 1) / rows, r = (t + cus - 1) / cus;
+  return r * (rows == 256 ? 100 : rows == 192 ? kCost192 : 60);
 }
 
 int launch_chain2(const ChainArgs& a, hipStream_t st) {
   // in-kernel noise (PSTL_FLAG_RNG) rides in the MFMA shadow; a caller's noise tensor (the parity tests) or no noise at all
   // is handled in the epilogue
   if (a.mu_only) return chain2_wg_rows(a) == 128 ? launch_chain2_t<false, true, 2>(a, st) : launch_chain2_t<false, true, 4>(a, st);
+  if (chain2_wg_rows(a) == 192) return a.rng ? launch_chain2_t<true, false, 3>(a, st) : launch_chain2_t<false, false, 3>(a, st);
   return a.rng ? launch_chain2_t<true, false, 4>(a, st) : launch_chain2_t<false, false, 4>(a, st);
 }
 

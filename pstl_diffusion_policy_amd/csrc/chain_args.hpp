@@ -73,7 +73,8 @@ struct ChainArgs {
 // and all 256 hidden features) and the split-f16 weights streamed L2 -> LDS; same arithmetic as k_chain's default form, other
 // summation order.  chain2_eligible: the launches it takes (see there).  Returns a PSTL_* status.
 bool chain2_eligible(const ChainArgs& a);
-int chain2_wg_rows(const ChainArgs& a);   // rows per workgroup the launch would use: 256, or 128 for some single-step launches
+int chain2_wg_rows(const ChainArgs& a);   // rows per workgroup the launch would use: 256; 192 for some multi-step, 128 for some single-step launches
+long chain2_step_cost(const ChainArgs& a);  // a reverse step of the launch, in per cent of one 256-row tile-step (rounds x the tile's cost)
 int launch_chain2(const ChainArgs& a, hipStream_t st);
 
 }  // namespace pstl

@@ -1704,16 +1704,21 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
   return launch_status();
 }
 
-// Batches that k_chain2 runs faster than k_chain.  Multi-step launches: its workgroups own 256 rows for the whole launch, one
-// per CU at a time, so the launch takes ceil(workgroups / CUs) rounds -- it pays when those rounds are (nearly) full.  The
-// single-step launches of the guided phase: one workgroup per CU walks the tiles, no rounds -- measured faster than k_chain's
-// single-step layout at every size from 32 832 rows up (31 against 46 us; 786 432 rows: 335 against 445 us), so it takes
-// every batch the latency layout does not (profiles/r5/chain2_single_step_sizes.txt).
+// Batches that k_chain2 runs faster than k_chain.  Multi-step launches: its workgroups own 256 (or 192) rows for the whole launch,
+// one per CU at a time, so the launch takes ceil(workgroups / CUs) rounds of its tile-step (chain2_step_cost: in per cent of the
+// 256-row tile-step, 25.6 us) against k_chain's rounds x tiles per group x 1.91 us (7.46 per cent per tile) -- it pays where
+// its rounds are (nearly) full: from 45 056 rows (235 workgroups of 192 rows) and at every size from 196 608 rows up, not at
+// 24 576 ... 40 960 rows nor where a round would be mostly empty (profiles/r5/chain2_192_row_workgroups.txt).  The single-step
+// launches of the guided phase: one workgroup per CU walks the tiles, no rounds -- measured faster than k_chain's single-step
+// layout at every size from 24 576 rows up, so it takes every batch the latency layout does not
+// (profiles/r5/chain2_single_step_sizes.txt).
 inline bool chain2_pays(long N, bool single_step) {
   if (single_step) return sparse_tiles_per_group(N) == 0;
-  const long cus = cu_count(), n_wg = (N + 255) / 256;
-  const long rounds = (n_wg + cus - 1) / cus;
-  return n_wg >= cus && n_wg * 8 >= rounds * cus * 7;   // >= 7/8 of the CU-rounds busy
+  const long cus = cu_count(), n_tiles = (N + kTileRows - 1) / kTileRows;
+  const long g = tiles_per_group_balanced(N), rk = ((n_tiles + g - 1) / g + cus - 1) / cus;
+  ChainArgs a = {};
+  a.N = N;
+  return chain2_step_cost(a) * 100 < rk * g * 746 * 97 / 100;   // (both sides in 0.01 % of a 256-row tile-step; 3 % in hand for k_chain)
 }
 
 // cfg->chain_waves: 0, 16 = both networks on split-f16 MFMA: every fp32 operand as two half pieces, three

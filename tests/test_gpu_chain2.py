@@ -307,3 +307,30 @@ def test_chain2_single_step_128_row_workgroups(dev):
     assert layq[1] == 8 and layq[2] == 1                       # 24 576 rows: 192 tiles of 128, one each
     assert torch.equal(gq, gh[:sbq.N]) and torch.equal(gh, got[:sbh.N])
     assert not w.chain_overflowed()
+
+
+def test_chain2_192_row_workgroups(dev):
+    """Multi-step launches take 192-row workgroups (three row tiles per wave) where rounds of them cost less than rounds of 256-row
+    ones: 98 304 rows = 512 workgroups of 192 = two full rounds on 256 CUs.  Against k_chain on the same in-kernel noise (<= 2e-5),
+    and bit for bit against the 256-row form that the whole batch of 196 608 rows gets, of which these rows are a shard."""
+    from pstl_diffusion_policy_amd import ffi
+    from pstl_diffusion_policy_amd.engine import Sampler, SceneBatch
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("sized for 256 CUs")
+    hp, scene, w, sb = _setup(dev, 1024, 64, 2, seed=17)
+    steps, seed = 9, 77
+    vs, n_all = float(sb.valid.sum()), sb.N
+    half = SceneBatch({k: v[:512].clone() for k, v in scene.items()}, 64, hp, dev, global_valid_sum=vs, global_rows=n_all)
+    assert ffi.rollout_layout(sb.cfg(steps, ffi.PSTL_FLAG_RNG, 0, 0), True)[:2] == (2, 16)
+    assert ffi.rollout_layout(half.cfg(steps, ffi.PSTL_FLAG_RNG, 0, 0), True)[:2] == (2, 12)
+    outs = {}
+    for name, b, cw in (("full", sb, 0), ("half", half, 0), ("half_k_chain", half, 16)):
+        sm = Sampler(w, hp, chain_waves=cw)
+        _, base_p, _ = sm.encode(b, need_rect=False)
+        x = sm.fill_normal(b, steps, steps, seed)
+        emit = sm.rollout(b, base_p, x, None, steps, n_emit=2, seed=seed)
+        outs[name] = (x.clone(), emit.clone())
+        assert not w.chain_overflowed()
+    assert torch.equal(outs["half"][0], outs["full"][0][:half.N]) and torch.equal(outs["half"][1], outs["full"][1][:, :half.N])
+    d = (outs["half"][0] - outs["half_k_chain"][0]).abs().max().item()
+    assert 0.0 < d <= 2e-5, d

@@ -415,14 +415,16 @@ def test_balanced_workgroup_sizes_do_not_change_results(dev, bs):
     S, steps = 64, 8
     scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=2, S=S, seed=31, invalid_lane_frac=0.2, stlp_mode="wide").items()
              if k not in ("params", "pre_stlp", "tj_scores_prior")}
-    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    # (chain_waves = 16 pins the whole batch to k_chain's throughput layout: with 0 the 267-scene batch's launch goes to k_chain2,
+    # whose sums run in another order; the shard runs the default, i.e. k_chain's latency layout)
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp, chain_waves=16)
     kw = dict(rect_head=True, multi_cands=3, want_scores3=False, seed=5)
     sb = SceneBatch(scene, S, hp, dev)
     full = sm.sampling_region(sb, steps, None, None, **kw)
     lo, hi = bs - 30, bs - 6
     sub = {k: v[lo:hi].contiguous() for k, v in scene.items()}
     r0, r1 = lo * S * 3, hi * S * 3
-    part = sm.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=r0), steps, None, None, **kw)
+    part = Sampler(sm.w, hp).sampling_region(SceneBatch(sub, S, hp, dev, row_offset=r0), steps, None, None, **kw)
     for k in ("final_controls", "final_scores", "sel_controls"):
         assert torch.isfinite(full[k]).all() and torch.equal(part[k], full[k][r0:r1]), k
 

@@ -22,6 +22,7 @@ args = sys.argv[1:]
 rounds = 7
 single = False
 chain_waves = 0
+BS = 4096
 while args and args[0].startswith("--"):
     if args[0] == "--rounds":
         rounds = int(args[1]); args = args[2:]
@@ -29,6 +30,8 @@ while args and args[0].startswith("--"):
         single = True; args = args[1:]
     elif args[0] == "--cw":
         chain_waves = int(args[1]); args = args[2:]
+    elif args[0] == "--bs":
+        BS = int(args[1]); args = args[2:]
     else:
         raise SystemExit("unknown option " + args[0])
 vdir = os.path.join(ROOT, "tools", "dbg", "_variants")
@@ -47,7 +50,7 @@ def load(path):
 libs = [("base", ffi.lib())] + [(n, load(os.path.join(vdir, "libpstl_%s.so" % n))) for n in names]
 dev = torch.device("cuda:0")
 hp = default_hparams()
-bs, S, K, steps = 4096, 64, 2, 40
+bs, S, K, steps = BS, 64, 2, 40
 sd = init_state_dict(1007)
 w = PackedWeights(sd, dev)
 scene = make_scene_batch(bs, K=K, S=S, seed=3, stlp_mode="wide")
