@@ -163,7 +163,7 @@ __device__ __forceinline__ float clip_keep_nan(float v, float m) { return v < -m
 // chunk 6's phases.
 template <bool RNG, bool MU, int RT>
 __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
-  static_assert(RT == 4 || (RT == 3 && !MU) || (RT == 2 && MU && !RNG), "see noise_l3 / noise_b: chunk pair p draws row tile p's noise");
+  static_assert(RT == 4 || RT == 3 || (RT == 2 && MU && !RNG), "see noise_l3 / noise_b: chunk pair p draws row tile p's noise");
   typedef Carve<RT> C;
   constexpr int kWgRows = C::kWgRows, kOffXq = C::kOffXq, kOffCrow = C::kOffCrow, kOffBrow = C::kOffBrow, kOffB2 = C::kOffB2,
                 kOffB3 = C::kOffB3, kOffCoef = C::kOffCoef, kOffRc = C::kOffRc;
@@ -951,8 +951,9 @@ int chain2_wg_rows(const ChainArgs& a) {
     const long t3 = (a.N + 191) / 192, r3 = (t3 + cus - 1) / cus;
     return r3 * kCost192 < r4 * 100 ? 192 : 256;
   }
-  const long t2 = (a.N + 127) / 128, r2 = (t2 + cus - 1) / cus;
-  return r2 * 60 < r4 * 100 ? 128 : 256;
+  const long t3 = (a.N + 191) / 192, r3 = (t3 + cus - 1) / cus, t2 = (a.N + 127) / 128, r2 = (t2 + cus - 1) / cus;
+  const long c4 = r4 * 100, c3 = r3 * kCost192, c2 = r2 * 60;
+  return c2 < c4 && c2 <= c3 ? 128 : c3 < c4 ? 192 : 256;
 }
 
 long chain2_step_cost(const ChainArgs& a) {
@@ -967,7 +968,11 @@ long chain2_step_cost(const ChainArgs& a) {
 int launch_chain2(const ChainArgs& a, hipStream_t st) {
   // in-kernel noise (PSTL_FLAG_RNG) rides in the MFMA shadow; a caller's noise tensor (the parity tests) or no noise at all
   // is handled in the epilogue
-  if (a.mu_only) return chain2_wg_rows(a) == 128 ? launch_chain2_t<false, true, 2>(a, st) : launch_chain2_t<false, true, 4>(a, st);
+  if (a.mu_only) {
+    const int rows = chain2_wg_rows(a);
+    return rows == 128 ? launch_chain2_t<false, true, 2>(a, st) : rows == 192 ? launch_chain2_t<false, true, 3>(a, st)
+                                                                                 : launch_chain2_t<false, true, 4>(a, st);
+  }
   if (chain2_wg_rows(a) == 192) return a.rng ? launch_chain2_t<true, false, 3>(a, st) : launch_chain2_t<false, false, 3>(a, st);
   return a.rng ? launch_chain2_t<true, false, 4>(a, st) : launch_chain2_t<false, false, 4>(a, st);
 }

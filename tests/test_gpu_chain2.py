@@ -281,31 +281,29 @@ def _single_mu(dev, sm, w, sb, x0, cw, steps=10, i=4):
     return x, ffi.rollout_layout(cfg, False)
 
 
-def test_chain2_single_step_128_row_workgroups(dev):
-    """Where 256-row tiles would leave CUs idle the single-step form runs 128-row workgroups (two row tiles per wave): 24 576 rows
-    as one tile per workgroup, 98 304 rows as three tiles walked per workgroup -- against k_chain (<= 2e-6), and bit for bit against
-    the 256-row form that a batch of 49 152 rows gets, of which the 24 576 rows are a shard."""
+def test_chain2_single_step_row_tiles_per_wave(dev):
+    """The single-step form picks its rows per workgroup by what fills the CUs: 196 608 rows walk three 256-row tiles per CU,
+    98 304 rows two 192-row tiles, 49 152 rows one 192-row tile each, 24 576 rows one 128-row tile each.  Against k_chain
+    (<= 2e-6), and every smaller batch -- a shard of the larger one -- bit for bit against it."""
     from pstl_diffusion_policy_amd.engine import Sampler, SceneBatch
-    cus = torch.cuda.get_device_properties(0).multi_processor_count
-    if cus != 256:
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
         pytest.skip("sized for 256 CUs")
-    hp, scene, w, sb = _setup(dev, 512, 64, 2, seed=91)
+    hp, scene, w, sb = _setup(dev, 1024, 64, 2, seed=91)
     g = torch.Generator(device=dev).manual_seed(5)
     x0 = torch.randn(sb.N, 40, device=dev, generator=g)
     sm2, sm16 = Sampler(w, hp, chain_waves=2), Sampler(w, hp, chain_waves=16)
     got, lay = _single_mu(dev, sm2, w, sb, x0, 2)
-    assert lay[0] == 2 and lay[1] == 8 and lay[2] == 3          # k_chain2, 8 sixteen-row tiles per workgroup, three walked
+    assert lay == (2, 16, 3), lay                              # k_chain2, 16 sixteen-row tiles per workgroup, three walked
     ref, _ = _single_mu(dev, sm16, w, sb, x0, 16)
     assert 0.0 < (got - ref).abs().max().item() <= 2e-6
-    half = {k: v[:256].clone() for k, v in scene.items()}
-    sbh = SceneBatch(half, 64, hp, dev, global_valid_sum=float(sb.valid.sum()), global_rows=sb.N)
-    gh, layh = _single_mu(dev, sm2, w, sbh, x0[:sbh.N], 2)
-    assert layh[1] == 16                                       # 49 152 rows: 192 tiles of 256
-    quarter = {k: v[:128].clone() for k, v in scene.items()}
-    sbq = SceneBatch(quarter, 64, hp, dev, global_valid_sum=float(sb.valid.sum()), global_rows=sb.N)
-    gq, layq = _single_mu(dev, sm2, w, sbq, x0[:sbq.N], 2)
-    assert layq[1] == 8 and layq[2] == 1                       # 24 576 rows: 192 tiles of 128, one each
-    assert torch.equal(gq, gh[:sbq.N]) and torch.equal(gh, got[:sbh.N])
+    vs = float(sb.valid.sum())
+    prev = got
+    for n_scn, want in ((512, (2, 12, 2)), (256, (2, 12, 1)), (128, (2, 8, 1))):
+        part = SceneBatch({k: v[:n_scn].clone() for k, v in scene.items()}, 64, hp, dev, global_valid_sum=vs, global_rows=sb.N)
+        gp, layp = _single_mu(dev, sm2, w, part, x0[:part.N], 2)
+        assert layp == want, (n_scn, layp)
+        assert torch.equal(gp, prev[:part.N]), n_scn
+        prev = gp
     assert not w.chain_overflowed()
 
 
