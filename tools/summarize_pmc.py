@@ -23,7 +23,8 @@ def short(name):
         n = "k_chain<%s,%s,pt%s>" % m.groups()
     elif "k_chain2" in name:      # the row-stationary kernel (round 5), <RNG, MU>: <true, false> draws its noise itself,
         # <false, true> is the single-step (mu-only) form whose workgroups walk the tiles
-        n = "k_chain2<%s>" % ("rng" if "k_chain2<true, false>" in name else "single_step" if "k_chain2<false, true>" in name
+        # (a third parameter since the round's last third: row tiles per wave -- 4 at the default bench's size)
+        n = "k_chain2<%s>" % ("rng" if "k_chain2<true, false" in name else "single_step" if "k_chain2<false, true" in name
                               else "noise_in")
     elif "k_chain" in name:
         n = "k_chain<8,%s>" % ("true" if "k_chain<8, true" in name else "false")
