@@ -90,7 +90,8 @@ typedef struct pstl_cfg {
                               the throughput layout; the results are bit-identical; 0 also hands the multi-step
                               denoiser launches of batches that (nearly) fill rounds of 256- or 192-row workgroups --
                               from 45 056 rows on 256 CUs -- and the single-step (mu_only = 1) launches of every batch
-                              above the latency layout's sizes to the row-stationary kernel k_chain2: same arithmetic and domain,
+                              above the latency layout's sizes -- and RefineNet's inference pass of such batches -- to
+                              the row-stationary kernel k_chain2: same arithmetic and domain,
                               another summation order; 2: k_chain2 for every launch it can take whatever the batch
                               size, the other launches as 16); 8 or 4 = fp32
                               MFMA (v_mfma_f32_16x16x4_f32) with 8 / 4 waves per workgroup; 32 = policy_net

@@ -161,8 +161,13 @@ __device__ __forceinline__ float clip_keep_nan(float v, float m) { return v < -m
 // launch are paid once per CU and not once per 256 rows.  The next tile's state arrives by LDS-DMA straight into the wave's
 // lane-private image (issued in the tail, when the current tile's image has been read), its scene rows in the middle of
 // chunk 6's phases.
-template <bool RNG, bool MU, int RT>
+//
+// MODE 2 (REF): RefineNet's inference pass (Net.rect_forward, nusc_model.py:182-235) in the same tile-walking form -- rect_net's
+// weights, the scene rows without a timestep row, the input init + pooled[scene][mode][shard] (merge_net's max-pool, k_merge_pool),
+// and the tanh interval head instead of the DDPM update; the image keeps init, which the head needs again.
+template <bool RNG, int MODE, int RT>
 __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
+  constexpr bool MU = MODE != 0, REF = MODE == 2;
   static_assert(RT == 4 || RT == 3 || (RT == 2 && MU && !RNG), "see noise_l3 / noise_b: chunk pair p draws row tile p's noise");
   typedef Carve<RT> C;
   constexpr int kWgRows = C::kWgRows, kOffXq = C::kOffXq, kOffCrow = C::kOffCrow, kOffBrow = C::kOffBrow, kOffB2 = C::kOffB2,
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   {
     b2s[tid] = a.packed[a.off.b2 + tid] * kAcc;
     if (tid < 48) b3s[tid] = a.packed[a.off.b3 + tid] * kAcc;
-    if (tid < nsteps) {   // reverse-step coefficients (nusc_train.py:580-587): x' = a x + sb z - kk (eps_net + b3),  a = (1 - c1) / sqrt(alpha)
+    if (!REF && tid < nsteps) {   // reverse-step coefficients (nusc_train.py:580-587): x' = a x + sb z - kk (eps_net + b3),  a = (1 - c1) / sqrt(alpha)
       const int i = a.step_hi - tid;
       const float al = a.alpha[i], ah = a.alpha_hat[i], be = a.beta[i];
       const float c1 = (1.0f - al) / sqrtf(1.0f - ah), inv_sa = 1.0f / sqrtf(al);
@@ -214,20 +219,21 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       const bool noisy = !MU && i > 1 && (RNG || a.noise);   // the reference adds zeros at the last step
       coef[tid] = f32x4{kk, inv_sa - kk, noisy ? sqrtf(be) : 0.0f, 0.0f};
     }
-    if (MU) tbs[tid] = a.tbias[(long)a.step_hi * kHid2 + tid];
+    const float tb0 = REF ? 0.0f : a.tbias[(long)a.step_hi * kHid2 + tid];   // (rect_net has no timestep columns)
+    if (MU) tbs[tid] = tb0;
     const long nscn_rows = (wg_row0 + kWgRows - 1 > last_row ? last_row : wg_row0 + kWgRows - 1);
     const int nscn = (int)(nscn_rows / a.rows_per_scene - scene_first) + 1;
     for (int s = 0; s < kMaxScn; ++s) {
       const int ss = s < nscn ? s : nscn - 1;
       const float bvv = a.base[(scene_first + ss) * kHid2 + tid];
       brow[s * 256 + tid] = bvv;
-      crow[s * 256 + tid] = (bvv + a.tbias[(long)a.step_hi * kHid2 + tid]) * kAcc;
+      crow[s * 256 + tid] = (bvv + tb0) * kAcc;
     }
   }
   const unsigned long long seed = a.seed_dev ? uniform_u64(a.seed_dev) : a.seed;
   unsigned ovf = 0;
   if (tid == 0 && blockIdx.x == 0) {   // the weights themselves: max |w| as the packer recorded it (status word 0 = policy_net)
-    const float wm = reinterpret_cast<const float*>(a.status)[-2];
+    const float wm = reinterpret_cast<const float*>(a.status)[REF ? -1 : -2];
     if (!(wm < PSTL_SPLIT_F16_WMAX)) atomicOr(a.status, 1u);
   }
 
@@ -269,6 +275,20 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
     xh[1][rt] = __builtin_bit_cast(f16x8, uw4{h1[0], h1[1], 0u, 0u}), xl[1][rt] = __builtin_bit_cast(f16x8, uw4{l1[0], l1[1], 0u, 0u});
   };
 
+  // REF: the input is init + pooled[scene][mode][shard] (nusc_model.py:186-200); r = this lane's row
+  auto add_pooled = [&](long r, f32x4& q0, f32x4& q1, f32x4& q2) {
+    if constexpr (REF) {
+      if (a.pooled) {
+        const unsigned ru = (unsigned)r, rps = (unsigned)a.rows_per_scene;
+        const unsigned b = ru / rps, rr = ru - b * rps, sm = rr / 3u, m = rr - 3u * sm, sh = sm / (unsigned)(a.S / a.n_shards);
+        const float* pp = a.pooled + ((long)(b * 3u + m) * a.n_shards + sh) * kCtrl2 + 4 * g;
+        q0 += *reinterpret_cast<const f32x4*>(pp);
+        q1 += *reinterpret_cast<const f32x4*>(pp + 16);
+        if (g < 2) q2 += *reinterpret_cast<const f32x4*>(pp + 32);
+      }
+    }
+  };
+
   // ---- the initial state: lane (g, col) of row tile rt holds columns 16 j + 4 g .. + 3 of row 16 rt + col ----
   const bool own2 = g < 2;            // tile j = 2: lanes g < 2 hold x 32..39, lanes g >= 2 the row constants hl | stlp | 0
   {
@@ -276,9 +296,9 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
     for (int rt = 0; rt < RT; ++rt) {
       long r = row0 + 16 * rt + col;
       if (r > last_row) r = last_row;
-      const float* xr = a.x_inout + r * kCtrl2;
-      const f32x4 q0 = *reinterpret_cast<const f32x4*>(xr + 4 * g);
-      const f32x4 q1 = *reinterpret_cast<const f32x4*>(xr + 16 + 4 * g);
+      const float* xr = (REF ? a.init : a.x_inout) + r * kCtrl2;
+      f32x4 q0 = *reinterpret_cast<const f32x4*>(xr + 4 * g);
+      f32x4 q1 = *reinterpret_cast<const f32x4*>(xr + 16 + 4 * g);
       f32x4 q2;
       if (own2) {
         q2 = *reinterpret_cast<const f32x4*>(xr + 32 + 4 * g);
@@ -289,6 +309,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       xq[(rt * 3 + 0) * 64] = q0;
       xq[(rt * 3 + 1) * 64] = q1;
       xq[(rt * 3 + 2) * 64] = q2;
+      add_pooled(r, q0, q1, q2);
       make_x_pieces(rt, q0, q1, q2);
       if (!MU && a.n_emit >= a.steps && a.step_hi == a.steps - 1 && row0 + 16 * rt + col <= last_row) {   // x_T is entry 0 of the full list
         const f32x4 sc = f32x4{a.w_max, a.a_max, a.w_max, a.a_max};
@@ -751,6 +772,15 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 3; ++j) qv[rt][j] = xq[(rt * 3 + j) * 64];
+    float vio[RT];   // REF: 1 where the row's score says "violated" (only those rows are refined), on its way like qv
+    if constexpr (REF) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        long r = row0 + 16 * rt + col;
+        if (r > last_row) r = last_row;
+        vio[rt] = a.scores[r];
+      }
+    }
     if (!(PSTL_C2_ABL & 64)) static_for<NCONV>([&](auto i_tag) { conv_step(accB, i_tag); });
     if constexpr (MU) {
       // the next tile's state, straight into this wave's image (its reads above have returned): per row tile three 16-byte
@@ -767,7 +797,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
           if (tb0 > last_row) tb0 = last_row;
           const unsigned rem = (unsigned)(last_row - tb0);
           const unsigned lr = lc < rem ? lc : rem;                     // rows behind the end repeat the last one
-          const float* xb = a.x_inout + tb0 * kCtrl2;
+          const float* xb = (REF ? a.init : a.x_inout) + tb0 * kCtrl2;
           const unsigned voff = lr * (unsigned)(kCtrl2 * 4) + lg * 16u;
           const unsigned dst = (unsigned)kOffXq + (unsigned)((w * RT * 3 + rt * 3) * 64) * 16u;
           dma16(xb, voff, dst);
@@ -803,6 +833,24 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         f32x4 q = qv[rt][j];
+        if constexpr (REF) {
+          // interval head (nusc_model.py:212-229): the tanh of the output scales into the headroom init leaves
+          const float viol = vio[rt] < 0.0f ? 1.0f : 0.0f;
+          f32x4 o, v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = acc3[j][rt][e] * kInvAcc;
+            const float raw = tanhf(o[e]);
+            const float d = raw >= 0.0f ? raw * (sc[e] - q[e]) : raw * (q[e] - (-sc[e]));
+            v[e] = q[e] + d * viol;
+            if (a.clip) v[e] = clip_keep_nan(v[e], sc[e]);
+          }
+          if ((j < 2 || own2) && (unsigned)row0 + 16u * (unsigned)rt + lc <= (unsigned)last_row &&
+              !(fabsf((o[0] + o[1]) + (o[2] + o[3])) <= 3.0e38f))
+            atomicOr(a.status, 1u);
+          xn[rt][j] = v;
+          continue;
+        }
         if constexpr (!RNG) {
           const bool upd = j < 2 || own2;
           const unsigned trow0 = (unsigned)row0 + 16u * (unsigned)rt;
@@ -831,8 +879,8 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
           if ((j < 2 || own2) && in) {
             const f32x4 v0 = xn[rt][j];
             if (last) {
-              *reinterpret_cast<f32x4*>((a.x_inout + (long)trow0 * kCtrl2) + loff) = v0;
-              if (!(fabsf((v0[0] + v0[1]) + (v0[2] + v0[3])) <= 3.0e38f)) atomicOr(a.status, 1u);
+              *reinterpret_cast<f32x4*>(((REF ? a.out : a.x_inout) + (long)trow0 * kCtrl2) + loff) = v0;
+              if (!REF && !(fabsf((v0[0] + v0[1]) + (v0[2] + v0[3])) <= 3.0e38f)) atomicOr(a.status, 1u);
             }
             if (emit) {
               f32x4 v = v0 * sc;
@@ -857,13 +905,17 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
         for (int rt = 0; rt < RT; ++rt) {
           // (the last tile of the workgroup makes pieces of whatever its image holds -- nobody uses them: an `if (more)` around
           // this would leave the old pieces live through the whole tile-step as far as the register allocator can tell)
-          const f32x4 q0 = xq[(rt * 3 + 0) * 64], q1 = xq[(rt * 3 + 1) * 64];
+          f32x4 q0 = xq[(rt * 3 + 0) * 64], q1 = xq[(rt * 3 + 1) * 64];
           f32x4 q2 = xq[(rt * 3 + 2) * 64];
           const f32x4 rc = f32x4{rcw[(rt * 4 + 0) * 64], rcw[(rt * 4 + 1) * 64], rcw[(rt * 4 + 2) * 64], rcw[(rt * 4 + 3) * 64]};
           if (!own2) q2 = f32x4{rc[0], rc[1], rc[2], g == 2 ? rc[3] : 0.0f};
           FENCE();
           store_tile(rt);
           FENCE();
+          if constexpr (REF) {
+            long r = nwg_row0 + (long)w * (16 * RT) + 16 * rt + col;
+            add_pooled(r > last_row ? last_row : r, q0, q1, q2);
+          }
           make_x_pieces(rt, q0, q1, q2);
           FENCE();
         }
@@ -917,21 +969,22 @@ bool chain2_eligible(const ChainArgs& a) {
 // 12.55 ms per 39-step launch), 20.8 against 26.8 at 196 608 rows (profiles/r5/chain2_192_row_workgroups.txt)
 constexpr int kCost192 = 82;
 
-template <bool RNG, bool MU, int RT>
+template <bool RNG, int MODE, int RT>
 static int launch_chain2_t(const ChainArgs& a, hipStream_t st) {
+  constexpr bool MU = MODE != 0;
   long n_wg = (a.N + Carve<RT>::kWgRows - 1) / Carve<RT>::kWgRows;
   static int allowed_dev = -1, cus = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return PSTL_ERR_LAUNCH;
   if (allowed_dev != dev) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<RNG, MU, RT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<RNG, MODE, RT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             Carve<RT>::kLdsBytes) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       return PSTL_ERR_LAUNCH;
     allowed_dev = dev;
   }
   if (MU && n_wg > cus) n_wg = cus;   // one workgroup per CU walks the tiles
-  hipLaunchKernelGGL((k_chain2<RNG, MU, RT>), dim3((unsigned)n_wg), dim3(256), Carve<RT>::kLdsBytes, st, a);
+  hipLaunchKernelGGL((k_chain2<RNG, MODE, RT>), dim3((unsigned)n_wg), dim3(256), Carve<RT>::kLdsBytes, st, a);
   return launch_status();
 }
 
@@ -970,11 +1023,28 @@ int launch_chain2(const ChainArgs& a, hipStream_t st) {
   // is handled in the epilogue
   if (a.mu_only) {
     const int rows = chain2_wg_rows(a);
-    return rows == 128 ? launch_chain2_t<false, true, 2>(a, st) : rows == 192 ? launch_chain2_t<false, true, 3>(a, st)
-                                                                                 : launch_chain2_t<false, true, 4>(a, st);
+    return rows == 128 ? launch_chain2_t<false, 1, 2>(a, st) : rows == 192 ? launch_chain2_t<false, 1, 3>(a, st)
+                                                                             : launch_chain2_t<false, 1, 4>(a, st);
   }
-  if (chain2_wg_rows(a) == 192) return a.rng ? launch_chain2_t<true, false, 3>(a, st) : launch_chain2_t<false, false, 3>(a, st);
-  return a.rng ? launch_chain2_t<true, false, 4>(a, st) : launch_chain2_t<false, false, 4>(a, st);
+  if (chain2_wg_rows(a) == 192) return a.rng ? launch_chain2_t<true, 0, 3>(a, st) : launch_chain2_t<false, 0, 3>(a, st);
+  return a.rng ? launch_chain2_t<true, 0, 4>(a, st) : launch_chain2_t<false, 0, 4>(a, st);
+}
+
+// RefineNet's inference pass (k_chain's REFINE launches without saved activations): the tile-walking form with rect_net's
+// weights and the interval head.  Rows per workgroup as for the single-step denoiser launches.
+bool chain2_refine_eligible(const ChainArgs& a) {
+  if (!a.init || !a.out || !a.scores || a.h1_save || a.h2_save || a.pre_save) return false;
+  if (a.rows_per_scene % 16 != 0 || a.rows_per_scene < 48) return false;
+  if (a.pooled && (a.S <= 0 || a.n_shards <= 0 || a.rows_per_scene != 3 * a.S || a.S % a.n_shards != 0)) return false;
+  return true;
+}
+
+int launch_chain2_refine(const ChainArgs& a0, hipStream_t st) {
+  ChainArgs a = a0;
+  a.mu_only = 1, a.step_hi = a.step_lo = 1;   // (one evaluation per row; the row-tile choice of the single-step form)
+  const int rows = chain2_wg_rows(a);
+  return rows == 128 ? launch_chain2_t<false, 2, 2>(a, st) : rows == 192 ? launch_chain2_t<false, 2, 3>(a, st)
+                                                                           : launch_chain2_t<false, 2, 4>(a, st);
 }
 
 }  // namespace pstl

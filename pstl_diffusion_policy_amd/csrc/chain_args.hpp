@@ -76,5 +76,7 @@ bool chain2_eligible(const ChainArgs& a);
 int chain2_wg_rows(const ChainArgs& a);   // rows per workgroup the launch would use: 256; 192 for some multi-step, 128 for some single-step launches
 long chain2_step_cost(const ChainArgs& a);  // a reverse step of the launch, in per cent of one 256-row tile-step (rounds x the tile's cost)
 int launch_chain2(const ChainArgs& a, hipStream_t st);
+bool chain2_refine_eligible(const ChainArgs& a);   // RefineNet's inference pass (init / pooled / scores / out set, nothing saved)
+int launch_chain2_refine(const ChainArgs& a, hipStream_t st);
 
 }  // namespace pstl

@@ -1740,6 +1740,9 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
     if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(a.N, a.step_hi == a.step_lo))) && chain2_eligible(a))
       return launch_chain2(a, st);
   }
+  if constexpr (REFINE) {   // RefineNet's inference pass: k_chain2's tile-walking form, for the batches its single-step form takes
+    if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(a.N, true))) && chain2_refine_eligible(a)) return launch_chain2_refine(a, st);
+  }
   if (chain_waves == 16 || chain_waves == 2) chain_waves = 0;
   if (REFINE && chain_waves == 32) chain_waves = 8;    // bf16 pieces cost the interval head up to 9e-5 per pass
   if (REFINE && a.h1_save && chain_waves != 0) chain_waves = chain_waves == 4 ? 4 : 8;   // (no bf16-piece training forward)

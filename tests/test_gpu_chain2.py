@@ -332,3 +332,38 @@ def test_chain2_192_row_workgroups(dev):
     assert torch.equal(outs["half"][0], outs["full"][0][:half.N]) and torch.equal(outs["half"][1], outs["full"][1][:, :half.N])
     d = (outs["half"][0] - outs["half_k_chain"][0]).abs().max().item()
     assert 0.0 < d <= 2e-5, d
+
+
+@pytest.mark.parametrize("diverse,clip_rect", [(True, False), (False, True), (True, True)])
+def test_chain2_refine_form_against_k_chain(dev, diverse, clip_rect):
+    """RefineNet's inference pass on k_chain2 (tile-walking form, rect_net's weights, init + pooled as input, the tanh interval
+    head): against k_chain's on the same inputs (two summation orders of the same products: <= 1e-5 in physical controls of up to 5;
+    observed 3e-6), rows the
+    scores call satisfied are returned untouched in both, and a shard evaluated alone (one tile per workgroup, 128-row workgroups)
+    reproduces the rows of the whole batch (three 256-row tiles walked per CU) bit for bit -- the pooled maxima are per scene, so a
+    scene-aligned shard sees the same ones."""
+    from pstl_diffusion_policy_amd.engine import Sampler, SceneBatch
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("sized for 256 CUs")
+    hp, scene, w, sb = _setup(dev, 1024, 64, 2, seed=23)
+    g = torch.Generator(device=dev).manual_seed(9)
+    sc4 = torch.tensor([hp["mul_w_max"], hp["mul_a_max"]], device=dev).repeat(20)
+    init = (torch.rand(sb.N, 40, device=dev, generator=g) * 2 - 1) * sc4 * 0.9
+    scores = torch.randn(sb.N, device=dev, generator=g)
+    outs = []
+    for cw in (16, 2):
+        sm = Sampler(w, hp, chain_waves=cw)
+        _, _, base_r = sm.encode(sb, need_rect=True)
+        outs.append(sm.refine(sb, base_r, init, scores, diverse=diverse, clip_rect=clip_rect))
+        assert not w.chain_overflowed()
+    d = (outs[0] - outs[1]).abs().max().item()
+    assert 0.0 < d <= 1e-5, d
+    keep = scores >= 0
+    assert torch.equal(outs[1][keep], init[keep]) or clip_rect
+    sm = Sampler(w, hp, chain_waves=2)
+    lo, hi = 300, 428
+    sub = SceneBatch({k: v[lo:hi].clone() for k, v in scene.items()}, 64, hp, dev)
+    _, _, base_s = sm.encode(sub, need_rect=True)
+    r0, r1 = lo * 192, hi * 192
+    part = sm.refine(sub, base_s, init[r0:r1].contiguous(), scores[r0:r1].contiguous(), diverse=diverse, clip_rect=clip_rect)
+    assert torch.equal(part, outs[1][r0:r1])
