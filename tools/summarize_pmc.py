@@ -24,8 +24,10 @@ def short(name):
     elif "k_chain2" in name:      # the row-stationary kernel (round 5), <RNG, MU>: <true, false> draws its noise itself,
         # <false, true> is the single-step (mu-only) form whose workgroups walk the tiles
         # (a third parameter since the round's last third: row tiles per wave -- 4 at the default bench's size)
-        n = "k_chain2<%s>" % ("rng" if "k_chain2<true, false" in name else "single_step" if "k_chain2<false, true" in name
-                              else "noise_in")
+        # (<RNG, MODE, RT>: MODE 0 multi-step, 1 single-step, 2 RefineNet; earlier builds of the round: <RNG, MU[, RT]>)
+        n = "k_chain2<%s>" % ("rng" if re.search(r"k_chain2<true, (0|false)", name) else
+                              "single_step" if re.search(r"k_chain2<false, (1|true)", name) else
+                              "refine" if "k_chain2<false, 2" in name else "noise_in")
     elif "k_chain" in name:
         n = "k_chain<8,%s>" % ("true" if "k_chain<8, true" in name else "false")
     return n
