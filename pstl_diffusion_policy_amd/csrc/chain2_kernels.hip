@@ -1,6 +1,9 @@
-// chain2_kernels.hip -- k_chain2: the multi-step denoiser launch (policy_net, reverse diffusion A3-A5) with the ROWS
-// stationary and the WEIGHTS streamed.  Same arithmetic as k_chain's default form (mlp_kernels.hip: every fp32 operand as
-// two IEEE-half pieces, three v_mfma_f32_16x16x32_f16 products per fp32 product, fp32 accumulation), other dataflow:
+// chain2_kernels.hip -- k_chain2<RNG, MODE, RT>: the MLP chain of large batches with the ROWS stationary and the WEIGHTS
+// streamed -- MODE 0: the multi-step denoiser launch (policy_net, reverse diffusion A3-A5); 1: the guided phase's single-step
+// launches (mu only), one workgroup per CU walking the tiles; 2: RefineNet's inference pass (A11) in that tile-walking form.
+// Same arithmetic as k_chain's default form (mlp_kernels.hip: every fp32 operand as two IEEE-half pieces, three
+// v_mfma_f32_16x16x32_f16 products per fp32 product, fp32 accumulation), other dataflow (described for RT = 4 row tiles per
+// wave = 256 rows per workgroup; RT = 3 and 2 are built for batches those would leave CUs or rounds part empty):
 //
 //  * One workgroup = 4 waves, one per SIMD (up to 512 registers each), owns 256 rows for ALL reverse steps of the launch.
 //    A wave owns 64 rows (four 16-row tiles) and all 256 hidden features.  The ReLU'd, split layer-1 output of its rows --
@@ -16,7 +19,8 @@
 //    sched_barrier(0) (the compiler allocates registers, counts LDS waits and pads hazards; left to choose the order it
 //    puts a chunk's ~170 conversion instructions in front of the MFMAs they should hide under).
 //
-// Reference: nusc_model.py:97-180 (Net.forward, diffusion branch), nusc_train.py:557-587,628-655 (diffusion_rollout).
+// Reference: nusc_model.py:97-180 (Net.forward, diffusion branch), nusc_train.py:557-587,628-655 (diffusion_rollout),
+// nusc_model.py:182-235 (Net.rect_forward).
 // Built with -mllvm -amdgpu-mfma-vgpr-form (accumulators in the architectural half: the accumulation half is full).
 #include <type_traits>
 #include <utility>
@@ -35,8 +39,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-// RT = 16-row tiles per wave (template parameter of the kernel): 4 -- 256 rows per workgroup -- everywhere but in the single-step
-// form of batches that would leave CUs idle with 256-row tiles, which takes 2 (128 rows per workgroup)
+// RT = 16-row tiles per wave (template parameter of the kernel): 4 -- 256 rows per workgroup -- unless fewer fill the chip better
+// (chain2_wg_rows: 3 for some multi-step and tile-walking launches, 2 for tile-walking launches of 20 480 ... 40 960 rows)
 constexpr int kCtrl2 = 40, kHid2 = 256;
 constexpr int kSlotBytes = 22 * 1024, kRing = 3;
 constexpr int kMaxScn = 7;                 // scenes a workgroup's 256 rows may touch (rows_per_scene >= 48)
