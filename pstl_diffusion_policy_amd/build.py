@@ -34,16 +34,22 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(HERE, "..", "include", "pstl_hip.h"))
-    objs = []
-    for src, extra in UNITS:
+    objs, running = [], []
+    for src, extra in UNITS:      # the units compile side by side (chain2_kernels.hip alone is ~100 s: nine instantiations)
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _newer(o, [s] + headers):
             cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            running.append((cmd, subprocess.Popen(cmd)))
         objs.append(o)
+    for cmd, proc in running:
+        if proc.wait() != 0:
+            for _, other in running:      # (only the children started here; never by pattern)
+                if other.poll() is None:
+                    other.kill()
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
     if force or _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + LINK_LIBS + ["-o", LIB]
         if verbose:
