@@ -361,9 +361,9 @@ def test_chain2_refine_form_against_k_chain(dev, diverse, clip_rect):
     keep = scores >= 0
     assert torch.equal(outs[1][keep], init[keep]) or clip_rect
     sm = Sampler(w, hp, chain_waves=2)
-    lo, hi = 300, 428
-    sub = SceneBatch({k: v[lo:hi].clone() for k, v in scene.items()}, 64, hp, dev)
-    _, _, base_s = sm.encode(sub, need_rect=True)
-    r0, r1 = lo * 192, hi * 192
-    part = sm.refine(sub, base_s, init[r0:r1].contiguous(), scores[r0:r1].contiguous(), diverse=diverse, clip_rect=clip_rect)
-    assert torch.equal(part, outs[1][r0:r1])
+    for lo, hi in ((300, 428), (500, 756)):      # 24 576 rows: 128-row workgroups; 49 152 rows: 192-row workgroups
+        sub = SceneBatch({k: v[lo:hi].clone() for k, v in scene.items()}, 64, hp, dev)
+        _, _, base_s = sm.encode(sub, need_rect=True)
+        r0, r1 = lo * 192, hi * 192
+        part = sm.refine(sub, base_s, init[r0:r1].contiguous(), scores[r0:r1].contiguous(), diverse=diverse, clip_rect=clip_rect)
+        assert torch.equal(part, outs[1][r0:r1]), (lo, hi)
