@@ -171,7 +171,7 @@ __device__ __forceinline__ float clip_keep_nan(float v, float m) { return v < -m
 // and the tanh interval head instead of the DDPM update; the image keeps init, which the head needs again.
 template <bool RNG, int MODE, int RT>
 __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
-  constexpr bool MU = MODE != 0, REF = MODE == 2;
+  constexpr bool MU = MODE != 0, REF = MODE >= 2, SAVE = MODE == 3;   // (3: the training forward pass -- REF + saved activations)
   static_assert(RT == 4 || RT == 3 || (RT == 2 && MU && !RNG), "see noise_l3 / noise_b: chunk pair p draws row tile p's noise");
   typedef Carve<RT> C;
   constexpr int kWgRows = C::kWgRows, kOffXq = C::kOffXq, kOffCrow = C::kOffCrow, kOffBrow = C::kOffBrow, kOffB2 = C::kOffB2,
@@ -416,11 +416,29 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   };
   // conversion of a layer-1 chunk in the shadow of 48 slots: 3 steps in each of the first four slots, 2 in the others (96 in
   // 46 slots), and its pieces pinned as soon as a row tile's words are done (hi words: step 24 rt + 19, lo: 24 rt + 23)
+  // SAVE: quad g = 2 rt + t of chunk c -- the fp32 outputs relu(acc) / kAcc of features 16 (2 c + t) + 4 g .. + 3 of this lane's
+  // row of row tile rt -- goes to the activation buffer the backward pass reads (k_chain's save_hidden), in the slot in which its
+  // conversion starts (conversion group g = steps 12 g ..: the accumulators are whole until the next chunk's preloads)
+  auto save_quad = [&](float* buf, auto& S, int c, auto g_tag) {
+    if constexpr (SAVE) {
+      constexpr int gq = decltype(g_tag)::value, t = gq & 1, rt = gq >> 1;
+      const unsigned ln = here((unsigned)lane);
+      const unsigned trow0 = (unsigned)row0 + 16u * (unsigned)rt;
+      if (trow0 + (ln & 15u) <= (unsigned)last_row) {
+        const f32x4 v = S[t][rt];
+        f32x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = fmaxf(v[e], 0.0f) * kInvAcc;
+        *reinterpret_cast<f32x4*>((buf + (long)trow0 * kHid2) + ((ln & 15u) * (unsigned)kHid2 + (unsigned)(16 * (2 * c + t)) + 4u * (ln >> 4))) = h;
+      }
+    }
+  };
   auto conv_h1_slot = [&](auto& S, auto kb_tag, auto slot_tag) {
     constexpr int slot = decltype(slot_tag)::value;
     constexpr int first = slot < 4 ? 3 * slot : 12 + 2 * (slot - 4), cnt = slot < 4 ? 3 : 2;
     static_for<cnt>([&](auto u) {
       constexpr int i = first + decltype(u)::value;
+      if constexpr (SAVE && i < NCONV && i % 12 == 0) save_quad(a.h1_save, S, decltype(kb_tag)::value, Ic<i / 12>{});
       if constexpr (i < NCONV) conv_step(S, Ic<i>{});
     });
     static_for<RT>([&](auto rt_tag) {
@@ -631,7 +649,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   // ---- a layer-2 phase on D (chunk c, half HALF).  CONV 1: the layer-2 chunk before (S) is converted in its shadow and its
   // layer 3 follows the fourth k-block; CONV 2: S is layer 1's last chunk (pieces -> k-block 7 of h1).
   auto l2_phase = [&](auto& D, auto& S, auto half_tag, auto conv_tag, auto&& l3_fn, auto kind_tag, auto np_tag, int c_issue,
-                      int c3_issue, int c_bias, auto&& mid, auto&& slot_fn) {
+                      int c3_issue, int c_bias, auto&& mid, auto&& slot_fn, int c_conv = 0) {
     constexpr int HALF = decltype(half_tag)::value;
     constexpr int CONV = decltype(conv_tag)::value;
     FENCE();
@@ -647,6 +665,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
         common_fill(kq_tag, m_tag, kind_tag, np_tag, c_issue, c3_issue);
         if constexpr (CONV == 1 && !(PSTL_C2_ABL & 4)) {
           constexpr int i0 = 2 * (kq * NM + m);
+          if constexpr (SAVE && i0 < NCONV && i0 % 12 == 0) save_quad(a.h2_save, S, c_conv, Ic<i0 / 12>{});
           if constexpr (i0 < NCONV) conv_step(S, Ic<i0>{});
           if constexpr (i0 + 1 < NCONV) conv_step(S, Ic<i0 + 1>{});
         }
@@ -748,23 +767,23 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc3[j][rt] = *reinterpret_cast<const f32x4*>(b3s + 16 * j + 4 * g);
-    l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(0, Yes{}, k_); }, Ic<1>{}, Ic<6>{}, 2, 1, 0, none, noslot);   // A(1): layer 3 of chunk 0
+    l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(0, Yes{}, k_); }, Ic<1>{}, Ic<6>{}, 2, 1, 0, none, noslot, 0);   // A(1): layer 3 of chunk 0
     l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, 2, 0, 2, none, [&](auto s_) { noise_b(0, Yes{}, s_); });
     C2_STAMP(2)
 #pragma unroll 1
     for (int cc = 2; cc < 6; cc += 2) {
-      l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(cc >> 1, No{}, k_); }, Ic<1>{}, Ic<6>{}, cc + 1, cc, 0, none, noslot);
+      l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(cc >> 1, No{}, k_); }, Ic<1>{}, Ic<6>{}, cc + 1, cc, 0, none, noslot, cc - 1);
       C2_STAMP(3)
       l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, cc + 1, 0, cc + 1, none, [&](auto s_) { noise_b(cc >> 1, No{}, s_); });
       C2_STAMP(4)
-      l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(cc >> 1, Yes{}, k_); }, Ic<1>{}, Ic<6>{}, cc + 2, cc + 1, 0, none, noslot);
+      l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, [&](auto k_) { noise_l3(cc >> 1, Yes{}, k_); }, Ic<1>{}, Ic<6>{}, cc + 2, cc + 1, 0, none, noslot, cc);
       C2_STAMP(3)
       l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, cc + 2, 0, cc + 2, none, [&](auto s_) { noise_b(cc >> 1, Yes{}, s_); });
       C2_STAMP(4)
     }
-    l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, [&](auto k_) { if constexpr (RT > 3) noise_l3(3, No{}, k_); }, Ic<1>{}, Ic<6>{}, 7, 6, 0, load_nbase, noslot);    // A(6); issues A(7) + W3[6]
+    l2_phase(accA, accB, Ic<0>{}, Ic<1>{}, [&](auto k_) { if constexpr (RT > 3) noise_l3(3, No{}, k_); }, Ic<1>{}, Ic<6>{}, 7, 6, 0, load_nbase, noslot, 5);    // A(6); issues A(7) + W3[6]
     l2_phase(accA, accB, Ic<1>{}, Ic<0>{}, noslot, Ic<2>{}, Ic<4>{}, 7, 0, 7, write_ncrow, [&](auto s_) { if constexpr (RT > 3) noise_b(3, No{}, s_); });
-    l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, [&](auto k_) { if constexpr (RT > 3) noise_l3(3, Yes{}, k_); }, Ic<0>{}, Ic<6>{}, 0, 7, 0, none, noslot);    // A(7); issues P0 of the next step + W3[7]
+    l2_phase(accB, accA, Ic<0>{}, Ic<1>{}, [&](auto k_) { if constexpr (RT > 3) noise_l3(3, Yes{}, k_); }, Ic<0>{}, Ic<6>{}, 0, 7, 0, none, noslot, 6);    // A(7); issues P0 of the next step + W3[7]
     l2_phase(accB, accA, Ic<1>{}, Ic<0>{}, noslot, Ic<0>{}, Ic<4>{}, 1, 0, 0, none, [&](auto s_) { if constexpr (RT > 3) noise_b(3, Yes{}, s_); });    // B(7); issues P1 of the next step
     C2_STAMP(5)
     // tail: layer 3 of chunk 7.  Its W3 blocks sit in the slot of the NEXT tile-step's first phase (s_cur now): landed and
@@ -785,6 +804,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
         vio[rt] = a.scores[r];
       }
     }
+    if constexpr (SAVE) static_for<2 * RT>([&](auto g_tag) { save_quad(a.h2_save, accB, 7, g_tag); });
     if (!(PSTL_C2_ABL & 64)) static_for<NCONV>([&](auto i_tag) { conv_step(accB, i_tag); });
     if constexpr (MU) {
       // the next tile's state, straight into this wave's image (its reads above have returned): per row tile three 16-byte
@@ -849,9 +869,12 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
             v[e] = q[e] + d * viol;
             if (a.clip) v[e] = clip_keep_nan(v[e], sc[e]);
           }
-          if ((j < 2 || own2) && (unsigned)row0 + 16u * (unsigned)rt + lc <= (unsigned)last_row &&
-              !(fabsf((o[0] + o[1]) + (o[2] + o[3])) <= 3.0e38f))
-            atomicOr(a.status, 1u);
+          if ((j < 2 || own2) && (unsigned)row0 + 16u * (unsigned)rt + lc <= (unsigned)last_row) {
+            if (!(fabsf((o[0] + o[1]) + (o[2] + o[3])) <= 3.0e38f)) atomicOr(a.status, 1u);
+            if constexpr (SAVE)   // layer 3's output before the tanh (the backward pass's `pre`)
+              *reinterpret_cast<f32x4*>((a.pre_save + (long)((unsigned)row0 + 16u * (unsigned)rt) * kCtrl2) +
+                                        (lc * (unsigned)kCtrl2 + (unsigned)(16 * j) + 4u * lg)) = o;
+          }
           xn[rt][j] = v;
           continue;
         }
@@ -1037,7 +1060,9 @@ int launch_chain2(const ChainArgs& a, hipStream_t st) {
 // RefineNet's inference pass (k_chain's REFINE launches without saved activations): the tile-walking form with rect_net's
 // weights and the interval head.  Rows per workgroup as for the single-step denoiser launches.
 bool chain2_refine_eligible(const ChainArgs& a) {
-  if (!a.init || !a.out || !a.scores || a.h1_save || a.h2_save || a.pre_save) return false;
+  if (!a.init || !a.out || !a.scores) return false;
+  const int saves = (a.h1_save != nullptr) + (a.h2_save != nullptr) + (a.pre_save != nullptr);
+  if (saves != 0 && saves != 3) return false;   // inference, or the training forward pass with all three buffers
   if (a.rows_per_scene % 16 != 0 || a.rows_per_scene < 48) return false;
   if (a.pooled && (a.S <= 0 || a.n_shards <= 0 || a.rows_per_scene != 3 * a.S || a.S % a.n_shards != 0)) return false;
   return true;
@@ -1047,6 +1072,9 @@ int launch_chain2_refine(const ChainArgs& a0, hipStream_t st) {
   ChainArgs a = a0;
   a.mu_only = 1, a.step_hi = a.step_lo = 1;   // (one evaluation per row; the row-tile choice of the single-step form)
   const int rows = chain2_wg_rows(a);
+  if (a.h1_save)
+    return rows == 128 ? launch_chain2_t<false, 3, 2>(a, st) : rows == 192 ? launch_chain2_t<false, 3, 3>(a, st)
+                                                                             : launch_chain2_t<false, 3, 4>(a, st);
   return rows == 128 ? launch_chain2_t<false, 2, 2>(a, st) : rows == 192 ? launch_chain2_t<false, 2, 3>(a, st)
                                                                            : launch_chain2_t<false, 2, 4>(a, st);
 }

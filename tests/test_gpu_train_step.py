@@ -9,25 +9,30 @@ from conftest import golden_weights, hparams_for, load_golden, scene_from_golden
 pytestmark = pytest.mark.gpu
 
 
-def _setup(d, dev):
+def _setup(d, dev, chain_waves=0):
     from pstl_diffusion_policy_amd.engine import PackedWeights, RectTrainer, SceneBatch, Sampler
     from pstl_diffusion_policy_amd.synthetic import default_hparams
     bs, S, K, steps, seed, mc = [int(v) for v in d["meta"]]
     hp = hparams_for(d)
     sd = {k: torch.from_numpy(v).to(dev) for k, v in golden_weights(d).items()}
-    sm = Sampler(PackedWeights(sd, dev), hp)
+    sm = Sampler(PackedWeights(sd, dev), hp, chain_waves=chain_waves)
     sb = SceneBatch({k: torch.from_numpy(v) for k, v in scene_from_golden(d).items()}, S, hp, dev)
     return sm, sb, sd, RectTrainer(sm)
 
 
 # train_e8_heavy: rect_net with a trained network's dynamic range (tests/heavy_weights.py): the training forward pass runs
 # on the split-f16 chain too
+# chain_waves = 2: the training forward pass on k_chain2's tile-walking form (MODE 3: the saved activations h1, h2, pre written from
+# its conversions and its head), which large batches get by default
+@pytest.mark.parametrize("chain_waves", [0, 2])
 @pytest.mark.parametrize("name", ["train_e8_step", "train_e8_step_b", "train_e8_heavy", "train_e8_norm", "train_e8_trained"])
-def test_rect_train_step_matches_reference(name):
+def test_rect_train_step_matches_reference(name, chain_waves):
     dev = torch.device("cuda:0")
     d = load_golden(name)
     lr = float(d["meta_f"][0])
-    sm, sb, sd, tr = _setup(d, dev)
+    sm, sb, sd, tr = _setup(d, dev, chain_waves)
+    if chain_waves == 2 and sb.cfg(2).rows_per_scene % 16 != 0:
+        pytest.skip("k_chain2 takes scenes of a multiple of 16 rows")
     feature, _, base_r = sm.encode(sb)
     init = torch.from_numpy(d["sel_controls"]).reshape(sb.N, 40).to(dev)
     prev = torch.from_numpy(d["sel_scores"]).to(dev)
