@@ -18,7 +18,10 @@ UNITS = [("stl_kernels.hip", ["-ffp-contract=off", "-Xarch_device", "-mllvm=-mis
          ("mlp_kernels.hip", ["-Xarch_device", "-mllvm=-misched-prera-direction=topdown"]), ("train_kernels.hip", []),
          # chain2_kernels: one wave per SIMD with all 512 registers; the accumulation half holds the resident layer-1 output
          # (MFMA B operands), so the accumulators go to the architectural half ("VGPR form")
-         ("chain2_kernels.hip", ["-Xarch_device", "-mllvm=-amdgpu-mfma-vgpr-form"]),
+         # (compiled in three parts -- see the unit's PSTL_C2_PART: its twelve kernel instantiations take minutes in one piece)
+         ("chain2_kernels.hip", ["-Xarch_device", "-mllvm=-amdgpu-mfma-vgpr-form", "-DPSTL_C2_PART=0"], "chain2_kernels.o"),
+         ("chain2_kernels.hip", ["-Xarch_device", "-mllvm=-amdgpu-mfma-vgpr-form", "-DPSTL_C2_PART=1"], "chain2_kernels_p1.o"),
+         ("chain2_kernels.hip", ["-Xarch_device", "-mllvm=-amdgpu-mfma-vgpr-form", "-DPSTL_C2_PART=2"], "chain2_kernels_p2.o"),
          ("diversity_kernels.hip", ["-ffp-contract=off"]), ("stl_program.hip", ["-ffp-contract=off"])]
 LINK_LIBS = []   # no vendor BLAS: every kernel of the library is in csrc/
 
@@ -35,9 +38,10 @@ def build(force=False, verbose=True):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(HERE, "..", "include", "pstl_hip.h"))
     objs, running = [], []
-    for src, extra in UNITS:      # the units compile side by side (chain2_kernels.hip alone is ~100 s: nine instantiations)
+    for unit in UNITS:      # the units compile side by side
+        src, extra = unit[0], unit[1]
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, unit[2] if len(unit) > 2 else src.replace(".hip", ".o"))
         if force or _newer(o, [s] + headers):
             cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + extra + ["-c", s, "-o", o]
             if verbose:

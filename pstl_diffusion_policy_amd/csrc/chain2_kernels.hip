@@ -981,6 +981,20 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
 
 }  // namespace
 
+// The unit is compiled in three parts (build.py: -DPSTL_C2_PART=0 | 1 | 2; twelve instantiations of the kernel take minutes in one
+// piece): 0 = the multi-step forms and every host-side rule, 1 = the tile-walking forms of the denoiser's single steps and of
+// RefineNet's inference pass, 2 = RefineNet's training forward pass.  Undefined (tools/dbg builds): everything.
+#ifndef PSTL_C2_PART
+#define PSTL_C2_ALL 1
+#define PSTL_C2_PART -1
+#else
+#define PSTL_C2_ALL 0
+#endif
+int launch_chain2_walk(const ChainArgs& a, hipStream_t st, int rows);           // part 1
+int launch_chain2_refine_infer(const ChainArgs& a, hipStream_t st, int rows);   // part 1
+int launch_chain2_refine_train(const ChainArgs& a, hipStream_t st, int rows);   // part 2
+
+#if PSTL_C2_ALL || PSTL_C2_PART == 0
 bool chain2_eligible(const ChainArgs& a) {
   // multi-step segments, and the single-step launches of the guided phase (mu_only = 1) in the form whose workgroups walk
   // several tiles (one workgroup per 256 rows pays the prologue -- state, constant rows, the first two phases of the weight
@@ -991,6 +1005,8 @@ bool chain2_eligible(const ChainArgs& a) {
   if (a.step_hi - a.step_lo + 1 > kMaxLaunchSteps) return false;
   return true;
 }
+
+#endif
 
 // a 192-row tile-step in per cent of a 256-row one: 21.1 against 25.1 us at 786 432 rows (16 against 12 rounds: 13.17 against
 // 12.55 ms per 39-step launch), 20.8 against 26.8 at 196 608 rows (profiles/r5/chain2_192_row_workgroups.txt)
@@ -1015,6 +1031,7 @@ static int launch_chain2_t(const ChainArgs& a, hipStream_t st) {
   return launch_status();
 }
 
+#if PSTL_C2_ALL || PSTL_C2_PART == 0
 // Rows per workgroup of a launch.  Multi-step: 256.  Single-step (the workgroups walk tiles): 128 where that takes less time
 // per CU -- a 128-row tile-step is 0.6 of a 256-row one (16-17 against 26-29 us measured: each A operand read feeds half the
 // MFMAs), so it pays exactly where 256-row tiles would leave CUs idle: 24 576 rows are 96 tiles of 256 on 256 CUs or 192 of
@@ -1048,11 +1065,7 @@ long chain2_step_cost(const ChainArgs& a) {
 int launch_chain2(const ChainArgs& a, hipStream_t st) {
   // in-kernel noise (PSTL_FLAG_RNG) rides in the MFMA shadow; a caller's noise tensor (the parity tests) or no noise at all
   // is handled in the epilogue
-  if (a.mu_only) {
-    const int rows = chain2_wg_rows(a);
-    return rows == 128 ? launch_chain2_t<false, 1, 2>(a, st) : rows == 192 ? launch_chain2_t<false, 1, 3>(a, st)
-                                                                             : launch_chain2_t<false, 1, 4>(a, st);
-  }
+  if (a.mu_only) return launch_chain2_walk(a, st, chain2_wg_rows(a));
   if (chain2_wg_rows(a) == 192) return a.rng ? launch_chain2_t<true, 0, 3>(a, st) : launch_chain2_t<false, 0, 3>(a, st);
   return a.rng ? launch_chain2_t<true, 0, 4>(a, st) : launch_chain2_t<false, 0, 4>(a, st);
 }
@@ -1072,11 +1085,26 @@ int launch_chain2_refine(const ChainArgs& a0, hipStream_t st) {
   ChainArgs a = a0;
   a.mu_only = 1, a.step_hi = a.step_lo = 1;   // (one evaluation per row; the row-tile choice of the single-step form)
   const int rows = chain2_wg_rows(a);
-  if (a.h1_save)
-    return rows == 128 ? launch_chain2_t<false, 3, 2>(a, st) : rows == 192 ? launch_chain2_t<false, 3, 3>(a, st)
-                                                                             : launch_chain2_t<false, 3, 4>(a, st);
+  return a.h1_save ? launch_chain2_refine_train(a, st, rows) : launch_chain2_refine_infer(a, st, rows);
+}
+#endif
+
+#if PSTL_C2_ALL || PSTL_C2_PART == 1
+int launch_chain2_walk(const ChainArgs& a, hipStream_t st, int rows) {
+  return rows == 128 ? launch_chain2_t<false, 1, 2>(a, st) : rows == 192 ? launch_chain2_t<false, 1, 3>(a, st)
+                                                                           : launch_chain2_t<false, 1, 4>(a, st);
+}
+int launch_chain2_refine_infer(const ChainArgs& a, hipStream_t st, int rows) {
   return rows == 128 ? launch_chain2_t<false, 2, 2>(a, st) : rows == 192 ? launch_chain2_t<false, 2, 3>(a, st)
                                                                            : launch_chain2_t<false, 2, 4>(a, st);
 }
+#endif
+
+#if PSTL_C2_ALL || PSTL_C2_PART == 2
+int launch_chain2_refine_train(const ChainArgs& a, hipStream_t st, int rows) {
+  return rows == 128 ? launch_chain2_t<false, 3, 2>(a, st) : rows == 192 ? launch_chain2_t<false, 3, 3>(a, st)
+                                                                           : launch_chain2_t<false, 3, 4>(a, st);
+}
+#endif
 
 }  // namespace pstl

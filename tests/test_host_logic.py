@@ -82,7 +82,7 @@ def test_unknown_chain_arithmetic_is_refused():
     for v in ("108", "116", "708", "716", "1008"):
         assert "case %s:" % v in diag and "case %s:" % v not in body.replace(diag, "")
     from pstl_diffusion_policy_amd import build
-    assert not any("PSTL_DIAG" in f for _, fl in build.UNITS for f in fl)
+    assert not any("PSTL_DIAG" in f for unit in build.UNITS for f in unit[1])
 
 
 def test_missing_library_fails_loudly(monkeypatch):

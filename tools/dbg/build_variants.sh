@@ -15,7 +15,7 @@ for v in "$@"; do
   (
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $sched $flags \
       -c $c/mlp_kernels.hip -o $out/mlp_$n.o 2> $out/build_$n.log \
-    && hipcc --offload-arch=gfx950 -shared -fPIC $c/stl_kernels.o $out/mlp_$n.o $c/train_kernels.o $c/chain2_kernels.o $c/diversity_kernels.o \
+    && hipcc --offload-arch=gfx950 -shared -fPIC $c/stl_kernels.o $out/mlp_$n.o $c/train_kernels.o $c/chain2_kernels.o $c/chain2_kernels_p1.o $c/chain2_kernels_p2.o $c/diversity_kernels.o \
          $c/stl_program.o -o $out/libpstl_$n.so && rm -f $out/mlp_$n.o && echo "built $n" || { echo "FAILED $n"; tail -5 $out/build_$n.log; }
   ) &
   pids+=($!)

@@ -11,7 +11,7 @@ if [ "$1" = build ]; then
     n=${v%%:*}; f=${v#*:}
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Xarch_device -mllvm=-misched=gcn-iterative-ilp -DPSTL_G_ABL=$f \
       -c $c/stl_kernels.hip -o $out/stl_$n.o && \
-    hipcc --offload-arch=gfx950 -shared -fPIC $out/stl_$n.o $c/mlp_kernels.o $c/train_kernels.o $c/chain2_kernels.o $c/diversity_kernels.o \
+    hipcc --offload-arch=gfx950 -shared -fPIC $out/stl_$n.o $c/mlp_kernels.o $c/train_kernels.o $c/chain2_kernels.o $c/chain2_kernels_p1.o $c/chain2_kernels_p2.o $c/diversity_kernels.o \
       $c/stl_program.o -o $out/libpstl_g_$n.so && rm -f $out/stl_$n.o && echo built $n &
   done; wait
 else
