@@ -578,7 +578,7 @@ def main():
                                       "before=10,niters=1,lr=0.01" if guidance else None, rect_head),
                        "rows_per_gpu": N, "parallelism": "scene shards x%d, no data-path collective" % world,
                        "chain_waves": a.chain_waves,
-                       "noise": "in-kernel Philox4x32-10" if a.noise == "kernel" else "torch.randn tensors"},
+                       "noise": "in-kernel Philox4x32-7" if a.noise == "kernel" else "torch.randn tensors"},
             "stl_sat_rate": acc, "scene_sat_rate": sacc, "counts": [int(v) for v in counts.tolist()],
             "diversity": None if train else diversity_from_totals(div_totals),
             "roofline": {"bound": "mfma", "kernel": "%s (denoiser MLP chain, %d reverse steps per launch)" % (dom_kernel, nst),

@@ -210,7 +210,7 @@ int pstl_rollout_layout(const pstl_cfg* cfg, int multi_step, int* kernel, int* t
 
 
 /* out (N,40) = the N(0,1) values the kernels draw under PSTL_FLAG_RNG for reverse step `step` (step == cfg->steps
- * is the stream of the initial state x_T, reference nusc_train.py:563).  Philox4x32-10 + Box-Muller, a pure function of
+ * is the stream of the initial state x_T, reference nusc_train.py:563).  Philox4x32-7 (rng.hpp: kPhiloxRounds) + Box-Muller, a pure function of
  * (cfg->seed, cfg->row_offset + row, column, step). */
 int pstl_fill_normal(const pstl_cfg* cfg, int step, float* out, void* stream);
 

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
     });
   };
 
-  // ---- in-kernel noise (RNG): Philox4x32-10 + Box-Muller of rng.hpp (normal4: same operations, same bits), and
+  // ---- in-kernel noise (RNG): Philox4x32 (kPhiloxRounds) + Box-Muller of rng.hpp (normal4: same operations, same bits), and
   // Q = a x + sb z written over x in the wave's LDS image, as single-instruction-sized steps that ride beside the MFMAs of
   // layer 2 where no conversion runs (the second halves of its chunks and layer 3's k-blocks: noise_l3 / noise_b below): 64
   // steps per quad, 1.5 quads = 96 steps per chunk; chunk pair p does the three quads j = 0, 1, 2 of row tile p.
@@ -463,6 +463,8 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
   auto noise_sub = [&](int rt, auto j_tag, auto sub_tag) {
 #pragma clang fp contract(off)
     constexpr int j = decltype(j_tag)::value, sub = decltype(sub_tag)::value;
+    constexpr int R4 = 4 * kPhiloxRounds;   // four single-instruction steps per Philox round (rng.hpp), then 11 of Box-Muller and Q
+    static_assert(R4 + 11 < 64, "a quad's steps fit its 64 slots");
     const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
     const float k32 = 2.3283064365386963e-10f, c2 = -1.3862943611198906f;
     if constexpr (sub == 0) {
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
       const unsigned long long e = ((unsigned long long)a.row_offset + r) * 10u + (unsigned long long)(4 * j + (int)(ln >> 4));
       qx = (unsigned)e, qy = (unsigned)(e >> 32), qz = (unsigned)n_step, qw = 0x5053544Cu;
       qxv = xq[(rt * 3 + j) * 64];
-    } else if constexpr (sub <= 40) {
+    } else if constexpr (sub <= R4) {
       constexpr int r = (sub - 1) >> 2, ph = (sub - 1) & 3;
       const unsigned k0 = (unsigned)seed + (unsigned)r * W0, k1 = (unsigned)(seed >> 32) + (unsigned)r * W1;
       if constexpr (ph == 0) qp0 = (unsigned long long)M0 * qx;
@@ -482,32 +484,32 @@ __global__ __launch_bounds__(256) void k_chain2(ChainArgs a) {
         qz = (unsigned)(qp0 >> 32) ^ qw ^ k1;
         qx = qtx, qy = (unsigned)qp1, qw = (unsigned)qp0;
       }
-    } else if constexpr (sub == 41) {
+    } else if constexpr (sub == R4 + 1) {
       qu0 = ((float)qx + 1.0f) * k32;
-    } else if constexpr (sub == 42) {
+    } else if constexpr (sub == R4 + 2) {
       qu1 = (float)qy * k32;
-    } else if constexpr (sub == 43) {
+    } else if constexpr (sub == R4 + 3) {
       qu2 = ((float)qz + 1.0f) * k32;
-    } else if constexpr (sub == 44) {
+    } else if constexpr (sub == R4 + 4) {
       qu3 = (float)qw * k32;
-    } else if constexpr (sub == 45) {
+    } else if constexpr (sub == R4 + 5) {
       qr0 = __builtin_amdgcn_sqrtf(c2 * __builtin_amdgcn_logf(qu0));
-    } else if constexpr (sub == 46) {
+    } else if constexpr (sub == R4 + 6) {
       qr1 = __builtin_amdgcn_sqrtf(c2 * __builtin_amdgcn_logf(qu2));
-    } else if constexpr (sub == 47) {
+    } else if constexpr (sub == R4 + 7) {
       qzv[0] = qr0 * __builtin_amdgcn_cosf(qu1);
       qzv[1] = qr0 * __builtin_amdgcn_sinf(qu1);
-    } else if constexpr (sub == 48) {
+    } else if constexpr (sub == R4 + 8) {
       qzv[2] = qr1 * __builtin_amdgcn_cosf(qu3);
       qzv[3] = qr1 * __builtin_amdgcn_sinf(qu3);
-    } else if constexpr (sub == 49) {
+    } else if constexpr (sub == R4 + 9) {
       const float lsb = (j < 2 || own2) ? n_sb : 0.0f;
       qzv *= lsb;
-    } else if constexpr (sub == 50) {
+    } else if constexpr (sub == R4 + 10) {
       const float la = (j < 2 || own2) ? n_ca : 1.0f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) qzv[e] = __builtin_fmaf(la, qxv[e], qzv[e]);
-    } else if constexpr (sub == 51) {
+    } else if constexpr (sub == R4 + 11) {
       xq[(rt * 3 + j) * 64] = qzv;
     }
   };

@@ -1,4 +1,4 @@
-// rng.hpp -- counter-based normal noise for the reverse diffusion (Philox4x32-10 + Box-Muller).
+// rng.hpp -- counter-based normal noise for the reverse diffusion (Philox4x32-7 + Box-Muller).
 //
 // The reference draws its noise from torch's global generator (nusc_train.py:563,584), which cannot be reproduced
 // bit for bit on another device; parity tests therefore pass the noise in.  In production ("PSTL_FLAG_RNG") the
@@ -13,10 +13,18 @@ struct u32x4 {
   uint32_t x, y, z, w;
 };
 
-__host__ __device__ inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+// Rounds of the Philox4x32 bijection.  Round 6: 7 instead of 10 -- Philox4x32-7 is the variant Salmon et al. (SC'11, "Parallel
+// random numbers: as easy as 1, 2, 3", table 2) report as passing every test of BigCrush; 10 is their default with a margin.  The
+// rounds are a third of what the denoiser kernel issues beside its MFMAs per noise quad (csrc/chain2_kernels.hip: 52 -> 40
+// single-instruction steps), i.e. ~3 % of the dominant launch; the stream is this library's own (the reference draws from torch's
+// generator, which no other device reproduces), every consumer goes through this one constant, and tests/test_gpu_noise_quality.py
+// holds the drawn values to the moments and independence a sampler needs.
+constexpr int kPhiloxRounds = 7;
+
+__host__ __device__ inline u32x4 philox4x32(u32x4 c, uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < kPhiloxRounds; ++r) {
     const uint64_t p0 = (uint64_t)M0 * c.x, p1 = (uint64_t)M1 * c.z;
     u32x4 n;
     n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
@@ -48,7 +56,7 @@ __device__ inline float uniform_f32(const void* p) {
 __device__ inline void normal4(uint64_t seed, int64_t row, int quad, int step, float* out) {
 #pragma clang fp contract(off)
   const uint64_t e = (uint64_t)row * 10u + (uint64_t)quad;
-  const u32x4 r = philox4x32_10(u32x4{(uint32_t)e, (uint32_t)(e >> 32), (uint32_t)step, 0x5053544Cu}, (uint32_t)seed,
+  const u32x4 r = philox4x32(u32x4{(uint32_t)e, (uint32_t)(e >> 32), (uint32_t)step, 0x5053544Cu}, (uint32_t)seed,
                                 (uint32_t)(seed >> 32));
   const float k = 2.3283064365386963e-10f;  // 2^-32
   const float u0 = ((float)r.x + 1.0f) * k, u1 = (float)r.y * k;   // u0 in (0,1], u1 in [0,1]

@@ -56,6 +56,56 @@
 
 namespace pstl {
 
+// -DPSTL_STL_STAMP (diagnostic builds only; tools/dbg/stl_stamps.sh): PSTL_ST(k) books the shader cycles since the wave's previous
+// stamp to section k (s_memtime; lane 0 adds to a per-workgroup table in LDS, the kernel's tail adds that to a device table which
+// pstl_debug_stl_stamps hands out).  The one-wave-per-workgroup kernels only.  In every other build PSTL_ST(k) is nothing.
+#if defined(PSTL_STL_STAMP) && defined(__HIPCC__)
+constexpr int kStampSlots = 32;
+__device__ unsigned long long pstl_st_global[kStampSlots];
+#endif
+#if defined(PSTL_STL_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+__shared__ unsigned pstl_st_acc[kStampSlots];
+__shared__ unsigned pstl_st_last;
+__device__ __forceinline__ void pstl_st_begin() {
+  __builtin_amdgcn_sched_barrier(0);
+  if (threadIdx.x < kStampSlots) pstl_st_acc[threadIdx.x] = 0u;
+  const unsigned lo = (unsigned)__builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) pstl_st_last = lo;
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void pstl_st_mark(int k) {
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned lo = (unsigned)__builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) {
+    pstl_st_acc[k] += lo - pstl_st_last;
+    pstl_st_last = lo;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void pstl_st_end() {
+  __builtin_amdgcn_sched_barrier(0);
+  if (threadIdx.x < kStampSlots && pstl_st_acc[threadIdx.x]) atomicAdd(&pstl_st_global[threadIdx.x], (unsigned long long)pstl_st_acc[threadIdx.x]);
+  if (threadIdx.x == 0) atomicAdd(&pstl_st_global[kStampSlots - 1], 1ull);   // waves
+}
+#define PSTL_ST(k) pstl_st_mark(k)
+// (a value the section before the stamp produces: pinned in front of it, or the optimiser sinks the section's work to where the
+// value is used -- behind the stamp -- and books it to the wrong section)
+#define PSTL_ST_KEEP(x) asm volatile("" : "+v"(x))
+#define PSTL_ST_BEGIN() pstl_st_begin()
+#define PSTL_ST_END() pstl_st_end()
+#else
+#define PSTL_ST(k) ((void)0)
+#define PSTL_ST_KEEP(x) ((void)0)
+#define PSTL_ST_BEGIN() ((void)0)
+#define PSTL_ST_END() ((void)0)
+#endif
+// sections (tools/dbg/stl_stamps.py prints them under these names)
+enum {
+  ST_PROLOGUE = 0, ST_DYN = 1, ST_CLEAR = 2, ST_LANE_RANK = 3, ST_LANE_TAIL = 4, ST_LSE = 5, ST_FWD_FINISH = 6, ST_ADJ_HEAD = 7,
+  ST_ADJ_REDERIVE = 8, ST_ADJ_CLEAR = 9, ST_ADJ_LANE = 10, ST_ADJ_WEIGHTS = 11, ST_ADJ_COSTATE = 12, ST_EMIT = 13, ST_ZERO_EMIT = 14,
+  ST_OTHER = 15, ST_SELECT = 16
+};
+
 constexpr int kT = 20;        // horizon nt
 constexpr int kNseg = 15;     // lane waypoints
 constexpr int kFwin = 10;     // Eventually(0, nt//2)
@@ -72,6 +122,17 @@ constexpr int kScratchGradPre = 2 * kFwin;        // ... with the precomputed ge
 struct alignas(16) f4 {
   float x, y, z, w;
 };
+// a pair of floats the device compiler keeps in two adjacent registers and works on with the packed-fp32 instructions
+#if defined(__HIPCC__)
+typedef float v2f __attribute__((ext_vector_type(2)));
+#else
+struct v2f {
+  float x, y;
+};
+inline v2f operator-(v2f a, v2f b) { return v2f{a.x - b.x, a.y - b.y}; }
+inline v2f operator+(v2f a, v2f b) { return v2f{a.x + b.x, a.y + b.y}; }
+inline v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
+#endif
 
 // per-lane scratch: element i of this lane lives at p[i * stride]  (LDS: stride = blockDim.x, host: stride = 1)
 struct Scratch {
@@ -93,22 +154,27 @@ PSTL_HD void rec_clear(Rec& r) {
   r.ln[0] = r.ln[1] = r.ln[2] = 0u;
   r.cl[0] = r.cl[1] = r.cl[2] = r.cl[3] = r.cl[4] = 0u;
 }
-PSTL_HD void rec_put(Rec& r, int t, unsigned seg, unsigned win) {   // t dynamic: the words are picked by selects
-  const unsigned a = seg << (4 * (t & 7)), b = win << (8 * (t & 3));
-  const int wa = t >> 3, wb = t >> 2;
-  r.ln[0] |= wa == 0 ? a : 0u;
-  r.ln[1] |= wa == 1 ? a : 0u;
-  r.ln[2] |= wa == 2 ? a : 0u;
-  r.cl[0] |= wb == 0 ? b : 0u;
-  r.cl[1] |= wb == 1 ? b : 0u;
-  r.cl[2] |= wb == 2 ? b : 0u;
-  r.cl[3] |= wb == 3 ? b : 0u;
-  r.cl[4] |= wb == 4 ? b : 0u;
+// The record is two shift registers: every step's entry enters at the top and everything moves down by one entry (funnel
+// shifts: 3 + 5 instructions and two shift-ors per step; the "or into word t / 8" form it replaces picked its word with eight
+// selects).  rec_put must be called for t = 0 ... kT-1 in that order, exactly once each (stl_eval_rec does); afterwards step
+// t's clearance byte sits at bit 8 t of the 160-bit cl, its lane nibble at bit 16 + 4 t of the 96-bit ln.
+PSTL_HD unsigned funnel_shr(unsigned hi, unsigned lo, int sh) { return (lo >> sh) | (hi << (32 - sh)); }
+PSTL_HD void rec_put(Rec& r, int t, unsigned seg, unsigned win) {
+  (void)t;
+  r.ln[0] = funnel_shr(r.ln[1], r.ln[0], 4);
+  r.ln[1] = funnel_shr(r.ln[2], r.ln[1], 4);
+  r.ln[2] = (r.ln[2] >> 4) | (seg << 28);
+  r.cl[0] = funnel_shr(r.cl[1], r.cl[0], 8);
+  r.cl[1] = funnel_shr(r.cl[2], r.cl[1], 8);
+  r.cl[2] = funnel_shr(r.cl[3], r.cl[2], 8);
+  r.cl[3] = funnel_shr(r.cl[4], r.cl[3], 8);
+  r.cl[4] = (r.cl[4] >> 8) | (win << 24);
 }
 PSTL_HD unsigned rec_seg(const Rec& r, int t) {
-  const int wa = t >> 3;
+  static_assert(kT == 20, "the lane nibbles of 20 steps end at bit 16 of the 96-bit register");
+  const int bit = 16 + 4 * t, wa = bit >> 5;
   const unsigned x = wa == 0 ? r.ln[0] : (wa == 1 ? r.ln[1] : r.ln[2]);
-  return (x >> (4 * (t & 7))) & 15u;
+  return (x >> (bit & 31)) & 15u;
 }
 PSTL_HD unsigned rec_win(const Rec& r, int t) {
   const int wb = t >> 2;
@@ -167,19 +233,23 @@ PSTL_HD void prep_neighbor(const float* in, float* out) {
   out[11] = 0.0f;
 }
 
-// Prepared lane waypoint j of a 15-point lane: (x, y, heading, |w_j - w_{j+1}|) -- the length of the segment that starts
-// here (0 for the last point), computed with the very operations lane_eval used to spend per row and time step on it
-// (the segment is scene data: 20 x rows-per-scene evaluations shared one value).  `next` = waypoint j + 1 or null.
+// Prepared lane waypoint j of a 15-point lane: (x, y, heading, 1 / clamp(|w_j - w_{j+1}|, 1e-7)) -- the reciprocal of the
+// length of the segment that starts here; 0 for a segment of length 0 (an invalid lane's all-zero waypoints) and for the last
+// point.  The segment is scene data: 20 x rows-per-scene evaluations share the value.  Round 6: the reciprocal instead of the
+// length (round 4) -- compute_t2l_dist's `area / clamp(len, 1e-7)` is then one multiplication per row and step instead of an
+// IEEE division (~12 instructions); the product differs from the quotient by at most 1 ulp of a distance of a few metres.
+// `next` = waypoint j + 1 or null.
 PSTL_HD void prep_lane_point(const float* pt, const float* next, float* out) {
   out[0] = pt[0];
   out[1] = pt[1];
   out[2] = pt[2];
-  float bl = 0.0f;
+  float inv = 0.0f;
   if (next) {
     const float sx = pt[0] - next[0], sy = pt[1] - next[1];
-    bl = sqrtf(sx * sx + sy * sy);
+    const float bl = sqrtf(sx * sx + sy * sy);
+    if (bl != 0.0f) inv = 1.0f / fmaxf(bl, 1e-7f);
   }
-  out[3] = bl;
+  out[3] = inv;
 }
 
 PSTL_HD StlEnv make_env(float tau, float dt, float ego_L, float ego_W) {
@@ -201,10 +271,13 @@ struct Lse {
     s = 0.0f;
   }
   PSTL_HD void add(float a) {
-    const float hi = fmaxf(a, m);
-    const float e = PSTL_EXP(fminf(a, m) - hi);  // exp(-|a-m|); exp(-inf) = 0 on the first add
-    s = (a > m) ? (s * e + 1.0f) : (s + e);
-    m = hi;
+    // exp(-|a - m|) (exp(-inf) = 0 on the first add); the new maximum rescales the old sum, otherwise the term joins it.
+    // (the rescaling is one fused multiply-add -- the sum is a running one in any case, and torch.logsumexp's own
+    // order of summation is another)
+    const float d = a - m;
+    const float e = PSTL_EXP(-fabsf(d));
+    s = (d > 0.0f) ? __builtin_fmaf(s, e, 1.0f) : (s + e);
+    m = fmaxf(a, m);
   }
   PSTL_HD float value() const { return PSTL_LOG(s) + m; }
 };
@@ -217,6 +290,21 @@ PSTL_HD float lse2(float a, float b) {
 // ---------------------------------------------------------------------------------------------------------------
 // A9  signed lateral distance + heading error to the closest segment pair of a 15-waypoint lane
 // ---------------------------------------------------------------------------------------------------------------
+PSTL_HD unsigned geo_bits(float f) {
+  unsigned u;
+  __builtin_memcpy(&u, &f, 4);
+  return u;
+}
+PSTL_HD float geo_float(unsigned u) {
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+PSTL_HD unsigned umin3(unsigned a, unsigned b, unsigned c) {
+  const unsigned ab = a < b ? a : b;
+  return ab < c ? ab : c;
+}
+
 struct LaneHit {
   float d, th;
   float dd_dx, dd_dy, dth_dth;  // partials (only meaningful when requested)
@@ -230,34 +318,42 @@ PSTL_HD void lane_eval(const f4* lane, float px, float py, float pth, LaneHit& h
   if (seg >= 0) {
     jb = seg;
   } else {
+    // argmin_j (d_j + d_{j+1}), lowest index on ties (torch.argmin).  Only the INDEX is needed (the winner's distance is
+    // computed exactly below), so it rides in the four low mantissa bits of its sum -- sums are non-negative floats, whose bit
+    // patterns order like unsigned integers -- and one tree of unsigned minima finds the winner: 14 x (and-or) + 7 three-way
+    // minima instead of 14 x (compare + two selects), the most expensive instructions of this loop (profiles/r6/valu_rate.txt).
+    // Sums closer than 16 ulp (2^-20 relative: 4 um of the ~4 m between waypoints) count as ties; the distances themselves come
+    // from the 1-ulp hardware square root, and the positions they are measured from carry 30 um of float32 rounding at
+    // nuScenes' coordinates, so the ranking was never sharper than that.
     f4 p = lane[0];
     float ex = px - p.x, ey = py - p.y;
     float prev = PSTL_SQRT_RANK(ex * ex + ey * ey);
-    float best = INFINITY;
+    static_assert((kNseg - 1) % 2 == 0, "two pairs per three-way minimum");
+    unsigned best = 0xffffffffu, held = 0u;
     PSTL_UNROLL
     for (int j = 0; j < kNseg - 1; ++j) {
       const f4 n = lane[j + 1];
       ex = px - n.x;
       ey = py - n.y;
       const float cur = PSTL_SQRT_RANK(ex * ex + ey * ey);
-      const float s = prev + cur;
-      if (s < best) {  // strict: lowest index wins ties, like torch.argmin
-        best = s;
-        jb = j;
-      }
+      const unsigned key = (geo_bits(prev + cur) & ~15u) | (unsigned)j;
+      if (j & 1) best = umin3(best, held, key);
+      else held = key;
       prev = cur;
     }
+    jb = (int)(best & 15u);
+    PSTL_ST_KEEP(jb);
+    PSTL_ST(ST_LANE_RANK);
   }
   h.jb = jb;
   const f4 p2 = lane[jb], p3 = lane[jb + 1];
   const float area = px * (p2.y - p3.y) + p2.x * (p3.y - py) + p3.x * (py - p2.y);
-  const float bl = p2.w;   // |p2 - p3| = sqrtf(sx * sx + sy * sy), sx = p2.x - p3.x, sy = p2.y - p3.y: prep_lane_point
+  const float ibl = p2.w;   // 1 / clamp(|p2 - p3|, 1e-7), 0 for a degenerate segment: prep_lane_point
   const float qx = px - p2.x, qy = py - p2.y;
-  const bool normal = (bl != 0.0f);
-  const float cbl = fmaxf(bl, 1e-7f);
+  const bool normal = (ibl != 0.0f);
   float q2 = 0.0f, l2 = 0.0f;
   if (normal) {
-    h.d = area / cbl;
+    h.d = area * ibl;
   } else {   // a degenerate segment (an invalid lane's all-zero waypoints): the distance to the point itself
     q2 = qx * qx + qy * qy;
     l2 = sqrtf(fmaxf(q2, 1e-3f));
@@ -265,28 +361,26 @@ PSTL_HD void lane_eval(const f4* lane, float px, float py, float pth, LaneHit& h
   }
   const float du = p2.z - pth;
   float sdu = 0.0f, cdu = 1.0f;
-  if (GRAD) {
-    // The adjoint's own evaluation of the heading term.  It feeds a soft-min exponent (tau (thmax - h.th) / thmax), so it has to
-    // be good to ~1e-7 -- the hardware v_cos_f32 is not -- but not bit-equal to the forward sweep's cosf: for the heading errors
-    // that occur (|du| <= pi/4) the Taylor polynomials of 1 - cos and sin, truncated below 3e-8, in ~15 instructions instead
-    // of sincosf's ~45; beyond that the library call.
-    if (fabsf(du) <= 0.78f) {
-      const float x2 = du * du;
-      h.th = x2 * (0.5f - x2 * (0x1.555556p-5f - x2 * (0x1.6c16c2p-10f - x2 * 0x1.a01a02p-16f)));
-      sdu = du * (1.0f - x2 * (0x1.555556p-3f - x2 * (0x1.111112p-7f - x2 * 0x1.a01a02p-13f)));
-    } else {
-      PSTL_SINCOS(du, &sdu, &cdu);
-      h.th = 1.0f - cdu;
-    }
+  // The heading term 1 - cos(du).  It feeds a soft-min exponent (tau (thmax - h.th) / thmax), so it has to be good to ~1e-7 --
+  // the hardware v_cos_f32 is not.  For the heading errors that occur (|du| <= pi/4) the Taylor polynomial of 1 - cos,
+  // truncated below 3e-8, is CLOSER to the exact value than the reference's own float32 `1 - cos(du)` (whose cosine is rounded
+  // to 6e-8 next to 1) in ~8 instructions instead of cosf's ~30; beyond that the library call.  Round 4 introduced it for the
+  // adjoint's own evaluation; since round 6 the forward sweeps take the same value (so do the scores).
+  if (fabsf(du) <= 0.78f) {
+    const float x2 = du * du;
+    h.th = x2 * (0.5f - x2 * (0x1.555556p-5f - x2 * (0x1.6c16c2p-10f - x2 * 0x1.a01a02p-16f)));
+    if (GRAD) sdu = du * (1.0f - x2 * (0x1.555556p-3f - x2 * (0x1.111112p-7f - x2 * 0x1.a01a02p-13f)));
+  } else if (GRAD) {
+    PSTL_SINCOS(du, &sdu, &cdu);
+    h.th = 1.0f - cdu;
   } else {
     cdu = cosf(du);
     h.th = 1.0f - cdu;
   }
   if (GRAD) {
     if (normal) {
-      const float r = PSTL_RCP_ADJ(cbl);
-      h.dd_dx = (p2.y - p3.y) * r;
-      h.dd_dy = (p3.x - p2.x) * r;
+      h.dd_dx = (p2.y - p3.y) * ibl;
+      h.dd_dy = (p3.x - p2.x) * ibl;
     } else if (q2 >= 1e-3f) {
       const float r = PSTL_RCP_ADJ(l2);
       h.dd_dx = qx * r;
@@ -350,7 +444,7 @@ PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, f
         m2 = fminf(m2, dx * dx + dy * dy);
       }
       const float emax = fmaxf(fmaxf(fabsf(env.eoff[0]), fabsf(env.eoff[1])), fmaxf(fabsf(env.eoff[2]), fabsf(env.eoff[3])));
-      const float lb = sqrtf(m2) * 0.99999f - (emax + env.er + r) - 1e-3f;
+      const float lb = PSTL_SQRT_RANK(m2) * 0.99999f - (emax + env.er + r) - 1e-3f;   // (1-ulp square root: inside the margin)
       if (fminf(fmaxf(lb, -5.0f), 20.0f) >= best) continue;
     }
     float q = INFINITY;
@@ -360,17 +454,20 @@ PSTL_HD void clearance_eval(const StlEnv& env, const float* nei, int K, int t, f
       // value only: a tree of plain minima over the 16 independent pair distances (the same number as the sequential
       // "if (qq < q)" scan for any non-NaN input, without its compare -> select -> compare chain and the wait states
       // that go with it)
+      // (two neighbour circles per packed instruction: 5 packed operations per two pairs, every group of four independent of
+      // the others -- the (dx, dy)-packed form the vectoriser found by itself was 3 per pair in one dependent chain, an s_nop
+      // between every two of them; same operations on the same operands: same bits)
+      // (the minimum is a running one: only the recording sweep keeps the sixteen values for the equality search below)
       float qs[16];
+      const v2f nxa = v2f{nx[0], nx[1]}, nxb = v2f{nx[2], nx[3]}, nya = v2f{ny[0], ny[1]}, nyb = v2f{ny[2], ny[3]};
       PSTL_UNROLL
       for (int i = 0; i < 4; ++i) {
-        PSTL_UNROLL
-        for (int j = 0; j < 4; ++j) {
-          const float dx = ex[i] - nx[j], dy = ey[i] - ny[j];
-          qs[4 * i + j] = dx * dx + dy * dy;
-        }
+        const v2f exi = v2f{ex[i], ex[i]}, eyi = v2f{ey[i], ey[i]};
+        const v2f dxa = exi - nxa, dya = eyi - nya, dxb = exi - nxb, dyb = eyi - nyb;
+        const v2f qa = dxa * dxa + dya * dya, qb = dxb * dxb + dyb * dyb;
+        if (REC) qs[4 * i + 0] = qa.x, qs[4 * i + 1] = qa.y, qs[4 * i + 2] = qb.x, qs[4 * i + 3] = qb.y;
+        q = fminf(fminf(q, fminf(qa.x, qa.y)), fminf(qb.x, qb.y));
       }
-      q = fminf(fminf(fminf(qs[0], qs[1]), fminf(qs[2], qs[3])), fminf(fminf(qs[4], qs[5]), fminf(qs[6], qs[7])));
-      q = fminf(q, fminf(fminf(fminf(qs[8], qs[9]), fminf(qs[10], qs[11])), fminf(fminf(qs[12], qs[13]), fminf(qs[14], qs[15]))));
       if (REC) {   // which pair it was: the first one equal to the minimum (what the sequential "<" scan of the adjoint keeps)
         PSTL_UNROLL
         for (int n = 14; n >= 0; --n) pair = (qs[n] == q) ? (unsigned)n : pair;
@@ -643,16 +740,6 @@ struct GeoPre {
   int stride;
   PSTL_HD float at(int t, int c) const { return p[(kGeoSlots * t + c) * stride]; }
 };
-PSTL_HD unsigned geo_bits(float f) {
-  unsigned u;
-  __builtin_memcpy(&u, &f, 4);
-  return u;
-}
-PSTL_HD float geo_float(unsigned u) {
-  float f;
-  __builtin_memcpy(&f, &u, 4);
-  return f;
-}
 // Steps [t0, t1) of the row whose states `src` yields (the states of the steps before t0 are generated and dropped: the
 // dynamics are a handful of operations per step).  The very calls of stl_eval_rec<false, ., true, .>: same values, bit for bit.
 // ... and of stl_eval_grad's adjoint for the same step (the partials at the recorded winners; K > kRecMaxK: ranked again).
@@ -727,6 +814,8 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
   R2.init();
   const int mode = r.mode;
   const f4* sel_lane = lanes + (mode < 3 ? mode : 0) * kNseg;
+  // (thmax - th) / thmax, twenty times per row: the division once per row, then a product (1 ulp from the quotient)
+  const float ith = 1.0f / r.thmax;
   PSTL_NOUNROLL
   for (int t = 0; t < kT; ++t) {
     float x, y, th, v, c, s;
@@ -738,17 +827,27 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
       st.at(XY + 2 * kCk + k) = th;
       st.at(XY + 3 * kCk + k) = v;
     }
+    PSTL_ST_KEEP(x); PSTL_ST_KEEP(y); PSTL_ST_KEEP(c); PSTL_ST_KEEP(s); PSTL_ST_KEEP(v); PSTL_ST_KEEP(th);
+    PSTL_ST(ST_DYN);
     gv1.add(-over<NORM>(v - r.vmin, r.vf) * tau);
     gv2.add(-over<NORM>(-v + r.vmax, r.vf) * tau);
+    PSTL_ST_KEEP(gv1.s); PSTL_ST_KEEP(gv2.s); PSTL_ST_KEEP(gv1.m); PSTL_ST_KEEP(gv2.m);
+    PSTL_ST(ST_LSE);
     ClearHit ch;
     LaneHit h;
     clearance_eval<false, REC>(env, nei, K, t, x, y, c, s, ch);
+    PSTL_ST_KEEP(ch.dn);
+    PSTL_ST(ST_CLEAR);
     gsafe.add(-over<NORM>(ch.dn - r.dsafe, r.sf) * tau);
+    PSTL_ST_KEEP(gsafe.s); PSTL_ST_KEEP(gsafe.m);
+    PSTL_ST(ST_LSE);
     lane_eval<false>(ALL3 ? lanes : sel_lane, x, y, th, h);
     if (REC) rec_put(rec, t, (unsigned)h.jb, ch.win);
+    PSTL_ST_KEEP(h.d); PSTL_ST_KEEP(h.th);
+    PSTL_ST(ST_LANE_TAIL);
     {
       const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df);
-      const float a3 = -((r.thmax - h.th) / r.thmax) * tau;
+      const float a3 = -((r.thmax - h.th) * ith) * tau;
       // (the selected formula only: lane keeping reads the three "always" terms, the lane changes the two "reach" terms;
       // the kernels that map a wavefront to ONE (scene, mode) take one side of each branch as a whole)
       if (ALL3 || mode == 0) {
@@ -760,11 +859,13 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
     }
     if (ALL3) {
       lane_eval<false>(lanes + kNseg, x, y, th, h);
-      R1.step(tau, t, over<NORM>(h.d - r.dmin, r.df), over<NORM>(-h.d + r.dmax, r.df), -((r.thmax - h.th) / r.thmax) * tau, st, tab);
+      R1.step(tau, t, over<NORM>(h.d - r.dmin, r.df), over<NORM>(-h.d + r.dmax, r.df), -((r.thmax - h.th) * ith) * tau, st, tab);
       lane_eval<false>(lanes + 2 * kNseg, x, y, th, h);
-      R2.step(tau, t, over<NORM>(h.d - r.dmin, r.df), over<NORM>(-h.d + r.dmax, r.df), -((r.thmax - h.th) / r.thmax) * tau, st,
+      R2.step(tau, t, over<NORM>(h.d - r.dmin, r.df), over<NORM>(-h.d + r.dmax, r.df), -((r.thmax - h.th) * ith) * tau, st,
               tab + 2 * kFwin);
     }
+    PSTL_ST_KEEP(g1.s); PSTL_ST_KEEP(g2.s); PSTL_ST_KEEP(g3.s); PSTL_ST_KEEP(R1.tailb.s); PSTL_ST_KEEP(R1.tailt.s);
+    PSTL_ST(ST_LSE);
   }
   const float Lv1 = gv1.value(), Lv2 = gv2.value(), Ls = gsafe.value();
   const float Vv1 = -(Lv1 / tau), Vv2 = -(Lv2 / tau), Vs = -(Ls / tau);
@@ -804,6 +905,7 @@ PSTL_HD float stl_eval_rec(const StlEnv& env, const StlRow& r, const f4* lanes, 
     fo->Lv1 = Lv1, fo->Lv2 = Lv2, fo->Ls = Ls, fo->L1 = L1, fo->L2 = L2, fo->L3 = L3, fo->Lfb = Lfb, fo->Lft = Lft;
     fo->score = score;
   }
+  PSTL_ST(ST_FWD_FINISH);
   return score;
 }
 
@@ -838,15 +940,42 @@ struct AdjState {
   Rec rec;
 };
 
-// emit() is always called for t = T-1 ... 0, in that order; a row without gradient hands it exact zeros
+// 16 bytes = the control pairs of steps 2q, 2q + 1 of a row-major row (us == 1)
+PSTL_HD ctrl4 ctrl_quad(const float* u, int q) { return *reinterpret_cast<const ctrl4*>(u + 4 * q); }
+
+// emit() is always called for t = T-1 ... 0, in that order; a row without gradient hands it exact zeros.
+// Row-major rows: the loop used to read one control pair per step right in front of the emit() that needs it -- and emit()
+// stores to the same buffer, so no load could be moved up: twenty gather latencies in a row, a quarter of the lifetime of a
+// k_guidance_iter wavefront (stamp build, round 6).  Now four steps per iteration, their two 16-byte pieces requested one
+// iteration ahead: one exposed latency per row, ten loads instead of twenty.
 template <class EmitFn>
 PSTL_HD void stl_grad_zero(const float* u, long us, EmitFn emit) {
-  PSTL_NOUNROLL
-  for (int t = kT - 1; t >= 0; --t) {
-    float w, a;
-    ctrl_pair(u, us, t, w, a);
-    emit(t, 0.0f, 0.0f, w, a);
+  static_assert(kT % 4 == 0, "four steps per iteration");
+  if (us == 1) {
+    ctrl4 hi = ctrl_quad(u, kT / 2 - 1), lo = ctrl_quad(u, kT / 2 - 2);
+    PSTL_NOUNROLL
+    for (int it = kT / 4 - 1; it >= 0; --it) {
+      ctrl4 nhi = hi, nlo = lo;
+      if (it > 0) {   // (the pieces of the four steps below: nothing this iteration stores to)
+        nhi = ctrl_quad(u, 2 * it - 1);
+        nlo = ctrl_quad(u, 2 * it - 2);
+      }
+      emit(4 * it + 3, 0.0f, 0.0f, hi.z, hi.w);
+      emit(4 * it + 2, 0.0f, 0.0f, hi.x, hi.y);
+      emit(4 * it + 1, 0.0f, 0.0f, lo.z, lo.w);
+      emit(4 * it, 0.0f, 0.0f, lo.x, lo.y);
+      hi = nhi;
+      lo = nlo;
+    }
+  } else {
+    PSTL_NOUNROLL
+    for (int t = kT - 1; t >= 0; --t) {
+      float w, a;
+      ctrl_pair(u, us, t, w, a);
+      emit(t, 0.0f, 0.0f, w, a);
+    }
   }
+  PSTL_ST(ST_ZERO_EMIT);
 }
 
 // scratch: [checkpoints 4 x 5 | suffix tables 2 x 10]
@@ -884,6 +1013,12 @@ PSTL_HD void stl_grad_adjoint(const StlEnv& env, const StlRow& r, const f4* lane
     V[0] = -(Lv1 / tau), V[1] = -(Lv2 / tau), V[2] = Lfb / tau, V[3] = Lft / tau, V[4] = -(Ls / tau);
     n = 5;
   }
+  // (row-major rows: the 16-byte pieces of the last block's controls, requested before anything else -- see the block loop)
+  ctrl4 qa = ctrl4{0.0f, 0.0f, 0.0f, 0.0f}, qb = qa;
+  if (us == 1) {
+    qa = ctrl_quad(u, 2 * kCk - 2);
+    qb = ctrl_quad(u, 2 * kCk - 1);
+  }
   const float Lout = -score * tau;  // logsumexp of (-V_i tau)
   float om[6];
   PSTL_UNROLL
@@ -891,7 +1026,8 @@ PSTL_HD void stl_grad_adjoint(const StlEnv& env, const StlRow& r, const f4* lane
   const float o_v1 = om[0], o_v2 = om[1], o_s = (mode == 0) ? om[5] : om[4];
   {
     float w, a;
-    ctrl_pair(u, us, kT - 1, w, a);
+    if (us == 1) w = qb.z, a = qb.w;
+    else ctrl_pair(u, us, kT - 1, w, a);
     emit(kT - 1, 0.0f, 0.0f, w, a);  // the last control never reaches a scored state
   }
   if (mode != 0) {
@@ -911,10 +1047,11 @@ PSTL_HD void stl_grad_adjoint(const StlEnv& env, const StlRow& r, const f4* lane
       lt_prev = lt;
     }
   }
+  PSTL_ST(ST_ADJ_HEAD);
   // ---- adjoint, backwards in time -----------------------------------------------------------------------------
   float lx = 0.0f, ly = 0.0f, lth = 0.0f, lv = 0.0f;  // lambda_{t+1}
   const float dt = env.dt;
-  const float inv_thmax = PSTL_RCP_ADJ(r.thmax);   // (the heading predicate's divisor: here it only scales gradient weights)
+  const float inv_thmax = 1.0f / r.thmax;   // (the forward sweep's own reciprocal: s3 below is its value, bit for bit)
   // The states are not stored per step: block by block (4 steps), they are re-derived from the block's checkpoint with the
   // forward sweep's own operations (bit-identical), kept in registers, and consumed in reverse order.  The controls a
   // block reads (steps < its last one) have not been rewritten yet by emit(), which has only reached later steps.
@@ -924,19 +1061,33 @@ PSTL_HD void stl_grad_adjoint(const StlEnv& env, const StlRow& r, const f4* lane
     float bw[kCkStride], ba[kCkStride];   // stored controls of steps 4blk-1, 4blk, 4blk+1, 4blk+2: the ones emit() is called for
     {
       float x = st.at(CKP + blk), y = st.at(CKP + kCk + blk), th = st.at(CKP + 2 * kCk + blk), v = st.at(CKP + 3 * kCk + blk);
-      CtrlReader rd(u, us);
-      if (blk > 0) ctrl_pair(u, us, blk * kCkStride - 1, bw[0], ba[0]);
+      float wr[kCkStride - 1], ar[kCkStride - 1];   // stored controls of steps 4blk, 4blk+1, 4blk+2
+      if (us == 1) {
+        // Row-major rows: this block's two 16-byte pieces were requested while the block above was computed (qa, qb), and the
+        // ones of the block below are requested here -- emit() has only rewritten later steps, and stores nothing below step
+        // 4blk-1 before they land.  (One gather latency per block used to sit in front of the dynamics: a fifth of a wavefront's
+        // lifetime in k_guidance_iter.)  Step 4blk-1, which this block's last emit() takes, is the upper half of the second of them.
+        wr[0] = qa.x, ar[0] = qa.y, wr[1] = qa.z, ar[1] = qa.w, wr[2] = qb.x, ar[2] = qb.y;
+        if (blk > 0) {
+          qa = ctrl_quad(u, 2 * blk - 2);
+          qb = ctrl_quad(u, 2 * blk - 1);
+          bw[0] = qb.z, ba[0] = qb.w;
+        }
+      } else {
+        CtrlReader rd(u, us);
+        if (blk > 0) ctrl_pair(u, us, blk * kCkStride - 1, bw[0], ba[0]);
+        PSTL_UNROLL
+        for (int i = 0; i + 1 < kCkStride; ++i) rd.get(blk * kCkStride + i, wr[i], ar[i]);
+      }
       PSTL_UNROLL
       for (int i = 0; i < kCkStride; ++i) {
         float c, s;
         PSTL_SINCOS(th, &s, &c);   // (exact: see the note at kGeoSlots)
         bx[i] = x, by[i] = y, bth[i] = th, bv[i] = v, bc[i] = c, bs[i] = s;
         if (i + 1 < kCkStride) {
-          float wr, ar;
-          rd.get(blk * kCkStride + i, wr, ar);
-          bw[i + 1] = wr, ba[i + 1] = ar;
-          const float w = wr * wscale;
-          const float a = ar * ascale;
+          bw[i + 1] = wr[i], ba[i + 1] = ar[i];
+          const float w = wr[i] * wscale;
+          const float a = ar[i] * ascale;
           const float dx = v * c;
           const float dy = v * s;
           x = x + dx * dt;
@@ -946,6 +1097,7 @@ PSTL_HD void stl_grad_adjoint(const StlEnv& env, const StlRow& r, const f4* lane
         }
       }
     }
+  PSTL_ST(ST_ADJ_REDERIVE);
   PSTL_UNROLL   // (unrolled: the block's register arrays are then indexed by constants -- 24 selects per step otherwise)
   for (int i = kCkStride - 1; i >= 0; --i) {
     const int t = blk * kCkStride + i;
@@ -956,19 +1108,23 @@ PSTL_HD void stl_grad_adjoint(const StlEnv& env, const StlRow& r, const f4* lane
     // (--norm_stl: the predicates are a / f; the chain rule adds the factor 1 / f, as autograd's division does)
     gv = o_v1 * PSTL_EXP(-over<NORM>(v - r.vmin, r.vf) * tau - Lv1) - o_v2 * PSTL_EXP(-over<NORM>(-v + r.vmax, r.vf) * tau - Lv2);
     if (NORM) gv = gv / r.vf;
+    PSTL_ST(ST_ADJ_WEIGHTS);
     ClearHit ch;
     if (use_rec) {
       clearance_from_winner(env, nei, t, x, y, c, s, rec_win(rec, t), ch);
     } else {
       clearance_eval<true>(env, nei, K, t, x, y, c, s, ch);
     }
+    PSTL_ST(ST_ADJ_CLEAR);
     float gs = o_s * PSTL_EXP(-over<NORM>(ch.dn - r.dsafe, r.sf) * tau - Ls);
     if (NORM) gs = gs / r.sf;
     gx = gs * ch.d_dx;
     gy = gs * ch.d_dy;
     gth = gs * ch.d_dth;
     LaneHit h;
+    PSTL_ST(ST_ADJ_WEIGHTS);
     lane_eval<true>(lane, x, y, th, h, use_rec ? (int)rec_seg(rec, t) : -1);
+    PSTL_ST(ST_ADJ_LANE);
     const float s1 = over<NORM>(h.d - r.dmin, r.df), s2 = over<NORM>(-h.d + r.dmax, r.df), s3 = (r.thmax - h.th) * inv_thmax;
     float gd, gsth;  // d score / d d_t , d score / d s3_t
     if (mode == 0) {
@@ -988,6 +1144,7 @@ PSTL_HD void stl_grad_adjoint(const StlEnv& env, const StlRow& r, const f4* lane
     gx += gd * h.dd_dx;
     gy += gd * h.dd_dy;
     gth += gsth * (-inv_thmax) * h.dth_dth;
+    PSTL_ST(ST_ADJ_WEIGHTS);
     // lambda_t = direct_t + J_t^T lambda_{t+1}
     const float nlth = gth + lth + lx * (-(v * s) * dt) + ly * ((v * c) * dt);
     const float nlv = gv + lv + lx * (c * dt) + ly * (s * dt);
@@ -995,8 +1152,10 @@ PSTL_HD void stl_grad_adjoint(const StlEnv& env, const StlRow& r, const f4* lane
     ly = gy + ly;
     lth = nlth;
     lv = nlv;
+    PSTL_ST(ST_ADJ_COSTATE);
     // state_t = f(state_{t-1}, u_{t-1}):  th_t = th_{t-1} + w dt ; v_t = v_{t-1} + a dt
     emit(t - 1, lth * dt * wscale, lv * dt * ascale, pick4(bw, i), pick4(ba, i));
+    PSTL_ST(ST_EMIT);
   }
   }
 }
@@ -1029,6 +1188,7 @@ template <bool NORM = false, bool LAMBDA = true>
 PSTL_HD ChainOut stl_pre_chain(int which, const StlEnv& env, const StlRow& r, GeoPre pre, Scratch st) {
   const float tau = env.tau;
   const int mode = r.mode;
+  const float ith = 1.0f / r.thmax;   // (as stl_eval_rec)
   float o0 = 0.0f, o1 = 0.0f;
   if (which == 0) {
     Lse gv1, gv2;
@@ -1064,7 +1224,7 @@ PSTL_HD ChainOut stl_pre_chain(int which, const StlEnv& env, const StlRow& r, Ge
       Lse g3;
       g3.init();
       PSTL_NOUNROLL
-      for (int t = 0; t < kT; ++t) g3.add(-((r.thmax - pre.at(t, 2)) / r.thmax) * tau);
+      for (int t = 0; t < kT; ++t) g3.add(-((r.thmax - pre.at(t, 2)) * ith) * tau);
       o0 = g3.value();
     }
   } else {
@@ -1088,7 +1248,7 @@ PSTL_HD ChainOut stl_pre_chain(int which, const StlEnv& env, const StlRow& r, Ge
           const float band = -(lse2(-s1 * tau, -s2 * tau) / tau);
           av[k] = -band * tau;
         } else {
-          av[k] = -((r.thmax - pre.at(t, 2)) / r.thmax) * tau;
+          av[k] = -((r.thmax - pre.at(t, 2)) * ith) * tau;
         }
       }
       PSTL_UNROLL
@@ -1157,7 +1317,7 @@ PSTL_HD void adj_pre_direct(const StlEnv& env, const StlRow& r, const AdjCtx& C,
   const float tau = env.tau;
   const int mode = r.mode;
   const int LB = 0, LT = kFwin;
-  const float inv_thmax = PSTL_RCP_ADJ(r.thmax);
+  const float inv_thmax = 1.0f / r.thmax;
   const float o_v1 = C.om[0], o_v2 = C.om[1], o_s = (mode == 0) ? C.om[5] : C.om[4];
   const float v = pre.at(t, 3);
   gv = o_v1 * PSTL_EXP(-over<NORM>(v - r.vmin, r.vf) * tau - C.Lv1) - o_v2 * PSTL_EXP(-over<NORM>(-v + r.vmax, r.vf) * tau - C.Lv2);

@@ -109,10 +109,14 @@ static bool rows_by_mode(const pstl_cfg* cfg, bool staged) {
 // log-sum-exps each (stl_pre_chain), wave 0 combines them into the score.  Bit-identical scores.
 constexpr int kSplitWaves = 10;             // two time steps per wave
 
+// (five wavefronts per SIMD is what the selected-formula kernel's 7.8 KB of LDS per wavefront allow at K = 2: its registers are
+// held to that -- 96 --, or the wider packed clearance loop costs it a wavefront)
 template <bool ALL3, bool STAGED, bool GIVEN, bool NORM = false, bool SPLIT = false>
-__global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_stl_forward(StlArgs a) {
+__global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) __attribute__((amdgpu_waves_per_eu(ALL3 ? 4 : 5)))
+void k_stl_forward(StlArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(!SPLIT || (STAGED && !ALL3 && !GIVEN), "latency layout: staged tables, selected formula, controls");
+  if (!SPLIT) PSTL_ST_BEGIN();
   constexpr int NS = ALL3 ? kScratchFwd3 : kScratchFwd;
   const int lane = SPLIT ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
   const int wq = SPLIT ? (int)(threadIdx.x / kWave) : 0;
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_stl_for
   const Scratch st = {lds + lane, kWave};
   const long b = row / a.rows_per_scene;
   const StlRow r = load_row<NORM>(a.stlp, a.hl, row);
+  if (!SPLIT) PSTL_ST(ST_PROLOGUE);
   float best = -INFINITY;
   int best_rep = 0;
   const int rep_lo = a.rep_split ? (int)blockIdx.y : 0, rep_hi = a.rep_split ? rep_lo + 1 : a.reps;
@@ -188,6 +193,10 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave) void k_stl_for
     for (int i = 0; i < 10; ++i) dst[i] = src[i];
     a.sel_scores[row] = best;
     a.sel_idx[row] = best_rep;
+  }
+  if (!SPLIT) {
+    PSTL_ST(ST_SELECT);
+    PSTL_ST_END();
   }
 }
 
@@ -332,6 +341,7 @@ template <bool MULTI, bool STAGED, bool NORM = false, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1) void k_guidance_iter(GuideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(!SPLIT || STAGED, "the latency layout stages its scene tables");
+  if (!SPLIT) PSTL_ST_BEGIN();
   const unsigned long long seed = a.dyn ? uniform_u64(&a.dyn->seed) : a.seed;
   const float grad_scale = a.dyn ? uniform_f32(&a.dyn->grad_scale) : a.grad_scale;
   const int lane = SPLIT ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
@@ -374,6 +384,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
   const float* zr = a.z ? a.z + row * (2 * kT) : nullptr;
   float* er = a.emit_out ? a.emit_out + row * (2 * kT) : nullptr;
   const float inv_bc2 = 1.0f / a.bc2_sqrt;
+  if (!SPLIT) PSTL_ST(ST_PROLOGUE);
   // one element of the Adam update; returns the value that goes back to mu (and, through *emit_v, to emit_out)
   auto update = [=](int e, float p0, float g, float nscale, float zdrawn, float* emit_v) -> float {
     // torch.optim.Adam, single-tensor path, betas (0.9, 0.999), eps 1e-8 (see oracle guidance_update)
@@ -382,12 +393,20 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
       m = wm[e];
       v = wm[plane + e];
     }
+    float p;
+    if (!MULTI && __builtin_constant_p(g) && g == 0.0f) {
+      // A row without gradient (stl_grad_zero hands in the literal 0): with fresh moments m = v = 0 and the step is
+      // p0 + (neg_step * 0) / 1e-8 = p0 + (-0) = p0, bit for bit -- no arithmetic at all for the rows whose hinge is inactive
+      // (84 % of them by the last guided step of the bench workload) instead of ~22 instructions per element.
+      p = p0;
+    } else {
     m = m + 0.1f * (g - m);
     v = v * 0.999f + (0.001f * g) * g;
     // sqrt and both divisions in their hardware forms (1 ulp each: the step lr m / (sqrt(v) + eps) is at most lr, so the state
     // moves by < 1e-8 against the IEEE forms; v_sqrt_f32 takes a denormal v as 0, where eps = 1e-8 decides anyway)
     const float denom = PSTL_SQRT_ADJ(v) * inv_bc2 + 1e-8f;
-    float p = p0 + (a.neg_step * m) * PSTL_RCP_ADJ(denom);
+    p = p0 + (a.neg_step * m) * PSTL_RCP_ADJ(denom);
+    }
     if (MULTI) {
       wm[e] = m;
       wm[plane + e] = v;
@@ -539,6 +558,8 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
           apply(t, gw, ga, w0, a0, z4, held_mu, held_em);
         },
         PSTL_G_ABL == 2 ? a.N : 1, gs == 0.0f);   // an invalid lane has zero loss weight: Adam sees exact zeros, only the noise is added
+    PSTL_ST(ST_OTHER);
+    PSTL_ST_END();
   }
 }
 
@@ -1008,6 +1029,17 @@ static int allow_lds(const void* fn, size_t bytes) {
   if (n_seen < 64) seen[n_seen++] = Seen{fn, dev, bytes};
   return PSTL_OK;
 }
+
+#if defined(PSTL_STL_STAMP)
+// diagnostic builds only: the section table of the stamped kernels (32 x uint64 cycles; slot 31 = wavefronts), then zeroed
+extern "C" int pstl_debug_stl_stamps(unsigned long long* out32) {
+  if (hipDeviceSynchronize() != hipSuccess) return PSTL_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(pstl::pstl_st_global), 32 * sizeof(unsigned long long)) != hipSuccess) return PSTL_ERR_LAUNCH;
+  static const unsigned long long zero[32] = {};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(pstl::pstl_st_global), zero, sizeof(zero)) != hipSuccess) return PSTL_ERR_LAUNCH;
+  return PSTL_OK;
+}
+#endif
 
 extern "C" int pstl_prepare_scene(const pstl_cfg* cfg, const float* neighbors_traj, const float* currlane,
                                   const float* leftlane, const float* rightlane, float* nei_prep, float* lane_prep,

@@ -852,7 +852,7 @@ def generate_parser(argv=None):
     add("--test", action="store_true", default=False)
     add("--net_pretrained_path", "-P", type=str, default=None)
     add("--allow_random_init", action="store_true", default=False)   # not a reference flag: -P may name a missing file
-    # not a reference flag: x_T and the per-step noise of diffusion_rollout are drawn inside the HIP kernels (Philox4x32-10
+    # not a reference flag: x_T and the per-step noise of diffusion_rollout are drawn inside the HIP kernels (Philox4x32-7
     # keyed by a seed taken from torch's generator) instead of by one torch.randn_like call per reverse step
     add("--kernel_noise", action="store_true", default=False)
     add("--no_graph", action="store_true", default=False)     # --kernel_noise: eager launches instead of one HIP-graph replay per batch

@@ -84,7 +84,7 @@ def test_chain2_against_oracle_on_fresh_scenes(dev):
 
 
 def test_chain2_in_kernel_noise_is_the_fill_normal_stream(dev):
-    """k_chain2 draws its noise in the shadow of layer 2's MFMAs, as single-instruction steps of Philox4x32-10 + Box-Muller:
+    """k_chain2 draws its noise in the shadow of layer 2's MFMAs, as single-instruction steps of Philox4x32-7 + Box-Muller:
     the rollout must equal, bit for bit, the one fed with pstl_fill_normal's tensors (which the epilogue adds), and a block
     of scenes evaluated alone with the right row_offset must reproduce its rows of the full batch."""
     from pstl_diffusion_policy_amd.engine import Sampler, SceneBatch

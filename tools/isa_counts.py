@@ -15,7 +15,7 @@ from pstl_diffusion_policy_amd.build import UNITS, CSRC  # noqa: E402
 def main():
     unit = sys.argv[1]
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
-    extra = dict(UNITS)[unit]
+    extra = next(u[1] for u in UNITS if u[0] == unit)
     out = "/tmp/isa_%s.s" % unit.replace(".hip", "")
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + extra + sys.argv[3:] +
                           ["--cuda-device-only", "-S", os.path.join(CSRC, unit), "-o", out], stderr=subprocess.DEVNULL)
