@@ -27,12 +27,14 @@
 extern "C" {
 #endif
 
-#define PSTL_ABI_VERSION 5   /* 2: pstl_encode_scene takes a work buffer; --joint and --refinement entry points
+#define PSTL_ABI_VERSION 6   /* 2: pstl_encode_scene takes a work buffer; --joint and --refinement entry points
                                 3: status block in the packed weight buffer (pstl_packed_status_offset)
                                 4: pstl_cfg.dyn -- run-time parameters in device memory (HIP-graph replay)
                                 5: pstl_rollout_layout; chain_waves = 2 (the row-stationary denoiser kernel);
                                    pstl_train_create / pstl_train_destroy and the (empty) context argument of
-                                   pstl_refine_backward are gone */
+                                   pstl_refine_backward are gone
+                                6: pstl_cfg.plan_rows (every shard of a job on the same denoiser kernel); pstl_adam_step;
+                                   the prepared lane table's fourth float is the reciprocal segment length */
 
 /* compile-time shape of the path (reference defaults: nt=20, n_segs=15, hiddens=[256,256], feat 7*32) */
 #define PSTL_T 20
@@ -89,7 +91,7 @@ typedef struct pstl_cfg {
                               their denoiser launches in a latency layout, 1..4 tiles per workgroup; 16: always
                               the throughput layout; the results are bit-identical; 0 also hands the multi-step
                               denoiser launches of batches that (nearly) fill rounds of 256- or 192-row workgroups --
-                              from 45 056 rows on 256 CUs -- and the single-step (mu_only = 1) launches of every batch
+                              from 45 072 rows (2 817 sixteen-row tiles) on 256 CUs -- and the single-step (mu_only = 1) launches of every batch
                               above the latency layout's sizes -- and RefineNet's inference pass of such batches -- to
                               the row-stationary kernel k_chain2: same arithmetic and domain,
                               another summation order; 2: k_chain2 for every launch it can take whatever the batch
@@ -114,6 +116,13 @@ typedef struct pstl_cfg {
                            /* does not depend on how the batch is split over GPUs                                */
   const pstl_dyn* dyn;     /* device pointer or NULL.  Non-null: pstl_fill_normal, pstl_rollout and pstl_guidance_step */
                            /* read seed (and grad_scale) from it at kernel start and ignore the by-value ones           */
+  int64_t plan_rows;       /* chain_waves = 0 chooses between the two denoiser kernels (k_chain / k_chain2: the same     */
+                           /* arithmetic in two summation orders, last bits differ) by batch size.  0: by THIS call's    */
+                           /* rows -- a shard evaluated alone may then get other last bits than the same rows inside a   */
+                           /* larger batch.  > 0: by this row count instead, whatever the call's own size: a job passes  */
+                           /* the same number (its nominal rows per GPU) on every shard and every call, so that all of   */
+                           /* its rows go through the same kernel and a row's bits do not depend on the shard that       */
+                           /* holds it (the work-group layouts WITHIN a kernel never change results).                     */
 } pstl_cfg;
 
 /* state_dict blobs of the reference Net (nusc_model.py:20-46; keys "<net>.{0,2,4}.{weight,bias}").
@@ -277,6 +286,26 @@ int pstl_refine_train_forward(const pstl_cfg* cfg, float* packed, const float* b
  * divides by N * clip(mean(valid), 1e-2)). */
 int pstl_loss_grad(const pstl_cfg* cfg, const float* scores, const float* valid, float grad_scale, float* dscore,
                    float* loss_parts, void* stream);
+/* The optimiser of the training loop (reference nusc_train.py:1233: torch.optim.Adam over rect_net.parameters(), or over
+ * net.parameters() with --joint; :1522-1525 zero_grad / backward / step) on the device path: ONE step of Adam with torch's
+ * defaults (no weight decay, no amsgrad) over up to PSTL_ADAM_MAX_TENSORS tensors, operation for operation what torch's
+ * float32 update computes (csrc/adam_core.hpp; bit for bit against torch.optim.Adam in the tests), in one launch.
+ *   params / grads : HOST arrays of n_tensors DEVICE pointers (the live parameter tensors, updated in place, and their
+ *                    gradients), numel: HOST array of their element counts;
+ *   exp_avg, exp_avg_sq : the moments of all tensors back to back (sum of numel floats each), zeroed by the caller before the
+ *                    first step, otherwise owned by this function;
+ *   sched (sched_steps,2) : DEVICE table of the per-step scalars -lr / (1 - beta1^t), sqrt(1 - beta2^t), t = 1 ... sched_steps,
+ *                    which the caller computes in double precision as torch does and rounds to float32;
+ *   step           : DEVICE counter of the steps done (0 before the first); the launch reads its scalars at sched[*step] and
+ *                    a second, one-thread launch increments it -- nothing about a step is passed by value, so a captured
+ *                    training step replays with the right bias corrections.
+ *   one_minus_beta1, beta2, one_minus_beta2, eps : torch's Python scalars as float32 -- the differences 1 - beta formed in
+ *                    DOUBLE precision first (float32(1 - 0.999) is not 1 - float32(0.999)).
+ * The caller re-packs the networks whose tensors moved (pstl_repack_weights) before the kernels read them again. */
+#define PSTL_ADAM_MAX_TENSORS 32
+int pstl_adam_step(int n_tensors, float* const* params, const float* const* grads, const int64_t* numel, float* exp_avg,
+                   float* exp_avg_sq, const float* sched, int sched_steps, int32_t* step, float one_minus_beta1, float beta2,
+                   float one_minus_beta2, float eps, void* stream);
 size_t pstl_train_work_floats(const pstl_cfg* cfg);
 /* d loss / d rect_net parameters given dcontrols = d loss / d out_controls (from pstl_stl_backward).  w2, w3: the
  * reference-layout weights rect_net.2.weight (256,256), rect_net.4.weight (40,256).  Gradients in the reference layout:

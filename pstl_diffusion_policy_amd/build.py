@@ -1,7 +1,9 @@
 """Builds libpstl_hip.so (gfx950) in-tree with hipcc.  `python -m pstl_diffusion_policy_amd.build`."""
 import os
+import signal
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -22,7 +24,9 @@ UNITS = [("stl_kernels.hip", ["-ffp-contract=off", "-Xarch_device", "-mllvm=-mis
          ("chain2_kernels.hip", ["-Xarch_device", "-mllvm=-amdgpu-mfma-vgpr-form", "-DPSTL_C2_PART=0"], "chain2_kernels.o"),
          ("chain2_kernels.hip", ["-Xarch_device", "-mllvm=-amdgpu-mfma-vgpr-form", "-DPSTL_C2_PART=1"], "chain2_kernels_p1.o"),
          ("chain2_kernels.hip", ["-Xarch_device", "-mllvm=-amdgpu-mfma-vgpr-form", "-DPSTL_C2_PART=2"], "chain2_kernels_p2.o"),
-         ("diversity_kernels.hip", ["-ffp-contract=off"]), ("stl_program.hip", ["-ffp-contract=off"])]
+         ("diversity_kernels.hip", ["-ffp-contract=off"]), ("stl_program.hip", ["-ffp-contract=off"]),
+         # adam_kernels: torch.optim.Adam's float32 update, every operation rounded on its own (csrc/adam_core.hpp)
+         ("adam_kernels.hip", ["-ffp-contract=off"])]
 LINK_LIBS = []   # no vendor BLAS: every kernel of the library is in csrc/
 
 
@@ -46,14 +50,27 @@ def build(force=False, verbose=True):
             cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            running.append((cmd, subprocess.Popen(cmd)))
+            # (each compiler in a process group of its own: hipcc is a wrapper around clang children, and killing the wrapper alone
+            # would leave them writing an object file behind a failed build)
+            running.append((cmd, subprocess.Popen(cmd, start_new_session=True), o, time.time()))
         objs.append(o)
-    for cmd, proc in running:
+    times = {}
+    for cmd, proc, o, t0 in running:
         if proc.wait() != 0:
-            for _, other in running:      # (only the children started here; never by pattern)
+            for _, other, oo, _ in running:      # (only the process groups started here; never by pattern)
                 if other.poll() is None:
-                    other.kill()
+                    try:
+                        os.killpg(other.pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+                    other.wait()
+            for _, _, oo, _ in running:          # no output of the failed batch may pass for up to date next time
+                if os.path.exists(oo):
+                    os.remove(oo)
             raise subprocess.CalledProcessError(proc.returncode, cmd)
+        times[os.path.basename(o)] = time.time() - t0
+    if verbose and times:
+        print("compiled: " + ", ".join("%s %.0f s" % kv for kv in sorted(times.items())), flush=True)
     if force or _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + LINK_LIBS + ["-o", LIB]
         if verbose:

@@ -1018,16 +1018,16 @@ template <bool RNG, int MODE, int RT>
 static int launch_chain2_t(const ChainArgs& a, hipStream_t st) {
   constexpr bool MU = MODE != 0;
   long n_wg = (a.N + Carve<RT>::kWgRows - 1) / Carve<RT>::kWgRows;
-  static int allowed_dev = -1, cus = 0;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return PSTL_ERR_LAUNCH;
-  if (allowed_dev != dev) {
+  static DeviceOnce allowed;     // (per instantiation and DEVICE: pstl_common.hpp)
+  const int dev = current_device();
+  if (dev < 0) return PSTL_ERR_LAUNCH;
+  if (!allowed.done(dev)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<RNG, MODE, RT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            Carve<RT>::kLdsBytes) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                            Carve<RT>::kLdsBytes) != hipSuccess)
       return PSTL_ERR_LAUNCH;
-    allowed_dev = dev;
+    allowed.set(dev);
   }
+  const int cus = device_cus(dev);
   if (MU && n_wg > cus) n_wg = cus;   // one workgroup per CU walks the tiles
   hipLaunchKernelGGL((k_chain2<RNG, MODE, RT>), dim3((unsigned)n_wg), dim3(256), Carve<RT>::kLdsBytes, st, a);
   return launch_status();
@@ -1039,9 +1039,7 @@ static int launch_chain2_t(const ChainArgs& a, hipStream_t st) {
 // MFMAs), so it pays exactly where 256-row tiles would leave CUs idle: 24 576 rows are 96 tiles of 256 on 256 CUs or 192 of
 // 128 (29.7 -> 19.1 us per launch), 98 304 rows two of 256 per CU or three of 128 (61.6 -> 53.4 us).  Same bits either way.
 int chain2_wg_rows(const ChainArgs& a) {
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    return 256;
+  const int cus = device_cus();
   const long t4 = (a.N + 255) / 256, r4 = (t4 + cus - 1) / cus;
 #ifdef PSTL_C2_FORCE_ROWS
   if (!a.mu_only) return PSTL_C2_FORCE_ROWS;
@@ -1056,9 +1054,7 @@ int chain2_wg_rows(const ChainArgs& a) {
 }
 
 long chain2_step_cost(const ChainArgs& a) {
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    return 1L << 40;
+  const int cus = device_cus();
   const int rows = chain2_wg_rows(a);
   const long t = (a.N + rows - 1) / rows, r = (t + cus - 1) / cus;
   return r * (rows == 256 ? 100 : rows == 192 ? kCost192 : 60);

@@ -31,6 +31,7 @@ struct ChainOff {       // one of policy_net / rect_net
 
 struct ChainArgs {
   long N;
+  long plan_N;           // cfg->plan_rows: the row count the k_chain / k_chain2 choice of chain_waves = 0 is made for (0: N)
   int rows_per_scene;
   int steps;
   int step_hi, step_lo;

@@ -426,16 +426,7 @@ static __global__ void k_fill_words(int n, unsigned v, unsigned* p) {
   if (i < n) p[i] = v;
 }
 
-static long div_cu_count() {
-  static long n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-            ? p.multiProcessorCount : 256;
-  }
-  return n;
-}
+static long div_cu_count() { return device_cus(); }   // (of the current device: pstl_common.hpp)
 
 extern "C" int pstl_diversity(const pstl_cfg* cfg, const float* s0, const float* gt_traj, int gt_stride,
                               const float* controls, const float* scores, const float* valid, const float* alphas,

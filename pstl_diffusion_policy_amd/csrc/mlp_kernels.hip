@@ -1671,16 +1671,7 @@ size_t chain_lds_bytes() {
                   2 * 4 * 64 * 4) * sizeof(float);
 }
 
-inline int cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
-    n = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-  }
-  return n;
-}
+inline int cu_count() { return device_cus(); }   // (of the CURRENT device: pstl_common.hpp's per-device table)
 
 template <int NW, bool REFINE, int ABL = 0, bool UT = false, int PT = 0, bool PERSIST = false, bool SAVE = false,
           bool SPARSE = false>
@@ -1691,14 +1682,14 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
   const size_t lds = chain_lds_bytes<NW>();
   auto fn = k_chain<NW, REFINE, ABL, UT, PT, PERSIST, SAVE, SPARSE>;
   // (once per instantiation and device: the attribute call costs host time on every launch of a latency-bound caller)
-  static int allowed_dev = -1;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return PSTL_ERR_LAUNCH;
-  if (allowed_dev != dev) {
+  static DeviceOnce allowed;
+  const int dev = current_device();
+  if (dev < 0) return PSTL_ERR_LAUNCH;
+  if (!allowed.done(dev)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
       return PSTL_ERR_LAUNCH;
-    allowed_dev = dev;
+    allowed.set(dev);
   }
   hipLaunchKernelGGL(fn, grid, dim3(NW * 64), lds, st, a);
   return launch_status();
@@ -1707,7 +1698,7 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
 // Batches that k_chain2 runs faster than k_chain.  Multi-step launches: its workgroups own 256 (or 192) rows for the whole launch,
 // one per CU at a time, so the launch takes ceil(workgroups / CUs) rounds of its tile-step (chain2_step_cost: in per cent of the
 // 256-row tile-step, 25.6 us) against k_chain's rounds x tiles per group x 1.91 us (7.46 per cent per tile) -- it pays where
-// its rounds are (nearly) full: from 45 056 rows (235 workgroups of 192 rows) and at every size from 196 608 rows up, not at
+// its rounds are (nearly) full: from 45 072 rows (2 817 tiles: 235 workgroups of 192 rows against twelve-tile groups of k_chain) and at every size from 196 608 rows up, not at
 // 24 576 ... 40 960 rows nor where a round would be mostly empty (profiles/r5/chain2_192_row_workgroups.txt).  The single-step
 // launches of the guided phase: one workgroup per CU walks the tiles, no rounds -- measured faster than k_chain's single-step
 // layout at every size from 24 576 rows up, so it takes every batch the latency layout does not
@@ -1736,12 +1727,15 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   const bool latency = chain_waves == 0;
   // 2: the row-stationary kernel (k_chain2, chain2_kernels.hip) for every launch it can take, whatever the batch size; 0:
   // for the multi-step denoiser launches of batches that fill whole rounds of its 256-row workgroups (chain2_pays)
+  // (which of the two kernels: by the job's row count where the caller names one -- cfg->plan_rows, so that every shard of a
+  // job runs the same kernel whatever its own size --, by this call's otherwise)
+  const long plan = a.plan_N > 0 ? a.plan_N : a.N;
   if constexpr (!REFINE) {
-    if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(a.N, a.step_hi == a.step_lo))) && chain2_eligible(a))
+    if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(plan, a.step_hi == a.step_lo))) && chain2_eligible(a))
       return launch_chain2(a, st);
   }
   if constexpr (REFINE) {   // RefineNet's inference pass: k_chain2's tile-walking form, for the batches its single-step form takes
-    if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(a.N, true))) && chain2_refine_eligible(a)) return launch_chain2_refine(a, st);
+    if ((chain_waves == 2 || (chain_waves == 0 && chain2_pays(plan, true))) && chain2_refine_eligible(a)) return launch_chain2_refine(a, st);
   }
   if (chain_waves == 16 || chain_waves == 2) chain_waves = 0;
   if (REFINE && chain_waves == 32) chain_waves = 8;    // bf16 pieces cost the interval head up to 9e-5 per pass
@@ -1749,6 +1743,7 @@ int launch_chain_nw(int chain_waves, const ChainArgs& a, hipStream_t st) {
   if (chain_waves == 0) {
     if constexpr (!REFINE)
       if (ut && latency) {   // small batch: the latency layout, for multi-step and single-step launches alike
+        // (a shard much smaller than its job's plan, which chose k_chain for it: the layouts of ONE kernel give the same bits)
         const int g = sparse_tiles_per_group(a.N);
         if (g > 0) {
           ChainArgs b = a;
@@ -2032,6 +2027,7 @@ extern "C" int pstl_rollout(const pstl_cfg* cfg, float* packed, const float* bas
   if (n_emit < 0 || n_emit > cfg->steps || (n_emit > 0 && !emit_out)) return PSTL_ERR_ARG;
   ChainArgs a = {};
   a.N = n_rows(cfg);
+  a.plan_N = cfg->plan_rows > 0 ? (long)cfg->plan_rows : 0;
   if (a.N >= (1L << 31)) return PSTL_ERR_SHAPE;   // row indices are 32-bit inside the kernel (a shard of 2^31 rows is 344 GB)
   a.tiles_per_group = tiles_per_group(a.N);
   a.rows_per_scene = cfg->rows_per_scene;
@@ -2078,7 +2074,8 @@ extern "C" int pstl_rollout_layout(const pstl_cfg* cfg, int multi_step, int* ker
   a.N = N, a.rows_per_scene = cfg->rows_per_scene, a.step_hi = multi_step ? 2 : 1, a.step_lo = 1, a.mu_only = multi_step ? 0 : 1;
   const bool ut = cfg->rows_per_scene % kTileRows == 0;
   int k = 3, g = tiles_per_group(N);
-  if ((cw == 2 || (cw == 0 && chain2_pays(N, !multi_step))) && chain2_eligible(a)) {
+  const long plan = cfg->plan_rows > 0 ? (long)cfg->plan_rows : N;
+  if ((cw == 2 || (cw == 0 && chain2_pays(plan, !multi_step))) && chain2_eligible(a)) {
     k = 2, g = chain2_wg_rows(a) / kTileRows;
   } else if (cw == 0 || cw == 16 || cw == 2) {
     k = 1;
@@ -2138,6 +2135,7 @@ static int refine_impl(const pstl_cfg* cfg, float* packed, const float* base_rec
   }
   ChainArgs a = {};
   a.N = n_rows(cfg);
+  a.plan_N = cfg->plan_rows > 0 ? (long)cfg->plan_rows : 0;
   if (a.N >= (1L << 31)) return PSTL_ERR_SHAPE;   // row indices are 32-bit inside the kernel (a shard of 2^31 rows is 344 GB)
   a.tiles_per_group = tiles_per_group(a.N);
   a.rows_per_scene = cfg->rows_per_scene;

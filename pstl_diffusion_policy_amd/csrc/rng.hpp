@@ -19,7 +19,10 @@ struct u32x4 {
 // single-instruction steps), i.e. ~3 % of the dominant launch; the stream is this library's own (the reference draws from torch's
 // generator, which no other device reproduces), every consumer goes through this one constant, and tests/test_gpu_noise_quality.py
 // holds the drawn values to the moments and independence a sampler needs.
-constexpr int kPhiloxRounds = 7;
+#ifndef PSTL_PHILOX_ROUNDS
+#define PSTL_PHILOX_ROUNDS 7      // (-DPSTL_PHILOX_ROUNDS=10: the A/B build of tools/dbg/build_full_variant.sh)
+#endif
+constexpr int kPhiloxRounds = PSTL_PHILOX_ROUNDS;
 
 __host__ __device__ inline u32x4 philox4x32(u32x4 c, uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;

@@ -995,16 +995,7 @@ using namespace pstl;
 // the 64 rows of every workgroup share one scene (and the staged tables fit comfortably in LDS)
 static bool scene_staged(const pstl_cfg* cfg) { return cfg->rows_per_scene % kWave == 0 && cfg->K <= 16; }
 // up to one 64-row group per CU, the guidance kernel runs its latency layout (k_guidance_iter<.., SPLIT>)
-static long guidance_split_max_groups() {
-  static long n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-            ? p.multiProcessorCount : 256;
-  }
-  return n;
-}
+static long guidance_split_max_groups() { return device_cus(); }   // (of the current device: pstl_common.hpp)
 
 static int allow_lds(const void* fn, size_t bytes) {
   if (bytes <= 48 * 1024) return PSTL_OK;

@@ -1243,24 +1243,19 @@ extern "C" int pstl_refine_backward(const pstl_cfg* cfg, const float* w2 /* (256
   if (!exact && cfg->rows_per_scene % kFcRows == 0) {
     // one pass per layer (k_bwd_l2 / k_bwd_l1 above): each saved activation is read once
     // (per device: a process may drive several GPUs -- the CU count and the function attributes belong to the current one)
-    static int cus_dev = -1, cus = 0, lds_dev = -1;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return PSTL_ERR_LAUNCH;
-    if (cus_dev != dev) {
-      hipDeviceProp_t pr;
-      cus = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-      if (cus > kRedBlocks) cus = kRedBlocks;
-      cus_dev = dev;
-    }
+    static DeviceOnce lds_allowed;
+    const int dev = current_device();
+    if (dev < 0) return PSTL_ERR_LAUNCH;
+    int cus = device_cus(dev);
+    if (cus > kRedBlocks) cus = kRedBlocks;
     const long n_chunks = (N + kFcRows - 1) / kFcRows;
     const int nb2 = (int)(n_chunks < cus ? n_chunks : cus);
-    const bool lds_ok = lds_dev == dev;
-    if (!lds_ok) {
+    if (!lds_allowed.done(dev)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_l2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_l2_lds()) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_l1<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_l1_lds()) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_l1<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_l1_lds()) != hipSuccess)
         return PSTL_ERR_LAUNCH;
-      lds_dev = dev;
+      lds_allowed.set(dev);
     }
     // layer 2 and dW3:  dH2 = (dO W3) * [h2 > 0], db2, dW3 = dO^T h2
     hipLaunchKernelGGL(k_pack_wt_bf, dim3(16 * 2 * 2), dim3(256), 0, st, w3, kHid, kCtrl, kHid, 2, wpack);

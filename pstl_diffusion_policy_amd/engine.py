@@ -129,14 +129,19 @@ class SceneBatch:
     """
 
     def __init__(self, scene, S, hp, device, global_valid_sum=None, global_rows=None, row_offset=0, dyn=None,
-                 scale_in_dyn=False):
-        """dyn: None, or a 4-float32 device tensor laid out as a pstl_dyn (include/pstl_hip.h): the kernels then read the noise
+                 scale_in_dyn=False, plan_rows=0):
+        """plan_rows: the row count the default arithmetic (chain_waves = 0) picks its denoiser kernel for (pstl_cfg.plan_rows).
+        0: this batch's own rows.  A job that shards a batch passes the SAME number on every shard (shard.plan_rows: the rows of
+        its largest shard), so that all its rows run through the same kernel and a row's bits do not depend on the shard that
+        holds it; a single process that wants the bits of such a job passes the job's number.
+        dyn: None, or a 4-float32 device tensor laid out as a pstl_dyn (include/pstl_hip.h): the kernels then read the noise
         seed from its first 8 bytes and the guidance-loss scale from its third word -- which THIS constructor writes there, on
         the device, from the lane ids (no host synchronisation) -- instead of taking them by value: the launches of a whole
         planning step can be captured in a HIP graph and replayed with new inputs (nusc_sim.py).  scale_in_dyn: the caller has
         already put the scale there (SceneBatch.loss_scale of the host copy of the lane ids): nothing is computed here."""
         dev = torch.device(device)
         self.row_offset = int(row_offset)   # global index of the first row (in-kernel noise is keyed by global row)
+        self.plan_rows = int(plan_rows or 0)
         self.dyn = dyn
         # A batch that arrives in host memory (the closed-loop caller builds one scene per simulation step) crosses PCIe as
         # ONE staged copy instead of one per tensor, and the guidance-loss scale is taken from the host copy of the lane ids:
@@ -211,7 +216,7 @@ class SceneBatch:
 
     def cfg(self, steps, flags=0, chain_waves=0, seed=0):
         return ffi.make_cfg(self.bs, self.rps, self.S, self.K, steps, self.hp, flags, chain_waves, seed, self.row_offset,
-                            dyn=self.dyn)
+                            dyn=self.dyn, plan_rows=self.plan_rows)
 
 
 def guidance_triggered(i, steps, g):
@@ -651,6 +656,123 @@ class DynBlock:
         self.events[slot] = ev
 
 
+def adam_schedule(lr, betas, n_steps, first=1):
+    """(n_steps, 2) float32: -lr / (1 - beta1^t), sqrt(1 - beta2^t) for t = first ... first + n_steps - 1, computed in double
+    precision with the very Python expressions of torch/optim/adam.py (_single_tensor_adam) and rounded to float32 as torch
+    rounds its Python scalars: the table pstl_adam_step indexes with its device step counter."""
+    b1, b2 = float(betas[0]), float(betas[1])
+    out = np.empty((int(n_steps), 2), np.float32)
+    for k in range(int(n_steps)):
+        t = first + k
+        bias_correction1 = 1 - b1 ** t
+        bias_correction2 = 1 - b2 ** t
+        step_size = lr / bias_correction1
+        out[k, 0] = np.float32(-step_size)
+        out[k, 1] = np.float32(bias_correction2 ** 0.5)
+    return out
+
+
+class DeviceAdam:
+    """torch.optim.Adam (defaults: no weight decay, no amsgrad -- the reference's optimiser, nusc_train.py:1233) on the device
+    path: the moments, the table of per-step scalars and the step counter live in device memory and ONE launch of
+    pstl_adam_step updates every tensor (csrc/adam_kernels.hip; bit for bit torch's float32 update, tests/test_adam_core_hostsim.py
+    and tests/test_gpu_train_step.py).  Nothing of a step is passed by value, so a training step that ends in step() can be
+    captured in a HIP graph and replayed.
+
+    params: the live parameter tensors (contiguous float32, on one device), updated IN PLACE; their autograd version counters
+    are bumped so that Net.packed() / PackedWeights notice the change.  `adopt(optimizer, params)` wraps a caller's
+    torch.optim.Adam (the reference's training loop builds one): its hyper-parameters are taken over -- anything but Adam's
+    defaults besides lr / betas / eps is refused --, the lr of its first param group is re-read at every step (schedulers work),
+    and its own step() is never called."""
+
+    TABLE = 4096      # steps of scalars per table; the table is extended (outside any capture) when the count gets there
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("DeviceAdam: no parameters")
+        if len(self.params) > ffi.ADAM_MAX_TENSORS:
+            raise ValueError("DeviceAdam: at most %d tensors per step (include/pstl_hip.h)" % ffi.ADAM_MAX_TENSORS)
+        dev = self.params[0].device
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                raise ValueError("DeviceAdam: parameters must be contiguous float32 tensors on one device")
+        self.device, self.lr, self.betas, self.eps = dev, float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.numel = [int(p.numel()) for p in self.params]
+        total = sum(self.numel)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.steps_done = 0                 # host mirror of the device counter (eager steps and replays the caller reports)
+        self._table_first, self._table_lr, self.sched = None, None, None
+        self._numel_arr = (ctypes.c_int64 * len(self.numel))(*self.numel)
+        self._p_arr = (ctypes.c_void_p * len(self.params))(*[p.data_ptr() for p in self.params])
+        self._ensure_table()
+
+    @classmethod
+    def adopt(cls, optimizer, params):
+        """The DeviceAdam behind a caller's torch.optim.Adam (created on first use, kept on the optimizer object)."""
+        if isinstance(optimizer, cls):
+            return optimizer
+        mine = getattr(optimizer, "_pstl_device_adam", None)
+        ids = [id(p) for p in params]
+        if mine is None or mine._ids != ids:
+            if not isinstance(optimizer, torch.optim.Adam):
+                raise TypeError("train_step: the optimiser must be torch.optim.Adam (the reference's) or a DeviceAdam, not %s"
+                                % type(optimizer).__name__)
+            g = optimizer.param_groups[0]
+            for key, want in (("weight_decay", 0), ("amsgrad", False), ("maximize", False)):
+                if g.get(key, want) != want:
+                    raise NotImplementedError("DeviceAdam: torch.optim.Adam(%s=%r) is not built (the reference uses the defaults)"
+                                              % (key, g[key]))
+            mine = cls(params, lr=g["lr"], betas=g["betas"], eps=g["eps"])
+            mine._ids = ids
+            mine._group = g
+            optimizer._pstl_device_adam = mine
+        mine.lr = float(mine._group["lr"])
+        return mine
+
+    def _ensure_table(self):
+        """The table of per-step scalars covers the step about to be taken (and the lr it was built for is still the lr)."""
+        if (self.sched is None or self._table_lr != self.lr or not
+                (self._table_first <= self.steps_done + 1 < self._table_first + self.TABLE)):
+            first = self.steps_done + 1
+            tab = torch.from_numpy(adam_schedule(self.lr, self.betas, self.TABLE, first))
+            if self.sched is None:
+                self.sched = tab.to(self.device)
+            else:
+                self.sched.copy_(tab)        # in place: a captured step keeps reading this very buffer
+            self._table_first, self._table_lr = first, self.lr
+            self.step_dev.fill_(0)           # the counter indexes THIS table
+
+    def note_replays(self, n=1):
+        """A captured step() was replayed n times: the device counter moved, this brings the host's mirror along (it decides when
+        the table of per-step scalars must be extended -- outside any capture)."""
+        self.steps_done += int(n)
+
+    def step(self, grads):
+        """One optimiser step from `grads` (one tensor per parameter, same shapes)."""
+        if len(grads) != len(self.params):
+            raise ValueError("DeviceAdam.step: %d gradients for %d parameters" % (len(grads), len(self.params)))
+        gs = []
+        for p, g in zip(self.params, grads):
+            g = ffi.f32(g, self.device)
+            if g.numel() != p.numel():
+                raise ValueError("DeviceAdam.step: a gradient's size does not match its parameter's")
+            gs.append(g)
+        self._ensure_table()
+        g_arr = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+        ffi.check(ffi.lib().pstl_adam_step(len(gs), self._p_arr, g_arr, self._numel_arr, ffi.ptr(self.exp_avg),
+                                           ffi.ptr(self.exp_avg_sq), ffi.ptr(self.sched), self.TABLE,
+                                           ffi.ptr(self.step_dev, torch.int32), ctypes.c_float(1 - self.betas[0]),
+                                           ctypes.c_float(self.betas[1]), ctypes.c_float(1 - self.betas[1]),
+                                           ctypes.c_float(self.eps), ffi.stream()), "adam_step")
+        self.steps_done += 1
+        for p in self.params:      # (no arithmetic: the kernel wrote through the raw pointer; packed-weight caches key on this)
+            torch.autograd.graph.increment_version(p)
+        del gs
+
+
 def diversity_from_totals(totals, nt=ffi.T):
     """The reference's printed diversity numbers from the 12 additive totals of pstl_diversity (sums over shards add)."""
     t = [float(v) for v in (totals.tolist() if hasattr(totals, "tolist") else totals)]
@@ -675,8 +797,8 @@ def acc_from_counts(counts):
 class RectTrainer:
     """RefineNet training step under the STL loss (reference nusc_train.py:1400-1427,1522-1525 with
     compute_policy_loss :370-478 for --rect_head without --diverse_loss): forward with saved activations, STL adjoint,
-    head/MLP backward -> gradients of the six rect_net tensors in the reference layout.  The optimiser itself stays the
-    caller's torch.optim.Adam over `net.rect_net.parameters()`, exactly as in the reference."""
+    head/MLP backward -> gradients of the six rect_net tensors in the reference layout.  The optimiser is Adam as the
+    reference builds it (torch.optim.Adam over `net.rect_net.parameters()`), run on the device path: DeviceAdam / pstl_adam_step."""
 
     NAMES = ("rect_net.0.weight", "rect_net.0.bias", "rect_net.2.weight", "rect_net.2.bias", "rect_net.4.weight",
              "rect_net.4.bias")
@@ -833,13 +955,21 @@ class RectTrainer:
         return g
 
     def train_step(self, sb, params, optimizer, steps, x_T=None, noise=None, seed=None, multi_cands=5, coeffs=None,
-                   group=None, e7=None, stl_weight=1.0, merge=None, clip_rect=False, joint=False):
+                   group=None, e7=None, stl_weight=1.0, merge=None, clip_rect=False, joint=False, domain_check="eager"):
         """One optimisation step of config 5 on one batch shard: sampling under no-grad (rollout, candidate scoring and
         selection), RefineNet forward/backward under the STL loss, gradient all-reduce over the ranks (the loss is a
         mean over the GLOBAL batch, so per-rank gradients simply add), optimizer.step() on the caller's parameters.
         `params`: dict name -> live torch Parameter/Tensor for RectTrainer.NAMES (the weights used by the kernels are
         re-packed from them by the caller after the step).
-        joint (--joint): `params` holds RectTrainer.joint_names(merge) -- the encoders and merge_net are trained too."""
+        joint (--joint): `params` holds RectTrainer.joint_names(merge) -- the encoders and merge_net are trained too.
+        optimizer: the caller's torch.optim.Adam (adopted: hyper-parameters taken over, never stepped) or a DeviceAdam; the step
+        itself is pstl_adam_step on the device path.
+        domain_check: "eager" reads the split-f16 domain word (one 4-byte copy = one synchronisation) before the optimiser
+        consumes the gradients and repeats the step on the exact kernels when it is set; "deferred" reads nothing -- for a caller
+        that captures the step in a HIP graph (no synchronisation inside a capture) and calls `sampler.check_chain_domain()`
+        where it synchronises anyway; a step that left the domain has then already been applied."""
+        if domain_check not in ("eager", "deferred"):
+            raise ValueError("domain_check: 'eager' or 'deferred'")
         import torch.distributed as dist
         sm = self.sm
         use_merge = (e7 is not None) if merge is None else bool(merge)
@@ -873,13 +1003,20 @@ class RectTrainer:
         # every rank repeats the step and switches arithmetic together -- gradients of two arithmetics are never mixed, and
         # the shard split does not change which kernels ran.
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-        hit = sm.chain_waves in (0, 16, 2) and sm.w.chain_overflowed(clear=True)
-        if multi and sm.chain_waves in (0, 16, 2):
-            flag = torch.tensor([1 if hit else 0], dtype=torch.int32)
+        if domain_check == "deferred" and multi:
+            raise ValueError("train_step: the deferred domain check is for single-process (graph-captured) steps")
+        hit = domain_check == "eager" and sm.chain_waves in (0, 16, 2) and sm.w.chain_overflowed(clear=True)
+        if multi:
+            # EVERY rank joins this all-reduce, whatever arithmetic it is on (a rank already on the exact kernels used
+            # to skip it, and its peers' flag all-reduce then paired with its gradient all-reduce): word 0 = "a split-f16 launch of
+            # mine left the domain", word 1 = "I am on the exact kernels already".  Either one anywhere moves the whole job to the
+            # exact kernels for this step and the rest of the run: gradients of two arithmetics are never mixed.
+            flag = torch.tensor([1 if hit else 0, 0 if sm.chain_waves in (0, 16, 2) else 1], dtype=torch.int32)
             if dist.get_backend(group) != "gloo":
                 flag = flag.to(sb.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-            hit = bool(int(flag.item()))
+            f = [int(v) for v in flag.tolist()]
+            hit = sm.chain_waves in (0, 16, 2) and bool(f[0] or f[1])
         if hit:
             sm.use_exact_fp32("a layer input left the split-f16 domain |x| < 4094 (the state became non-finite)" +
                               (" on some rank" if multi else ""))
@@ -898,8 +1035,7 @@ class RectTrainer:
                 g[k] = flat[o:o + n].reshape(g[k].shape)
                 o += n
             loss = flat[o]
-        optimizer.zero_grad(set_to_none=True)
-        for k in names:
-            params[k].grad = g[k]
-        optimizer.step()
+        # the optimiser step on the device path: one launch of pstl_adam_step over the trained tensors -- a
+        # caller's torch.optim.Adam is adopted (its hyper-parameters and lr), never stepped; the caller re-packs afterwards
+        DeviceAdam.adopt(optimizer, [params[k] for k in names]).step([g[k] for k in names])
         return loss, scores

@@ -26,8 +26,9 @@ HID = 256
 FEAT = 224
 NEI_PREP = 12
 
-ABI_VERSION = 5      # include/pstl_hip.h PSTL_ABI_VERSION
+ABI_VERSION = 6      # include/pstl_hip.h PSTL_ABI_VERSION
 SPLIT_F16_WMAX = 63.9   # include/pstl_hip.h PSTL_SPLIT_F16_WMAX
+ADAM_MAX_TENSORS = 32   # include/pstl_hip.h PSTL_ADAM_MAX_TENSORS
 
 class PstlCfg(ctypes.Structure):
     _fields_ = [("bs", ctypes.c_int32), ("rows_per_scene", ctypes.c_int32), ("S", ctypes.c_int32),
@@ -36,7 +37,8 @@ class PstlCfg(ctypes.Structure):
                 ("tau", ctypes.c_float), ("thres", ctypes.c_float), ("w_max", ctypes.c_float),
                 ("a_max", ctypes.c_float), ("dt", ctypes.c_float), ("ego_L", ctypes.c_float),
                 ("ego_W", ctypes.c_float), ("reserved_f", ctypes.c_float),
-                ("seed", ctypes.c_uint64), ("row_offset", ctypes.c_int64), ("dyn", ctypes.c_void_p)]
+                ("seed", ctypes.c_uint64), ("row_offset", ctypes.c_int64), ("dyn", ctypes.c_void_p),
+                ("plan_rows", ctypes.c_int64)]
 
 
 class Mlp3(ctypes.Structure):
@@ -78,6 +80,7 @@ SIGNATURES = [
     ("pstl_select_plan", _I, [_C] + [_P] * 5),
     ("pstl_refine_train_forward", _I, [_C] + [_P] * 12),
     ("pstl_loss_grad", _I, [_C, _P, _P, _F, _P, _P, _P]),
+    ("pstl_adam_step", _I, [_I, _P, _P, _P, _P, _P, _P, _I, _P, _F, _F, _F, _F, _P]),
     ("pstl_train_work_floats", _Z, [_C]),
     ("pstl_refine_backward", _I, [_C] + [_P] * 20),
     ("pstl_diversity", _I, [_C, _P, _P, _I] + [_P] * 8),
@@ -150,8 +153,10 @@ def ptr(t, dtype=torch.float32):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def make_cfg(bs, rows_per_scene, S, K, steps, hp, flags=0, chain_waves=0, seed=0, row_offset=0, dyn=None):
-    """dyn: None, or a 4-float32 device tensor holding a pstl_dyn (seed as two 32-bit words, grad_scale, 0): the kernels read
+def make_cfg(bs, rows_per_scene, S, K, steps, hp, flags=0, chain_waves=0, seed=0, row_offset=0, dyn=None, plan_rows=0):
+    """plan_rows: the row count chain_waves = 0 picks its denoiser kernel for (0 = this call's own rows; a sharded job passes
+    its nominal rows per GPU everywhere: include/pstl_hip.h).
+    dyn: None, or a 4-float32 device tensor holding a pstl_dyn (seed as two 32-bit words, grad_scale, 0): the kernels read
     seed / grad_scale from it at run time (HIP-graph replay with new values, include/pstl_hip.h)."""
     if hp.get("norm_stl", False):     # --norm_stl travels with the hyper-parameters: every launch of the batch sees it
         flags = int(flags) | PSTL_FLAG_NORM_STL
@@ -160,7 +165,7 @@ def make_cfg(bs, rows_per_scene, S, K, steps, hp, flags=0, chain_waves=0, seed=0
                    tau=float(hp["smoothing_factor"]), thres=float(hp["stl_nn_thres"]), w_max=float(hp["mul_w_max"]),
                    a_max=float(hp["mul_a_max"]), dt=float(hp["dt"]), ego_L=float(hp["ego_L"]),
                    ego_W=float(hp["ego_W"]), reserved_f=0.0, seed=int(seed) & (2 ** 64 - 1), row_offset=int(row_offset),
-                   dyn=None if dyn is None else ptr(dyn).value)
+                   dyn=None if dyn is None else ptr(dyn).value, plan_rows=int(plan_rows))
 
 
 def f32(x, device):

@@ -148,3 +148,12 @@ void hostsim_stl_grad_norm(GRAD_ARGS) { stl_grad_t<true>(GRAD_PASS); }
 void hostsim_stl_grad_parts(GRAD_ARGS) { stl_grad_parts_t<false>(GRAD_PASS); }
 void hostsim_stl_grad_parts_norm(GRAD_ARGS) { stl_grad_parts_t<true>(GRAD_PASS); }
 }
+
+// ---- csrc/adam_core.hpp on the host: one Adam step over n elements with the scalars the device table would hold ------------
+#include "../../pstl_diffusion_policy_amd/csrc/adam_core.hpp"
+extern "C" void hostsim_adam_step(long n, float* p, float* m, float* v, const float* g, float neg_step_size, float bc2_sqrt,
+                                  float one_minus_beta1, float beta2, float one_minus_beta2, float eps) {
+  pstl::AdamScalars s;
+  s.neg_step_size = neg_step_size, s.bc2_sqrt = bc2_sqrt, s.beta2 = beta2, s.w1 = one_minus_beta1, s.w2 = one_minus_beta2, s.eps = eps;
+  for (long i = 0; i < n; ++i) pstl::adam_update(p[i], m[i], v[i], g[i], s);
+}

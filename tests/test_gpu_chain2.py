@@ -367,3 +367,37 @@ def test_chain2_refine_form_against_k_chain(dev, diverse, clip_rect):
         r0, r1 = lo * 192, hi * 192
         part = sm.refine(sub, base_s, init[r0:r1].contiguous(), scores[r0:r1].contiguous(), diverse=diverse, clip_rect=clip_rect)
         assert torch.equal(part, outs[1][r0:r1]), (lo, hi)
+
+
+def test_default_arithmetic_is_shard_invariant_under_a_job_wide_plan(dev):
+    """with chain_waves = 0 the library picks k_chain or k_chain2 by batch size -- the same products in two
+    summation orders -- so a shard evaluated alone could get other last bits than the same rows inside the whole batch.  A job
+    names ONE row count for that choice (pstl_cfg.plan_rows = SceneBatch(plan_rows=...), shard.plan_rows: its largest shard):
+    every shard then runs the kernel the others run, whatever its own size, and reproduces the batch's rows bit for bit in the
+    DEFAULT mode.  256 scenes x 192 rows = 49 152 rows take k_chain2's multi-step launch; a 24-scene shard alone would take
+    k_chain's latency layout -- without the plan it differs in the last bits (asserted too, so that the test cannot pass vacuously)."""
+    from pstl_diffusion_policy_amd import ffi
+    from pstl_diffusion_policy_amd.engine import Sampler, SceneBatch
+    from pstl_diffusion_policy_amd.shard import plan_rows
+    bs, S, K, steps, seed = 256, 64, 2, 9, 777
+    hp, scene, w, sb = _setup(dev, bs, S, K, seed=12)
+    sm = Sampler(w, hp, chain_waves=0)
+    guid = dict(enabled=True, before=3, niters=1, lr=0.01)
+    assert ffi.rollout_layout(sb.cfg(steps, ffi.PSTL_FLAG_RNG, 0))[0] == 2, "the whole batch is expected on k_chain2"
+    full = sm.sampling_region(sb, steps, None, None, rect_head=True, multi_cands=4, guidance=guid, seed=seed)
+    lo, hi = 100, 124
+    sub = {k: v[lo:hi].clone() for k, v in scene.items()}
+    r0, r1 = lo * S * 3, hi * S * 3
+    kw = dict(row_offset=r0, global_valid_sum=float(sb.valid.sum()), global_rows=sb.N)
+    alone = SceneBatch(sub, S, hp, dev, **kw)
+    assert ffi.rollout_layout(alone.cfg(steps, ffi.PSTL_FLAG_RNG, 0))[0] != 2, "the shard alone is expected on k_chain"
+    planned = SceneBatch(sub, S, hp, dev, plan_rows=sb.N, **kw)
+    assert ffi.rollout_layout(planned.cfg(steps, ffi.PSTL_FLAG_RNG, 0))[0] == 2
+    run = lambda b: sm.sampling_region(b, steps, None, None, rect_head=True, multi_cands=4, guidance=guid, seed=seed)
+    a, p = run(alone), run(planned)
+    for k in ("final_controls", "final_scores"):
+        assert torch.equal(p[k], full[k][r0:r1]), k
+    assert not torch.equal(a["final_controls"], full["final_controls"][r0:r1])
+    assert (a["final_controls"] - full["final_controls"][r0:r1]).abs().max().item() <= 2e-4
+    # the job-side helper: eight ranks over 256 scenes plan for 32 scenes' rows; seven scenes over eight ranks for one scene's
+    assert plan_rows(256, 8, 3 * S) == 32 * 3 * S and plan_rows(7, 8, 3 * S) == 3 * S

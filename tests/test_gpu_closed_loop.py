@@ -91,9 +91,11 @@ def test_latency_of_a_simulation_step_at_the_reference_settings(capsys):
     with capsys.disabled():
         print("\nclosed loop: median %.2f ms, worst %.2f ms per simulation step (192 rows, 100 steps, K=8, guidance)" % (med, worst))
     assert all(math.isfinite(r["best_score"]) for r in recs)
-    # wall clock including the host, on a shared box: the measured median is printed (0.86-0.91 ms with the HIP-graph replay;
-    # round 3: 1.3, round 2: 2.7); the bound only catches a return to per-launch host latency
-    assert med < 3.0, med
+    # wall clock including the host, on a shared box: the measured median is printed (0.84-0.91 ms with the HIP-graph replay;
+    # round 3: 1.3, round 2: 2.7).  The default bound, 3 ms, only catches a return to per-launch host latency on a pool whose
+    # hosts are shared; PSTL_STRICT_LATENCY=1 (a box of one's own) holds the run to the 1.8 ms of rounds 3-4
+    import os
+    assert med < (1.8 if os.environ.get("PSTL_STRICT_LATENCY") == "1" else 3.0), med
 
 
 def test_parameters_in_device_memory_equal_parameters_by_value():

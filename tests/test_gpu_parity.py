@@ -359,8 +359,63 @@ def test_full_size_properties(dev):
                               steps, None, None, rect_head=True, multi_cands=5, guidance=guid, seed=seed, want_scores3=False)
     assert torch.equal(part["final_controls"], full["final_controls"][lo * S * 3:hi * S * 3])
     assert torch.equal(part["final_scores"], full["final_scores"][lo * S * 3:hi * S * 3])
+    # ... and in the DEFAULT mode under the job's plan (pstl_cfg.plan_rows: the shard runs the kernel the batch ran)
+    part = sm.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=lo * S * 3, global_valid_sum=vsum, global_rows=N, plan_rows=N),
+                              steps, None, None, rect_head=True, multi_cands=5, guidance=guid, seed=seed, want_scores3=False)
+    assert torch.equal(part["final_controls"], full["final_controls"][lo * S * 3:hi * S * 3])
+    assert torch.equal(part["final_scores"], full["final_scores"][lo * S * 3:hi * S * 3])
     acc, sacc = acc_from_counts(full["counts"])
     assert 0.0 < acc < 1.0 and 0.0 < sacc <= 1.0
+
+
+def test_full_size_properties_e5(dev):
+    """BASELINE.json config 2 at its full size (e5: 4096 scenes x 64 x 3 = 786 432 rows, 50 diffusion steps, DDPM only -- no
+    guidance, no RefineNet, no clip): ONE 49-step launch of the denoiser kernel without clip or candidate emission, which only
+    bench.py's `also` block ran at this size.  Properties: the two halves evaluated on their own reproduce the
+    full run bit for bit and their counters add up; the counters agree with the scores; the un-clipped controls are the
+    normalised final state (normalize_diff without clip, nusc_train.py:647-655); a repeat gives the same bits."""
+    from pstl_diffusion_policy_amd import ffi
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler, acc_from_counts
+    from pstl_diffusion_policy_amd.synthetic import make_scene_batch
+    hp = _hp()
+    bs, S, K, steps, seed = 4096, 64, 2, 50, 19
+    scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=K, S=S, seed=4, invalid_lane_frac=0.2, stlp_mode="wide").items()
+             if k not in ("params", "pre_stlp", "tj_scores_prior")}
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    sb = SceneBatch(scene, S, hp, dev)
+    N = sb.N
+    assert N == 786432
+    assert ffi.rollout_layout(sb.cfg(steps, ffi.PSTL_FLAG_RNG, 0))[0] == 2        # the row-stationary kernel, one launch
+    sm.trace = []
+    full = sm.sampling_region(sb, steps, None, None, rect_head=False, seed=seed, want_scores3=False)
+    assert [(n, rows) for (_, _, n, rows) in sm.trace] == [(steps - 1, N)], "one 49-step launch over all rows"
+    sm.trace = None
+    again = sm.sampling_region(sb, steps, None, None, rect_head=False, seed=seed, want_scores3=False)
+    c = full["final_controls"]
+    assert torch.isfinite(c).all() and torch.isfinite(full["final_scores"]).all()
+    assert torch.equal(c, again["final_controls"]) and torch.equal(full["final_scores"], again["final_scores"])
+    # no clip: some controls of a random-init denoiser leave the range RefineNet's configs clip to
+    c3 = c.reshape(N, 20, 2)
+    assert c3[..., 0].abs().max().item() > hp["mul_w_max"] or c3[..., 1].abs().max().item() > hp["mul_a_max"]
+    cnt = full["counts"].tolist()
+    sat = (full["final_scores"] > 0) & (sb.valid > 0)
+    assert cnt[0] == int(sat.sum()) and cnt[1] == int(sb.valid.sum()) and cnt[2] == N and cnt[5] == 3 * bs
+    assert cnt[3] == int(sat.reshape(bs, S, 3).any(dim=1).sum())
+    # the scores are the scores of exactly these controls (a second scoring pass over them)
+    assert torch.equal(sm.score(sb, c.reshape(1, N, 40))["scores"][0], full["final_scores"])
+    total = torch.zeros(8, dtype=torch.int64, device=dev)
+    for half in range(2):
+        lo, hi = half * bs // 2, (half + 1) * bs // 2
+        sub = {k: v[lo:hi].contiguous() for k, v in scene.items()}
+        part = sm.sampling_region(SceneBatch(sub, S, hp, dev, row_offset=lo * S * 3, plan_rows=N), steps, None, None,
+                                  rect_head=False, seed=seed, want_scores3=False)
+        r0, r1 = lo * S * 3, hi * S * 3
+        assert torch.equal(part["final_controls"], c[r0:r1])
+        assert torch.equal(part["final_scores"], full["final_scores"][r0:r1])
+        total += part["counts"]
+    assert torch.equal(total, full["counts"])
+    acc, _ = acc_from_counts(full["counts"])
+    assert 0.0 < acc < 1.0
 
 
 @pytest.mark.parametrize("noise", ["kernel", "tensor"])

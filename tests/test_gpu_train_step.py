@@ -46,8 +46,10 @@ def test_rect_train_step_matches_reference(name, chain_waves):
     for k in tr.NAMES:
         ref = d["grad_" + k]
         np.testing.assert_allclose(g[k].cpu().numpy(), ref, rtol=5e-3, atol=5e-5 * np.abs(ref).max(), err_msg=k)
-        params[k].grad = g[k]
-    opt.step()
+    # the optimiser step on the device path (pstl_adam_step), with the hyper-parameters of the caller's torch.optim.Adam
+    from pstl_diffusion_policy_amd.engine import DeviceAdam
+    DeviceAdam.adopt(opt, [params[k] for k in tr.NAMES]).step([g[k] for k in tr.NAMES])
+    assert not opt.state, "the caller's torch optimiser is adopted, never stepped"
     for k in tr.NAMES:
         got, want, gref = params[k].detach().cpu().numpy(), d["after_" + k], d["grad_" + k]
         # Adam's first step moves every weight by lr * g/(|g| + 1e-8): where the gradient is at rounding-noise level its
@@ -334,3 +336,112 @@ def test_repacking_one_network_in_place_equals_a_full_pack():
         assert pw.chain_wmax == full.chain_wmax and pw.chain_wmax["rect_net"] == 7.5
     with pytest.raises(ValueError):
         pw.update({"rect_net.0.weight": sd["rect_net.0.weight"]})  # a network is packed whole
+
+
+@pytest.mark.parametrize("lr,betas,eps", [(3e-4, (0.9, 0.999), 1e-8), (0.01, (0.8, 0.99), 1e-6)])
+def test_device_adam_equals_torch_adam(lr, betas, eps):
+    """pstl_adam_step against torch.optim.Adam on the CPU (the reference's optimiser, nusc_train.py:1233) over ten steps on the
+    shapes of rect_net's six tensors: both moments bit for bit at every step -- the parameters too wherever torch's vectorised
+    CPU square root is the IEEE one (tests/test_adam_core_hostsim.py says why not everywhere), one ulp of the increment
+    otherwise --, the version counters bumped (what PackedWeights caches key on), the step counter on the device."""
+    from pstl_diffusion_policy_amd.engine import DeviceAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    shapes = [(256, 271), (256,), (256, 256), (256,), (40, 256), (40,)]
+    cpu = [(torch.randn(s, generator=g) * 0.05).requires_grad_() for s in shapes]
+    gpu = [p.detach().clone().to(dev).requires_grad_() for p in cpu]
+    opt = torch.optim.Adam(cpu, lr=lr, betas=betas, eps=eps)
+    dopt = DeviceAdam(gpu, lr=lr, betas=betas, eps=eps)
+    v0 = [p._version for p in gpu]
+    for t in range(10):
+        grads = [torch.randn(s, generator=g) * (10.0 ** float(torch.randint(-8, 1, (1,), generator=g))) for s in shapes]
+        grads[0][::5] = 0.0
+        for p, gr in zip(cpu, grads):
+            p.grad = gr.clone()
+        prev = [p.detach().clone() for p in cpu]
+        opt.step()
+        dopt.step([gr.to(dev) for gr in grads])
+        o = 0
+        for i, (pc, pg) in enumerate(zip(cpu, gpu)):
+            n = pc.numel()
+            st = opt.state[pc]
+            m = dopt.exp_avg[o:o + n].cpu().numpy().view(np.uint32)
+            v = dopt.exp_avg_sq[o:o + n].cpu().numpy()
+            assert np.array_equal(m, st["exp_avg"].numpy().reshape(-1).view(np.uint32)), (t, i)
+            assert np.array_equal(v.view(np.uint32), st["exp_avg_sq"].numpy().reshape(-1).view(np.uint32)), (t, i)
+            want, got = pc.detach().numpy().reshape(-1), pg.detach().cpu().numpy().reshape(-1)
+            ieee = torch.sqrt(st["exp_avg_sq"]).numpy().reshape(-1).view(np.uint32) == np.sqrt(v).view(np.uint32)
+            assert np.array_equal(got.view(np.uint32)[ieee], want.view(np.uint32)[ieee]), (t, i)
+            step = np.abs(want - prev[i].numpy().reshape(-1))
+            assert (np.abs(got - want) <= np.spacing(np.abs(want)) + 2.5e-7 * step).all(), (t, i)
+            with torch.no_grad():
+                pg.copy_(pc.detach())           # (every step is checked on its own)
+            o += n
+    assert int(dopt.step_dev.item()) == 10 and dopt.steps_done == 10
+    assert all(p._version > v for p, v in zip(gpu, v0))
+
+
+def test_training_step_replays_as_one_hip_graph():
+    """with the optimiser on the device path (pstl_adam_step: per-step scalars from a device table indexed by
+    a device counter) and the in-place re-pack of rect_net (pstl_repack_weights: kernels only), ONE captured HIP graph is a whole
+    training step of config 5 -- sampling under in-kernel noise (seed through a pstl_dyn block), RefineNet forward / STL adjoint /
+    backward, Adam, re-pack.  Three replays with three seeds must leave the weights that three eager steps leave, bit for bit."""
+    from pstl_diffusion_policy_amd.engine import (DeviceAdam, DynBlock, GraphCapture, PackedWeights, RectTrainer, Sampler, SceneBatch)
+    from pstl_diffusion_policy_amd.nusc_model import init_state_dict
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    dev = torch.device("cuda:0")
+    hp = default_hparams()
+    bs, S, K, steps = 24, 64, 2, 12
+    scene = {k: v.to(dev) for k, v in make_scene_batch(bs, K=K, S=S, seed=21, invalid_lane_frac=0.2, stlp_mode="wide").items()
+             if k not in ("params", "pre_stlp", "tj_scores_prior")}
+    sd0 = init_state_dict(1007)
+    seeds = [101, 202, 303]
+
+    def fresh():
+        sd = {k: v.to(dev).clone() for k, v in sd0.items()}
+        params = {k: sd[k].requires_grad_() for k in RectTrainer.NAMES}
+        pw = PackedWeights(sd, dev)
+        opt = DeviceAdam([params[k] for k in RectTrainer.NAMES], lr=3e-4)
+        return sd, params, pw, opt
+
+    # eager: three steps, re-packing rect_net after each
+    sd, params, pw, opt = fresh()
+    for s in seeds:
+        sb = SceneBatch(scene, S, hp, dev)
+        RectTrainer(Sampler(pw, hp)).train_step(sb, params, opt, steps, seed=s, multi_cands=3)
+        pw.update({k: v for k, v in sd.items() if k.startswith("rect_net.")}, read_status=False)
+    want = {k: params[k].detach().clone() for k in RectTrainer.NAMES}
+    assert opt.steps_done == 3
+
+    # one captured graph, replayed with the seed in device memory
+    sd, params, pw, opt = fresh()
+    dyn = DynBlock(dev)
+    vsum = float(sum(scene[k].sum().item() for k in ("curr_id", "left_id", "right_id"))) * S
+    dyn.set(seeds[0], SceneBatch.loss_scale(vsum, bs * S * 3))
+    sm = Sampler(pw, hp)
+
+    def body():
+        sb = SceneBatch(scene, S, hp, dev, dyn=dyn.dev, scale_in_dyn=True)
+        sb.grad_scale = dyn.grad_scale            # (the training loss takes its scale by value; the guidance scale sits in dyn)
+        loss, scores = RectTrainer(sm).train_step(sb, params, opt, steps, seed=0, multi_cands=3, domain_check="deferred")
+        pw.update({k: v for k, v in sd.items() if k.startswith("rect_net.")}, read_status=False)
+        return loss
+
+    # GraphCapture's warm-up runs the body eagerly: undo what those steps did to the weights and the optimiser before capturing
+    snap = {k: params[k].detach().clone() for k in RectTrainer.NAMES}
+    g = GraphCapture(body, warmup=1)
+    with torch.no_grad():
+        for k in RectTrainer.NAMES:
+            params[k].copy_(snap[k])
+    opt.exp_avg.zero_(), opt.exp_avg_sq.zero_(), opt.step_dev.zero_()
+    opt.steps_done = 0
+    pw.update({k: v for k, v in sd.items() if k.startswith("rect_net.")}, read_status=False)
+    for s in seeds:
+        dyn.set(s)
+        g.replay()
+        opt.note_replays(1)
+    torch.cuda.synchronize()
+    assert not sm.check_chain_domain(fallback=False)
+    assert int(opt.step_dev.item()) == 3
+    for k in RectTrainer.NAMES:
+        assert torch.equal(params[k].detach(), want[k]), k

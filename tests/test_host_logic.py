@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert float(re.search(r"#define PSTL_SPLIT_F16_WMAX ([0-9.]+)f", header).group(1)) == ffi.SPLIT_F16_WMAX
     assert L.pstl_packed_weight_floats() > 540952          # at least the reference parameter count
     assert L.pstl_error_string(-2).decode().startswith("shape")
-    assert ctypes.sizeof(ffi.PstlCfg) == 88      # ABI 4: + the pstl_dyn device pointer
+    assert ctypes.sizeof(ffi.PstlCfg) == 96      # ABI 4: + the pstl_dyn device pointer; ABI 6: + plan_rows
 
 
 def test_binding_signatures_match_the_header_prototypes():
