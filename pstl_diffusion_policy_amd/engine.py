@@ -1037,5 +1037,7 @@ class RectTrainer:
             loss = flat[o]
         # the optimiser step on the device path: one launch of pstl_adam_step over the trained tensors -- a
         # caller's torch.optim.Adam is adopted (its hyper-parameters and lr), never stepped; the caller re-packs afterwards
+        for k in names:      # (what loss.backward() leaves behind in the reference's loop: the gradients stay inspectable)
+            params[k].grad = g[k]
         DeviceAdam.adopt(optimizer, [params[k] for k in names]).step([g[k] for k in names])
         return loss, scores
