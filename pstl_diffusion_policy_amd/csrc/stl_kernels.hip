@@ -59,11 +59,30 @@ __device__ __forceinline__ StlRow load_row(const float* stlp, const float* hl, l
 // share one scene): the wave copies the scene's lane waypoints and prepared neighbour circles into LDS once, and every
 // later read is an LDS broadcast instead of a latency-bound global load.  Otherwise they are read from global memory.
 // Dynamic LDS layout: [scratch: n_scratch x 64 floats][lanes: 3*15 float4][neighbours: K*20*12 floats].
+// The workgroup this block stands for.  With by_mode (a wavefront = 64 samples of one (scene, mode)) the gps = rows_per_scene / 64
+// blocks of a scene read interleaved rows -- row = (b S + s) 3 + mode: the three modes of a sample are 160 bytes apart, so the
+// same 128-byte lines serve three wavefronts -- and the dispatcher deals consecutive blocks round-robin over the 8 XCDs, each
+// with an L2 of its own: every line was fetched by up to three L2s (943 B per row-evaluation of k_guidance_iter against 425 B
+// algorithmic, profiles/r5/pmc_summary.json).  So within every run of 8 gps blocks, block 8 j + x (XCD x, for speed only: the
+// placement is observed, not promised) stands for block x gps + j: a scene's blocks share an XCD and arrive there back to back.
+__device__ __forceinline__ long virt_block(int by_mode, int rows_per_scene) {
+  const long x = blockIdx.x;
+#ifdef PSTL_NO_XCD_MAP      // (A/B builds: tools/dbg/build_full_variant.sh noxcd -DPSTL_NO_XCD_MAP)
+  return x;
+#endif
+  if (!by_mode) return x;
+  const long gps = rows_per_scene / kWave, G = 8 * gps;
+  if (x >= ((long)gridDim.x / G) * G) return x;       // the last, partial run keeps its order
+  const long r = x % G;
+  return x - r + (r % 8) * gps + r / 8;
+}
+
 template <bool STAGED>
 __device__ __forceinline__ void scene_tables(float* lds, int n_scratch, const float* lane_prep, const float* nei_prep,
-                                             int K, int rows_per_scene, long row, const f4*& lanes, const float*& nei) {
+                                             int K, int rows_per_scene, long row, const f4*& lanes, const float*& nei,
+                                             int by_mode = 0) {
   if (STAGED) {
-    const long b = ((long)blockIdx.x * kWave) / rows_per_scene;  // uniform over the workgroup
+    const long b = (virt_block(by_mode, rows_per_scene) * kWave) / rows_per_scene;  // uniform over the workgroup
     f4* sl = reinterpret_cast<f4*>(lds + n_scratch * kWave);
     f4* sn = sl + 3 * kNseg + 3;  // keep 16-byte alignment and a little padding
     const f4* gl = reinterpret_cast<const f4*>(lane_prep) + b * 3 * kNseg;
@@ -91,7 +110,7 @@ inline size_t stl_lds_bytes(int n_scratch, int K, bool staged) {
 // invalid lane skips both sweeps, a satisfied row the adjoint -- instead of idling beside the lanes that cannot.
 // The workgroup -> scene map is unchanged (blockIdx.x * 64 / rows_per_scene), which is what scene_tables relies on.
 __device__ __forceinline__ long map_row(int by_mode, int rows_per_scene, int lane = -1) {
-  const long blk = blockIdx.x;
+  const long blk = virt_block(by_mode, rows_per_scene);
   if (lane < 0) lane = threadIdx.x;
   if (!by_mode) return blk * kWave + lane;
   const int gps = rows_per_scene / kWave;   // workgroups per scene = 3 * (S / 64)
@@ -123,7 +142,8 @@ void k_stl_forward(StlArgs a) {
   long row = SPLIT ? (long)blockIdx.x * kWave + lane : map_row(a.by_mode, a.rows_per_scene, lane);
   const f4* lanes;
   const float* nei;
-  scene_tables<STAGED>(lds, NS, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes, nei);
+  scene_tables<STAGED>(lds, NS, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes, nei,
+                       SPLIT ? 0 : a.by_mode);   // (the latency layout takes 64 consecutive rows: its blocks keep their order)
   const bool live = row < a.N;
   if (!SPLIT && !live) return;
   if (!live) row = a.N - 1;
@@ -276,7 +296,7 @@ __global__ __launch_bounds__(kWave) void k_stl_backward(GradArgs a) {
   const f4* lanes;
   const float* nei;
   scene_tables<STAGED>(lds, kScratchGrad, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes,
-                       nei);
+                       nei, a.by_mode);
   if (row >= a.N) return;
   const Scratch st = {lds + threadIdx.x, kWave};
   const long b = row / a.rows_per_scene;
@@ -350,7 +370,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
   const f4* lanes;
   const float* nei;
   constexpr int NS = SPLIT ? kScratchGradPre : kScratchGrad;
-  scene_tables<STAGED>(lds, NS, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes, nei);
+  scene_tables<STAGED>(lds, NS, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes, nei, a.by_mode);
   GeoPre pre = {nullptr, 0};
   if (SPLIT) {
     const bool live0 = row < a.N;
@@ -603,7 +623,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) v
   const f4* lanes;
   const float* nei;
   scene_tables<STAGED>(lds, kScratchGrad, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes,
-                       nei);
+                       nei, a.by_mode);
   if (row >= a.N) return;
   const Scratch st = {lds + threadIdx.x, kWave};
   const long b = row / a.rows_per_scene;
@@ -700,7 +720,7 @@ __global__ __launch_bounds__(kWave) void k_mix_select(MixArgs a) {
   const long row = map_row(a.by_mode, a.rows_per_scene);
   const f4* lanes;
   const float* nei;
-  scene_tables<STAGED>(lds, kScratchFwd, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes, nei);
+  scene_tables<STAGED>(lds, kScratchFwd, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes, nei, a.by_mode);
   constexpr int E = 2 * kT;
   bool mix = false;
   if (row < a.N) {
@@ -749,7 +769,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) v
   const f4* lanes;
   const float* nei;
   scene_tables<STAGED>(lds, kScratchGrad, a.lane_prep, a.nei_prep, a.K, a.rows_per_scene, row < a.N ? row : a.N - 1, lanes,
-                       nei);
+                       nei, a.by_mode);
   if (row >= a.N) return;
   const Scratch st = {lds + threadIdx.x, kWave};
   const long b = row / a.rows_per_scene;
