@@ -398,7 +398,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
   const float vr = a.valid[row];
   const float gs = grad_scale * vr;
   const float thres = a.thres;
-  const bool last = (a.iter == a.niters - 1);
+  const bool last = MULTI ? (a.iter == a.niters - 1) : true;   // (one iteration per guided step -- the !MULTI build -- is always the last)
   const long plane = a.N * (2 * kT);
   float* wm = MULTI ? a.work + row * (2 * kT) : nullptr;
   const float* zr = a.z ? a.z + row * (2 * kT) : nullptr;
@@ -438,12 +438,29 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
       }
     }
     if (!last) return p;
-    const float zv = a.rng ? zdrawn : (zr ? zr[e] : 0.0f);
-    const float x = p + a.sqrt_beta * zv;
+    // (zdrawn: this element of the step's noise quad -- drawn in the kernel, read from the caller's tensor, or zero: noise_quad)
+    const float x = p + a.sqrt_beta * zdrawn;
     float c = x * nscale;
     if (a.clip) c = c < -nscale ? -nscale : (c > nscale ? nscale : c);   // torch.clip: a NaN stays a NaN
     *emit_v = c;
     return x;
+  };
+  // The noise of time steps 2 q, 2 q + 1 (elements 4 q .. 4 q + 3 of the row): drawn here (PSTL_FLAG_RNG: one Philox block), one
+  // 16-byte read of the caller's tensor (the parity tests), or zeros (the last reverse step).  Round 6: until now every ELEMENT
+  // chose its source by itself -- a scalar branch or two and, in tensor mode, a 4-byte gather with a full wait, forty times a row.
+  auto noise_quad = [=](int q) -> f4 {
+    f4 z4 = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (!last) return z4;
+    if (a.rng) {
+      if (a.step > 1) {
+        float zz[4];
+        normal4(seed, a.row_offset + row, q, a.step, zz);
+        z4 = f4{zz[0], zz[1], zz[2], zz[3]};
+      }
+    } else if (zr) {
+      z4 = *reinterpret_cast<const f4*>(zr + 4 * q);
+    }
+    return z4;
   };
   // the update of time step t: Adam on (w, a), and on the last iteration the noise (quad z4 of steps t | 1 and t & ~1) and emission
   // (Both callers walk t = T-1 ... 0, an odd step right before its even neighbour: the odd step's results wait in `held` and
@@ -548,12 +565,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
     __syncthreads();
     if (PSTL_DBG_GEXIT == 5) return;
     if (!live) return;
-    f4 z4 = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (a.rng && a.step > 1 && last) {
-      float zz[4];
-      normal4(seed, a.row_offset + row, wq, a.step, zz);
-      z4 = f4{zz[0], zz[1], zz[2], zz[3]};
-    }
+    const f4 z4 = noise_quad(wq);
     f4 held_mu = f4{0.0f, 0.0f, 0.0f, 0.0f}, held_em = held_mu;
     for (int t = 2 * wq + 1; t >= 2 * wq; --t) {
       float w0, a0;
@@ -570,11 +582,7 @@ __global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1)
             int t, float gw, float ga, float w0, float a0) mutable {
           // a noise quad covers two time steps (elements 4q .. 4q+3); emit() comes in the order t = T-1 ... 0, so the quad is
           // drawn at the odd step and kept for the even one: one Philox draw per two time steps
-          if (a.rng && a.step > 1 && last && (t & 1)) {
-            float zz[4];
-            normal4(seed, a.row_offset + row, t >> 1, a.step, zz);
-            z4 = f4{zz[0], zz[1], zz[2], zz[3]};
-          }
+          if (t & 1) z4 = noise_quad(t >> 1);
           apply(t, gw, ga, w0, a0, z4, held_mu, held_em);
         },
         PSTL_G_ABL == 2 ? a.N : 1, gs == 0.0f);   // an invalid lane has zero loss weight: Adam sees exact zeros, only the noise is added

@@ -155,6 +155,11 @@ def test_bench_with_eight_ranks():
     assert line["n_gpus"] == 8 and line["scaling"] == "weak"
     N = bs * S * 3
     assert line["config"]["rows_per_gpu"] == N and line["counts"][2] == world * N and line["counts"][5] == world * bs * 3
+    # who took part: eight records in the final all-gather, as many distinct devices as the box has
+    rk = line["ranks"]
+    assert rk["world_size"] == 8 and rk["ranks_seen"] == 8 and rk["distinct_devices"] == min(max(ndev, 1), 8)
+    assert rk["backend"].startswith("gloo" if ndev < 8 else "nccl") and rk["host_scalar_exchange_ms_per_step"] >= 0.0
+    assert line["config"]["plan_rows"] == N and line["config"]["rows_whole_job"] == world * N
     # the same eight shards, one after the other
     dev = torch.device("cuda:0")
     hp = default_hparams()
@@ -170,6 +175,21 @@ def test_bench_with_eight_ranks():
                                  seed=987654321 + 2, diversity=True)      # (the second call of the job: one warm-up, one step)
         total += out["counts"]
     assert line["counts"] == [int(v) for v in total.tolist()]
+
+
+def test_bench_strong_scaling_splits_a_fixed_job():
+    """`--scaling strong --total_scenes T`: a fixed job in contiguous blocks of scenes (BASELINE config 4 as written, at test
+    size): three ranks over seven scenes take 3 + 2 + 2, every rank plans for the largest shard, the counters cover the job."""
+    S, T, world = 64, 7, 3
+    ndev = torch.cuda.device_count()
+    run = _bench(["--gpus", str(world), "--scaling", "strong", "--total_scenes", str(T), "--steps", "1", "--warmup", "1",
+                  "--no_cpu_baseline"], None if ndev >= world else {"PSTL_BENCH_BACKEND": "gloo"})
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == world and line["scaling"] == "strong"
+    assert line["config"]["rows_whole_job"] == T * S * 3 and line["config"]["rows_per_gpu"] == 3 * S * 3      # rank 0: three scenes
+    assert line["config"]["plan_rows"] == 3 * S * 3 and line["counts"][2] == T * S * 3 and line["counts"][5] == T * 3
+    assert line["ranks"]["ranks_seen"] == world and line["value"] > 0
 
 
 # ---- N > 1 training: RectTrainer.train_step all-reduces the gradients (the loss is a mean over the GLOBAL batch) ---------
