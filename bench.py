@@ -739,7 +739,7 @@ def main():
     # instructions per row-evaluation from the committed PMC pass (SQ_INSTS_VALU / rows of that launch) x the row-evaluation
     # rate measured live in this run x 4 issue cycles per wavefront instruction / (1024 SIMDs x the clock of the PMC run)
     pmc_path = None
-    for rnd in ("r5", "r4", "r3", "r2"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2"):
         cand = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
         if os.path.exists(cand):
             pmc_path = cand
@@ -751,10 +751,22 @@ def main():
             per_row = v["SQ_INSTS_VALU"] / v["rows_per_launch"]       # wavefront instructions per row-evaluation (1/64 each)
             clk = float(v["clock_GHz"]) * 1e9
             info["valu_wave_insts_per_row_eval"] = per_row
-            info["valu_issue_frac"] = per_row * info["row_evals_per_s"] * 4.0 / (1024.0 * clk)
-            info["valu_issue_frac_pmc_run"] = v.get("valu_issue_frac")
-            info["valu_issue_note"] = ("SQ_INSTS_VALU per row-evaluation (%s) x live row-evaluations/s x 4 cycles / (1024 SIMDs x "
-                                       "%.2f GHz)" % (os.path.relpath(pmc_path, ROOT), clk / 1e9))
+            # SIMD cycles per wavefront vector instruction, live: 1024 SIMDs x clock / (instructions per row-evaluation x the
+            # run's row-evaluations/s).  What a SIMD CAN issue was measured in round 6 (profiles/r6/valu_rate.txt: 2.0 - 3.7
+            # cycles by kind at 3 waves per SIMD, 1.6 - 3.1 at 5; transcendentals 5.7 / 5.3); rounds 3-5 assumed 4 for all of
+            # them, which is what `valu_issue_frac_4cycle_model` still divides by (kept for comparison with those rounds).
+            waves = 3 if kind == "guidance" else 5
+            floor = 2.9 if kind == "guidance" else 2.3       # mix-weighted estimate for these kernels' instruction mix
+            info["valu_cycles_per_inst_per_simd"] = 1024.0 * clk / (per_row * info["row_evals_per_s"])
+            info["waves_per_simd"] = waves
+            info["issue_floor_cycles_per_inst_estimate"] = floor
+            info["frac_of_issue_floor"] = floor / info["valu_cycles_per_inst_per_simd"]
+            info["valu_issue_frac_4cycle_model"] = per_row * info["row_evals_per_s"] * 4.0 / (1024.0 * clk)
+            info["valu_issue_note"] = ("SQ_INSTS_VALU per row-evaluation (%s) x live row-evaluations/s against 1024 SIMDs x %.2f GHz; "
+                                       "issue floor: profiles/r6/valu_rate.txt weighted by the kernels' instruction mix (an estimate)"
+                                       % (os.path.relpath(pmc_path, ROOT), clk / 1e9))
+            if v.get("hbm_bytes_per_row_eval"):
+                info["hbm_bytes_per_row_eval_pmc"] = v["hbm_bytes_per_row_eval"]
     # HBM bytes of that launch from the committed PMC passes (FETCH_SIZE/WRITE_SIZE cannot be read inside this process);
     # only quoted when this run is the configuration those passes were collected on
     traffic = None

@@ -18,6 +18,8 @@
 // entropy bin edges are float32 expressions that must round like the reference's separate torch ops.
 #include "pstl_common.hpp"
 
+#include <type_traits>
+
 namespace pstl {
 namespace {
 
@@ -201,27 +203,48 @@ __global__ __launch_bounds__(SPLIT ? kDivWaves * kWave : kWave) void k_diversity
   // ---- per-step convex-hull area of the satisfied samples (nusc_api.py:838-865) --------------------------------
   double vol = 0.0;
   if (mode_valid && n_sat >= 3 && !(PSTL_DIV_SKIP & 2)) {
+    // (Round 6: B time steps per pass through the sorting network -- the 21 x 2 cross-lane exchanges of ONE sort are a chain of
+    // ~120-cycle ds_bpermute round trips, which is what the sort's 0.31 ms were; B independent sorts in lock-step put B
+    // exchanges in flight per stage.  The single wave takes four steps at a time, a wave of the ten-wave layout its two.)
+    auto sort_steps = [&](auto b_tag, int tfirst) {
+      constexpr int B = decltype(b_tag)::value;
+      float px[B], py[B];
 #pragma unroll
-    for (int t = 0; t < kT; ++t) {
-      if (SPLIT && (t >> 1) != wq) continue;   // (wave-uniform; the register arrays keep their constant indices)
-      // bitonic sort across the 64 lanes, key (x, y); unsatisfied samples carry +inf and end up behind the others
-      float px = sat ? xr[t] : INFINITY, py = sat ? yr[t] : INFINITY;
+      for (int b = 0; b < B; ++b) {   // unsatisfied samples carry +inf and end up behind the others
+        float xv = 0.0f, yv = 0.0f;
+#pragma unroll
+        for (int t = 0; t < kT; ++t)   // (constant indices into the register arrays; tfirst is wave-uniform)
+          if (t == tfirst + b) xv = xr[t], yv = yr[t];
+        px[b] = sat ? xv : INFINITY, py[b] = sat ? yv : INFINITY;
+      }
 #pragma unroll
       for (int k = 2; k <= kWave; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-          const float qx = __shfl_xor(px, j), qy = __shfl_xor(py, j);
           const bool up = (lane & k) == 0;            // this block of k lanes sorts ascending
           const bool lower = (lane & j) == 0;         // this lane keeps the smaller element of its pair when ascending
           const bool take_min = (up == lower);
-          const bool q_less = lex_less(qx, qy, px, py);
-          const bool p_less = lex_less(px, py, qx, qy);
-          const bool swap = take_min ? q_less : p_less;
-          px = swap ? qx : px;
-          py = swap ? qy : py;
+          float qx[B], qy[B];
+#pragma unroll
+          for (int b = 0; b < B; ++b) qx[b] = __shfl_xor(px[b], j), qy[b] = __shfl_xor(py[b], j);
+#pragma unroll
+          for (int b = 0; b < B; ++b) {
+            const bool q_less = lex_less(qx[b], qy[b], px[b], py[b]);
+            const bool p_less = lex_less(px[b], py[b], qx[b], qy[b]);
+            const bool swap = take_min ? q_less : p_less;
+            px[b] = swap ? qx[b] : px[b];
+            py[b] = swap ? qy[b] : py[b];
+          }
         }
       }
-      s_pts[t][lane] = make_float2(px, py);
+#pragma unroll
+      for (int b = 0; b < B; ++b) s_pts[tfirst + b][lane] = make_float2(px[b], py[b]);
+    };
+    if (SPLIT) {
+      sort_steps(std::integral_constant<int, 2>{}, 2 * wq);
+    } else {
+#pragma unroll
+      for (int t0 = 0; t0 < kT; t0 += 4) sort_steps(std::integral_constant<int, 4>{}, t0);   // (unrolled: constant register indices)
     }
     __syncthreads();
     double sh = 0.0;
@@ -236,9 +259,11 @@ __global__ __launch_bounds__(SPLIT ? kDivWaves * kWave : kWave) void k_diversity
       // the two topmost stack entries live in registers: o (below), p (top); k = stack size
       int k = 0;
       float2 o = org, p = org;
-      for (int ii = 0; ii < n_sat; ++ii) {
+      float2 qn = P[upper ? n_sat - 1 : 0];     // (the next point is requested one iteration ahead: its LDS latency sat in front
+      for (int ii = 0; ii < n_sat; ++ii) {      //  of every iteration's first cross product)
         const int i = upper ? n_sat - 1 - ii : ii;
-        const float2 q = P[i];
+        const float2 q = qn;
+        if (ii + 1 < n_sat) qn = P[upper ? i - 1 : i + 1];
         while (k >= 2) {
           const double cr = ((double)p.x - (double)o.x) * ((double)q.y - (double)o.y) -
                             ((double)p.y - (double)o.y) * ((double)q.x - (double)o.x);

@@ -64,6 +64,13 @@ def _worker(rank, world, port, out_path):
     _, tot = _oracle_div(sub, u, score, rows.valid, S, hp)
     counts2, totals = gather_final(local_counts, tot)
     assert torch.equal(counts, counts2)
+    # the same reduction with the rank's identity riding along (bench.py's self-proving line): the sums do not change, every
+    # rank sees one record per rank and -- two processes here -- two distinct identities
+    from pstl_diffusion_policy_amd.shard import device_identity, distinct_devices
+    seen = {}
+    counts3, totals3 = gather_final(local_counts, tot, ident=device_identity(None)[0], seen=seen)
+    assert torch.equal(counts3, counts2) and torch.equal(totals3, totals)
+    assert seen["ranks_seen"] == world and distinct_devices(seen) == world
     if rank == 0:
         torch.save({"vsum": vsum, "vrows": vrows, "counts": counts, "totals": totals}, out_path)
     dist.barrier()

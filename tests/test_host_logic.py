@@ -200,3 +200,38 @@ def test_packed_weight_key_sees_every_way_a_parameter_can_change():
     changed()
     net.load_state_dict({k: v + 1 for k, v in sd.items()})               # the usual copy_ into the existing storages
     changed()
+
+
+def test_bench_guided_gate_counts_and_explains_outlier_rows():
+    """bench.py's in-run version of the guided-outlier gate (tests/conftest.py: guided_outlier_rows) on
+    synthetic errors: a row that leaves 1e-4 at a guided step on an element whose recorded |g| is in Adam's eps regime is
+    excluded and explained; one that leaves it at an un-guided step, or on an element with a solid gradient, is not explained."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    steps, N = 12, 6
+    guid = dict(enabled=True, before=3, niters=1, lr=0.01)          # guided reverse steps: 3, 2, 1
+    grads = [torch.full((N, 20, 2), 1e-3) for _ in range(3)]        # one Adam.step() per guided step, in rollout order
+    grads[0][2, 5, 1] = 3e-8                                          # row 2, element 11 at reverse step 3: eps regime
+    err = torch.zeros(steps, N, 40)
+    err[steps - 3:, 2, 11] = 5e-3                                     # leaves 1e-4 in the state after reverse step 3, stays off
+    bad, explained, tiny = bench.guided_gate(err, grads, steps, guid)
+    assert bad.tolist() == [False, False, True, False, False, False] and explained and tiny == 1
+    err2 = err.clone()
+    err2[steps - 3:, 4, 7] = 2e-4                                     # a solid gradient there: not Adam's discontinuity
+    bad, explained, _ = bench.guided_gate(err2, grads, steps, guid)
+    assert bad.tolist()[4] and not explained
+    err3 = torch.zeros(steps, N, 40)
+    err3[4:, 1, 0] = 1e-3                                             # leaves 1e-4 after reverse step 8: not a guided step
+    bad, explained, _ = bench.guided_gate(err3, grads, steps, guid)
+    assert bad.tolist()[1] and not explained
+
+
+def test_shard_plan_rows_and_device_identity():
+    from pstl_diffusion_policy_amd import shard
+    assert shard.plan_rows(4096, 8, 192) == 512 * 192 and shard.plan_rows(7, 8, 192) == 192 and shard.plan_rows(9, 2, 48) == 5 * 48
+    ident, text = shard.device_identity(None)
+    assert len(ident) == 2 and all(-2 ** 63 <= v < 2 ** 63 for v in ident) and text.startswith("host-pid:")
+    assert shard.device_identity(None)[0] == ident                  # stable within a process

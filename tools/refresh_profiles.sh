@@ -4,7 +4,7 @@
 # bench lines of every workload, rocprofv3 kernel stats/trace of the default bench, three separate PMC passes
 # (FETCH_SIZE, WRITE_SIZE, SQ/GRBM) and their summary (tools/summarize_pmc.py).
 set -u
-r=${1:-r4}
+r=${1:-r6}
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/profiles_$r
 mkdir -p "$out"

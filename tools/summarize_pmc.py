@@ -81,9 +81,12 @@ if sq:
     if clock and "SQ_VALU_MFMA_BUSY_CYCLES" in sq:
         summ["mfma_pipe_util"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (clock * dur * SIMDS)
     summ["mfma_insts"] = sq.get("SQ_INSTS_MFMA")
-# The one-row-per-lane STL kernels against their real roofline, the vector issue port: every VALU instruction of a wavefront
-# takes 4 issue cycles on its SIMD (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'), so
-#   valu_issue_frac = SQ_INSTS_VALU x 4 / (1024 SIMDs x launch cycles).
+# The one-row-per-lane STL kernels against the vector issue port.  Rounds 3-5 priced every wavefront instruction at 4 cycles of
+# its SIMD (valu_issue_frac_4cycle_model below); round 6 measured what a SIMD issues by kind and occupancy
+# (profiles/r6/valu_rate.txt: 1.3 - 3.7 cycles, transcendentals 4.6 - 5.7), so the figure to read is
+#   valu_cycles_per_inst_per_simd = 1024 SIMDs x launch cycles / SQ_INSTS_VALU
+# against ~2.9 (three waves per SIMD, k_guidance_iter) / ~2.3 (five, k_stl_forward) for these kernels' instruction mix.
+# HBM bytes per row-evaluation: (2 x FETCH_SIZE + WRITE_SIZE) of the kernel's launches / rows (FETCH doubled per the guide).
 # (k_guidance_iter: one launch per guided step over all rows; k_stl_forward: the largest launch = the 5-candidate scoring.)
 stl = {}
 val = out["per_kernel"].get("VALU", {})
@@ -104,8 +107,16 @@ for kind, kname in (("guidance", "k_guidance_iter"), ("score", "k_stl_forward"))
                  "SQ_WAIT_INST_LDS": avg("SQ_WAIT_INST_LDS"), "SQ_WAVES": avg("SQ_WAVES"), "SQ_INSTS_SALU": avg("SQ_INSTS_SALU"),
                  "SQ_INSTS_LDS": avg("SQ_INSTS_LDS"),
                  "valu_insts_per_wave": avg("SQ_INSTS_VALU") / avg("SQ_WAVES") if avg("SQ_WAVES") else None,
-                 "valu_issue_frac": avg("SQ_INSTS_VALU") * 4.0 / (SIMDS * clock * dur) if clock else None,
+                 "valu_issue_frac_4cycle_model": avg("SQ_INSTS_VALU") * 4.0 / (SIMDS * clock * dur) if clock else None,
+                 "valu_cycles_per_inst_per_simd": SIMDS * clock * dur / avg("SQ_INSTS_VALU") if clock else None,
                  "rows_per_launch": int(sys.argv[2]) * (5 if kind == "score" else 1) if len(sys.argv) > 2 else None,
                  "K": int(sys.argv[3]) if len(sys.argv) > 3 else None}
+for kind, kname in (("guidance", "k_guidance_iter"), ("score", "k_stl_forward")):
+    fe, wr = out["per_kernel"].get("FETCH_SIZE", {}).get(kname), out["per_kernel"].get("WRITE_SIZE", {}).get(kname)
+    if kind in stl and fe and wr and stl[kind].get("rows_per_launch"):
+        # (k_stl_forward's passes average its two launches per step -- five candidates + the final scoring = six row-evaluations
+        # per row over two launches: three per launch on average)
+        rows = stl[kind]["rows_per_launch"] if kind == "guidance" else stl[kind]["rows_per_launch"] / 5 * 3
+        stl[kind]["hbm_bytes_per_row_eval"] = (2.0 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024.0 / rows
 out = {"summary_dominant_kernel": summ, "stl_kernels": stl, "per_kernel": out["per_kernel"]}
 print(json.dumps(out, indent=1))
