@@ -54,21 +54,28 @@ def build(force=False, verbose=True):
             # would leave them writing an object file behind a failed build)
             running.append((cmd, subprocess.Popen(cmd, start_new_session=True), o, time.time()))
         objs.append(o)
-    times = {}
-    for cmd, proc, o, t0 in running:
-        if proc.wait() != 0:
-            for _, other, oo, _ in running:      # (only the process groups started here; never by pattern)
-                if other.poll() is None:
-                    try:
-                        os.killpg(other.pid, signal.SIGKILL)
-                    except OSError:
-                        pass
-                    other.wait()
-            for _, _, oo, _ in running:          # no output of the failed batch may pass for up to date next time
-                if os.path.exists(oo):
-                    os.remove(oo)
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
-        times[os.path.basename(o)] = time.time() - t0
+    times, pending = {}, list(running)
+    while pending:          # (polled, so that the time printed for a unit is its own and not that of the slowest one before it)
+        time.sleep(0.2)
+        for item in list(pending):
+            cmd, proc, o, t0 = item
+            rc = proc.poll()
+            if rc is None:
+                continue
+            pending.remove(item)
+            if rc != 0:
+                for _, other, _, _ in running:      # (only the process groups started here; never by pattern)
+                    if other.poll() is None:
+                        try:
+                            os.killpg(other.pid, signal.SIGKILL)
+                        except OSError:
+                            pass
+                        other.wait()
+                for _, _, oo, _ in running:          # no output of the failed batch may pass for up to date next time
+                    if os.path.exists(oo):
+                        os.remove(oo)
+                raise subprocess.CalledProcessError(rc, cmd)
+            times[os.path.basename(o)] = time.time() - t0
     if verbose and times:
         print("compiled: " + ", ".join("%s %.0f s" % kv for kv in sorted(times.items())), flush=True)
     if force or _newer(LIB, objs):
