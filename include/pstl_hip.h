@@ -174,7 +174,8 @@ int pstl_time_bias(const float* packed, int steps, float* tbias /* (steps,256) *
 /* ---- per-batch scene preparation ---------------------------------------------------------------------------- */
 /* neighbors_traj (bs,K,T,7) = valid,x,y,th,v,L,W ; lanes (bs,15,3) x,y,th.
  * nei_prep (bs,K,T,12): valid, r, cx[4], cy[4], 0, 0  (circle row of each neighbour, utils.py:465-497);
- * lane_prep (bs,3,15,4): x, y, th, length of the segment to the next waypoint (0 for the last) for curr,left,right --
+ * lane_prep (bs,3,15,4): x, y, th, 1 / clamp(length of the segment to the next waypoint, 1e-7) -- 0 for a segment of length 0
+ *   and for the last waypoint (ABI 6; until ABI 5: the length itself) -- for curr,left,right;
  *   opaque to the caller: the STL entry points below take exactly what this call wrote. */
 int pstl_prepare_scene(const pstl_cfg* cfg, const float* neighbors_traj, const float* currlane, const float* leftlane,
                        const float* rightlane, float* nei_prep, float* lane_prep, void* stream);
