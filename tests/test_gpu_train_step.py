@@ -338,13 +338,17 @@ def test_repacking_one_network_in_place_equals_a_full_pack():
         pw.update({"rect_net.0.weight": sd["rect_net.0.weight"]})  # a network is packed whole
 
 
-@pytest.mark.parametrize("lr,betas,eps", [(3e-4, (0.9, 0.999), 1e-8), (0.01, (0.8, 0.99), 1e-6)])
-def test_device_adam_equals_torch_adam(lr, betas, eps):
+@pytest.mark.parametrize("lr,betas,eps,table", [(3e-4, (0.9, 0.999), 1e-8, None), (0.01, (0.8, 0.99), 1e-6, 4)])
+def test_device_adam_equals_torch_adam(lr, betas, eps, table, monkeypatch):
     """pstl_adam_step against torch.optim.Adam on the CPU (the reference's optimiser, nusc_train.py:1233) over ten steps on the
     shapes of rect_net's six tensors: both moments bit for bit at every step -- the parameters too wherever torch's vectorised
     CPU square root is the IEEE one (tests/test_adam_core_hostsim.py says why not everywhere), one ulp of the increment
-    otherwise --, the version counters bumped (what PackedWeights caches key on), the step counter on the device."""
+    otherwise --, the version counters bumped (what PackedWeights caches key on), the step counter on the device.  table = 4: a
+    table of four steps, so that the in-place refresh of the per-step scalars (and the counter's reset) happens twice in the run;
+    that run also changes the learning rate half-way, as a scheduler would (the table is rebuilt for the new rate)."""
     from pstl_diffusion_policy_amd.engine import DeviceAdam
+    if table:
+        monkeypatch.setattr(DeviceAdam, "TABLE", table)
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(11)
     shapes = [(256, 271), (256,), (256, 256), (256,), (40, 256), (40,)]
@@ -354,6 +358,10 @@ def test_device_adam_equals_torch_adam(lr, betas, eps):
     dopt = DeviceAdam(gpu, lr=lr, betas=betas, eps=eps)
     v0 = [p._version for p in gpu]
     for t in range(10):
+        if table and t == 5:
+            lr = lr * 0.5
+            opt.param_groups[0]["lr"] = lr
+            dopt.lr = lr
         grads = [torch.randn(s, generator=g) * (10.0 ** float(torch.randint(-8, 1, (1,), generator=g))) for s in shapes]
         grads[0][::5] = 0.0
         for p, gr in zip(cpu, grads):
@@ -377,7 +385,7 @@ def test_device_adam_equals_torch_adam(lr, betas, eps):
             with torch.no_grad():
                 pg.copy_(pc.detach())           # (every step is checked on its own)
             o += n
-    assert int(dopt.step_dev.item()) == 10 and dopt.steps_done == 10
+    assert dopt.steps_done == 10 and int(dopt.step_dev.item()) == (10 if not table else 10 - dopt._table_first + 1)
     assert all(p._version > v for p, v in zip(gpu, v0))
 
 
