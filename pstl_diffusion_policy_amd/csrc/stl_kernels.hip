@@ -108,7 +108,8 @@ inline size_t stl_lds_bytes(int n_scratch, int K, bool staged) {
 // takes 64 samples of ONE (scene, mode) instead of 64 consecutive rows.  Rows of a (scene, mode) share their lane, their
 // validity and mostly their fate (satisfied or not), so whole wavefronts take the cheap exits of stl_eval_grad -- an
 // invalid lane skips both sweeps, a satisfied row the adjoint -- instead of idling beside the lanes that cannot.
-// The workgroup -> scene map is unchanged (blockIdx.x * 64 / rows_per_scene), which is what scene_tables relies on.
+// The workgroup -> scene map is that of the block this one stands for (virt_block(...) * 64 / rows_per_scene): scene_tables and
+// the per-scene lists of --refinement (k_mix_select, k_mixopt) take the scene from there, never from blockIdx.x itself.
 __device__ __forceinline__ long map_row(int by_mode, int rows_per_scene, int lane = -1) {
   const long blk = virt_block(by_mode, rows_per_scene);
   if (lane < 0) lane = threadIdx.x;
@@ -753,7 +754,9 @@ __global__ __launch_bounds__(kWave) void k_mix_select(MixArgs a) {
   }
   const unsigned long long m = __ballot(mix);
   if (m == 0ull) return;
-  const long scene = ((long)blockIdx.x * kWave) / a.rows_per_scene;   // uniform over the wavefront (rows_per_scene % 64 == 0)
+  // the scene of the block this one stands for (virt_block: the one its rows and its staged tables belong to), uniform over
+  // the wavefront (rows_per_scene % 64 == 0)
+  const long scene = (virt_block(a.by_mode, a.rows_per_scene) * kWave) / a.rows_per_scene;
   int base = 0;
   if (threadIdx.x == 0) base = atomicAdd(a.mix_count + scene, __popcll(m));
   base = __shfl(base, 0);
@@ -765,8 +768,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) v
   extern __shared__ __attribute__((aligned(16))) float lds[];
   long row = map_row(a.by_mode, a.rows_per_scene);
   if (COMPACT) {   // wavefront j of a scene takes entries [64 j, 64 j + 64) of the scene's list of rows to mix
-    const long scene = ((long)blockIdx.x * kWave) / a.rows_per_scene;
-    const int j = (int)(blockIdx.x % (a.rows_per_scene / kWave));
+    const long vb = virt_block(a.by_mode, a.rows_per_scene);   // (scene_tables stages the tables of THIS block's scene)
+    const long scene = (vb * kWave) / a.rows_per_scene;
+    const int j = (int)(vb % (a.rows_per_scene / kWave));
     const int n = a.mix_count[scene];
     if (j * kWave >= n) return;                               // whole wavefront: nothing left
     const int idx = j * kWave + threadIdx.x;

@@ -129,6 +129,33 @@ def test_trajopt_full_size_split_and_sharded(ctx):
     assert torch.isfinite(a).all() and (a - p0).abs().max().item() <= 6 * 0.01 * 3.2
 
 
+def test_refinement_full_size_sharded(ctx):
+    """--refinement's mixing loop on all 786 432 rows (by-mode wavefronts regrouped per XCD, the rows to mix packed per scene):
+    bitwise reproducible, untouched where the reference leaves a row alone, and a quarter of the scenes evaluated alone -- with
+    the batch's loss scale -- reproduces its rows bit for bit, gradients included (the regrouped blocks read the tables and
+    the list of the scene they stand for)."""
+    sm, sb, dev = ctx["sm"], ctx["sb"], ctx["dev"]
+    N, iters = sb.N, 3
+    g = torch.Generator(device=dev).manual_seed(29)
+    clist = torch.rand(100, N, 40, device=dev, generator=g) * 2 - 1            # 12.6 GB
+    cin = torch.rand(N, 40, device=dev, generator=g) * 2 - 1
+    out, tr = sm.refinement(sb, cin, clist, iters=iters, trace=True)
+    out2 = sm.refinement(sb, cin, clist, iters=iters)
+    assert torch.equal(out, out2) and torch.isfinite(out).all()
+    sc0 = sm.score(sb, cin.reshape(1, N, 40))["scores"][0]
+    keep = ~((sc0 <= 0) & (sb.valid > 0))                                       # nusc_train.py:1045-1046: these rows are copied
+    assert torch.equal(out[keep], cin[keep]) and 0.05 * N < int((~keep).sum()) < N
+    assert (tr[:, keep] == 0).all()
+    for q in (1, 3):
+        lo, hi = q * BS // 4, (q + 1) * BS // 4
+        r0, r1 = lo * S * 3, hi * S * 3
+        sub = _sub(ctx, lo, hi)
+        sub.grad_scale = sb.grad_scale
+        o, t = sm.refinement(sub, cin[r0:r1].contiguous(), clist[:, r0:r1].contiguous(), iters=iters, trace=True)
+        assert torch.equal(o, out[r0:r1]) and torch.equal(t, tr[:, r0:r1]), q
+    del clist
+
+
 def test_dpp_loss_full_size_is_invariant_to_scene_order(ctx):
     """Reversing the order of the scenes permutes the groups: group diversities and gradients permute with them."""
     from pstl_diffusion_policy_amd import ffi

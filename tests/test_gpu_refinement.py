@@ -77,3 +77,35 @@ def test_cli_refinement_runs(capsys):
     assert "###[00]" in capsys.readouterr().out and 0.0 <= md("acc") <= 1.0
     with pytest.raises(IndexError):
         nt.main(base + ["--diffusion_steps", "50"])
+
+
+def test_refinement_is_shard_invariant_where_blocks_are_regrouped_by_xcd():
+    """Batches of >= 8 scenes with S % 64 == 0 run their wavefronts by (scene, mode) with the blocks regrouped per XCD
+    (stl_kernels.hip, virt_block): the per-scene lists of rows to mix and the staged scene tables must follow the block a
+    workgroup STANDS FOR, not blockIdx.x.  20 scenes (two full runs of eight + a partial one that keeps its order) against the
+    same scenes in shards of 4 (no regrouping at all): given the batch's loss scale (the reference's loss is a MEAN over the
+    batch, so 1/N reaches every gradient and, through Adam's eps, the last bits) a row's arithmetic knows nothing of its batch,
+    so bit for bit -- and every iteration's gradient too.  Some rows must actually be mixed, or the test says nothing.
+    (Before the lists followed virt_block, rows were evaluated against a neighbouring scene's tables: errors of ~1.0.)"""
+    from pstl_diffusion_policy_amd.engine import PackedWeights, SceneBatch, Sampler
+    from pstl_diffusion_policy_amd.synthetic import default_hparams, make_scene_batch
+    dev = torch.device("cuda:0")
+    hp = default_hparams()
+    bs, S, K, n_list, iters = 20, 64, 2, 100, 6
+    scene = make_scene_batch(bs, K=K, S=S, seed=41, invalid_lane_frac=0.2, stlp_mode="wide")
+    sb = SceneBatch(scene, S, hp, dev)
+    sm = Sampler(PackedWeights(golden_weights(), dev), hp)
+    g = torch.Generator(device=dev).manual_seed(17)
+    clist = torch.rand(n_list, sb.N, 40, device=dev, generator=g) * 2 - 1
+    cin = (torch.rand(sb.N, 40, device=dev, generator=g) * 2 - 1).contiguous()
+    out, tr = sm.refinement(sb, cin, clist, iters=iters, trace=True)
+    mixed = (out != cin).any(dim=1)
+    assert 0.05 * sb.N < int(mixed.sum()) < sb.N, int(mixed.sum())
+    rps = 3 * S
+    for lo in range(0, bs, 4):
+        sub = SceneBatch({k: v[lo:lo + 4].clone() for k, v in scene.items()}, S, hp, dev)
+        sub.grad_scale = sb.grad_scale
+        r0, r1 = lo * rps, (lo + 4) * rps
+        o, t = sm.refinement(sub, cin[r0:r1].contiguous(), clist[:, r0:r1].contiguous(), iters=iters, trace=True)
+        assert torch.equal(o, out[r0:r1]), lo
+        assert torch.equal(t, tr[:, r0:r1]), lo
