@@ -9,7 +9,9 @@ echo "probe: chain launch $ms ms (limit $lim)"
 if python3 -c "import sys; sys.exit(0 if float('$ms') < float('$lim') else 1)"; then
   bash tools/refresh_profiles.sh $r > gpurun_out/refresh_$r.log 2>&1
   python3 tools/paper_metric.py --kernel_noise --batches 12 2>/dev/null > gpurun_out/profiles_$r/paper_metric_cli_graph_replay.json
-  tools/dbg/stl_stamps.sh run > gpurun_out/profiles_$r/stl_stamps_round6_kernels.txt 2>/dev/null
+  # (needs tools/dbg/_variants/libpstl_ststamp.so built HERE first: tools/dbg/stl_stamps.sh build; an empty result is dropped)
+  tools/dbg/stl_stamps.sh run > gpurun_out/stl_stamps.tmp 2>gpurun_out/stl_stamps.err
+  [ -s gpurun_out/stl_stamps.tmp ] && mv gpurun_out/stl_stamps.tmp gpurun_out/profiles_$r/stl_stamps_round6_kernels.txt
   python3 -c "
 import json
 d=json.loads(open('gpurun_out/profiles_$r/bench_default.json').read().strip().splitlines()[-1])
