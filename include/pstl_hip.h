@@ -299,7 +299,9 @@ int pstl_loss_grad(const pstl_cfg* cfg, const float* scores, const float* valid,
  *                    which the caller computes in double precision as torch does and rounds to float32;
  *   step           : DEVICE counter of the steps done (0 before the first); the launch reads its scalars at sched[*step] and
  *                    a second, one-thread launch increments it -- nothing about a step is passed by value, so a captured
- *                    training step replays with the right bias corrections.
+ *                    training step replays with the right bias corrections.  *step >= sched_steps reads the table's LAST
+ *                    entry: a table long enough for float32(1 - beta^t) to have become 1.0 for both betas (17 323 steps for
+ *                    (0.9, 0.999)) ends at the scalars' limits and is exact for every later step.
  *   one_minus_beta1, beta2, one_minus_beta2, eps : torch's Python scalars as float32 -- the differences 1 - beta formed in
  *                    DOUBLE precision first (float32(1 - 0.999) is not 1 - float32(0.999)).
  * The caller re-packs the networks whose tensors moved (pstl_repack_weights) before the kernels read them again. */

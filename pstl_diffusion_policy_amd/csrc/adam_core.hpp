@@ -2,7 +2,8 @@
 // nusc_train.py:1233: Adam over rect_net.parameters() -- net.parameters() with --joint --, default betas, eps, no weight decay,
 // no amsgrad), operation for operation what torch's single-tensor CPU path computes in float32
 // (torch/optim/adam.py: _single_tensor_adam; ATen lerp / addcmul / addcdiv kernels):
-//   exp_avg.lerp_(grad, 1 - beta1)                          m = m + w (g - m)                 (|w| < 0.5: this branch of lerp)
+//   exp_avg.lerp_(grad, 1 - beta1)                          m = fma(w, g - m, m)  if |w| < 0.5 (beta1 > 0.5: the defaults),
+//                                                               fma(w - 1, g - m, g)  otherwise (ATen's lerp keeps the weight small)
 //   exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)  v = v beta2 + ((1 - beta2) g) g
 //   denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
 //   param.addcdiv_(exp_avg, denom, value=-step_size)        p = p + (value m) / denom
@@ -31,7 +32,7 @@ struct AdamScalars {
 };
 
 PSTL_ADAM_HD void adam_update(float& p, float& m, float& v, float g, const AdamScalars& s) {
-  m = fmaf(s.w1, g - m, m);
+  m = fabsf(s.w1) < 0.5f ? fmaf(s.w1, g - m, m) : fmaf(s.w1 - 1.0f, g - m, g);
   v = fmaf(s.w2 * g, g, v * s.beta2);
   const float denom = sqrtf(v) / s.bc2_sqrt + s.eps;
   p = p + (s.neg_step_size * m) / denom;

@@ -685,7 +685,22 @@ class DeviceAdam:
     defaults besides lr / betas / eps is refused --, the lr of its first param group is re-read at every step (schedulers work),
     and its own step() is never called."""
 
-    TABLE = 4096      # steps of scalars per table; the table is extended (outside any capture) when the count gets there
+    TABLE = None      # steps of scalars per table; None: as many as the scalars need to reach their limits (see table_len)
+    TABLE_MAX = 1 << 18
+
+    @classmethod
+    def table_len(cls, betas):
+        """Steps after which float32(1 - beta^t) is 1.0 for both betas (beta^t < 2^-25): from there on -lr / (1 - beta1^t) and
+        sqrt(1 - beta2^t) no longer change, and the kernel, which clamps its index to the table's last entry, stays exact for any
+        number of replays without the host touching the table (defaults: 17 330 steps, 139 KB).  Betas too close to 1 for
+        TABLE_MAX entries get a table that is extended from the host instead (note_replays)."""
+        if cls.TABLE:
+            return int(cls.TABLE)
+        n = 2
+        for b in betas:
+            if 0.0 < b < 1.0:
+                n = max(n, int(math.ceil(-25.0 * math.log(2.0) / math.log(b))) + 2)
+        return min(n, cls.TABLE_MAX)
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         self.params = [p for p in params]
@@ -705,6 +720,8 @@ class DeviceAdam:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.steps_done = 0                 # host mirror of the device counter (eager steps and replays the caller reports)
         self._table_first, self._table_lr, self.sched = None, None, None
+        self.table_steps = self.table_len(self.betas)
+        self._table_final = False           # the table's last entry holds the scalars' limits: nothing to extend, ever
         self._numel_arr = (ctypes.c_int64 * len(self.numel))(*self.numel)
         self._p_arr = (ctypes.c_void_p * len(self.params))(*[p.data_ptr() for p in self.params])
         self._ensure_table()
@@ -734,10 +751,13 @@ class DeviceAdam:
 
     def _ensure_table(self):
         """The table of per-step scalars covers the step about to be taken (and the lr it was built for is still the lr)."""
-        if (self.sched is None or self._table_lr != self.lr or not
-                (self._table_first <= self.steps_done + 1 < self._table_first + self.TABLE)):
+        inside = self.sched is not None and self._table_first <= self.steps_done + 1 < self._table_first + self.table_steps
+        past_final = self.sched is not None and self._table_final and self.steps_done + 1 >= self._table_first
+        if self.sched is None or self._table_lr != self.lr or not (inside or past_final):
             first = self.steps_done + 1
-            tab = torch.from_numpy(adam_schedule(self.lr, self.betas, self.TABLE, first))
+            tab = adam_schedule(self.lr, self.betas, self.table_steps, first)
+            self._table_final = bool(tab[-1, 0] == np.float32(-self.lr) and tab[-1, 1] == np.float32(1.0))
+            tab = torch.from_numpy(tab)
             if self.sched is None:
                 self.sched = tab.to(self.device)
             else:
@@ -746,9 +766,12 @@ class DeviceAdam:
             self.step_dev.fill_(0)           # the counter indexes THIS table
 
     def note_replays(self, n=1):
-        """A captured step() was replayed n times: the device counter moved, this brings the host's mirror along (it decides when
-        the table of per-step scalars must be extended -- outside any capture)."""
+        """A captured step() was replayed n times: the device counter moved, this brings the host's mirror along and -- outside
+        any capture -- extends the table of per-step scalars if the next step would leave it.  With the default table (table_len:
+        it ends at the scalars' limits) that never happens and calling this late costs nothing; with a table cut short (betas
+        very close to 1) call it at least every `table_steps` replays, or the steps past the table run on its last entry."""
         self.steps_done += int(n)
+        self._ensure_table()
 
     def step(self, grads):
         """One optimiser step from `grads` (one tensor per parameter, same shapes)."""
@@ -763,7 +786,7 @@ class DeviceAdam:
         self._ensure_table()
         g_arr = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
         ffi.check(ffi.lib().pstl_adam_step(len(gs), self._p_arr, g_arr, self._numel_arr, ffi.ptr(self.exp_avg),
-                                           ffi.ptr(self.exp_avg_sq), ffi.ptr(self.sched), self.TABLE,
+                                           ffi.ptr(self.exp_avg_sq), ffi.ptr(self.sched), self.table_steps,
                                            ffi.ptr(self.step_dev, torch.int32), ctypes.c_float(1 - self.betas[0]),
                                            ctypes.c_float(self.betas[1]), ctypes.c_float(1 - self.betas[1]),
                                            ctypes.c_float(self.eps), ffi.stream()), "adam_step")

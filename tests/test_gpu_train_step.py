@@ -338,14 +338,18 @@ def test_repacking_one_network_in_place_equals_a_full_pack():
         pw.update({"rect_net.0.weight": sd["rect_net.0.weight"]})  # a network is packed whole
 
 
-@pytest.mark.parametrize("lr,betas,eps,table", [(3e-4, (0.9, 0.999), 1e-8, None), (0.01, (0.8, 0.99), 1e-6, 4)])
-def test_device_adam_equals_torch_adam(lr, betas, eps, table, monkeypatch):
+@pytest.mark.parametrize("lr,betas,eps,table,n_steps", [(3e-4, (0.9, 0.999), 1e-8, None, 10), (0.01, (0.8, 0.99), 1e-6, 4, 10),
+                                                        (0.02, (0.1, 0.2), 1e-8, None, 20)])
+def test_device_adam_equals_torch_adam(lr, betas, eps, table, n_steps, monkeypatch):
     """pstl_adam_step against torch.optim.Adam on the CPU (the reference's optimiser, nusc_train.py:1233) over ten steps on the
     shapes of rect_net's six tensors: both moments bit for bit at every step -- the parameters too wherever torch's vectorised
-    CPU square root is the IEEE one (tests/test_adam_core_hostsim.py says why not everywhere), one ulp of the increment
+    CPU square root is the IEEE one (tests/test_adam_core_hostsim.py says why not everywhere), at most three ulps of the increment
     otherwise --, the version counters bumped (what PackedWeights caches key on), the step counter on the device.  table = 4: a
     table of four steps, so that the in-place refresh of the per-step scalars (and the counter's reset) happens twice in the run;
-    that run also changes the learning rate half-way, as a scheduler would (the table is rebuilt for the new rate)."""
+    that run also changes the learning rate half-way, as a scheduler would (the table is rebuilt for the new rate).  The third
+    case runs PAST its table: with betas (0.1, 0.2) the per-step scalars reach their limits after 13 steps, the table ends there
+    (DeviceAdam.table_len), and steps 14-20 read its last entry -- still torch's update (what lets a captured step be replayed
+    any number of times with no host involvement)."""
     from pstl_diffusion_policy_amd.engine import DeviceAdam
     if table:
         monkeypatch.setattr(DeviceAdam, "TABLE", table)
@@ -357,7 +361,7 @@ def test_device_adam_equals_torch_adam(lr, betas, eps, table, monkeypatch):
     opt = torch.optim.Adam(cpu, lr=lr, betas=betas, eps=eps)
     dopt = DeviceAdam(gpu, lr=lr, betas=betas, eps=eps)
     v0 = [p._version for p in gpu]
-    for t in range(10):
+    for t in range(n_steps):
         if table and t == 5:
             lr = lr * 0.5
             opt.param_groups[0]["lr"] = lr
@@ -381,11 +385,13 @@ def test_device_adam_equals_torch_adam(lr, betas, eps, table, monkeypatch):
             ieee = torch.sqrt(st["exp_avg_sq"]).numpy().reshape(-1).view(np.uint32) == np.sqrt(v).view(np.uint32)
             assert np.array_equal(got.view(np.uint32)[ieee], want.view(np.uint32)[ieee]), (t, i)
             step = np.abs(want - prev[i].numpy().reshape(-1))
-            assert (np.abs(got - want) <= np.spacing(np.abs(want)) + 2.5e-7 * step).all(), (t, i)
+            assert (np.abs(got - want) <= np.spacing(np.abs(want)) + 4e-7 * step).all(), (t, i)
             with torch.no_grad():
                 pg.copy_(pc.detach())           # (every step is checked on its own)
             o += n
-    assert dopt.steps_done == 10 and int(dopt.step_dev.item()) == (10 if not table else 10 - dopt._table_first + 1)
+    assert dopt.steps_done == n_steps and int(dopt.step_dev.item()) == n_steps - dopt._table_first + 1
+    if n_steps > 10:
+        assert dopt.table_steps == 13 and dopt._table_final and dopt._table_first == 1
     assert all(p._version > v for p, v in zip(gpu, v0))
 
 
