@@ -7,6 +7,8 @@
 // S = 64), so a wave's lanes read the same addresses and the loads are served from L1/L2 as broadcasts.
 // The work is VALU/transcendental bound (~10^3 exp/log/sqrt and ~2*10^4 flops per row evaluation against 160 B of
 // per-row input), nowhere near the HBM roofline; see DESIGN.md.
+#include <stdlib.h>
+
 #include "pstl_common.hpp"
 #include "rng.hpp"
 #include "stl_core.hpp"
@@ -100,6 +102,17 @@ __device__ __forceinline__ void scene_tables(float* lds, int n_scratch, const fl
 }
 
 __host__ __device__ inline int stl_table_floats(int K) { return (3 * kNseg + 3) * 4 + K * kT * kNeiPrep; }   // staged lanes + neighbours
+// (timing builds only, -DPSTL_DBG_LDS_ENV: extra dynamic LDS from the environment = fewer resident wavefronts, for occupancy
+// sweeps without rebuilding -- tools/dbg/occupancy_sweep.sh; every other build: nothing)
+static inline size_t dbg_lds_pad(const char* name) {
+#ifdef PSTL_DBG_LDS_ENV
+  const char* v = getenv(name);
+  return v ? (size_t)atol(v) : 0;
+#else
+  (void)name;
+  return 0;
+#endif
+}
 inline size_t stl_lds_bytes(int n_scratch, int K, bool staged) {
   return ((size_t)n_scratch * kWave + (staged ? (size_t)(3 * kNseg + 3) * 4 + (size_t)K * kT * kNeiPrep : 0)) * sizeof(float);
 }
@@ -1127,7 +1140,7 @@ extern "C" int pstl_stl_forward(const pstl_cfg* cfg, const float* s0, const floa
   // (the selected-formula kernel gains from wavefronts of one (scene, mode): its formula branches become wave-uniform; the
   // all-three kernel evaluates everything for every row anyway)
   a.by_mode = (!scores3 && rows_by_mode(cfg, staged)) ? 1 : 0;
-  const size_t lds = stl_lds_bytes(scores3 ? kScratchFwd3 : kScratchFwd, cfg->K, staged);
+  const size_t lds = stl_lds_bytes(scores3 ? kScratchFwd3 : kScratchFwd, cfg->K, staged) + dbg_lds_pad("PSTL_DBG_LDS_PAD_FORWARD");
   void (*fn)(StlArgs);
   if (cfg->flags & PSTL_FLAG_NORM_STL) {
     if (states)
@@ -1231,10 +1244,7 @@ extern "C" int pstl_guidance_step(const pstl_cfg* cfg, const float* s0, const fl
   const dim3 grid((unsigned)((a.N + kWave - 1) / kWave));
   const bool staged = scene_staged(cfg);
   a.by_mode = rows_by_mode(cfg, staged) ? 1 : 0;
-#ifndef PSTL_DBG_LDS_PAD
-#define PSTL_DBG_LDS_PAD 0   // (timing builds of tools/dbg/ab.sh: fewer resident wavefronts)
-#endif
-  const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged) + PSTL_DBG_LDS_PAD;
+  const size_t lds = stl_lds_bytes(kScratchGrad, cfg->K, staged) + dbg_lds_pad("PSTL_DBG_LDS_PAD_GUIDANCE");
   void (*fn)(GuideArgs) = niters > 1 ? (staged ? k_guidance_iter<true, true> : k_guidance_iter<true, false>)
                                      : (staged ? k_guidance_iter<false, true> : k_guidance_iter<false, false>);
   if (cfg->flags & PSTL_FLAG_NORM_STL)
