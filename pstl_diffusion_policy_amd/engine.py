@@ -784,6 +784,8 @@ class DeviceAdam:
                 raise ValueError("DeviceAdam.step: a gradient's size does not match its parameter's")
             gs.append(g)
         self._ensure_table()
+        for i, p in enumerate(self.params):     # (a parameter whose storage was replaced, e.g. by load_state_dict(assign=True))
+            self._p_arr[i] = p.data_ptr()
         g_arr = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
         ffi.check(ffi.lib().pstl_adam_step(len(gs), self._p_arr, g_arr, self._numel_arr, ffi.ptr(self.exp_avg),
                                            ffi.ptr(self.exp_avg_sq), ffi.ptr(self.sched), self.table_steps,

@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Xarch_device -mllvm=-misched=gcn-iterative-ilp -DPSTL_STL_STAMP \
     -c $c/stl_kernels.hip -o $out/stl_stamp.o && \
   hipcc --offload-arch=gfx950 -shared -fPIC $out/stl_stamp.o $c/mlp_kernels.o $c/train_kernels.o $c/chain2_kernels.o $c/chain2_kernels_p1.o $c/chain2_kernels_p2.o \
-    $c/diversity_kernels.o $c/stl_program.o -o $out/libpstl_ststamp.so && rm -f $out/stl_stamp.o && echo built
+    $c/diversity_kernels.o $c/stl_program.o $c/adam_kernels.o -o $out/libpstl_ststamp.so && rm -f $out/stl_stamp.o && echo built
 else
   shift; cd $root; python3 tools/dbg/with_lib.py $out/libpstl_ststamp.so tools/dbg/stl_stamps.py "$@"
 fi
