@@ -372,7 +372,10 @@ constexpr int kGeoFloats = kGeoSlots * kT;   // per lane
 #define PSTL_G_ABL 0
 #endif
 template <bool MULTI, bool STAGED, bool NORM = false, bool SPLIT = false>
-__global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave, SPLIT ? 2 : 1) void k_guidance_iter(GuideArgs a) {
+// (registers: the staged one-wave forms are held to the 168 of three wavefronts per SIMD -- what their 12.9 KB of LDS allow anyway --,
+// the ten-wave form to the 96 of its two workgroups per CU)
+__global__ __launch_bounds__(SPLIT ? kSplitWaves * kWave : kWave)
+__attribute__((amdgpu_waves_per_eu(SPLIT ? 5 : (STAGED ? 3 : 2)))) void k_guidance_iter(GuideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(!SPLIT || STAGED, "the latency layout stages its scene tables");
   if (!SPLIT) PSTL_ST_BEGIN();
