@@ -1374,7 +1374,7 @@ PSTL_HD void adj_pre_costate(const StlEnv& env, GeoPre pre, float wscale, float 
   }
 }
 
-template <bool NORM = false, class DScoreFn, class EmitFn>
+template <bool NORM = false, bool WAVE_ZERO = false, class DScoreFn, class EmitFn>
 PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes, const float* nei, int K, const float* s0,
                             const float* u, Scratch st, float wscale, float ascale, DScoreFn dscore_fn, EmitFn emit,
                             long us = 1, bool inert = false) {
@@ -1387,33 +1387,36 @@ PSTL_HD float stl_eval_grad(const StlEnv& env, const StlRow& r, const f4* lanes,
   AdjState S;
   const float score = stl_grad_forward<NORM>(env, r, lanes, nei, K, s0, u, st, wscale, ascale, us, S);
   const float dscore_in = dscore_fn(score);
-#if defined(__HIP_DEVICE_COMPILE__)
   // A lane is a row and a wavefront executes both sides of a branch its lanes disagree on: where SOME rows of a wavefront are
-  // past their hinge and some are not, `if (dscore_in == 0) zero else adjoint` ran the adjoint for the one AND the whole of
-  // stl_grad_zero -- twenty control gathers, the noise, the stores -- for the other, one after the other (profiles/r6: the ten
-  // guidance launches of the bench workload took LONGER, 3.70 ms, than with every row past its hinge, 3.56).  So only a
-  // wavefront in which NO row has a gradient takes the zero path; in a mixed one every row that ran the forward sweep walks the
-  // adjoint, a satisfied one with dscore_in = 0: all its terms are products with that zero, and what reaches emit() is replaced
-  // by the literal 0 the zero path hands in (Adam on an exact zero with fresh moments returns the parameter bit for bit, as
-  // there: p0 + (neg_step * 0) / eps).  The host build (tests/hostsim) keeps the per-row form: the same values.
-  if (__builtin_amdgcn_ballot_w64(dscore_in != 0.0f) == 0ull) {
-    stl_grad_zero(u, us, emit);
+  // past their hinge and some are not, the per-row branch below runs the adjoint for the one AND the whole of stl_grad_zero for
+  // the other, one after the other.  WAVE_ZERO (device code only; the callers whose emit() stores lane-contiguously -- the
+  // traj-opt and --refinement loops, element-major work buffers): only a wavefront in which NO row has a gradient takes the zero
+  // path; in a mixed one every row that ran the forward sweep walks the adjoint, a satisfied one with dscore_in = 0, and what
+  // reaches emit() for it is the literal 0 the zero path hands in (same values: Adam on an exact zero leaves what the zero path
+  // leaves).  Traj-opt loop +5 %.  NOT for the callers that scatter 16-byte pieces of row-major rows (k_guidance_iter, the
+  // training adjoint): measured there (profiles/r6/wave_level_zero_decision_ab.txt), the launches got 1.7 % faster but wrote
+  // TWICE the bytes to HBM (227 -> 455 MB per launch) -- with every row's stores spread over the adjoint's duration the partly
+  // written lines of the rows in flight (~9 MB per XCD) no longer fit the 4 MB L2 and leave it piece by piece.
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (WAVE_ZERO) {
+    if (__builtin_amdgcn_ballot_w64(dscore_in != 0.0f) == 0ull) {
+      stl_grad_zero(u, us, emit);
+      return score;
+    }
+    const bool has_grad = dscore_in != 0.0f;
+    stl_grad_adjoint<NORM>(env, r, lanes, nei, K, u, st, wscale, ascale, us, S, dscore_in,
+                           [&emit, has_grad](int t, float gw, float ga, float w, float a) {
+                             emit(t, has_grad ? gw : 0.0f, has_grad ? ga : 0.0f, w, a);
+                           });
     return score;
   }
-  const bool has_grad = dscore_in != 0.0f;
-  stl_grad_adjoint<NORM>(env, r, lanes, nei, K, u, st, wscale, ascale, us, S, dscore_in,
-                         [&emit, has_grad](int t, float gw, float ga, float w, float a) {
-                           emit(t, has_grad ? gw : 0.0f, has_grad ? ga : 0.0f, w, a);
-                         });
-  return score;
-#else
+#endif
   if (dscore_in == 0.0f) {   // e.g. a hinge loss on a satisfied row: the adjoint would produce exact zeros
     stl_grad_zero(u, us, emit);
     return score;
   }
   stl_grad_adjoint<NORM>(env, r, lanes, nei, K, u, st, wscale, ascale, us, S, dscore_in, emit);
   return score;
-#endif
 }
 
 }  // namespace pstl

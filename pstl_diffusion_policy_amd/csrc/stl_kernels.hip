@@ -683,7 +683,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) v
       wm[e * N] = m;
       wm[plane + e * N] = v;
     };
-    score = stl_eval_grad(
+    score = stl_eval_grad<false, true>(   // (WAVE_ZERO: this loop's emit() stores lane-contiguously)
         a.env, r, lanes, nei, a.K, a.s0 + b * 4, u, st, 1.0f, 1.0f,
         [=](float sc) { return (thres - sc > 0.0f) ? -gs : 0.0f; },
         [=](int t, float gw, float ga, float w0, float a0) {
@@ -867,7 +867,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 4))) v
         U[(long)e * P] = B[(long)e * P] * rt[0] + acc;
       }
     }
-    stl_eval_grad(
+    stl_eval_grad<false, true>(   // (WAVE_ZERO, as in k_trajopt)
         a.env, r, lanes, nei, a.K, a.s0 + b * 4, U, st, 1.0f, 1.0f,
         [=](float sc) { return (thres - sc > 0.0f) ? -gs : 0.0f; },
         [=](int t, float gw, float ga, float, float) {
